@@ -1,0 +1,1109 @@
+/*
+ * lsc_oracle.c -- CPU restatement of the lsc_planner replanning tick (see lsc_oracle.h).
+ * TEST INFRASTRUCTURE ONLY -- never linked into the product library.
+ *
+ * Written from the behaviour of the reference (file:line cited per function); no source is
+ * copied.  float32 is used exactly where the reference holds octomap::point3d (float[3]) and
+ * float64 exactly where it uses double, because the LSC margins depend on those roundings.
+ * Compile with -ffp-contract=off (the reference's x86-64 build has no FMA contraction).
+ */
+#include "lsc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+/* ------------------------------------------------------------------------------------------
+ * Constants
+ * ---------------------------------------------------------------------------------------- */
+
+static int binom(int n, int k)
+{
+    if (k < 0 || k > n) return 0;
+    int r = 1;
+    for (int i = 1; i <= k; i++) r = r * (n - k + i) / i;
+    return r;
+}
+
+/* include/polynomial.hpp:415-426 : B(i,j) = C(n,i) C(n-i,n-j) (-1)^(j-i), j>=i */
+void orc_bernstein_basis(double B[ORC_NC * ORC_NC])
+{
+    for (int i = 0; i < ORC_NC; i++)
+        for (int j = 0; j < ORC_NC; j++)
+            B[i * ORC_NC + j] = (j >= i) ? binom(ORC_N, i) * binom(ORC_N - i, ORC_N - j) * (((j - i) & 1) ? -1.0 : 1.0)
+                                         : 0.0;
+}
+
+/* include/polynomial.hpp:224-234 : n (n-1) ... (n-phi+1), 0 when n < phi */
+static int falling(int n, int phi)
+{
+    if (n < phi) return 0;
+    int c = 1;
+    for (int i = 0; i < phi; i++) c *= n - i;
+    return c;
+}
+
+/* src/traj_optimizer.cpp:169-184 with phi_n = 1: Q = B Z B^T dt^(-2 phi + 1) */
+void orc_qbase(double dt, double Q[ORC_NC * ORC_NC])
+{
+    double B[ORC_NC * ORC_NC], Z[ORC_NC * ORC_NC], T[ORC_NC * ORC_NC];
+    orc_bernstein_basis(B);
+    const int k = ORC_PHI;
+    for (int i = 0; i < ORC_NC; i++)
+        for (int j = 0; j < ORC_NC; j++) {
+            int den = i + j - 2 * k + 1;
+            Z[i * ORC_NC + j] = (den > 0) ? (double)falling(i, k) * falling(j, k) / den : 0.0;
+        }
+    for (int i = 0; i < ORC_NC; i++)
+        for (int j = 0; j < ORC_NC; j++) {
+            double s = 0;
+            for (int l = 0; l < ORC_NC; l++) s += B[i * ORC_NC + l] * Z[l * ORC_NC + j];
+            T[i * ORC_NC + j] = s;
+        }
+    double scale = pow(dt, -2 * k + 1);
+    for (int i = 0; i < ORC_NC; i++)
+        for (int j = 0; j < ORC_NC; j++) {
+            double s = 0;
+            for (int l = 0; l < ORC_NC; l++) s += T[i * ORC_NC + l] * B[j * ORC_NC + l];
+            Q[i * ORC_NC + j] = s * scale;
+        }
+}
+
+/* src/traj_optimizer.cpp:186-236 : rows 0..2 initial pos/vel/acc, then 3 continuity rows per junction */
+void orc_aeq_base(double dt, double A[(ORC_PHI * ORC_M) * ORC_SEGV])
+{
+    /* derivative stencils at the start / end of a degree-5 Bernstein segment */
+    static const double start[3][ORC_NC] = {{1, 0, 0, 0, 0, 0}, {-1, 1, 0, 0, 0, 0}, {1, -2, 1, 0, 0, 0}};
+    static const double end[3][ORC_NC] = {{0, 0, 0, 0, 0, 1}, {0, 0, 0, 0, -1, 1}, {0, 0, 0, 1, -2, 1}};
+    memset(A, 0, sizeof(double) * (ORC_PHI * ORC_M) * ORC_SEGV);
+    int nn = 1;
+    for (int j = 0; j < ORC_PHI; j++) {
+        for (int i = 0; i < ORC_NC; i++) A[j * ORC_SEGV + i] = pow(dt, -j) * nn * start[j][i];
+        nn *= ORC_N - j;
+    }
+    for (int m = 1; m < ORC_M; m++) {
+        nn = 1;
+        for (int j = 0; j < ORC_PHI; j++) {
+            int r = ORC_PHI + ORC_PHI * (m - 1) + j;
+            for (int i = 0; i < ORC_NC; i++) {
+                A[r * ORC_SEGV + ORC_NC * (m - 1) + i] = pow(dt, -j) * nn * end[j][i];
+                A[r * ORC_SEGV + ORC_NC * m + i] = -pow(dt, -j) * nn * start[j][i];
+            }
+            nn *= ORC_N - j;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * GJK between conv(pts) and the origin.  Follows src/openGJK/openGJK.cpp:
+ *   sub-distance predicates :181-241, S1D :243-256, S2D :259-313, S3D :315-631,
+ *   support :633-655, main loop :674-780.
+ * Vertex slots keep the reference's order (slot nv-1 is the vertex just added) because
+ * the sub-algorithms' decisions and the order after a reduction depend on it.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef double v3[3];
+
+static inline double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cpy3(double *d, const double *s) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+static inline void cross3(const double *a, const double *b, double *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* origin projected on the line through p and q (:149-161) */
+static void foot_line(const double *p, const double *q, double *v)
+{
+    v3 pq = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+    double t = dot3(p, pq) / dot3(pq, pq);
+    for (int i = 0; i < 3; i++) v[i] = p[i] - pq[i] * t;
+}
+
+/* origin projected on the plane through p, q, r (:163-179) */
+static void foot_plane(const double *p, const double *q, const double *r, double *v)
+{
+    v3 pq, pr, nrm;
+    for (int i = 0; i < 3; i++) pq[i] = p[i] - q[i];
+    for (int i = 0; i < 3; i++) pr[i] = p[i] - r[i];
+    cross3(pq, pr, nrm);
+    double t = dot3(nrm, p) / dot3(nrm, nrm);
+    for (int i = 0; i < 3; i++) v[i] = nrm[i] * t;
+}
+
+/* does the origin project inside edge p->q, seen from p?  (:181-193) */
+static int edge_keeps(const double *p, const double *q)
+{
+    double t = 0;
+    for (int i = 0; i < 3; i++) t += (p[i] * p[i] - p[i] * q[i]);
+    return t > 0;
+}
+
+/* (:195-218): 1 when the origin lies on the far side of edge pq within triangle pqr's plane */
+static int edge_rejects(const double *p, const double *q, const double *r)
+{
+    v3 pq, pr, a, b;
+    for (int i = 0; i < 3; i++) pq[i] = q[i] - p[i];
+    for (int i = 0; i < 3; i++) pr[i] = r[i] - p[i];
+    cross3(pq, pr, a);
+    cross3(pq, a, b);
+    double t = 0;
+    for (int i = 0; i < 3; i++) t = t + (p[i] * b[i]);
+    return t < 0;
+}
+
+/* (:220-241): 0 when p.(pq x pr) > 0 */
+static int face_side(const double *p, const double *q, const double *r)
+{
+    v3 pq, pr, a;
+    for (int i = 0; i < 3; i++) pq[i] = q[i] - p[i];
+    for (int i = 0; i < 3; i++) pr[i] = r[i] - p[i];
+    cross3(pq, pr, a);
+    double t = 0;
+    for (int i = 0; i < 3; i++) t = t + (p[i] * a[i]);
+    return (t > 0) ? 0 : 1;
+}
+
+typedef struct {
+    int nv;
+    v3 w[4];
+} gjk_simplex;
+
+static void sub_1d(gjk_simplex *s, double *v)
+{
+    const double *a = s->w[1], *b = s->w[0];
+    if (edge_keeps(a, b)) {
+        foot_line(a, b, v);
+    } else {
+        cpy3(v, a);
+        s->nv = 1;
+        cpy3(s->w[0], a);
+    }
+}
+
+static void sub_2d(gjk_simplex *s, double *v)
+{
+    const double *a = s->w[2], *b = s->w[1], *c = s->w[0];
+    int ab = edge_keeps(a, b);
+    int ac = edge_keeps(a, c);
+    int in_bc = !edge_rejects(a, b, c);
+    int in_cb = !edge_rejects(a, c, b);
+    enum { FACE, EDGE_AB, EDGE_AC, VERT } pick;
+    if (ab) {
+        if (in_bc) pick = (ac && !in_cb) ? EDGE_AC : FACE;
+        else pick = EDGE_AB;
+    } else if (ac) {
+        pick = in_cb ? FACE : EDGE_AC;
+    } else {
+        pick = VERT;
+    }
+    switch (pick) {
+    case FACE:
+        foot_plane(a, b, c, v);
+        break;
+    case EDGE_AB: /* slots become [a, b] */
+        foot_line(a, b, v);
+        s->nv = 2;
+        cpy3(s->w[0], s->w[2]);
+        break;
+    case EDGE_AC: /* slots become [c, a] */
+        foot_line(a, c, v);
+        s->nv = 2;
+        cpy3(s->w[1], s->w[2]);
+        break;
+    case VERT:
+        cpy3(v, a);
+        s->nv = 1;
+        cpy3(s->w[0], s->w[2]);
+        break;
+    }
+}
+
+/* keep {a, p, q} as a triangle: slots [q, p, a] */
+static void keep_tri(gjk_simplex *s, const double *a, const double *p, const double *q)
+{
+    v3 ta, tp, tq;
+    cpy3(ta, a); cpy3(tp, p); cpy3(tq, q);
+    s->nv = 3;
+    cpy3(s->w[2], ta); cpy3(s->w[1], tp); cpy3(s->w[0], tq);
+}
+/* keep {a, p} as an edge: slots [p, a] */
+static void keep_edge(gjk_simplex *s, const double *a, const double *p)
+{
+    v3 ta, tp;
+    cpy3(ta, a); cpy3(tp, p);
+    s->nv = 2;
+    cpy3(s->w[1], ta); cpy3(s->w[0], tp);
+}
+
+static void sub_3d(gjk_simplex *s, double *v)
+{
+    v3 a, P[3]; /* P[2], P[1], P[0] = the three older vertices in slot order 2,1,0 */
+    cpy3(a, s->w[3]);
+    for (int t = 0; t < 3; t++) cpy3(P[t], s->w[t]);
+    v3 e2, e1, e0;
+    for (int t = 0; t < 3; t++) { e2[t] = P[2][t] - a[t]; e1[t] = P[1][t] - a[t]; e0[t] = P[0][t] - a[t]; }
+
+    int keep[3];
+    keep[2] = edge_keeps(a, P[2]);
+    keep[1] = edge_keeps(a, P[1]);
+    keep[0] = edge_keeps(a, P[0]);
+    int nkeep = keep[2] + keep[1] + keep[0];
+    if (nkeep == 0) {
+        cpy3(v, a);
+        s->nv = 1;
+        cpy3(s->w[0], a);
+        return;
+    }
+
+    /* orientation of the tetrahedron: e1 . (e0 x e2) evaluated as a cofactor expansion (:138-140) */
+    double det = e1[0] * ((e0[1] * e2[2]) - (e2[1] * e0[2])) - e1[1] * (e0[0] * e2[2] - e2[0] * e0[2]) +
+                 e1[2] * (e0[0] * e2[1] - e2[0] * e0[1]);
+    int flip = (det > 0) ? 0 : 1;
+    int f2 = face_side(a, P[1], P[0]) - flip; f2 *= f2; /* face opposite slot 2 */
+    int f1 = face_side(a, P[0], P[2]) - flip; f1 *= f1; /* face opposite slot 1 */
+    int f0 = face_side(a, P[2], P[1]) - flip; f0 *= f0; /* face opposite slot 0 */
+
+    int k, i, j;
+    switch (f2 + f1 + f0) {
+    case 3: /* origin inside the tetrahedron */
+        v[0] = v[1] = v[2] = 0;
+        s->nv = 4;
+        return;
+    case 2: /* exactly one face sees the origin: drop the opposite vertex, keep slot order */
+        s->nv = 3;
+        if (!f2) {
+            cpy3(s->w[2], a);
+        } else if (!f1) {
+            cpy3(s->w[1], P[2]);
+            cpy3(s->w[2], a);
+        } else {
+            cpy3(s->w[0], P[1]);
+            cpy3(s->w[1], P[2]);
+            cpy3(s->w[2], a);
+        }
+        sub_2d(s, v);
+        return;
+    case 1: {
+        s->nv = 3;
+        if (f2) { k = 2; i = 1; j = 0; }
+        else if (f1) { k = 1; i = 0; j = 2; }
+        else { k = 0; i = 2; j = 1; }
+        const double *pi = P[i], *pj = P[j], *pk = P[k];
+        if (nkeep == 1) {
+            if (keep[k]) {
+                if (!edge_rejects(a, pk, pi)) { keep_tri(s, a, pi, pk); foot_plane(a, pi, pk, v); }
+                else if (!edge_rejects(a, pk, pj)) { keep_tri(s, a, pj, pk); foot_plane(a, pj, pk, v); }
+                else { keep_edge(s, a, pk); foot_line(a, pk, v); }
+            } else if (keep[i]) {
+                if (!edge_rejects(a, pi, pk)) { keep_tri(s, a, pi, pk); foot_plane(a, pi, pk, v); }
+                else { keep_edge(s, a, pi); foot_line(a, pi, v); }
+            } else {
+                if (!edge_rejects(a, pj, pk)) { keep_tri(s, a, pj, pk); foot_plane(a, pj, pk, v); }
+                else { keep_edge(s, a, pj); foot_line(a, pj, v); }
+            }
+        } else if (nkeep == 2) {
+            if (keep[i]) {
+                if (!edge_rejects(a, pk, pi)) {
+                    if (!edge_rejects(a, pi, pk)) { keep_tri(s, a, pi, pk); foot_plane(a, pi, pk, v); }
+                    else { keep_edge(s, a, pk); foot_line(a, pk, v); }
+                } else {
+                    if (!edge_rejects(a, pk, pj)) { keep_tri(s, a, pj, pk); foot_plane(a, pj, pk, v); }
+                    else { keep_edge(s, a, pk); foot_line(a, pk, v); }
+                }
+            } else if (keep[j]) {
+                if (!edge_rejects(a, pk, pj)) {
+                    if (!edge_rejects(a, pj, pk)) { keep_tri(s, a, pj, pk); foot_plane(a, pj, pk, v); }
+                    else { keep_edge(s, a, pj); foot_line(a, pj, v); }
+                } else {
+                    if (!edge_rejects(a, pk, pi)) { keep_tri(s, a, pi, pk); foot_plane(a, pi, pk, v); }
+                    else { keep_edge(s, a, pk); foot_line(a, pk, v); }
+                }
+            }
+            /* else: reference leaves v and the 3 oldest slots untouched (:497-499) */
+        } else {
+            int r_ik = edge_rejects(a, pi, pk);
+            int r_jk = edge_rejects(a, pj, pk);
+            int r_ki = edge_rejects(a, pk, pi);
+            int r_kj = edge_rejects(a, pk, pj);
+            if (r_ki && r_kj) { keep_edge(s, a, pk); foot_line(a, pk, v); }
+            else if (r_ki) {
+                if (r_jk) { keep_edge(s, a, pj); foot_line(a, pj, v); }
+                else { keep_tri(s, a, pj, pk); foot_plane(a, pk, pj, v); }
+            } else {
+                if (r_ik) { keep_edge(s, a, pi); foot_line(a, pi, v); }
+                else { keep_tri(s, a, pi, pk); foot_plane(a, pk, pi, v); }
+            }
+        }
+        return;
+    }
+    case 0:
+        if (nkeep == 1) {
+            if (keep[1]) { k = 2; i = 1; j = 0; }
+            else if (keep[0]) { k = 1; i = 0; j = 2; }
+            else { k = 0; i = 2; j = 1; }
+            const double *pi = P[i], *pj = P[j], *pk = P[k];
+            if (!edge_rejects(a, pi, pj)) { keep_tri(s, a, pi, pj); foot_plane(a, pi, pj, v); }
+            else if (!edge_rejects(a, pi, pk)) { keep_tri(s, a, pi, pk); foot_plane(a, pi, pk, v); }
+            else { keep_edge(s, a, pi); foot_line(a, pi, v); }
+        } else if (nkeep == 2) {
+            s->nv = 3;
+            if (!keep[1]) { k = 2; i = 1; j = 0; }
+            else if (!keep[0]) { k = 1; i = 0; j = 2; }
+            else { k = 0; i = 2; j = 1; }
+            const double *pi = P[i], *pj = P[j], *pk = P[k];
+            if (!edge_rejects(a, pj, pk)) {
+                if (!edge_rejects(a, pk, pj)) { keep_tri(s, a, pj, pk); foot_plane(a, pj, pk, v); }
+                else if (!edge_rejects(a, pk, pi)) { keep_tri(s, a, pi, pk); foot_plane(a, pk, pi, v); }
+                else { keep_edge(s, a, pk); foot_line(a, pk, v); }
+            } else if (!edge_rejects(a, pj, pi)) { keep_tri(s, a, pi, pj); foot_plane(a, pi, pj, v); }
+            else { keep_edge(s, a, pj); foot_line(a, pj, v); }
+        }
+        /* nkeep == 3: reference does nothing; simplex stays at 4 vertices and the loop ends */
+        return;
+    }
+}
+
+double orc_gjk_origin(const double (*pts)[3], int npts, double v[3], int *nvrtx, int *iters)
+{
+    const double eps_rel = 1e-10, eps_tot = 1e-12;
+    gjk_simplex s;
+    v3 sup; /* current support point of the hull */
+    double wmax2 = 0;
+    int k = 0;
+
+    cpy3(v, pts[0]);
+    for (int t = 0; t < 3; t++) v[t] = pts[0][t] - 0.0;
+    s.nv = 1;
+    cpy3(s.w[0], v);
+    cpy3(sup, pts[0]);
+
+    do {
+        k++;
+        v3 neg = {-v[0], -v[1], -v[2]};
+        /* support(:633-655): first strict improvement over the previous support's score */
+        double best = dot3(sup, neg);
+        int better = -1;
+        for (int i = 0; i < npts; i++) {
+            double sc = dot3(pts[i], neg);
+            if (sc > best) { best = sc; better = i; }
+        }
+        if (better >= 0) cpy3(sup, pts[better]);
+        v3 w = {sup[0] - 0.0, sup[1] - 0.0, sup[2] - 0.0};
+
+        double vv = dot3(v, v);
+        double gap = vv - dot3(v, w);
+        if (gap <= eps_rel * vv || gap < eps_tot) break;
+        if (vv < eps_rel * eps_rel) break;
+
+        cpy3(s.w[s.nv], w);
+        s.nv++;
+        switch (s.nv) {
+        case 4: sub_3d(&s, v); break;
+        case 3: sub_2d(&s, v); break;
+        case 2: sub_1d(&s, v); break;
+        }
+        for (int j = 0; j < s.nv; j++) {
+            double t = dot3(s.w[j], s.w[j]);
+            if (t > wmax2) wmax2 = t;
+        }
+        if (dot3(v, v) <= eps_tot * eps_tot * wmax2) break;
+    } while (s.nv != 4 && k != 25);
+
+    if (nvrtx) *nvrtx = s.nv;
+    if (iters) *iters = k;
+    return sqrt(dot3(v, v));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * float32 point semantics (octomath::Vector3: float storage, float arithmetic, double norm)
+ * ---------------------------------------------------------------------------------------- */
+
+static inline float f32_dot(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static void f32_normalize(float *a)
+{
+    float n2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+    double len = sqrt((double)n2);
+    if (len > 0) {
+        float l = (float)len;
+        a[0] /= l; a[1] /= l; a[2] /= l;
+    }
+}
+
+static double f32_dist(const float *a, const float *b)
+{
+    float d[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+    float n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    return sqrt((double)n2);
+}
+
+/* src/traj_planner.cpp:2030-2043 + include/geometry.hpp:364-394 */
+void orc_normal_between_polys(const float (*pa)[3], const float (*po)[3], int npts, float normal[3])
+{
+    double rel[8][3];
+    for (int i = 0; i < npts; i++)
+        for (int t = 0; t < 3; t++) {
+            float r = pa[i][t] - po[i][t];
+            rel[i][t] = (double)r;
+        }
+    double v[3];
+    orc_gjk_origin((const double(*)[3])rel, npts, v, NULL, NULL);
+    for (int t = 0; t < 3; t++) normal[t] = 0.0f + (float)v[t];
+    f32_normalize(normal);
+}
+
+/* src/traj_planner.cpp:829-864 (agent branch) and :997-1016 */
+void orc_shift_traj(const float *prev, float *out)
+{
+    for (int k = 0; k < 3; k++) {
+        const float *p = prev + k * ORC_SEGV;
+        float *o = out + k * ORC_SEGV;
+        for (int m = 0; m < ORC_M - 1; m++)
+            for (int i = 0; i < ORC_NC; i++) o[m * ORC_NC + i] = p[(m + 1) * ORC_NC + i];
+        for (int i = 0; i < ORC_NC; i++) o[(ORC_M - 1) * ORC_NC + i] = p[(ORC_M - 1) * ORC_NC + ORC_N];
+    }
+}
+
+/* src/traj_planner.cpp:699-712 / :1030-1037: pos + vel * m_intp * dt, point3d * double -> float factor */
+void orc_const_vel_traj(const float pos[3], const float vel[3], double dt, float *out)
+{
+    for (int m = 0; m < ORC_M; m++)
+        for (int i = 0; i < ORC_NC; i++) {
+            double m_intp = m + (double)i / ORC_N;
+            for (int k = 0; k < 3; k++) {
+                float a = vel[k] * (float)m_intp;
+                float b = a * (float)dt;
+                out[k * ORC_SEGV + m * ORC_NC + i] = pos[k] + b;
+            }
+        }
+}
+
+/* src/traj_planner.cpp:1336-1404 (AGENT obstacle, previous-solution prediction) */
+void orc_lsc_pair(const float *init_traj, const float *obs_traj, double r_a, double r_o, double dw_a,
+                  double dw_o, float normal[ORC_M][3], double d[ORC_M][ORC_NC])
+{
+    double downwash = (dw_a * r_a + dw_o * r_o) / (r_a + r_o);
+    for (int m = 0; m < ORC_M; m++) {
+        float pa[ORC_NC][3], po[ORC_NC][3];
+        for (int i = 0; i < ORC_NC; i++) {
+            int c = m * ORC_NC + i;
+            pa[i][0] = init_traj[c]; pa[i][1] = init_traj[ORC_SEGV + c];
+            pa[i][2] = (float)((double)init_traj[2 * ORC_SEGV + c] / downwash); /* util.hpp:231-240 */
+            po[i][0] = obs_traj[c]; po[i][1] = obs_traj[ORC_SEGV + c];
+            po[i][2] = (float)((double)obs_traj[2 * ORC_SEGV + c] / downwash);
+        }
+        float nv[3];
+        orc_normal_between_polys((const float(*)[3])pa, (const float(*)[3])po, ORC_NC, nv);
+        double collision_dist = r_o + r_a;
+        for (int i = 0; i < ORC_NC; i++) {
+            float rel[3] = {pa[i][0] - po[i][0], pa[i][1] - po[i][1], pa[i][2] - po[i][2]};
+            d[m][i] = 0.5 * (collision_dist + (double)f32_dot(rel, nv));
+        }
+        nv[2] = (float)((double)nv[2] / downwash);
+        normal[m][0] = nv[0]; normal[m][1] = nv[1]; normal[m][2] = nv[2];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * QP assembly (src/traj_optimizer.cpp:261-548)
+ * ---------------------------------------------------------------------------------------- */
+
+/* :541-548 */
+int orc_terminal_segments(const float goal[3], const float pos[3], double v_nom, double dt)
+{
+    double flight = f32_dist(goal, pos) / v_nom;
+    int t = (int)((ORC_M * dt - flight + 1e-9) / dt);
+    return t > 1 ? t : 1;
+}
+
+static inline int vidx(int k, int m, int i) { return k * ORC_SEGV + m * ORC_NC + i; }
+
+int orc_qp_assemble(const orc_params *prm, const float state[9], const float goal[3], double v_nom,
+                    const double vmax[3], const double amax[3], int n_obs, const float *obs_traj,
+                    const float *normal, const double *d, const float *sfc, double *P, double *c, double *cst,
+                    double *lo, double *hi, orc_row *rows)
+{
+    const double dt = prm->dt;
+    double Q[ORC_NC * ORC_NC], Aeq[(ORC_PHI * ORC_M) * ORC_SEGV];
+    orc_qbase(dt, Q);
+    orc_aeq_base(dt, Aeq);
+
+    /* bounds :274-303 */
+    for (int k = 0; k < 3; k++)
+        for (int m = 0; m < ORC_M; m++)
+            for (int i = 0; i < ORC_NC; i++) {
+                int r = vidx(k, m, i);
+                if (m == 0 && i < 3) { lo[r] = -INFINITY; hi[r] = INFINITY; }
+                else { lo[r] = (double)prm->world_min[k]; hi[r] = (double)prm->world_max[k]; }
+            }
+
+    /* cost :328-372 ; objective = x' (w_c Q) x + w_t sum |c - g|^2  =>  (1/2) x' P x with P = 2 w_c Q (+2 w_t) */
+    memset(P, 0, sizeof(double) * ORC_NV * ORC_NV);
+    memset(c, 0, sizeof(double) * ORC_NV);
+    *cst = 0;
+    for (int k = 0; k < 3; k++)
+        for (int m = 0; m < ORC_M; m++)
+            for (int i = 0; i < ORC_NC; i++)
+                for (int j = 0; j < ORC_NC; j++)
+                    if (Q[i * ORC_NC + j] != 0 && prm->w_control != 0)
+                        P[vidx(k, m, i) * ORC_NV + vidx(k, m, j)] += 2.0 * prm->w_control * Q[i * ORC_NC + j];
+    int T = orc_terminal_segments(goal, state, v_nom, dt);
+    for (int m = ORC_M - T; m < ORC_M; m++)
+        for (int k = 0; k < 3; k++) {
+            int r = vidx(k, m, ORC_N);
+            double g = (double)goal[k];
+            P[r * ORC_NV + r] += 2.0 * prm->w_terminal;
+            c[r] += -2.0 * prm->w_terminal * g;
+            *cst += prm->w_terminal * g * g;
+        }
+
+    int nr = 0;
+    /* equalities :394-405 */
+    for (int k = 0; k < 3; k++)
+        for (int r = 0; r < ORC_PHI * ORC_M; r++) {
+            orc_row *R = &rows[nr++];
+            R->nnz = 0; R->sense = 0;
+            for (int j = 0; j < ORC_SEGV; j++)
+                if (Aeq[r * ORC_SEGV + j] != 0) {
+                    R->idx[R->nnz] = k * ORC_SEGV + j;
+                    R->val[R->nnz] = Aeq[r * ORC_SEGV + j];
+                    R->nnz++;
+                }
+            R->rhs = (r < 3) ? (double)state[3 * r + k] : 0.0;
+        }
+    /* SFC :409-434 ; Box::convertToLSCs src/collision_constraints.cpp:37-59 */
+    if (prm->use_sfc && sfc) {
+        for (int m = 0; m < ORC_M; m++)
+            for (int f = 0; f < 6; f++) {
+                int ax = f / 2;
+                double sgn = (f & 1) ? -1.0 : 1.0;
+                double dd = (f & 1) ? -(double)sfc[m * 6 + 3 + ax] : (double)sfc[m * 6 + ax];
+                for (int j = 0; j < ORC_NC; j++) {
+                    if (m == 0 && j < ORC_PHI) continue;
+                    orc_row *R = &rows[nr++];
+                    R->nnz = 1; R->sense = 1;
+                    R->idx[0] = vidx(ax, m, j); R->val[0] = sgn; R->rhs = dd;
+                }
+            }
+    }
+    /* LSC :437-466 */
+    for (int oi = 0; oi < n_obs; oi++)
+        for (int m = 0; m < ORC_M; m++)
+            for (int i = 0; i < ORC_NC; i++) {
+                if (m == 0 && i < ORC_PHI) continue;
+                const float *nv = normal + (oi * ORC_M + m) * 3;
+                orc_row *R = &rows[nr++];
+                R->nnz = 3; R->sense = 1;
+                double rhs = d[(oi * ORC_M + m) * ORC_NC + i];
+                for (int k = 0; k < 3; k++) {
+                    double q = (double)obs_traj[(oi * 3 + k) * ORC_SEGV + m * ORC_NC + i];
+                    R->idx[k] = vidx(k, m, i);
+                    R->val[k] = (double)nv[k];
+                    rhs += (double)nv[k] * q;
+                }
+                R->rhs = rhs;
+            }
+    /* dynamic limits :468-525 */
+    for (int k = 0; k < 3; k++)
+        for (int m = 0; m < ORC_M; m++) {
+            for (int i = 0; i < ORC_N; i++) {
+                if (m == 0 && (i == 0 || i == 1)) continue;
+                for (int sg = 0; sg < 2; sg++) {
+                    double f = (sg ? -1.0 : 1.0) * pow(dt, -1) * ORC_N;
+                    orc_row *R = &rows[nr++];
+                    R->nnz = 2; R->sense = 2;
+                    R->idx[0] = vidx(k, m, i + 1); R->val[0] = f;
+                    R->idx[1] = vidx(k, m, i); R->val[1] = -f;
+                    R->rhs = vmax[k];
+                }
+            }
+            for (int i = 0; i < ORC_N - 1; i++) {
+                if (m == 0 && i == 0) continue;
+                for (int sg = 0; sg < 2; sg++) {
+                    double f = (sg ? -1.0 : 1.0) * pow(dt, -2) * ORC_N * (ORC_N - 1);
+                    orc_row *R = &rows[nr++];
+                    R->nnz = 3; R->sense = 2;
+                    R->idx[0] = vidx(k, m, i + 2); R->val[0] = f;
+                    R->idx[1] = vidx(k, m, i + 1); R->val[1] = -2 * f;
+                    R->idx[2] = vidx(k, m, i); R->val[2] = f;
+                    R->rhs = amax[k];
+                }
+            }
+        }
+    /* stop at horizon :527-536 */
+    for (int k = 0; k < 3; k++)
+        for (int i = 1; i < ORC_PHI; i++) {
+            orc_row *R = &rows[nr++];
+            R->nnz = 2; R->sense = 0;
+            R->idx[0] = vidx(k, ORC_M - 1, ORC_N); R->val[0] = 1.0;
+            R->idx[1] = vidx(k, ORC_M - 1, ORC_N - i); R->val[1] = -1.0;
+            R->rhs = 0.0;
+        }
+    return nr;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Exact convex QP solve in fp64: equality constraints removed with an orthonormal null-space
+ * basis (Householder QR of Aeq^T), inequalities handled by a Mehrotra predictor-corrector
+ * interior-point method.  Stands where CPLEX's dual simplex stood (src/traj_optimizer.cpp:76).
+ * ---------------------------------------------------------------------------------------- */
+
+#define NV ORC_NV
+
+static int chol_factor(double *A, int n)
+{
+    for (int j = 0; j < n; j++) {
+        double s = A[j * n + j];
+        for (int k = 0; k < j; k++) s -= A[j * n + k] * A[j * n + k];
+        if (!(s > 0)) return -1;
+        double l = sqrt(s);
+        A[j * n + j] = l;
+        for (int i = j + 1; i < n; i++) {
+            double t = A[i * n + j];
+            for (int k = 0; k < j; k++) t -= A[i * n + k] * A[j * n + k];
+            A[i * n + j] = t / l;
+        }
+    }
+    return 0;
+}
+
+static void chol_solve(const double *L, int n, double *b)
+{
+    for (int i = 0; i < n; i++) {
+        double t = b[i];
+        for (int k = 0; k < i; k++) t -= L[i * n + k] * b[k];
+        b[i] = t / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double t = b[i];
+        for (int k = i + 1; k < n; k++) t -= L[k * n + i] * b[k];
+        b[i] = t / L[i * n + i];
+    }
+}
+
+int orc_qp_solve(const double *P, const double *c, double cst, const double *lo, const double *hi,
+                 const orc_row *rows, int nrows, double *x, double *cost, int *iters, double *kkt)
+{
+    /* ---- split rows ---- */
+    int neq = 0, nin = 0;
+    for (int r = 0; r < nrows; r++) (rows[r].sense == 0) ? neq++ : nin++;
+    int nb = 0;
+    for (int j = 0; j < NV; j++) { if (isfinite(lo[j])) nb++; if (isfinite(hi[j])) nb++; }
+    const int R = nin + nb;
+
+    /* inequalities as g'x <= h, sparse */
+    orc_row *G = (orc_row *)malloc(sizeof(orc_row) * (size_t)(R > 0 ? R : 1));
+    int gi = 0;
+    for (int r = 0; r < nrows; r++) {
+        if (rows[r].sense == 0) continue;
+        G[gi] = rows[r];
+        if (rows[r].sense == 1) {
+            for (int j = 0; j < G[gi].nnz; j++) G[gi].val[j] = -G[gi].val[j];
+            G[gi].rhs = -G[gi].rhs;
+        }
+        G[gi].sense = 2;
+        gi++;
+    }
+    for (int j = 0; j < NV; j++) {
+        if (isfinite(hi[j])) { G[gi].nnz = 1; G[gi].idx[0] = j; G[gi].val[0] = 1; G[gi].rhs = hi[j]; G[gi].sense = 2; gi++; }
+        if (isfinite(lo[j])) { G[gi].nnz = 1; G[gi].idx[0] = j; G[gi].val[0] = -1; G[gi].rhs = -lo[j]; G[gi].sense = 2; gi++; }
+    }
+
+    /* ---- Householder QR of Aeq^T (NV x neq) ---- */
+    double *W = (double *)calloc((size_t)NV * neq, sizeof(double));
+    double *beq = (double *)calloc((size_t)neq, sizeof(double));
+    {
+        int e = 0;
+        for (int r = 0; r < nrows; r++) {
+            if (rows[r].sense != 0) continue;
+            for (int j = 0; j < rows[r].nnz; j++) W[rows[r].idx[j] * neq + e] = rows[r].val[j];
+            beq[e] = rows[r].rhs;
+            e++;
+        }
+    }
+    double *HV = (double *)calloc((size_t)NV * neq, sizeof(double)); /* reflector k in column k */
+    for (int k = 0; k < neq; k++) {
+        double nrm = 0;
+        for (int i = k; i < NV; i++) nrm += W[i * neq + k] * W[i * neq + k];
+        nrm = sqrt(nrm);
+        double alpha = (W[k * neq + k] > 0) ? -nrm : nrm;
+        double vn = 0;
+        for (int i = k; i < NV; i++) {
+            double t = W[i * neq + k] - ((i == k) ? alpha : 0.0);
+            HV[i * neq + k] = t;
+            vn += t * t;
+        }
+        vn = sqrt(vn);
+        if (vn > 0) for (int i = k; i < NV; i++) HV[i * neq + k] /= vn;
+        for (int j = k; j < neq; j++) {
+            double s = 0;
+            for (int i = k; i < NV; i++) s += HV[i * neq + k] * W[i * neq + j];
+            for (int i = k; i < NV; i++) W[i * neq + j] -= 2 * s * HV[i * neq + k];
+        }
+    }
+    /* W now holds R (upper neq x neq).  Q e_j = H_0 ... H_{neq-1} e_j */
+    const int ny = NV - neq;
+    double *Z = (double *)calloc((size_t)NV * ny, sizeof(double));
+    double *xp = (double *)calloc(NV, sizeof(double));
+    {
+        /* xp = Q [R^-T beq ; 0] */
+        double *t = (double *)calloc(NV, sizeof(double));
+        for (int i = 0; i < neq; i++) {
+            double s = beq[i];
+            for (int k = 0; k < i; k++) s -= W[k * neq + i] * t[k];
+            t[i] = s / W[i * neq + i];
+        }
+        for (int k = neq - 1; k >= 0; k--) {
+            double s = 0;
+            for (int i = k; i < NV; i++) s += HV[i * neq + k] * t[i];
+            for (int i = k; i < NV; i++) t[i] -= 2 * s * HV[i * neq + k];
+        }
+        memcpy(xp, t, sizeof(double) * NV);
+        for (int j = 0; j < ny; j++) {
+            memset(t, 0, sizeof(double) * NV);
+            t[neq + j] = 1;
+            for (int k = neq - 1; k >= 0; k--) {
+                double s = 0;
+                for (int i = k; i < NV; i++) s += HV[i * neq + k] * t[i];
+                for (int i = k; i < NV; i++) t[i] -= 2 * s * HV[i * neq + k];
+            }
+            for (int i = 0; i < NV; i++) Z[i * ny + j] = t[i];
+        }
+        free(t);
+    }
+
+    /* ---- reduced cost: Hy = Z'PZ, gy = Z'(P xp + c) ---- */
+    double *PZ = (double *)calloc((size_t)NV * ny, sizeof(double));
+    double *Hy = (double *)calloc((size_t)ny * ny, sizeof(double));
+    double *gy = (double *)calloc(ny, sizeof(double));
+    for (int i = 0; i < NV; i++)
+        for (int l = 0; l < NV; l++) {
+            double p = P[i * NV + l];
+            if (p == 0) continue;
+            for (int j = 0; j < ny; j++) PZ[i * ny + j] += p * Z[l * ny + j];
+        }
+    for (int i = 0; i < NV; i++)
+        for (int a = 0; a < ny; a++) {
+            double z = Z[i * ny + a];
+            for (int b = 0; b < ny; b++) Hy[a * ny + b] += z * PZ[i * ny + b];
+        }
+    {
+        double t[NV];
+        for (int i = 0; i < NV; i++) {
+            double s = c[i];
+            for (int l = 0; l < NV; l++) s += P[i * NV + l] * xp[l];
+            t[i] = s;
+        }
+        for (int a = 0; a < ny; a++) {
+            double s = 0;
+            for (int i = 0; i < NV; i++) s += Z[i * ny + a] * t[i];
+            gy[a] = s;
+        }
+    }
+
+    double *y = (double *)calloc(ny, sizeof(double));
+    double *s = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
+    double *z = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
+    double *ds = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
+    double *dz = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
+    double *rp = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
+    double *u = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
+    double *K = (double *)calloc((size_t)ny * ny, sizeof(double));
+    double Kx[NV * NV], xx[NV], dx[NV], tx[NV];
+    double *rd = (double *)calloc(ny, sizeof(double));
+    double *dy = (double *)calloc(ny, sizeof(double));
+    double *KxZ = (double *)calloc((size_t)NV * ny, sizeof(double));
+
+#define X_FROM_Y(yy, out, with_xp)                                                    \
+    for (int i_ = 0; i_ < NV; i_++) {                                                 \
+        double s_ = (with_xp) ? xp[i_] : 0.0;                                         \
+        for (int a_ = 0; a_ < ny; a_++) s_ += Z[i_ * ny + a_] * (yy)[a_];             \
+        (out)[i_] = s_;                                                               \
+    }
+#define ROWDOT(r_, vec) ({ double s_ = 0; for (int j_ = 0; j_ < G[r_].nnz; j_++) s_ += G[r_].val[j_] * (vec)[G[r_].idx[j_]]; s_; })
+
+    /* build K = Hy + Z' (sum w_r g_r g_r') Z */
+    #define BUILD_K(wvec)                                                             \
+    do {                                                                              \
+        memset(Kx, 0, sizeof(Kx));                                                    \
+        for (int r_ = 0; r_ < R; r_++) {                                              \
+            double w_ = (wvec)[r_];                                                   \
+            for (int a_ = 0; a_ < G[r_].nnz; a_++)                                    \
+                for (int b_ = 0; b_ < G[r_].nnz; b_++)                                \
+                    Kx[G[r_].idx[a_] * NV + G[r_].idx[b_]] += w_ * G[r_].val[a_] * G[r_].val[b_]; \
+        }                                                                             \
+        memset(KxZ, 0, sizeof(double) * NV * ny);                                     \
+        for (int i_ = 0; i_ < NV; i_++)                                               \
+            for (int l_ = 0; l_ < NV; l_++) {                                         \
+                double p_ = Kx[i_ * NV + l_];                                         \
+                if (p_ == 0) continue;                                                \
+                for (int j_ = 0; j_ < ny; j_++) KxZ[i_ * ny + j_] += p_ * Z[l_ * ny + j_]; \
+            }                                                                         \
+        memcpy(K, Hy, sizeof(double) * ny * ny);                                      \
+        for (int i_ = 0; i_ < NV; i_++)                                               \
+            for (int a_ = 0; a_ < ny; a_++) {                                         \
+                double z_ = Z[i_ * ny + a_];                                          \
+                if (z_ == 0) continue;                                                \
+                for (int b_ = 0; b_ < ny; b_++) K[a_ * ny + b_] += z_ * KxZ[i_ * ny + b_]; \
+            }                                                                         \
+    } while (0)
+
+    /* Z' G' uvec -> out (ny) */
+    #define GT_APPLY(uvec, out)                                                       \
+    do {                                                                              \
+        memset(tx, 0, sizeof(tx));                                                    \
+        for (int r_ = 0; r_ < R; r_++)                                                \
+            for (int j_ = 0; j_ < G[r_].nnz; j_++) tx[G[r_].idx[j_]] += G[r_].val[j_] * (uvec)[r_]; \
+        for (int a_ = 0; a_ < ny; a_++) {                                             \
+            double s_ = 0;                                                            \
+            for (int i_ = 0; i_ < NV; i_++) s_ += Z[i_ * ny + a_] * tx[i_];           \
+            (out)[a_] = s_;                                                           \
+        }                                                                             \
+    } while (0)
+
+    int status = 1, it = 0;
+    double hmax = 1.0;
+    for (int r = 0; r < R; r++) { double a = fabs(G[r].rhs); if (a > hmax) hmax = a; }
+
+    /* ---- initial point: least-squares start (H + A'A) y = -g + A'h ---- */
+    for (int r = 0; r < R; r++) u[r] = 1.0;
+    BUILD_K(u);
+    if (chol_factor(K, ny) != 0) goto done;
+    {
+        X_FROM_Y(y, xx, 1); /* y = 0 -> xx = xp */
+        for (int r = 0; r < R; r++) u[r] = G[r].rhs - ROWDOT(r, xx);
+        GT_APPLY(u, dy);
+        for (int a = 0; a < ny; a++) dy[a] -= gy[a];
+        chol_solve(K, ny, dy);
+        memcpy(y, dy, sizeof(double) * ny);
+        X_FROM_Y(y, xx, 1);
+        double mins = INFINITY, minz = INFINITY;
+        for (int r = 0; r < R; r++) {
+            double sl = G[r].rhs - ROWDOT(r, xx);
+            s[r] = sl; z[r] = -sl;
+            if (s[r] < mins) mins = s[r];
+            if (z[r] < minz) minz = z[r];
+        }
+        if (mins <= 0) for (int r = 0; r < R; r++) s[r] += 1.0 - mins;
+        if (minz <= 0) for (int r = 0; r < R; r++) z[r] += 1.0 - minz;
+    }
+
+    for (it = 0; it < 80; it++) {
+        X_FROM_Y(y, xx, 1);
+        /* residuals */
+        GT_APPLY(z, rd);
+        double rdn = 0, rpn = 0, gap = 0;
+        for (int a = 0; a < ny; a++) {
+            double t = gy[a];
+            for (int b = 0; b < ny; b++) t += Hy[a * ny + b] * y[b];
+            rd[a] += t;
+            if (fabs(rd[a]) > rdn) rdn = fabs(rd[a]);
+        }
+        for (int r = 0; r < R; r++) {
+            rp[r] = ROWDOT(r, xx) + s[r] - G[r].rhs;
+            if (fabs(rp[r]) > rpn) rpn = fabs(rp[r]);
+            gap += s[r] * z[r];
+        }
+        double mu = (R > 0) ? gap / R : 0.0;
+        double obj = cst;
+        for (int i = 0; i < NV; i++) {
+            double t = 0;
+            for (int l = 0; l < NV; l++) t += P[i * NV + l] * xx[l];
+            obj += xx[i] * (0.5 * t + c[i]);
+        }
+        /* optimal: primal residual at round-off, duality gap 1e-9 relative, stationarity small.
+         * (the normal-equation solve loses digits as z/s grows, so rd is held to a looser bound) */
+        int gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
+        if (rpn <= 1e-9 * hmax && rdn <= 1e-5 * (1.0 + fabs(obj)) && gap_ok) {
+            status = 0;
+            break;
+        }
+        if (getenv("ORC_DEBUG")) fprintf(stderr, "it %d rp %.3e rd %.3e gap %.3e obj %.9g\n", it, rpn, rdn, gap, obj);
+        if (!isfinite(rdn) || !isfinite(rpn) || !isfinite(mu)) break;
+
+        for (int r = 0; r < R; r++) u[r] = z[r] / s[r];
+        BUILD_K(u);
+        if (chol_factor(K, ny) != 0) {
+            if (getenv("ORC_DEBUG")) fprintf(stderr, "chol failed\n");
+            /* K lost definiteness to round-off: accept only if already within 1e-7 relative gap */
+            if (rpn <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) status = 0;
+            break;
+        }
+
+        /* predictor (sigma = 0): rc = s.z */
+        double *rhs = dy;
+        for (int r = 0; r < R; r++) u[r] = (z[r] * rp[r] - s[r] * z[r]) / s[r];
+        GT_APPLY(u, rhs);
+        for (int a = 0; a < ny; a++) rhs[a] = -rd[a] - rhs[a];
+        chol_solve(K, ny, rhs);
+        X_FROM_Y(dy, dx, 0);
+        double alpha = 1.0;
+        for (int r = 0; r < R; r++) {
+            double adx = ROWDOT(r, dx);
+            ds[r] = -rp[r] - adx;
+            dz[r] = (-s[r] * z[r] + z[r] * rp[r] + z[r] * adx) / s[r];
+            if (ds[r] < 0) { double t = -s[r] / ds[r]; if (t < alpha) alpha = t; }
+            if (dz[r] < 0) { double t = -z[r] / dz[r]; if (t < alpha) alpha = t; }
+        }
+        double mu_aff = 0;
+        for (int r = 0; r < R; r++) mu_aff += (s[r] + alpha * ds[r]) * (z[r] + alpha * dz[r]);
+        mu_aff = (R > 0) ? mu_aff / R : 0.0;
+        double sigma = (mu > 0) ? pow(mu_aff / mu, 3.0) : 0.0;
+
+        /* corrector: rc = s.z + ds_aff.dz_aff - sigma mu */
+        for (int r = 0; r < R; r++) {
+            double rc = s[r] * z[r] + ds[r] * dz[r] - sigma * mu;
+            u[r] = (z[r] * rp[r] - rc) / s[r];
+            ds[r] = rc; /* stash rc */
+        }
+        GT_APPLY(u, rhs);
+        for (int a = 0; a < ny; a++) rhs[a] = -rd[a] - rhs[a];
+        chol_solve(K, ny, rhs);
+        X_FROM_Y(dy, dx, 0);
+        alpha = 1.0;
+        double amax_ = INFINITY;
+        for (int r = 0; r < R; r++) {
+            double rc = ds[r];
+            double adx = ROWDOT(r, dx);
+            ds[r] = -rp[r] - adx;
+            dz[r] = (-rc + z[r] * rp[r] + z[r] * adx) / s[r];
+            if (ds[r] < 0) { double t = -s[r] / ds[r]; if (t < amax_) amax_ = t; }
+            if (dz[r] < 0) { double t = -z[r] / dz[r]; if (t < amax_) amax_ = t; }
+        }
+        alpha = 0.99 * amax_;
+        if (alpha > 1.0) alpha = 1.0;
+        for (int a = 0; a < ny; a++) y[a] += alpha * dy[a];
+        for (int r = 0; r < R; r++) { s[r] += alpha * ds[r]; z[r] += alpha * dz[r]; }
+    }
+
+done:
+    X_FROM_Y(y, xx, 1);
+    memcpy(x, xx, sizeof(double) * NV);
+    {
+        double obj = cst;
+        for (int i = 0; i < NV; i++) {
+            double t = 0;
+            for (int l = 0; l < NV; l++) t += P[i * NV + l] * xx[l];
+            obj += xx[i] * (0.5 * t + c[i]);
+        }
+        if (cost) *cost = obj;
+    }
+    if (iters) *iters = it;
+    if (kkt) {
+        /* stationarity in the null space of Aeq, primal / dual infeasibility, complementarity */
+        double st = 0, pf = 0, df = 0, cp = 0;
+        GT_APPLY(z, rd);
+        for (int a = 0; a < ny; a++) {
+            double t = gy[a];
+            for (int b = 0; b < ny; b++) t += Hy[a * ny + b] * y[b];
+            if (fabs(t + rd[a]) > st) st = fabs(t + rd[a]);
+        }
+        for (int r = 0; r < R; r++) {
+            double sl = G[r].rhs - ROWDOT(r, xx);
+            if (-sl > pf) pf = -sl;
+            if (-z[r] > df) df = -z[r];
+            if (fabs(sl * z[r]) > cp) cp = fabs(sl * z[r]);
+        }
+        for (int r = 0; r < nrows; r++) {
+            if (rows[r].sense != 0) continue;
+            double t = -rows[r].rhs;
+            for (int j = 0; j < rows[r].nnz; j++) t += rows[r].val[j] * xx[rows[r].idx[j]];
+            if (fabs(t) > pf) pf = fabs(t);
+        }
+        kkt[0] = st; kkt[1] = pf; kkt[2] = df; kkt[3] = cp;
+    }
+    free(G); free(W); free(beq); free(HV); free(Z); free(xp); free(PZ); free(Hy); free(gy);
+    free(y); free(s); free(z); free(ds); free(dz); free(rp); free(u); free(K); free(rd); free(dy); free(KxZ);
+    return status;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * State propagation: getStateFromControlPoints at t = dt (include/polynomial.hpp:63-97).
+ * t/dt = 1 -> segment 1, local parameter 0: Bernstein weights are exactly (1,0,0,...).
+ * ---------------------------------------------------------------------------------------- */
+void orc_next_state(const float *traj, double dt, float state[9])
+{
+    const float fn = (float)ORC_N, fn1 = (float)(ORC_N - 1), finv = (float)pow(dt, -1);
+    for (int k = 0; k < 3; k++) {
+        const float *c1 = traj + k * ORC_SEGV + ORC_NC; /* segment 1 */
+        float v0 = ((c1[1] - c1[0]) * fn) * finv;
+        float v1 = ((c1[2] - c1[1]) * fn) * finv;
+        float a0 = ((v1 - v0) * fn1) * finv;
+        double px = 0.0 + (double)c1[0] * 1.0;
+        double vx = 0.0 + (double)v0 * 1.0;
+        double ax = 0.0 + (double)a0 * 1.0;
+        state[k] = (float)px;
+        state[3 + k] = (float)vx;
+        state[6 + k] = (float)ax;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * One synchronous tick (src/multi_sync_simulator.cpp:249-337 + src/traj_planner.cpp:344-425)
+ * ---------------------------------------------------------------------------------------- */
+int orc_tick(const orc_params *prm, int N, const float *state, const float *goal, const float *prev_traj,
+             int planner_seq, const double *radius, const double *downwash, const double *vmax,
+             const double *amax, const double *vnom, float *stale_traj, float *sfc_io, float *out_traj,
+             double *out_cost, int *out_status, int *out_iters, float *out_normal, double *out_d, int nthreads)
+{
+    const int n_obs = N - 1;
+    int rc = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 1 ? nthreads : 1)
+#endif
+    for (int qi = 0; qi < N; qi++) {
+        float init_traj[ORC_NV];
+        float *obs_traj = (float *)malloc(sizeof(float) * ORC_NV * (size_t)(n_obs > 0 ? n_obs : 1));
+        float *nrm = (float *)malloc(sizeof(float) * 3 * ORC_M * (size_t)(n_obs > 0 ? n_obs : 1));
+        double *dd = (double *)malloc(sizeof(double) * ORC_NC * ORC_M * (size_t)(n_obs > 0 ? n_obs : 1));
+        orc_row *rows = (orc_row *)malloc(sizeof(orc_row) * (size_t)(51 + 27 * n_obs + 252 + 162));
+        double *P = (double *)malloc(sizeof(double) * ORC_NV * ORC_NV);
+        double c[ORC_NV], lo[ORC_NV], hi[ORC_NV], x[ORC_NV], cst;
+
+        /* own initial trajectory :997-1016 (current-velocity model while planner_seq < 2) */
+        if (planner_seq < 2) orc_const_vel_traj(state + 9 * qi, state + 9 * qi + 3, prm->dt, init_traj);
+        else orc_shift_traj(prev_traj + (size_t)qi * ORC_NV, init_traj);
+
+        int oi = 0;
+        for (int qj = 0; qj < N; qj++) {
+            if (qj == qi) continue;
+            float *ot = obs_traj + (size_t)oi * ORC_NV;
+            if (planner_seq < 2) orc_const_vel_traj(state + 9 * qj, state + 9 * qj + 3, prm->dt, ot);
+            else orc_shift_traj(prev_traj + (size_t)qj * ORC_NV, ot);
+            double r_o = prm->obs_f32 ? (double)(float)radius[qj] : radius[qj];
+            double dw_o = prm->obs_f32 ? (double)(float)downwash[qj] : downwash[qj];
+            orc_lsc_pair(init_traj, ot, radius[qi], r_o, downwash[qi], dw_o,
+                         (float(*)[3])(nrm + (size_t)oi * ORC_M * 3), (double(*)[ORC_NC])(dd + (size_t)oi * ORC_M * ORC_NC));
+            oi++;
+        }
+        if (out_normal) memcpy(out_normal + (size_t)qi * n_obs * ORC_M * 3, nrm, sizeof(float) * 3 * ORC_M * (size_t)n_obs);
+        if (out_d) memcpy(out_d + (size_t)qi * n_obs * ORC_M * ORC_NC, dd, sizeof(double) * ORC_NC * ORC_M * (size_t)n_obs);
+
+        const float *sfc = (prm->use_sfc && sfc_io) ? sfc_io + (size_t)qi * ORC_M * 6 : NULL;
+        int nr = orc_qp_assemble(prm, state + 9 * qi, goal + 3 * qi, vnom[qi], vmax + 3 * qi, amax + 3 * qi, n_obs,
+                                 obs_traj, nrm, dd, sfc, P, c, &cst, lo, hi, rows);
+        double cost;
+        int iters = 0;
+        int st = orc_qp_solve(P, c, cst, lo, hi, rows, nr, x, &cost, &iters, NULL);
+        float *o = out_traj + (size_t)qi * ORC_NV;
+        float *stale = stale_traj + (size_t)qi * ORC_NV;
+        if (st == 0) {
+            for (int j = 0; j < ORC_NV; j++) { o[j] = (float)x[j]; stale[j] = o[j]; }
+            out_cost[qi] = cost;
+        } else {
+            /* src/traj_planner.cpp:1553-1584: exception swallowed, optimiser's stale trajectory reused */
+            for (int j = 0; j < ORC_NV; j++) o[j] = stale[j];
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            rc = 1;
+        }
+        out_status[qi] = st;
+        if (out_iters) out_iters[qi] = iters;
+        free(obs_traj); free(nrm); free(dd); free(rows); free(P);
+    }
+    return rc;
+}

@@ -1,0 +1,122 @@
+/*
+ * lsc_oracle.h -- CPU restatement ("oracle") of the per-agent replanning tick of
+ * qwerty35/lsc_planner.  TEST INFRASTRUCTURE ONLY: nothing under lsc_planner_amd/
+ * may include, link or call this.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and there only as the checker.
+ *
+ * Parity pinning (see DESIGN.md "Oracle"):
+ *   - GJK           : pinned against the reference's own openGJK built in-container
+ *                     (oracle/_ref, tests/golden/gjk_vectors.npz)
+ *   - QP assembly   : pinned against the reference fixture log/QPmodel.lp
+ *                     (tests/golden/qpmodel_lp.json)
+ *   - QP optimum    : CPLEX 20.1 is proprietary and absent -> PARITY UNPINNED for the
+ *                     optimiser itself; the oracle certifies its optimum by KKT
+ *                     residuals and is cross-checked against scipy in tests.
+ *
+ * Layouts (shared with the product C-ABI so that buffers compare element-wise):
+ *   traj   : float  [N][3][M*(n+1)]   axis-major, x[k*30 + m*6 + i]   (M=5, n=5)
+ *   state  : float  [N][9]            pos(3), vel(3), acc(3)
+ *   normal : float  [N][N-1][M][3]    LSC normal (already de-scaled: z / downwash)
+ *   d      : double [N][N-1][M][n+1]  LSC margins
+ */
+#ifndef LSC_ORACLE_H
+#define LSC_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_M 5
+#define ORC_N 5
+#define ORC_PHI 3
+#define ORC_NC (ORC_N + 1)            /* control points per segment   */
+#define ORC_SEGV (ORC_M * ORC_NC)     /* 30 variables per axis        */
+#define ORC_NV (3 * ORC_SEGV)         /* 90 QP variables              */
+#define ORC_NEQ (3 * (ORC_PHI * ORC_M) + 3 * (ORC_PHI - 1)) /* 45 + 6 = 51 */
+
+typedef struct {
+    double dt;               /* segment time (0.2)                         */
+    double w_control;        /* opt/control_input_weight (0.01)            */
+    double w_terminal;       /* opt/terminal_weight (1)                    */
+    float  world_min[3];     /* mission world box (float32 as point3d)     */
+    float  world_max[3];
+    double reset_threshold;  /* multisim/reset_threshold (0.15)            */
+    int    use_sfc;          /* world/use_octomap                          */
+    int    obs_f32;          /* 1: obstacle radius/downwash pass through a float32 message field */
+} orc_params;
+
+/* one sparse QP row:  sum val[j]*x[idx[j]]  (sense)  rhs ; sense: 0 '=', 1 '>=', 2 '<=' */
+typedef struct {
+    int    nnz;
+    int    idx[9];
+    double val[9];
+    double rhs;
+    int    sense;
+} orc_row;
+
+/* ---- constants (src/traj_optimizer.cpp:169-236, include/polynomial.hpp:415-428) ---- */
+void orc_bernstein_basis(double B[ORC_NC * ORC_NC]);
+void orc_qbase(double dt, double Q[ORC_NC * ORC_NC]);
+void orc_aeq_base(double dt, double A[(ORC_PHI * ORC_M) * ORC_SEGV]);
+
+/* ---- GJK: distance origin <-> conv(pts)  (src/openGJK/openGJK.cpp:633-780) ---- */
+double orc_gjk_origin(const double (*pts)[3], int npts, double v[3], int *nvrtx, int *iters);
+
+/* ---- closest point + float32 normalise (include/geometry.hpp:364-394, src/traj_planner.cpp:2030-2043) ---- */
+void orc_normal_between_polys(const float (*pa)[3], const float (*po)[3], int npts, float normal[3]);
+
+/* ---- prediction / initial trajectory (src/traj_planner.cpp:699-712, 829-878, 997-1061) ---- */
+void orc_shift_traj(const float *prev /*[3][30]*/, float *out /*[3][30]*/);
+void orc_const_vel_traj(const float pos[3], const float vel[3], double dt, float *out /*[3][30]*/);
+
+/* ---- LSC for one (agent, obstacle) pair (src/traj_planner.cpp:1310-1407) ---- */
+void orc_lsc_pair(const float *init_traj /*[3][30]*/, const float *obs_traj /*[3][30]*/,
+                  double r_a, double r_o, double dw_a, double dw_o,
+                  float normal[ORC_M][3], double d[ORC_M][ORC_NC]);
+
+/* ---- QP assembly in the reference's row order (src/traj_optimizer.cpp:261-548) ---- */
+int  orc_terminal_segments(const float goal[3], const float pos[3], double v_nom, double dt);
+/* rows must hold at least 51 + 27*n_obs + 252 (+162 with SFC) entries; returns #rows.
+ * P is the dense 90x90 Hessian of (1/2)x'Px, c the linear term, cst the constant. */
+int  orc_qp_assemble(const orc_params *prm, const float state[9], const float goal[3], double v_nom,
+                     const double vmax[3], const double amax[3],
+                     int n_obs, const float *obs_traj /*[n_obs][3][30]*/,
+                     const float *normal /*[n_obs][M][3]*/, const double *d /*[n_obs][M][6]*/,
+                     const float *sfc /*[M][6] or NULL*/,
+                     double *P, double *c, double *cst, double *lo, double *hi, orc_row *rows);
+
+/* ---- exact fp64 QP solve (replaces CPLEX, src/traj_optimizer.cpp:31-154) ----
+ * status: 0 optimal, 1 infeasible / not converged (caller keeps stale trajectory)
+ * kkt[4] (optional): stationarity, primal infeasibility, dual infeasibility, complementarity */
+int  orc_qp_solve(const double *P, const double *c, double cst, const double *lo, const double *hi,
+                  const orc_row *rows, int nrows, double *x, double *cost, int *iters, double *kkt);
+
+/* ---- state propagation (include/polynomial.hpp:63-97 at t = dt; multi_sync_simulator.cpp:190-247) ---- */
+void orc_next_state(const float *traj /*[3][30]*/, double dt, float state[9]);
+
+/* ---- one synchronous replan tick for the whole swarm (multi_sync_simulator.cpp:320-337) ----
+ * planner_seq is the value AFTER TrajPlanner::plan's increment (1 on the first tick).
+ * stale_traj: optimiser's previous `trajectory` member per agent (kept on failure); updated in place.
+ * sfc_io: [N][M][6] persistent SFC boxes (NULL when !use_sfc).
+ * out_normal / out_d may be NULL.  nthreads<=1 -> sequential like the reference. */
+int  orc_tick(const orc_params *prm, int N, const float *state, const float *goal, const float *prev_traj,
+              int planner_seq, const double *radius, const double *downwash,
+              const double *vmax, const double *amax, const double *vnom,
+              float *stale_traj, float *sfc_io,
+              float *out_traj, double *out_cost, int *out_status, int *out_iters,
+              float *out_normal, double *out_d, int nthreads);
+
+/* ---- EDT + SFC (include/corridor_constructor.hpp:18-245; dynamicEDT3D restated) ---- */
+typedef struct {
+    const float *dist;   /* dense [nx][ny][nz], metres, truncated */
+    int nx, ny, nz;
+    int key_min[3];      /* octomap key of cell (0,0,0)            */
+    double res;
+} orc_edt;
+int  orc_expand_box(const orc_params *prm, const orc_edt *edt, double world_res,
+                    const float point[3], const float goal[3], double radius, double box[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,273 @@
+"""ctypes front-end of the CPU oracle (oracle/liblsc_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never from lsc_planner_amd/.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+M, NDEG, NC, SEGV, NV = 5, 5, 6, 30, 90
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_fp = ctypes.POINTER(ctypes.c_float)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+class OrcParams(ctypes.Structure):
+    _fields_ = [
+        ("dt", ctypes.c_double),
+        ("w_control", ctypes.c_double),
+        ("w_terminal", ctypes.c_double),
+        ("world_min", ctypes.c_float * 3),
+        ("world_max", ctypes.c_float * 3),
+        ("reset_threshold", ctypes.c_double),
+        ("use_sfc", ctypes.c_int),
+        ("obs_f32", ctypes.c_int),
+    ]
+
+
+class OrcRow(ctypes.Structure):
+    _fields_ = [
+        ("nnz", ctypes.c_int),
+        ("idx", ctypes.c_int * 9),
+        ("val", ctypes.c_double * 9),
+        ("rhs", ctypes.c_double),
+        ("sense", ctypes.c_int),
+    ]
+
+
+class OrcEdt(ctypes.Structure):
+    _fields_ = [
+        ("dist", _fp),
+        ("nx", ctypes.c_int), ("ny", ctypes.c_int), ("nz", ctypes.c_int),
+        ("key_min", ctypes.c_int * 3),
+        ("res", ctypes.c_double),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liblsc_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("lsc_oracle.c", "lsc_oracle_sfc.c", "lsc_oracle.h")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liblsc_oracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(os.path.join(_HERE, "_ref", "libref_opengjk.so"))):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build())
+        L.orc_gjk_origin.restype = ctypes.c_double
+        L.orc_gjk_origin.argtypes = [_dp, ctypes.c_int, _dp, _ip, _ip]
+        L.orc_qbase.argtypes = [ctypes.c_double, _dp]
+        L.orc_aeq_base.argtypes = [ctypes.c_double, _dp]
+        L.orc_lsc_pair.argtypes = [_fp, _fp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _fp, _dp]
+        L.orc_qp_assemble.restype = ctypes.c_int
+        L.orc_qp_assemble.argtypes = [ctypes.POINTER(OrcParams), _fp, _fp, ctypes.c_double, _dp, _dp, ctypes.c_int,
+                                      _fp, _fp, _dp, _fp, _dp, _dp, _dp, _dp, _dp, ctypes.POINTER(OrcRow)]
+        L.orc_qp_solve.restype = ctypes.c_int
+        L.orc_qp_solve.argtypes = [_dp, _dp, ctypes.c_double, _dp, _dp, ctypes.POINTER(OrcRow), ctypes.c_int, _dp, _dp, _ip, _dp]
+        L.orc_next_state.argtypes = [_fp, ctypes.c_double, _fp]
+        L.orc_shift_traj.argtypes = [_fp, _fp]
+        L.orc_const_vel_traj.argtypes = [_fp, _fp, ctypes.c_double, _fp]
+        L.orc_terminal_segments.restype = ctypes.c_int
+        L.orc_terminal_segments.argtypes = [_fp, _fp, ctypes.c_double, ctypes.c_double]
+        L.orc_tick.restype = ctypes.c_int
+        L.orc_tick.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp,
+                               _fp, _fp, _fp, _dp, _ip, _ip, _fp, _dp, ctypes.c_int]
+        if hasattr(L, "orc_expand_box"):
+            L.orc_expand_box.restype = ctypes.c_int
+            L.orc_expand_box.argtypes = [ctypes.POINTER(OrcParams), ctypes.POINTER(OrcEdt), ctypes.c_double, _fp, _fp, ctypes.c_double, _dp]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def make_params(dt=0.2, w_control=0.01, w_terminal=1.0, world_min=(-10, -10, 0), world_max=(10, 10, 2.5),
+                reset_threshold=0.15, use_sfc=False, obs_f32=False):
+    p = OrcParams()
+    p.dt, p.w_control, p.w_terminal = dt, w_control, w_terminal
+    for k in range(3):
+        p.world_min[k] = np.float32(world_min[k])
+        p.world_max[k] = np.float32(world_max[k])
+    p.reset_threshold = reset_threshold
+    p.use_sfc = int(use_sfc)
+    p.obs_f32 = int(obs_f32)
+    return p
+
+
+def gjk_origin(pts):
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    v = np.zeros(3)
+    nv, it = ctypes.c_int(), ctypes.c_int()
+    d = lib().orc_gjk_origin(_d(pts), len(pts), _d(v), ctypes.byref(nv), ctypes.byref(it))
+    return d, v, nv.value, it.value
+
+
+def qbase(dt=0.2):
+    q = np.zeros((NC, NC))
+    lib().orc_qbase(dt, _d(q))
+    return q
+
+
+def aeq_base(dt=0.2):
+    a = np.zeros((15, SEGV))
+    lib().orc_aeq_base(dt, _d(a))
+    return a
+
+
+def lsc_pair(init_traj, obs_traj, r_a, r_o, dw_a, dw_o):
+    it = np.ascontiguousarray(init_traj, dtype=np.float32)
+    ot = np.ascontiguousarray(obs_traj, dtype=np.float32)
+    nrm = np.zeros((M, 3), np.float32)
+    d = np.zeros((M, NC))
+    lib().orc_lsc_pair(_f(it), _f(ot), r_a, r_o, dw_a, dw_o, _f(nrm), _d(d))
+    return nrm, d
+
+
+def next_state(traj, dt=0.2):
+    t = np.ascontiguousarray(traj, dtype=np.float32)
+    s = np.zeros(9, np.float32)
+    lib().orc_next_state(_f(t), dt, _f(s))
+    return s
+
+
+def shift_traj(prev):
+    p = np.ascontiguousarray(prev, dtype=np.float32)
+    o = np.zeros_like(p)
+    lib().orc_shift_traj(_f(p), _f(o))
+    return o
+
+
+def const_vel_traj(pos, vel, dt=0.2):
+    pos = np.ascontiguousarray(pos, np.float32)
+    vel = np.ascontiguousarray(vel, np.float32)
+    o = np.zeros(NV, np.float32)
+    lib().orc_const_vel_traj(_f(pos), _f(vel), dt, _f(o))
+    return o.reshape(3, SEGV)
+
+
+class QP:
+    """Assembled QP of one agent in the reference's row order."""
+
+    def __init__(self, P, c, cst, lo, hi, rows, nrows):
+        self.P, self.c, self.cst, self.lo, self.hi = P, c, cst, lo, hi
+        self._rows, self.nrows = rows, nrows
+
+    def row(self, r):
+        R = self._rows[r]
+        return [R.idx[j] for j in range(R.nnz)], [R.val[j] for j in range(R.nnz)], R.rhs, R.sense
+
+    def dense(self):
+        """(Aeq, beq, G, h) with inequalities as G x <= h (bounds appended: +x<=hi then -x<=-lo per variable)."""
+        eq, be, G, h = [], [], [], []
+        for r in range(self.nrows):
+            idx, val, rhs, sense = self.row(r)
+            a = np.zeros(NV)
+            a[idx] = val
+            if sense == 0:
+                eq.append(a); be.append(rhs)
+            elif sense == 1:
+                G.append(-a); h.append(-rhs)
+            else:
+                G.append(a); h.append(rhs)
+        for j in range(NV):
+            if np.isfinite(self.hi[j]):
+                a = np.zeros(NV); a[j] = 1; G.append(a); h.append(self.hi[j])
+            if np.isfinite(self.lo[j]):
+                a = np.zeros(NV); a[j] = -1; G.append(a); h.append(-self.lo[j])
+        return np.array(eq), np.array(be), np.array(G), np.array(h)
+
+    def solve(self):
+        x = np.zeros(NV)
+        cost = ctypes.c_double()
+        it = ctypes.c_int()
+        kkt = np.zeros(4)
+        st = lib().orc_qp_solve(_d(self.P), _d(self.c), self.cst, _d(self.lo), _d(self.hi), self._rows, self.nrows,
+                                _d(x), ctypes.byref(cost), ctypes.byref(it), _d(kkt))
+        return st, x, cost.value, it.value, kkt
+
+
+def qp_assemble(prm, state, goal, v_nom, vmax, amax, obs_traj, normal, d, sfc=None):
+    state = np.ascontiguousarray(state, np.float32)
+    goal = np.ascontiguousarray(goal, np.float32)
+    vmax = np.ascontiguousarray(vmax, np.float64)
+    amax = np.ascontiguousarray(amax, np.float64)
+    obs_traj = np.ascontiguousarray(obs_traj, np.float32)
+    normal = np.ascontiguousarray(normal, np.float32)
+    d = np.ascontiguousarray(d, np.float64)
+    n_obs = obs_traj.shape[0] if obs_traj.size else 0
+    rows = (OrcRow * (51 + 27 * n_obs + 252 + 162))()
+    P = np.zeros((NV, NV)); c = np.zeros(NV); lo = np.zeros(NV); hi = np.zeros(NV)
+    cst = ctypes.c_double()
+    sfc_p = _f(np.ascontiguousarray(sfc, np.float32)) if sfc is not None else None
+    nr = lib().orc_qp_assemble(ctypes.byref(prm), _f(state), _f(goal), v_nom, _d(vmax), _d(amax), n_obs,
+                               _f(obs_traj), _f(normal), _d(d), sfc_p, _d(P), _d(c), ctypes.byref(cst), _d(lo), _d(hi), rows)
+    return QP(P, c, cst.value, lo, hi, rows, nr)
+
+
+class Swarm:
+    """Persistent per-swarm oracle state: mirrors what MultiSyncSimulator + N TrajPlanners hold between ticks."""
+
+    def __init__(self, prm, radius, downwash, vmax, amax, vnom):
+        self.prm = prm
+        self.N = len(radius)
+        self.radius = np.ascontiguousarray(radius, np.float64)
+        self.downwash = np.ascontiguousarray(downwash, np.float64)
+        self.vmax = np.ascontiguousarray(vmax, np.float64).reshape(self.N, 3)
+        self.amax = np.ascontiguousarray(amax, np.float64).reshape(self.N, 3)
+        self.vnom = np.ascontiguousarray(vnom, np.float64)
+        self.stale = np.zeros((self.N, 3, SEGV), np.float32)
+        self.cost = np.zeros(self.N)
+        self.sfc = np.zeros((self.N, M, 6), np.float32)
+
+    def tick(self, state, goal, prev_traj, planner_seq, want_lsc=False, nthreads=1):
+        N = self.N
+        state = np.ascontiguousarray(state, np.float32).reshape(N, 9)
+        goal = np.ascontiguousarray(goal, np.float32).reshape(N, 3)
+        prev = np.ascontiguousarray(prev_traj, np.float32).reshape(N, 3, SEGV)
+        out = np.zeros((N, 3, SEGV), np.float32)
+        status = np.zeros(N, np.int32)
+        iters = np.zeros(N, np.int32)
+        nrm = np.zeros((N, max(N - 1, 1), M, 3), np.float32) if want_lsc else None
+        dd = np.zeros((N, max(N - 1, 1), M, NC)) if want_lsc else None
+        lib().orc_tick(ctypes.byref(self.prm), N, _f(state), _f(goal), _f(prev), planner_seq, _d(self.radius),
+                       _d(self.downwash), _d(self.vmax), _d(self.amax), _d(self.vnom), _f(self.stale),
+                       _f(self.sfc) if self.prm.use_sfc else None, _f(out), _d(self.cost), _i(status), _i(iters),
+                       _f(nrm) if want_lsc else None, _d(dd) if want_lsc else None, nthreads)
+        res = {"traj": out, "cost": self.cost.copy(), "status": status, "iters": iters}
+        if want_lsc:
+            res["normal"], res["d"] = nrm, dd
+        return res
+
+
+def ref_gjk_lib():
+    """The REFERENCE's openGJK (oracle/_ref), or None when it has not been built / shipped."""
+    p = os.path.join(_HERE, "_ref", "libref_opengjk.so")
+    if not os.path.exists(p):
+        return None
+    L = ctypes.CDLL(p)
+    L.ref_gjk.restype = ctypes.c_double
+    L.ref_gjk.argtypes = [_dp, ctypes.c_int, _dp, ctypes.c_int, _dp, _ip]
+    return L
