@@ -1,0 +1,140 @@
+/*
+ * lsc_planner_amd.h -- C ABI of the MI355X-native replanning path for qwerty35/lsc_planner.
+ *
+ * One call per replan tick for the WHOLE swarm replaces the reference's sequential
+ *     for (qi...) agents[qi]->plan(sim_current_time);            src/multi_sync_simulator.cpp:320-328
+ * i.e. for every agent: prediction shift -> LSC construction -> (SFC) -> QP solve
+ *     TrajPlanner::planImpl / planLSC                            src/traj_planner.cpp:344-425
+ *     TrajPlanner::generateLSC (GJK normals + margins)           src/traj_planner.cpp:1310-1407
+ *     TrajPlanner::generateFeasibleSFC + CorridorConstructor     src/traj_planner.cpp:1451-1491,
+ *                                                                include/corridor_constructor.hpp:18-245
+ *     TrajOptimizer::solve / getTrajectory / getQPcost (CPLEX)   src/traj_optimizer.cpp:31-166
+ * The inputs of all agents are frozen before any agent plans (multi_sync_simulator.cpp:249-304),
+ * so one batched launch is semantically identical to the reference's loop.
+ *
+ * Conventions: plain C, caller owns every host buffer, the context owns device memory and the
+ * per-agent persistent state (optimiser's last trajectory, SFC history).  Functions return 0 on
+ * success or a negative LSC_E* code; nothing throws across the boundary.  A context is not
+ * thread-safe (the reference's caller is single-threaded).  There is NO CPU fallback: every entry
+ * point that computes fails with LSC_ENODEV when no gfx950 device is usable.
+ *
+ * Layouts
+ *   traj   float  [N][3][M*(n+1)]   axis-major control points, index k*30 + m*6 + i  (M=5, n=5)
+ *                                   == TrajOptimizer's variable order (src/traj_optimizer.cpp:277)
+ *   state  float  [N][9]            position, velocity, acceleration (octomap::point3d = float32)
+ *   goal   float  [N][3]            agent.current_goal_position (output of goal planning)
+ */
+#ifndef LSC_PLANNER_AMD_H
+#define LSC_PLANNER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSC_M 5          /* segments   : horizon / dt, launch/simulation.launch:60-61            */
+#define LSC_DEG 5        /* Bernstein degree n (only n=5, phi=3 exist: traj_optimizer.cpp:190-207) */
+#define LSC_NC 6
+#define LSC_SEGV 30
+#define LSC_NV 90
+
+#define LSC_OK 0
+#define LSC_EINVAL (-1)   /* bad argument                                              */
+#define LSC_ENODEV (-2)   /* no usable HIP device / kernel image (no CPU fallback)     */
+#define LSC_ENOMEM (-3)
+#define LSC_EHIP (-4)     /* HIP runtime error, see lsc_last_error()                   */
+#define LSC_ESTATE (-5)   /* call order (e.g. tick before set_agents)                  */
+
+/* per-agent status written by a tick (PlanningReport analogue, include/sp_const.hpp) */
+#define LSC_STATUS_OK 0          /* QP solved, trajectory replaced                                       */
+#define LSC_STATUS_INFEASIBLE 1  /* solver failed: optimiser's previous trajectory kept, like the reference
+                                    (exception swallowed, src/traj_planner.cpp:1553-1584)                */
+#define LSC_STATUS_CAPACITY 3    /* more active LSC rows than the configured LDS row capacity            */
+
+typedef struct lsc_ctx lsc_ctx;
+
+/* Param fields that reach the hot path (src/param.cpp:4-144, launch/testall_empty.launch:36-101) */
+typedef struct {
+    double dt;                 /* traj/dt                     0.2  */
+    double control_weight;     /* opt/control_input_weight    0.01 */
+    double terminal_weight;    /* opt/terminal_weight         1.0  */
+    float  world_min[3];       /* mission world box (Mission::world_min/max, float32) */
+    float  world_max[3];
+    int    use_octomap;        /* world/use_octomap: adds the SFC rows                 */
+    double world_resolution;   /* world/resolution (0.1)                               */
+    int    device;             /* HIP device ordinal                                   */
+    int    max_rows_per_cp;    /* LDS row capacity per control point; 0 = min(N-1, 64) */
+    int    max_iters;          /* interior-point iteration cap; 0 = 50                 */
+    int    prune;              /* 1 (default via lsc_default_config): drop LSC rows that are provably
+                                  redundant inside the reachable box; 0: keep all 27(N-1) rows  */
+} lsc_config;
+
+void lsc_default_config(lsc_config *cfg);
+
+/* TrajPlanner ctor x N + TrajOptimizer ctor (src/traj_planner.cpp:4-73, src/traj_optimizer.cpp:4-25) */
+lsc_ctx *lsc_create(const lsc_config *cfg);
+void     lsc_destroy(lsc_ctx *ctx);
+const char *lsc_last_error(const lsc_ctx *ctx);
+
+/* Mission::agents (src/mission.cpp:60-130): radius, downwash, max_vel[3], max_acc[3], nominal_velocity.
+ * Doubles, as in struct Agent (include/sp_const.hpp:153-165); an agent seen as somebody else's
+ * obstacle has its radius/downwash rounded through float32 (dynamic_msgs::Obstacle), which the
+ * reference fixture log/QPmodel.lp pins.  Resets the per-agent persistent state. */
+int lsc_set_agents(lsc_ctx *ctx, int N, const double *radius, const double *downwash,
+                   const double *max_vel /*[N][3]*/, const double *max_acc /*[N][3]*/, const double *nominal_vel);
+
+/* Shard of agents [first, first+count) planned by this context (agent-sharded multi-GPU); default all. */
+int lsc_set_shard(lsc_ctx *ctx, int first, int count);
+
+/* TrajPlanner::setDistMap (src/traj_planner.cpp:168): dense EDT, metres, [nx][ny][nz], copied to HBM.
+ * key_min = octomap key of cell (0,0,0).  Only used when use_octomap. */
+int lsc_set_distmap(lsc_ctx *ctx, const float *edt, int nx, int ny, int nz, const int key_min[3], double res);
+
+/* One replan tick, host buffers in and out (H2D + kernels + D2H inside).
+ *   planner_seq : TrajPlanner::planner_seq AFTER its increment in plan() (1 on the first tick):
+ *                 < 2 selects the current-velocity prediction (src/traj_planner.cpp:830-833, 998-1000)
+ *   state/goal/prev_traj : all N agents (prev_traj = every agent's getTraj() of the previous tick)
+ *   out_traj/out_cost/out_status/out_iters : the shard's agents only, [count]...
+ *   out_lsc_normal [count][N-1][M][3] float, out_lsc_d [count][N-1][M][n+1] double, out_sfc [count][M][6]
+ *                 : optional (NULL to skip) dense constraint dumps (CollisionConstraints::getLSC/getSFC). */
+int lsc_replan_tick(lsc_ctx *ctx, const float *state, const float *goal, const float *prev_traj, int planner_seq,
+                    float *out_traj, double *out_cost, int *out_status, int *out_iters,
+                    float *out_lsc_normal, double *out_lsc_d, float *out_sfc);
+
+/* ---- device-resident stepping (no host round trip inside a tick) -------------------------------
+ * The caller (e.g. a torch tensor) owns device buffers and the stream; pointers are device pointers.
+ *   d_state [N][9], d_goal [N][3], d_traj_prev [N][3][30] : read
+ *   d_traj_next [N][3][30] : the shard's rows [first,first+count) are written (full table so that an
+ *                            all-gather can run in place across ranks)
+ *   d_cost [N] double, d_status [N] int, d_iters [N] int : shard's entries written                */
+int lsc_tick_device(lsc_ctx *ctx, const float *d_state, const float *d_goal, const float *d_traj_prev,
+                    int planner_seq, float *d_traj_next, double *d_cost, int *d_status, int *d_iters,
+                    void *hip_stream);
+
+/* MultiSyncSimulator::update()'s ideal-state step on device: state[qi] = traj[qi] evaluated at t = dt
+ * (getFutureStateMsg -> getStateFromControlPoints, include/polynomial.hpp:63-97).  All N agents. */
+int lsc_propagate_device(lsc_ctx *ctx, const float *d_traj, float *d_state, void *hip_stream);
+
+/* Dense LSC sweep only (TrajPlanner::generateLSC for every ordered pair), device buffers:
+ *   d_normal [count][N-1][M][3] float, d_d [count][N-1][M][n+1] double. */
+int lsc_sweep_device(lsc_ctx *ctx, const float *d_state, const float *d_traj_prev, int planner_seq,
+                     float *d_normal, double *d_d, void *hip_stream);
+
+/* GJK distance origin <-> conv(points) for `count` independent 6-point hulls (device kernel; test hook
+ * for src/openGJK/openGJK.cpp:674-780).  pts [count][6][3] double (host), v [count][3], dist [count]. */
+int lsc_gjk_batch(lsc_ctx *ctx, const double *pts, int count, double *v, double *dist);
+
+/* Introspection used by bench.py: name / average device time (ms, HIP events) of the kernels timed since
+ * the last reset.  which: 0 = plan kernel, 1 = dense sweep kernel. */
+int lsc_kernel_time_ms(lsc_ctx *ctx, int which, double *avg_ms, long *launches);
+int lsc_set_timing(lsc_ctx *ctx, int enabled);
+
+/* Active (non-redundant) LSC rows each agent's QP carried in the last tick, [N] (diagnostics). */
+int lsc_last_row_counts(lsc_ctx *ctx, int *rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

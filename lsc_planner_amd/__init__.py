@@ -1,0 +1,16 @@
+"""lsc_planner_amd -- MI355X-native per-agent replanning loop for qwerty35/lsc_planner.
+
+Only what the hot path needs lives here:
+  csrc/        gfx950 kernels + the C ABI (include/lsc_planner_amd.h)  -> liblsc_hip.so
+  _lib.py      ctypes binding of that ABI (fails loudly when the library or a GPU is missing)
+  planner.py   host-side mirror of the reference's TrajPlanner / TrajOptimizer surface, batched per tick
+  mission.py   mission JSON loader + the circle-swap / random-swarm generators of the BASELINE configs
+  simulator.py headless MultiSyncSimulator loop (update -> plan -> isFinished)
+  sharded.py   agent-sharded multi-GPU stepping (one process per GPU, torch.distributed all-gather)
+"""
+from ._lib import LscError, load_library, lib_path  # noqa: F401
+from .mission import Mission, load_mission, circle_swap, random_swarm  # noqa: F401
+from .planner import SwarmPlanner, PlannerConfig  # noqa: F401
+
+__all__ = ["LscError", "load_library", "lib_path", "Mission", "load_mission", "circle_swap", "random_swarm",
+           "SwarmPlanner", "PlannerConfig"]

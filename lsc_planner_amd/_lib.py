@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI declared in include/lsc_planner_amd.h.
+
+There is no CPU fallback: if liblsc_hip.so is missing this raises, and every compute entry point fails
+when no gfx950 device is usable.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+M, DEG, NC, SEGV, NV = 5, 5, 6, 30, 90
+
+STATUS_OK, STATUS_INFEASIBLE, STATUS_CAPACITY = 0, 1, 3
+
+
+class LscError(RuntimeError):
+    pass
+
+
+class LscConfig(ctypes.Structure):
+    _fields_ = [
+        ("dt", ctypes.c_double),
+        ("control_weight", ctypes.c_double),
+        ("terminal_weight", ctypes.c_double),
+        ("world_min", ctypes.c_float * 3),
+        ("world_max", ctypes.c_float * 3),
+        ("use_octomap", ctypes.c_int),
+        ("world_resolution", ctypes.c_double),
+        ("device", ctypes.c_int),
+        ("max_rows_per_cp", ctypes.c_int),
+        ("max_iters", ctypes.c_int),
+        ("prune", ctypes.c_int),
+    ]
+
+
+# every symbol include/lsc_planner_amd.h declares
+EXPORTS = [
+    "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
+    "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_propagate_device", "lsc_sweep_device",
+    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_set_timing", "lsc_last_row_counts",
+]
+
+
+def lib_path():
+    return os.path.join(_HERE, "liblsc_hip.so")
+
+
+def load_library():
+    """Loads liblsc_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise LscError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(p)
+    vp, ip, dp, fp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)
+    L.lsc_default_config.argtypes = [ctypes.POINTER(LscConfig)]
+    L.lsc_default_config.restype = None
+    L.lsc_create.argtypes = [ctypes.POINTER(LscConfig)]
+    L.lsc_create.restype = vp
+    L.lsc_destroy.argtypes = [vp]
+    L.lsc_destroy.restype = None
+    L.lsc_last_error.argtypes = [vp]
+    L.lsc_last_error.restype = ctypes.c_char_p
+    L.lsc_set_agents.argtypes = [vp, ctypes.c_int, dp, dp, dp, dp, dp]
+    L.lsc_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.lsc_set_distmap.argtypes = [vp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ctypes.c_double]
+    L.lsc_replan_tick.argtypes = [vp, fp, fp, fp, ctypes.c_int, fp, dp, ip, ip, fp, dp, fp]
+    L.lsc_tick_device.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp]
+    L.lsc_propagate_device.argtypes = [vp, vp, vp, vp]
+    L.lsc_sweep_device.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]
+    L.lsc_gjk_batch.argtypes = [vp, dp, ctypes.c_int, dp, dp]
+    L.lsc_kernel_time_ms.argtypes = [vp, ctypes.c_int, dp, ctypes.POINTER(ctypes.c_long)]
+    L.lsc_set_timing.argtypes = [vp, ctypes.c_int]
+    L.lsc_last_row_counts.argtypes = [vp, ip]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int or name not in ("lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error"):
+            fn.restype = ctypes.c_int
+    _LIB = L
+    return L

@@ -1,0 +1,452 @@
+// lsc_abi.cpp -- C ABI (include/lsc_planner_amd.h) over the gfx950 kernels.  Host side only: builds the
+// per-context constants once (what TrajOptimizer's constructor does per agent in the reference,
+// src/traj_optimizer.cpp:4-25), owns HBM buffers and persistent per-agent state, launches kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lsc_planner_amd.h"
+#include "lsc_kernels.h"
+
+using namespace lsc;
+
+namespace {
+
+int binom(int n, int k)
+{
+    if (k < 0 || k > n) return 0;
+    long r = 1;
+    for (int i = 1; i <= k; i++) r = r * (n - k + i) / i;
+    return (int)r;
+}
+
+// Q_base = B Z B^T dt^(-2 phi + 1), phi = 3, phi_n = 1   (src/traj_optimizer.cpp:169-184; B from
+// include/polynomial.hpp:415-426)
+void build_qbase(double dt, double Q[NC * NC])
+{
+    const int n = DEG, phi = 3;
+    double B[NC][NC], Z[NC][NC], T[NC][NC];
+    for (int i = 0; i <= n; i++)
+        for (int j = 0; j <= n; j++) B[i][j] = j >= i ? binom(n, i) * binom(n - i, n - j) * (((j - i) & 1) ? -1.0 : 1.0) : 0.0;
+    auto fall = [](int a, int p) { if (a < p) return 0; int c = 1; for (int i = 0; i < p; i++) c *= a - i; return c; };
+    for (int i = 0; i <= n; i++)
+        for (int j = 0; j <= n; j++) {
+            int den = i + j - 2 * phi + 1;
+            Z[i][j] = den > 0 ? (double)fall(i, phi) * fall(j, phi) / den : 0.0;
+        }
+    for (int i = 0; i <= n; i++)
+        for (int j = 0; j <= n; j++) { double s = 0; for (int l = 0; l <= n; l++) s += B[i][l] * Z[l][j]; T[i][j] = s; }
+    const double sc = std::pow(dt, -2 * phi + 1);
+    for (int i = 0; i <= n; i++)
+        for (int j = 0; j <= n; j++) { double s = 0; for (int l = 0; l <= n; l++) s += T[i][l] * B[j][l]; Q[i * NC + j] = s * sc; }
+}
+
+struct HostModel {
+    Model m;
+    std::vector<uint32_t> terms;
+    std::vector<uint32_t> entries;
+};
+
+void build_model(const lsc_config &cfg, HostModel &H)
+{
+    Model &m = H.m;
+    std::memset(&m, 0, sizeof(m));
+    m.dt = cfg.dt; m.w_c = cfg.control_weight; m.w_t = cfg.terminal_weight;
+    m.hv_scale = cfg.dt / DEG;
+    m.ha_scale = cfg.dt * cfg.dt / (DEG * (DEG - 1));
+    double Q[NC * NC];
+    build_qbase(cfg.dt, Q);
+    for (int i = 0; i < NC * NC; i++) m.Qh[i] = 2.0 * cfg.control_weight * Q[i];
+
+    // x_t as a combination of the 13 free variables of an axis (see lsc_model.hpp)
+    double Zm[SEGV][NYA];
+    std::memset(Zm, 0, sizeof(Zm));
+    for (int mm = 0; mm < M; mm++)
+        for (int i = 0; i < NC; i++) {
+            const int t = mm * NC + i;
+            if (mm == M - 1 && i >= 3) { Zm[t][12] = 1.0; continue; }        // stop at the horizon
+            if (i >= 3) { Zm[t][3 * mm + (i - 3)] = 1.0; continue; }
+            if (mm == 0) continue;                                         // fixed by the current state
+            const int u3 = 3 * (mm - 1), u4 = u3 + 1, u5 = u3 + 2;          // c_{m-1,3..5}
+            if (i == 0) Zm[t][u5] = 1.0;
+            if (i == 1) { Zm[t][u5] = 2.0; Zm[t][u4] = -1.0; }
+            if (i == 2) { Zm[t][u5] = 4.0; Zm[t][u4] = -4.0; Zm[t][u3] = 1.0; }
+        }
+    for (int t = 0; t < SEGV; t++) {
+        int n = 0;
+        for (int a = 0; a < NYA; a++)
+            if (Zm[t][a] != 0.0) { m.x_i[t][n] = a; m.x_c[t][n] = Zm[t][a]; n++; }
+        m.x_n[t] = n;
+    }
+    for (int a = 0; a < NYA; a++) {
+        int n = 0;
+        for (int t = 0; t < SEGV; t++)
+            if (Zm[t][a] != 0.0) { m.t_t[a][n] = t; m.t_c[a][n] = Zm[t][a]; n++; }
+        m.t_n[a] = n;
+    }
+    // Hc = Z^T blockdiag(Qh) Z
+    for (int a = 0; a < NYA; a++)
+        for (int b = 0; b < NYA; b++) {
+            double s = 0;
+            for (int mm = 0; mm < M; mm++)
+                for (int i = 0; i < NC; i++)
+                    for (int j = 0; j < NC; j++) s += Zm[mm * NC + i][a] * m.Qh[i * NC + j] * Zm[mm * NC + j][b];
+            m.Hc[a * NYA + b] = s;
+        }
+
+    // Hessian assembly terms: K[(k,a),(k',b)] += Z[t][a] Z[t'][b] * Wx[(k,t),(k',t')]
+    auto scomp = [](int k, int kk) { if (k > kk) std::swap(k, kk); return k == 0 ? kk : (k == 1 ? 2 + kk : 5); };  // xx xy xz yy yz zz
+    auto axis_of = [](int g) { return g < 36 ? (g % 9) / 3 : g - 36; };
+    auto var_of = [](int g) { return g < 36 ? (g / 9) * 3 + (g % 3) : 12; };
+    H.terms.clear(); H.entries.clear();
+    int n_entries = 0;
+    for (int gi = 0; gi < NY; gi++)
+        for (int gj = 0; gj <= gi; gj++) {
+            const int k = axis_of(gi), kk = axis_of(gj), a = var_of(gi), b = var_of(gj);
+            std::map<int, int> acc;  // src -> integer coefficient
+            for (int p = 0; p < m.t_n[a]; p++)
+                for (int q = 0; q < m.t_n[b]; q++) {
+                    const int t = m.t_t[a][p], tt = m.t_t[b][q];
+                    const int c = (int)std::lround(m.t_c[a][p] * m.t_c[b][q]);
+                    if (t == tt) {
+                        acc[W_S + t * 6 + scomp(k, kk)] += c;
+                        if (k == kk) acc[W_D + k * SEGV + t] += c;
+                    } else if (k == kk && t / NC == tt / NC) {
+                        const int lo = t < tt ? t : tt, df = t < tt ? tt - t : t - tt;
+                        if (df == 1) acc[W_1 + k * SEGV + lo] += c;
+                        if (df == 2) acc[W_2 + k * SEGV + lo] += c;
+                    }
+                }
+            bool any = false;
+            for (auto &kv : acc) if (kv.second != 0) any = true;
+            if (!any && !(k == kk && m.Hc[a * NYA + b] != 0.0)) continue;
+            if (gi - gj > BAND) { std::fprintf(stderr, "lsc: band violated (%d,%d)\n", gi, gj); std::abort(); }
+            H.entries.push_back(((uint32_t)gi << 16) | (uint32_t)gj);
+            H.entries.push_back((uint32_t)H.terms.size());
+            for (auto &kv : acc) {
+                if (kv.second == 0) continue;
+                if (kv.second < -128 || kv.second > 127 || kv.first >= 1024) { std::fprintf(stderr, "lsc: term overflow\n"); std::abort(); }
+                H.terms.push_back(((uint32_t)gi << 0) * 0u | ((uint32_t)kv.first << 8) | (uint32_t)(kv.second + 128));
+            }
+            n_entries++;
+        }
+    H.entries.push_back(0);
+    H.entries.push_back((uint32_t)H.terms.size());
+    m.n_entries = n_entries;
+    m.n_terms = (int)H.terms.size();
+    for (int k = 0; k < 3; k++) { m.world_min[k] = cfg.world_min[k]; m.world_max[k] = cfg.world_max[k]; }
+    m.use_sfc = cfg.use_octomap;
+    m.prune = cfg.prune;
+    m.max_iters = cfg.max_iters > 0 ? cfg.max_iters : 50;
+}
+
+}  // namespace
+
+struct lsc_ctx {
+    lsc_config cfg;
+    HostModel hm;
+    int N = 0, first = 0, count = 0, cap = 0;
+    std::string err;
+    bool timing = false;
+    // device
+    Model *d_model = nullptr;
+    uint32_t *d_terms = nullptr, *d_entries = nullptr;
+    double *d_radius = nullptr, *d_radius_obs = nullptr, *d_downwash = nullptr, *d_downwash_obs = nullptr;
+    double *d_vmax = nullptr, *d_amax = nullptr, *d_vnom = nullptr;
+    float *d_stale = nullptr, *d_sfc = nullptr;
+    int *d_nrows = nullptr;
+    // buffers of the host-pointer tick
+    float *d_state = nullptr, *d_goal = nullptr, *d_prev = nullptr, *d_next = nullptr;
+    double *d_cost = nullptr;
+    int *d_status = nullptr, *d_iters = nullptr;
+    float *d_onormal = nullptr;
+    double *d_od = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double t_ms[2] = {0, 0};
+    long t_n[2] = {0, 0};
+};
+
+#define HIPCHK(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return LSC_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+extern "C" {
+
+void lsc_default_config(lsc_config *cfg)
+{
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->dt = 0.2; cfg->control_weight = 0.01; cfg->terminal_weight = 1.0;
+    cfg->world_min[0] = -10; cfg->world_min[1] = -10; cfg->world_min[2] = 0;
+    cfg->world_max[0] = 10; cfg->world_max[1] = 10; cfg->world_max[2] = 2.5f;
+    cfg->use_octomap = 0; cfg->world_resolution = 0.1; cfg->device = 0;
+    cfg->max_rows_per_cp = 0; cfg->max_iters = 50; cfg->prune = 1;
+}
+
+lsc_ctx *lsc_create(const lsc_config *cfg)
+{
+    if (!cfg || !(cfg->dt > 0)) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) {
+        std::fprintf(stderr, "lsc_create: no usable HIP device (there is no CPU fallback)\n");
+        return nullptr;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
+    lsc_ctx *c = new lsc_ctx();
+    c->cfg = *cfg;
+    build_model(*cfg, c->hm);
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
+              hipEventCreate(&c->ev1) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_terms, sizeof(uint32_t) * (c->hm.terms.size() + 2)) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_entries, sizeof(uint32_t) * c->hm.entries.size()) == hipSuccess;
+    ok = ok && hipMalloc(&c->d_model, sizeof(Model)) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_terms, c->hm.terms.data(), sizeof(uint32_t) * c->hm.terms.size(), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_entries, c->hm.entries.data(), sizeof(uint32_t) * c->hm.entries.size(), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { lsc_destroy(c); return nullptr; }
+    return c;
+}
+
+static void free_agents(lsc_ctx *c)
+{
+    void *ptrs[] = {c->d_radius, c->d_radius_obs, c->d_downwash, c->d_downwash_obs, c->d_vmax, c->d_amax, c->d_vnom,
+                    c->d_stale, c->d_sfc, c->d_nrows, c->d_state, c->d_goal, c->d_prev, c->d_next, c->d_cost, c->d_status,
+                    c->d_iters, c->d_onormal, c->d_od};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    c->d_radius = c->d_radius_obs = c->d_downwash = c->d_downwash_obs = c->d_vmax = c->d_amax = c->d_vnom = nullptr;
+    c->d_stale = c->d_sfc = c->d_state = c->d_goal = c->d_prev = c->d_next = nullptr;
+    c->d_cost = nullptr; c->d_status = c->d_iters = c->d_nrows = nullptr; c->d_onormal = nullptr; c->d_od = nullptr;
+}
+
+void lsc_destroy(lsc_ctx *c)
+{
+    if (!c) return;
+    free_agents(c);
+    if (c->d_model) (void)hipFree(c->d_model);
+    if (c->d_terms) (void)hipFree(c->d_terms);
+    if (c->d_entries) (void)hipFree(c->d_entries);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *lsc_last_error(const lsc_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwash, const double *max_vel,
+                   const double *max_acc, const double *nominal_vel)
+{
+    if (!c || N < 1 || !radius || !downwash || !max_vel || !max_acc || !nominal_vel) return LSC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    free_agents(c);
+    c->N = N; c->first = 0; c->count = N;
+    int cap = c->cfg.max_rows_per_cp > 0 ? c->cfg.max_rows_per_cp : 64;
+    if (cap > N - 1) cap = N - 1;
+    if (cap < 1) cap = 1;
+    // keep the kernel's LDS request under the 160 KiB a workgroup may own
+    while (cap > 1 && plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, cap) > 160 * 1024) cap--;
+    c->cap = cap;
+    c->hm.m.cap = cap;
+    HIPCHK(c, hipMemcpy(c->d_model, &c->hm.m, sizeof(Model), hipMemcpyHostToDevice));
+    std::vector<double> r_obs(N), dw_obs(N);
+    for (int i = 0; i < N; i++) { r_obs[i] = (double)(float)radius[i]; dw_obs[i] = (double)(float)downwash[i]; }
+    auto up = [&](double **dst, const double *src, size_t n) -> hipError_t {
+        hipError_t e = hipMalloc(dst, sizeof(double) * n);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, src, sizeof(double) * n, hipMemcpyHostToDevice);
+    };
+    HIPCHK(c, up(&c->d_radius, radius, N));
+    HIPCHK(c, up(&c->d_radius_obs, r_obs.data(), N));
+    HIPCHK(c, up(&c->d_downwash, downwash, N));
+    HIPCHK(c, up(&c->d_downwash_obs, dw_obs.data(), N));
+    HIPCHK(c, up(&c->d_vmax, max_vel, 3 * (size_t)N));
+    HIPCHK(c, up(&c->d_amax, max_acc, 3 * (size_t)N));
+    HIPCHK(c, up(&c->d_vnom, nominal_vel, N));
+    HIPCHK(c, hipMalloc(&c->d_stale, sizeof(float) * NV * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_stale, 0, sizeof(float) * NV * (size_t)N));   // TrajOptimizer::trajectory starts at (0,0,0)
+    HIPCHK(c, hipMalloc(&c->d_sfc, sizeof(float) * M * 6 * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_sfc, 0, sizeof(float) * M * 6 * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_nrows, sizeof(int) * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_state, sizeof(float) * 9 * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_goal, sizeof(float) * 3 * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_prev, sizeof(float) * NV * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_next, sizeof(float) * NV * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_cost, sizeof(double) * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_cost, 0, sizeof(double) * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_status, sizeof(int) * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_iters, sizeof(int) * (size_t)N));
+    return LSC_OK;
+}
+
+int lsc_set_shard(lsc_ctx *c, int first, int count)
+{
+    if (!c || c->N == 0) return LSC_ESTATE;
+    if (first < 0 || count < 1 || first + count > c->N) return LSC_EINVAL;
+    c->first = first; c->count = count;
+    return LSC_OK;
+}
+
+int lsc_set_distmap(lsc_ctx *c, const float *, int, int, int, const int *, double)
+{
+    if (!c) return LSC_EINVAL;
+    c->err = "lsc_set_distmap: SFC path not built yet";
+    return LSC_ESTATE;
+}
+
+static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const float *d_goal, const float *d_prev, int seq,
+                          float *d_next, double *d_cost, int *d_status, int *d_iters)
+{
+    if (c->N == 0) return LSC_ESTATE;
+    a.model = c->d_model; a.terms = c->d_terms; a.entries = c->d_entries;
+    a.N = c->N; a.first = c->first; a.count = c->count; a.planner_seq = seq; a.cap = c->cap;
+    a.state = d_state; a.goal = d_goal; a.traj_prev = d_prev;
+    a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
+    a.vmax = c->d_vmax; a.amax = c->d_amax; a.vnom = c->d_vnom;
+    a.traj_next = d_next; a.cost = d_cost; a.status = d_status; a.iters = d_iters; a.nrows = c->d_nrows;
+    a.stale = c->d_stale; a.sfc = c->cfg.use_octomap ? c->d_sfc : nullptr;
+    a.out_normal = nullptr; a.out_d = nullptr;
+    return LSC_OK;
+}
+
+static int run_plan(lsc_ctx *c, const PlanArgs &a, hipStream_t st)
+{
+    const size_t smem = plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, c->cap);
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
+    HIPCHK(c, launch_plan(a, smem, st));
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, st));
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->t_ms[0] += ms; c->t_n[0]++;
+    }
+    return LSC_OK;
+}
+
+int lsc_tick_device(lsc_ctx *c, const float *d_state, const float *d_goal, const float *d_traj_prev, int planner_seq,
+                    float *d_traj_next, double *d_cost, int *d_status, int *d_iters, void *hip_stream)
+{
+    if (!c || !d_state || !d_goal || !d_traj_prev || !d_traj_next || !d_cost || !d_status || !d_iters) return LSC_EINVAL;
+    PlanArgs a;
+    int rc = fill_plan_args(c, a, d_state, d_goal, d_traj_prev, planner_seq, d_traj_next, d_cost, d_status, d_iters);
+    if (rc) return rc;
+    return run_plan(c, a, (hipStream_t)hip_stream);
+}
+
+int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const float *prev_traj, int planner_seq,
+                    float *out_traj, double *out_cost, int *out_status, int *out_iters, float *out_lsc_normal,
+                    double *out_lsc_d, float *out_sfc)
+{
+    if (!c || !state || !goal || !prev_traj || !out_traj || !out_cost || !out_status) return LSC_EINVAL;
+    if (c->N == 0) return LSC_ESTATE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const size_t N = c->N, cnt = c->count, first = c->first, nobs = N - 1;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_state, state, sizeof(float) * 9 * N, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_goal, goal, sizeof(float) * 3 * N, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_prev, prev_traj, sizeof(float) * NV * N, hipMemcpyHostToDevice, st));
+    PlanArgs a;
+    int rc = fill_plan_args(c, a, c->d_state, c->d_goal, c->d_prev, planner_seq, c->d_next, c->d_cost, c->d_status, c->d_iters);
+    if (rc) return rc;
+    if (out_lsc_normal || out_lsc_d) {
+        if (!c->d_onormal) {
+            HIPCHK(c, hipMalloc(&c->d_onormal, sizeof(float) * 3 * M * nobs * N + 16));
+            HIPCHK(c, hipMalloc(&c->d_od, sizeof(double) * NC * M * nobs * N + 16));
+        }
+        a.out_normal = c->d_onormal; a.out_d = c->d_od;
+    }
+    rc = run_plan(c, a, st);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out_traj, c->d_next + first * NV, sizeof(float) * NV * cnt, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(out_cost, c->d_cost + first, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(out_status, c->d_status + first, sizeof(int) * cnt, hipMemcpyDeviceToHost, st));
+    if (out_iters) HIPCHK(c, hipMemcpyAsync(out_iters, c->d_iters + first, sizeof(int) * cnt, hipMemcpyDeviceToHost, st));
+    if (out_lsc_normal) HIPCHK(c, hipMemcpyAsync(out_lsc_normal, c->d_onormal, sizeof(float) * 3 * M * nobs * cnt, hipMemcpyDeviceToHost, st));
+    if (out_lsc_d) HIPCHK(c, hipMemcpyAsync(out_lsc_d, c->d_od, sizeof(double) * NC * M * nobs * cnt, hipMemcpyDeviceToHost, st));
+    if (out_sfc) HIPCHK(c, hipMemcpyAsync(out_sfc, c->d_sfc + first * M * 6, sizeof(float) * M * 6 * cnt, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    return LSC_OK;
+}
+
+int lsc_propagate_device(lsc_ctx *c, const float *d_traj, float *d_state, void *hip_stream)
+{
+    if (!c || !d_traj || !d_state) return LSC_EINVAL;
+    if (c->N == 0) return LSC_ESTATE;
+    HIPCHK(c, launch_propagate(d_traj, d_state, c->N, c->cfg.dt, (hipStream_t)hip_stream));
+    return LSC_OK;
+}
+
+int lsc_sweep_device(lsc_ctx *c, const float *d_state, const float *d_traj_prev, int planner_seq, float *d_normal,
+                     double *d_d, void *hip_stream)
+{
+    if (!c || !d_state || !d_traj_prev || !d_normal || !d_d) return LSC_EINVAL;
+    if (c->N < 2) return LSC_ESTATE;
+    SweepArgs a;
+    a.N = c->N; a.first = c->first; a.count = c->count; a.planner_seq = planner_seq; a.dtf = (float)c->cfg.dt;
+    a.state = d_state; a.traj_prev = d_traj_prev;
+    a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
+    a.out_normal = d_normal; a.out_d = d_d;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
+    HIPCHK(c, launch_sweep(a, st));
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev1, st));
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->t_ms[1] += ms; c->t_n[1]++;
+    }
+    return LSC_OK;
+}
+
+int lsc_gjk_batch(lsc_ctx *c, const double *pts, int count, double *v, double *dist)
+{
+    if (!c || !pts || count < 1 || !v || !dist) return LSC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    double *d_p = nullptr, *d_v = nullptr, *d_d = nullptr;
+    HIPCHK(c, hipMalloc(&d_p, sizeof(double) * 18 * (size_t)count));
+    HIPCHK(c, hipMalloc(&d_v, sizeof(double) * 3 * (size_t)count));
+    HIPCHK(c, hipMalloc(&d_d, sizeof(double) * (size_t)count));
+    HIPCHK(c, hipMemcpy(d_p, pts, sizeof(double) * 18 * (size_t)count, hipMemcpyHostToDevice));
+    HIPCHK(c, launch_gjk(d_p, count, d_v, d_d, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(v, d_v, sizeof(double) * 3 * (size_t)count, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dist, d_d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+    (void)hipFree(d_p); (void)hipFree(d_v); (void)hipFree(d_d);
+    return LSC_OK;
+}
+
+int lsc_set_timing(lsc_ctx *c, int enabled)
+{
+    if (!c) return LSC_EINVAL;
+    c->timing = enabled != 0;
+    c->t_ms[0] = c->t_ms[1] = 0; c->t_n[0] = c->t_n[1] = 0;
+    return LSC_OK;
+}
+
+int lsc_kernel_time_ms(lsc_ctx *c, int which, double *avg_ms, long *launches)
+{
+    if (!c || which < 0 || which > 1 || !avg_ms) return LSC_EINVAL;
+    *avg_ms = c->t_n[which] ? c->t_ms[which] / c->t_n[which] : 0.0;
+    if (launches) *launches = c->t_n[which];
+    return LSC_OK;
+}
+
+// read-back of per-agent active LSC row counts of the last tick (diagnostics for bench / tests)
+int lsc_last_row_counts(lsc_ctx *c, int *rows /*[N]*/)
+{
+    if (!c || !rows || c->N == 0) return LSC_EINVAL;
+    HIPCHK(c, hipMemcpy(rows, c->d_nrows, sizeof(int) * (size_t)c->N, hipMemcpyDeviceToHost));
+    return LSC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// lsc_kernels.h -- argument blocks shared by the kernels (lsc_kernels.hip) and the C ABI (lsc_abi.cpp)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "lsc_model.hpp"
+
+#define LSC_STATUS_OK_K 0
+#define LSC_STATUS_INFEASIBLE_K 1
+#define LSC_STATUS_CAPACITY_K 3
+
+namespace lsc {
+
+struct PlanArgs {
+    const Model *model;
+    const uint32_t *terms;     // packed Hessian assembly terms
+    const uint32_t *entries;   // [n_entries+1][2] : (gi<<16|gj, first term)
+    int N, first, count, planner_seq, cap;
+    const float *state;        // [N][9]
+    const float *goal;         // [N][3]
+    const float *traj_prev;    // [N][90]
+    const double *radius, *radius_obs, *downwash, *downwash_obs;  // [N]; *_obs = value rounded through float32
+    const double *vmax, *amax; // [N][3]
+    const double *vnom;        // [N]
+    float *traj_next;          // [N][90]
+    double *cost;              // [N]
+    int *status, *iters, *nrows;
+    float *stale;              // [N][90] optimiser's last good trajectory (persistent)
+    const float *sfc;          // [N][M][6] or null
+    float *out_normal;         // optional dense dump [count][N-1][M][3]
+    double *out_d;             // optional dense dump [count][N-1][M][6]
+};
+
+struct SweepArgs {
+    int N, first, count, planner_seq;
+    float dtf;
+    const float *state, *traj_prev;
+    const double *radius, *radius_obs, *downwash, *downwash_obs;
+    float *out_normal;
+    double *out_d;
+};
+
+size_t plan_smem_bytes(int n_terms, int n_entries, int cap);
+hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st);
+hipError_t launch_sweep(const SweepArgs &a, hipStream_t st);
+hipError_t launch_propagate(const float *traj, float *state, int N, double dt, hipStream_t st);
+hipError_t launch_gjk(const double *pts, int count, double *v, double *dist, hipStream_t st);
+
+}  // namespace lsc

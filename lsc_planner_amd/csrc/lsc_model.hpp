@@ -1,0 +1,58 @@
+// lsc_model.hpp -- problem constants shared by host and device.
+//
+// What TrajOptimizer builds once per agent (buildQBase / buildAeqBase, src/traj_optimizer.cpp:169-236)
+// is the same for every agent and tick, so it is built ONCE per context on the host and kept in HBM.
+// The 51 equality rows (initial state, C^2 continuity at 4 junctions, stop-at-horizon:
+// src/traj_optimizer.cpp:394-405, 527-536) are eliminated analytically instead of being handed to a
+// solver: per axis the 13 free variables are
+//     y[3m + (i-3)] = c_{m,i}  for m = 0..3, i = 3..5,      y[12] = c_{4,3} = c_{4,4} = c_{4,5}
+// and the other control points follow from
+//     c_{0,0} = p,  c_{0,1} = p + v dt/n,  c_{0,2} = a dt^2/(n(n-1)) + 2 c_{0,1} - c_{0,0}
+//     c_{m,0} = c_{m-1,5},  c_{m,1} = 2 c_{m-1,5} - c_{m-1,4},  c_{m,2} = 4 c_{m-1,5} - 4 c_{m-1,4} + c_{m-1,3}
+// (same feasible set as the reference's equality rows; 39 unknowns per agent instead of 90 + 51 duals).
+#pragma once
+#include <stdint.h>
+
+namespace lsc {
+
+constexpr int M = 5, DEG = 5, NC = 6, SEGV = 30, NV = 90;
+constexpr int NYA = 13;        // free variables per axis
+constexpr int NY = 39;         // free variables per agent
+constexpr int NCP = 30;        // control points per agent (27 carry constraints)
+constexpr int KLD = 41;        // leading dimension of the 39x39 matrices in LDS (bank spread)
+constexpr int BAND = 11;       // half bandwidth of the reduced Hessian in cluster-major order
+constexpr int AXROWS = 6 * NV; // bound(2) / velocity(2) / acceleration(2) row slots per variable
+
+// global (cluster-major) index of free variable a of axis k: clusters of 3 axes x 3 locals
+__host__ __device__ inline int yglob(int k, int a) { return a < 12 ? (a / 3) * 9 + k * 3 + (a % 3) : 36 + k; }
+
+struct Model {
+    double dt, w_c, w_t;
+    double hv_scale;          // dt / n          : velocity rows are kept as  +-(c_{i+1}-c_i) <= vmax dt/n
+    double ha_scale;          // dt^2 / (n(n-1)) : acceleration rows as +-(c_{i+2}-2c_{i+1}+c_i) <= amax dt^2/(n(n-1))
+    double Qh[NC * NC];       // 2 w_c Q_base : Hessian block of one segment (objective has no 1/2)
+    double Hc[NYA * NYA];     // Z^T blockdiag(Qh) Z for one axis
+    // x_t = sum_j xc[t][j] * y[xi[t][j]]   (t >= 3);  x_0..2 come from the state
+    int    x_n[SEGV];
+    int    x_i[SEGV][3];
+    double x_c[SEGV][3];
+    // y_a enters x_t with coefficient t_c  (transpose of the map above)
+    int    t_n[NYA];
+    int    t_t[NYA][4];
+    double t_c[NYA][4];
+    // Hessian assembly terms: K[dest] += coef * W[src]; packed dest(11b) | src(10b) | coef+128 (8b), grouped by
+    // destination; entry e owns terms [k_off[e], k_off[e+1])
+    int    n_entries;         // lower-band entries of the 39x39 matrix
+    int    n_terms;
+    float  world_min[3], world_max[3];
+    int    use_sfc, prune, max_iters, cap;
+};
+
+// offsets inside the x-space weight array W that the assembly terms read from
+constexpr int W_D = 0;          // [3][30] diagonal        (bounds + velocity + acceleration stencils)
+constexpr int W_1 = 90;         // [3][30] (t, t+1) coupling
+constexpr int W_2 = 180;        // [3][30] (t, t+2) coupling
+constexpr int W_S = 270;        // [30][6]  LSC blocks  sum w n n^T : xx, xy, xz, yy, yz, zz
+constexpr int W_SIZE = 450;
+
+}  // namespace lsc

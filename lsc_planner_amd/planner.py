@@ -1,0 +1,181 @@
+"""Host-side mirror of the reference's per-agent planner surface, batched over the swarm.
+
+The reference drives N TrajPlanner objects sequentially (src/multi_sync_simulator.cpp:320-328); each owns a
+TrajOptimizer (include/traj_optimizer.hpp:20-28).  SwarmPlanner keeps the same vocabulary --
+set_current_state / set_obs_prev_trajs / plan / get_traj / get_qp_cost / get_planning_report -- but one
+`plan()` is one C-ABI call for all agents (include/lsc_planner_amd.h).
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import LscConfig, LscError, M, NC, NV, SEGV
+
+
+@dataclass
+class PlannerConfig:
+    dt: float = 0.2                  # traj/dt
+    control_input_weight: float = 0.01
+    terminal_weight: float = 1.0
+    use_octomap: bool = False
+    world_resolution: float = 0.1
+    device: int = 0
+    max_rows_per_cp: int = 0
+    max_iters: int = 50
+    prune: bool = True
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+
+
+class SwarmPlanner:
+    """All agents' TrajPlanner + TrajOptimizer state behind one context of liblsc_hip.so."""
+
+    def __init__(self, mission, config=None):
+        self.L = _lib.load_library()
+        self.cfg = config or PlannerConfig()
+        self.mission = mission
+        c = LscConfig()
+        self.L.lsc_default_config(ctypes.byref(c))
+        c.dt, c.control_weight, c.terminal_weight = self.cfg.dt, self.cfg.control_input_weight, self.cfg.terminal_weight
+        for k in range(3):
+            c.world_min[k] = float(mission.world_min[k])
+            c.world_max[k] = float(mission.world_max[k])
+        c.use_octomap = int(self.cfg.use_octomap)
+        c.world_resolution = self.cfg.world_resolution
+        c.device = self.cfg.device
+        c.max_rows_per_cp = self.cfg.max_rows_per_cp
+        c.max_iters = self.cfg.max_iters
+        c.prune = int(self.cfg.prune)
+        self._c = c
+        self.ctx = self.L.lsc_create(ctypes.byref(c))
+        if not self.ctx:
+            raise LscError("lsc_create failed: no usable gfx950 device (there is no CPU fallback)")
+        self.N = mission.qn
+        self.first, self.count = 0, self.N
+        self._check(self.L.lsc_set_agents(self.ctx, self.N, _dp(np.ascontiguousarray(mission.radius, np.float64)),
+                                          _dp(np.ascontiguousarray(mission.downwash, np.float64)),
+                                          _dp(np.ascontiguousarray(mission.max_vel, np.float64)),
+                                          _dp(np.ascontiguousarray(mission.max_acc, np.float64)),
+                                          _dp(np.ascontiguousarray(mission.nominal_velocity, np.float64))))
+        # TrajPlanner state (src/traj_planner.cpp:41-48)
+        self.planner_seq = 0
+        self.traj_curr = np.zeros((self.N, 3, SEGV), np.float32)
+        self.qp_cost = np.zeros(self.N)
+        self.planning_report = np.zeros(self.N, np.int32)
+        self.iters = np.zeros(self.N, np.int32)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LscError(f"lsc error {rc}: {self.L.lsc_last_error(self.ctx).decode()}")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.lsc_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_shard(self, first, count):
+        self._check(self.L.lsc_set_shard(self.ctx, first, count))
+        self.first, self.count = first, count
+
+    # ---- host-buffer tick: TrajPlanner::plan for every agent of the shard -----------------------------
+    def plan(self, state, current_goal, obs_prev_trajs, want_constraints=False):
+        """state [N][9], current_goal [N][3], obs_prev_trajs [N][3][30] (every agent's previous getTraj()).
+        Returns dict(traj [count][3][30], cost, status, iters[, normal, d])."""
+        N, cnt = self.N, self.count
+        state = np.ascontiguousarray(state, np.float32).reshape(N, 9)
+        goal = np.ascontiguousarray(current_goal, np.float32).reshape(N, 3)
+        prev = np.ascontiguousarray(obs_prev_trajs, np.float32).reshape(N, 3, SEGV)
+        self.planner_seq += 1                                   # src/traj_planner.cpp:127
+        out = np.zeros((cnt, 3, SEGV), np.float32)
+        cost = self.qp_cost[self.first:self.first + cnt].copy()
+        status = np.zeros(cnt, np.int32)
+        iters = np.zeros(cnt, np.int32)
+        nrm = np.zeros((cnt, max(N - 1, 1), M, 3), np.float32) if want_constraints else None
+        dd = np.zeros((cnt, max(N - 1, 1), M, NC), np.float64) if want_constraints else None
+        self._check(self.L.lsc_replan_tick(self.ctx, _fp(state), _fp(goal), _fp(prev), self.planner_seq, _fp(out), _dp(cost),
+                                           _ip(status), _ip(iters), _fp(nrm) if want_constraints else None,
+                                           _dp(dd) if want_constraints else None, None))
+        sl = slice(self.first, self.first + cnt)
+        self.traj_curr[sl] = out
+        self.qp_cost[sl] = cost
+        self.planning_report[sl] = status
+        self.iters[sl] = iters
+        res = {"traj": out, "cost": cost, "status": status, "iters": iters}
+        if want_constraints:
+            res["normal"], res["d"] = nrm, dd
+        return res
+
+    # ---- getters with the reference's names ------------------------------------------------------------
+    def get_traj(self):
+        return self.traj_curr
+
+    def get_qp_cost(self):
+        return self.qp_cost
+
+    def get_planning_report(self):
+        return self.planning_report
+
+    def get_planner_seq(self):
+        return self.planner_seq
+
+    def row_counts(self):
+        rows = np.zeros(self.N, np.int32)
+        self._check(self.L.lsc_last_row_counts(self.ctx, _ip(rows)))
+        return rows
+
+    def gjk_batch(self, pts):
+        pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 6, 3)
+        v = np.zeros((len(pts), 3))
+        d = np.zeros(len(pts))
+        self._check(self.L.lsc_gjk_batch(self.ctx, _dp(pts), len(pts), _dp(v), _dp(d)))
+        return v, d
+
+    # ---- device-resident stepping (torch tensors own the memory) ---------------------------------------
+    def tick_device(self, state, goal, traj_prev, traj_next, cost, status, iters, planner_seq, stream=0):
+        self._check(self.L.lsc_tick_device(self.ctx, state.data_ptr(), goal.data_ptr(), traj_prev.data_ptr(), planner_seq,
+                                           traj_next.data_ptr(), cost.data_ptr(), status.data_ptr(), iters.data_ptr(), stream))
+
+    def propagate_device(self, traj, state, stream=0):
+        self._check(self.L.lsc_propagate_device(self.ctx, traj.data_ptr(), state.data_ptr(), stream))
+
+    def sweep_device(self, state, traj_prev, planner_seq, normal, d, stream=0):
+        self._check(self.L.lsc_sweep_device(self.ctx, state.data_ptr(), traj_prev.data_ptr(), planner_seq, normal.data_ptr(),
+                                            d.data_ptr(), stream))
+
+    def set_timing(self, on):
+        self._check(self.L.lsc_set_timing(self.ctx, int(on)))
+
+    def kernel_time_ms(self, which=0):
+        ms = ctypes.c_double()
+        n = ctypes.c_long()
+        self._check(self.L.lsc_kernel_time_ms(self.ctx, which, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+
+def next_state_host(traj, dt=0.2):
+    """getStateFromControlPoints at t = dt in float32 (include/polynomial.hpp:63-97), numpy, all agents."""
+    t = np.asarray(traj, np.float32).reshape(-1, 3, SEGV)
+    c1 = t[:, :, NC:NC + 3]
+    fn, fn1, finv = np.float32(5), np.float32(4), np.float32(dt ** -1)
+    v0 = ((c1[:, :, 1] - c1[:, :, 0]) * fn) * finv
+    v1 = ((c1[:, :, 2] - c1[:, :, 1]) * fn) * finv
+    a0 = ((v1 - v0) * fn1) * finv
+    return np.concatenate([c1[:, :, 0], v0, a0], axis=1).astype(np.float32)
