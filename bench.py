@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""bench.py -- agent-replans/sec of the MI355X replanning path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one synchronous replan tick of the whole swarm: prediction shift -> LSC construction -> QP solve for
+every agent (the reference's MultiSyncSimulator::plan loop), followed by the ideal-state propagation that feeds the
+next tick.  Everything stays resident in HBM during the timed region (no host round trip inside a tick).
+
+Workload (config.workload): BASELINE.json configs[2], the 64-agent circle swap on the empty map
+(matlab/mission_generator.m geometry, R = 8 m, z = 1 m, testall_empty.launch parameters), goal input =
+desired goal (goal_mode=static; the reference's grid/A* goal planner is SURVEY 8(f)#1, outside this path).
+With --gpus G the swarm is 64*G agents on a circle of radius 8*G (same spacing), agent-sharded 64 per GPU with one
+all-gather of the new trajectories per tick: weak scaling.
+
+One JSON line on rank 0 with `roofline` (plan kernel), `roofline_sweep` (dense LSC sweep, HBM-bound) and
+`cpu_baseline` (the oracle = CPU restatement of the reference path, timed on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (guide: half the 157.3 TF fp32 vector rate)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_flops(n_agents, iters_total):
+    """per interior-point iteration per agent ~ (N-1)*1.0 kflop + 0.3 Mflop (fp64)."""
+    return float(iters_total) * ((n_agents - 1) * 1.0e3 + 0.3e6)
+
+
+def cpu_baseline(ms, seconds_target=15.0, max_ticks=40):
+    """Oracle (CPU restatement of the reference path) on the same mission from its start, sequential over agents
+    like the reference, then once more with OpenMP over agents on all cores."""
+    from oracle import oracle as O
+    from lsc_planner_amd.planner import next_state_host
+    N = ms.qn
+    out = {}
+    for label, threads in (("seq", 1), ("omp", os.cpu_count() or 1)):
+        prm = O.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+        sw = O.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+        state = np.zeros((N, 9), np.float32)
+        state[:, :3] = ms.start
+        traj = np.zeros((N, 3, 30), np.float32)
+        t0 = time.perf_counter()
+        ticks = 0
+        budget = seconds_target if threads == 1 else seconds_target / 3
+        while ticks < max_ticks and (time.perf_counter() - t0) < budget:
+            r = sw.tick(state, ms.goal, traj, ticks + 1, nthreads=threads)
+            traj = r["traj"]
+            state = next_state_host(traj)
+            ticks += 1
+        dt = time.perf_counter() - t0
+        out[label] = (N * ticks / dt, ticks, dt, threads)
+    seq, omp = out["seq"], out["omp"]
+    return {
+        "value": round(seq[0], 2), "unit": "agent-replans/s", "cores": 1, "kind": "port",
+        "sample": f"first {seq[1]} ticks of the same {N}-agent mission ({seq[2]:.1f} s), sequential over agents like "
+                  f"MultiSyncSimulator::plan; CPLEX absent -> oracle's exact fp64 QP solve",
+        "all_cores_value": round(omp[0], 2), "all_cores": omp[3],
+        "reference_published": "9.47 ms per agent-plan = ~106 replans/s (16 agents, forest map, hardware unknown, "
+                               "log/summary_LSC_16agents.csv:2)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--agents-per-gpu", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-leg", action="store_true")
+    ap.add_argument("--no-prune", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import lsc_planner_amd as L
+    from lsc_planner_amd.sharded import shard_bounds, all_gather_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    G = max(world, 1)
+    if args.gpus != G and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={G}; using {G}", file=sys.stderr)
+
+    n_agents = args.agents_per_gpu * G
+    R = 8.0 * n_agents / 64.0
+    ms = L.circle_swap(n_agents, circle_radius=R, z=1.0, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune))
+    first, count = shard_bounds(n_agents, G, rank)
+    counts = [shard_bounds(n_agents, G, r)[1] for r in range(G)]
+    pl.set_shard(first, count)
+
+    f32 = dict(dtype=torch.float32, device=dev)
+    state = torch.zeros((n_agents, 9), **f32)
+    state[:, :3] = torch.from_numpy(ms.start).to(dev)
+    goal = torch.from_numpy(ms.goal).to(dev).contiguous()
+    traj_a = torch.zeros((n_agents, 90), **f32)
+    traj_b = torch.zeros((n_agents, 90), **f32)
+    cost = torch.zeros(n_agents, dtype=torch.float64, device=dev)
+    status = torch.zeros(n_agents, dtype=torch.int32, device=dev)
+    iters = torch.zeros(n_agents, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    seq = 0
+
+    def tick(prev, nxt):
+        nonlocal seq
+        seq += 1
+        pl.tick_device(state, goal, prev, nxt, cost, status, iters, seq, stream)
+        if G > 1:
+            all_gather_rows(dist, nxt, first, count, counts)
+        pl.propagate_device(nxt, state, stream)
+
+    def sync():
+        if G > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    prev, nxt = traj_a, traj_b
+    for _ in range(args.warmup):
+        tick(prev, nxt)
+        prev, nxt = nxt, prev
+    sync()
+    pl.iterations_total(reset=True)
+    pl.set_timing(True)
+    bad = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tick(prev, nxt)
+        prev, nxt = nxt, prev
+    sync()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_n = pl.kernel_time_ms(0)
+    iters_total = pl.iterations_total(reset=False)
+    bad = int((status[first:first + count] != 0).sum().item())
+    rows = pl.row_counts()[first:first + count]
+    pl.set_timing(False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    it_t = torch.tensor([float(iters_total)], dtype=torch.float64, device=dev)
+    if G > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    iters_total = float(it_t.item())
+
+    result = None
+    if rank == 0:
+        value = n_agents * args.steps / elapsed
+        flops = algorithmic_flops(n_agents, iters_total / G) / max(k_n, 1)   # per launch of this rank's kernel
+        ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        result = {
+            "metric": "agent-replans/sec (whole node)", "value": round(value, 1), "unit": "agent-replans/s",
+            "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n_agents}-agent generated circle swap (R={R:g} m, z=1 m), empty map, LSC mode, "
+                                   f"dt 0.2 s, M=5 n=5, goal_mode=static, {args.agents_per_gpu} agents per GPU, "
+                                   "device-resident ticks (plan kernel + state propagation"
+                                   + (", RCCL all-gather of trajectories per tick)" if G > 1 else ")"),
+                       "agents": n_agents, "parallelism": f"agent-shard x{G}", "prune_redundant_rows": not args.no_prune},
+            "qp": {"mean_ip_iterations": round(iters_total / (n_agents * args.steps), 2), "failed_agents_last_tick": bad,
+                   "active_lsc_rows_last_tick_mean": float(np.mean(rows)), "active_lsc_rows_last_tick_max": int(np.max(rows)),
+                   "reference_rows_per_agent": 27 * (n_agents - 1)},
+            "roofline": {"kernel": "lsc_plan_kernel", "bound": "valu_fp64", "achieved": round(ach, 5),
+                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_VALU_PEAK_TFLOPS, 7),
+                         "traffic": None, "avg_launch_ms": round(k_ms, 5), "launches": k_n,
+                         "note": "latency-bound: one 256-lane workgroup per agent; algorithmic flops = IP iterations x "
+                                 "((N-1) kflop + 0.3 Mflop) per SURVEY 8(d); neither HBM nor MFMA bounds this kernel"},
+        }
+
+    # ---- dense LSC sweep kernel (the HBM-class stage of SURVEY 8(d)): N(N-1)*180 B written per launch
+    nobs = n_agents - 1
+    nrm = torch.empty((count, nobs, 5, 3), **f32)
+    dd = torch.empty((count, nobs, 5, 6), dtype=torch.float64, device=dev)
+    for _ in range(3):
+        pl.sweep_device(state, prev, seq + 1, nrm, dd, stream)
+    torch.cuda.synchronize()
+    pl.set_timing(True)
+    for _ in range(20):
+        pl.sweep_device(state, prev, seq + 1, nrm, dd, stream)
+    torch.cuda.synchronize()
+    s_ms, s_n = pl.kernel_time_ms(1)
+    pl.set_timing(False)
+    if rank == 0:
+        # bytes as materialised by this implementation: fp32 normal x3 + fp64 d x6 per (pair, segment), plus reads
+        wr = count * nobs * 5 * (3 * 4 + 6 * 8)
+        alg = count * nobs * 180 + n_agents * 404
+        result["roofline_sweep"] = {"kernel": "lsc_sweep_kernel", "bound": "hbm",
+                                    "achieved": round(alg / (s_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                                    "avg_launch_ms": round(s_ms, 5), "bytes_written_per_launch": wr,
+                                    "algorithmic_bytes_per_launch": alg,
+                                    "note": "N(N-1)*180 B + N*404 B per SURVEY 8(d); at this N the working set is "
+                                            "L2/Infinity-Cache resident and the launch is latency-bound"}
+
+    # ---- per-tick latency through the host-buffer ABI (H2D + kernel + D2H, PCIe-inclusive): p50 / p99
+    if not args.no_latency_leg and rank == 0 and G == 1:
+        from lsc_planner_amd.planner import next_state_host
+        pl2 = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune))
+        st = np.zeros((n_agents, 9), np.float32)
+        st[:, :3] = ms.start
+        tj = np.zeros((n_agents, 3, 30), np.float32)
+        lat = []
+        for i in range(120):
+            t1 = time.perf_counter()
+            r = pl2.plan(st, ms.goal, tj)
+            lat.append(time.perf_counter() - t1)
+            tj = r["traj"]
+            st = next_state_host(tj)
+        lat = np.asarray(lat[10:]) * 1e3
+        result["latency_host_abi_ms"] = {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),
+                                         "ticks": len(lat), "agent_replans_per_s": round(n_agents / (np.mean(lat) * 1e-3), 1),
+                                         "note": "lsc_replan_tick: host buffers in/out, PCIe-inclusive, synchronous"}
+        pl2.close()
+
+    if rank == 0 and G == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(ms)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result))
+    pl.close()
+    if G > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,17 @@ int lsc_set_timing(lsc_ctx *ctx, int enabled);
 /* Active (non-redundant) LSC rows each agent's QP carried in the last tick, [N] (diagnostics). */
 int lsc_last_row_counts(lsc_ctx *ctx, int *rows);
 
+/* Sum over agents of interior-point iterations since the last reset (bench flop accounting). Synchronises. */
+int lsc_iterations_total(lsc_ctx *ctx, long long *total, int reset);
+
+/* Diagnostics.  lsc_phase_profile: enable=1 selects the instrumented plan kernel and clears its counters, 0 goes
+ * back to the production kernel, -1 only reads; out (may be NULL) gets [N][12] cycle counts (100 MHz wall clock)
+ * per phase: setup, LSC build, IP init, residual pass, row reduction, Hessian assembly, Cholesky, triangular
+ * solves, affine pass, corrector pass, step+update, output.  lsc_solver_residuals: [N][4] last duality gap,
+ * primal residual, stationarity residual, objective. */
+int lsc_phase_profile(lsc_ctx *ctx, int enable, long long *out);
+int lsc_solver_residuals(lsc_ctx *ctx, double *out);
+
 #ifdef __cplusplus
 }
 #endif

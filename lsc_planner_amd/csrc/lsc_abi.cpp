@@ -160,6 +160,10 @@ struct lsc_ctx {
     double *d_vmax = nullptr, *d_amax = nullptr, *d_vnom = nullptr;
     float *d_stale = nullptr, *d_sfc = nullptr;
     int *d_nrows = nullptr;
+    long long *d_iters_acc = nullptr;
+    long long *d_prof = nullptr;
+    double *d_dbg = nullptr;
+    bool profiling = false;
     // buffers of the host-pointer tick
     float *d_state = nullptr, *d_goal = nullptr, *d_prev = nullptr, *d_next = nullptr;
     double *d_cost = nullptr;
@@ -167,10 +171,22 @@ struct lsc_ctx {
     float *d_onormal = nullptr;
     double *d_od = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double t_ms[2] = {0, 0};
-    long t_n[2] = {0, 0};
+    // kernel timing: one HIP event pair per launch, recorded on the launch stream, read back on query
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[2];
+    size_t ev_used[2] = {0, 0};
 };
+
+static int timing_begin(lsc_ctx *c, int which, hipStream_t st, hipEvent_t *e1)
+{
+    if (c->ev_used[which] == c->ev_pool[which].size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return LSC_EHIP;
+        c->ev_pool[which].push_back({a, b});
+    }
+    auto &p = c->ev_pool[which][c->ev_used[which]++];
+    *e1 = p.second;
+    return hipEventRecord(p.first, st) == hipSuccess ? LSC_OK : LSC_EHIP;
+}
 
 #define HIPCHK(ctx, call)                                                                     \
     do {                                                                                      \
@@ -205,8 +221,7 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
     lsc_ctx *c = new lsc_ctx();
     c->cfg = *cfg;
     build_model(*cfg, c->hm);
-    bool ok = hipStreamCreate(&c->stream) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
-              hipEventCreate(&c->ev1) == hipSuccess;
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess;
     ok = ok && hipMalloc(&c->d_terms, sizeof(uint32_t) * (c->hm.terms.size() + 2)) == hipSuccess;
     ok = ok && hipMalloc(&c->d_entries, sizeof(uint32_t) * c->hm.entries.size()) == hipSuccess;
     ok = ok && hipMalloc(&c->d_model, sizeof(Model)) == hipSuccess;
@@ -219,12 +234,12 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
 static void free_agents(lsc_ctx *c)
 {
     void *ptrs[] = {c->d_radius, c->d_radius_obs, c->d_downwash, c->d_downwash_obs, c->d_vmax, c->d_amax, c->d_vnom,
-                    c->d_stale, c->d_sfc, c->d_nrows, c->d_state, c->d_goal, c->d_prev, c->d_next, c->d_cost, c->d_status,
+                    c->d_stale, c->d_sfc, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_goal, c->d_prev, c->d_next, c->d_cost, c->d_status,
                     c->d_iters, c->d_onormal, c->d_od};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->d_radius = c->d_radius_obs = c->d_downwash = c->d_downwash_obs = c->d_vmax = c->d_amax = c->d_vnom = nullptr;
     c->d_stale = c->d_sfc = c->d_state = c->d_goal = c->d_prev = c->d_next = nullptr;
-    c->d_cost = nullptr; c->d_status = c->d_iters = c->d_nrows = nullptr; c->d_onormal = nullptr; c->d_od = nullptr;
+    c->d_cost = nullptr; c->d_status = c->d_iters = c->d_nrows = nullptr; c->d_iters_acc = nullptr; c->d_prof = nullptr; c->d_dbg = nullptr; c->d_onormal = nullptr; c->d_od = nullptr;
 }
 
 void lsc_destroy(lsc_ctx *c)
@@ -234,8 +249,8 @@ void lsc_destroy(lsc_ctx *c)
     if (c->d_model) (void)hipFree(c->d_model);
     if (c->d_terms) (void)hipFree(c->d_terms);
     if (c->d_entries) (void)hipFree(c->d_entries);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int w = 0; w < 2; w++)
+        for (auto &p : c->ev_pool[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -276,6 +291,13 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMalloc(&c->d_sfc, sizeof(float) * M * 6 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_sfc, 0, sizeof(float) * M * 6 * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_nrows, sizeof(int) * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * PROF_PHASES * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * PROF_PHASES * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_dbg, sizeof(double) * 4 * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_dbg, 0, sizeof(double) * 4 * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_state, sizeof(float) * 9 * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_goal, sizeof(float) * 3 * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_prev, sizeof(float) * NV * (size_t)N));
@@ -311,24 +333,20 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.state = d_state; a.goal = d_goal; a.traj_prev = d_prev;
     a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
     a.vmax = c->d_vmax; a.amax = c->d_amax; a.vnom = c->d_vnom;
-    a.traj_next = d_next; a.cost = d_cost; a.status = d_status; a.iters = d_iters; a.nrows = c->d_nrows;
+    a.traj_next = d_next; a.cost = d_cost; a.status = d_status; a.iters = d_iters; a.nrows = c->d_nrows; a.iters_acc = c->d_iters_acc;
     a.stale = c->d_stale; a.sfc = c->cfg.use_octomap ? c->d_sfc : nullptr;
     a.out_normal = nullptr; a.out_d = nullptr;
+    a.dbg = c->d_dbg; a.prof = c->profiling ? c->d_prof : nullptr;
     return LSC_OK;
 }
 
 static int run_plan(lsc_ctx *c, const PlanArgs &a, hipStream_t st)
 {
     const size_t smem = plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, c->cap);
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
+    hipEvent_t e1 = nullptr;
+    if (c->timing && timing_begin(c, 0, st, &e1) != LSC_OK) return LSC_EHIP;
     HIPCHK(c, launch_plan(a, smem, st));
-    if (c->timing) {
-        HIPCHK(c, hipEventRecord(c->ev1, st));
-        HIPCHK(c, hipEventSynchronize(c->ev1));
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->t_ms[0] += ms; c->t_n[0]++;
-    }
+    if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
     return LSC_OK;
 }
 
@@ -396,15 +414,10 @@ int lsc_sweep_device(lsc_ctx *c, const float *d_state, const float *d_traj_prev,
     a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
     a.out_normal = d_normal; a.out_d = d_d;
     hipStream_t st = (hipStream_t)hip_stream;
-    if (c->timing) HIPCHK(c, hipEventRecord(c->ev0, st));
+    hipEvent_t e1 = nullptr;
+    if (c->timing && timing_begin(c, 1, st, &e1) != LSC_OK) return LSC_EHIP;
     HIPCHK(c, launch_sweep(a, st));
-    if (c->timing) {
-        HIPCHK(c, hipEventRecord(c->ev1, st));
-        HIPCHK(c, hipEventSynchronize(c->ev1));
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->t_ms[1] += ms; c->t_n[1]++;
-    }
+    if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
     return LSC_OK;
 }
 
@@ -429,15 +442,60 @@ int lsc_set_timing(lsc_ctx *c, int enabled)
 {
     if (!c) return LSC_EINVAL;
     c->timing = enabled != 0;
-    c->t_ms[0] = c->t_ms[1] = 0; c->t_n[0] = c->t_n[1] = 0;
+    c->ev_used[0] = c->ev_used[1] = 0;
     return LSC_OK;
 }
 
 int lsc_kernel_time_ms(lsc_ctx *c, int which, double *avg_ms, long *launches)
 {
     if (!c || which < 0 || which > 1 || !avg_ms) return LSC_EINVAL;
-    *avg_ms = c->t_n[which] ? c->t_ms[which] / c->t_n[which] : 0.0;
-    if (launches) *launches = c->t_n[which];
+    double tot = 0;
+    for (size_t i = 0; i < c->ev_used[which]; i++) {
+        auto &p = c->ev_pool[which][i];
+        HIPCHK(c, hipEventSynchronize(p.second));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, p.first, p.second));
+        tot += ms;
+    }
+    *avg_ms = c->ev_used[which] ? tot / (double)c->ev_used[which] : 0.0;
+    if (launches) *launches = (long)c->ev_used[which];
+    return LSC_OK;
+}
+
+// Diagnostics: phase profile of the plan kernel.  enable=1 switches to the instrumented kernel variant and clears
+// the counters; out (may be null) receives [N][12] cycle counts (100 MHz wall clock) accumulated since then.
+int lsc_phase_profile(lsc_ctx *c, int enable, long long *out)
+{
+    if (!c || c->N == 0) return LSC_EINVAL;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (out) HIPCHK(c, hipMemcpy(out, c->d_prof, sizeof(long long) * PROF_PHASES * (size_t)c->N, hipMemcpyDeviceToHost));
+    if (enable >= 0) {
+        c->profiling = enable != 0;
+        HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * PROF_PHASES * (size_t)c->N));
+    }
+    return LSC_OK;
+}
+
+// last (gap, |rp|, |rd|, objective) of every agent's solve, [N][4]
+int lsc_solver_residuals(lsc_ctx *c, double *out)
+{
+    if (!c || !out || c->N == 0) return LSC_EINVAL;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, c->d_dbg, sizeof(double) * 4 * (size_t)c->N, hipMemcpyDeviceToHost));
+    return LSC_OK;
+}
+
+// sum over agents of the interior-point iterations run since the last reset (bench flop accounting)
+int lsc_iterations_total(lsc_ctx *c, long long *total, int reset)
+{
+    if (!c || !total || c->N == 0) return LSC_EINVAL;
+    std::vector<long long> h(c->N);
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(h.data(), c->d_iters_acc, sizeof(long long) * (size_t)c->N, hipMemcpyDeviceToHost));
+    long long t = 0;
+    for (long long v : h) t += v;
+    *total = t;
+    if (reset) HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (size_t)c->N));
     return LSC_OK;
 }
 

@@ -26,11 +26,15 @@ struct PlanArgs {
     float *traj_next;          // [N][90]
     double *cost;              // [N]
     int *status, *iters, *nrows;
+    long long *iters_acc;      // [N] running sum of interior-point iterations (bench accounting), may be null
     float *stale;              // [N][90] optimiser's last good trajectory (persistent)
     const float *sfc;          // [N][M][6] or null
     float *out_normal;         // optional dense dump [count][N-1][M][3]
     double *out_d;             // optional dense dump [count][N-1][M][6]
+    double *dbg;               // optional [N][4]: last (gap, |rp|, |rd|, objective) seen by the solver
+    long long *prof;           // optional [N][12] phase cycle counters (selects the instrumented kernel)
 };
+constexpr int PROF_PHASES = 12;
 
 struct SweepArgs {
     int N, first, count, planner_seq;

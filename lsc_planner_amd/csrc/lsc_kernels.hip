@@ -234,8 +234,26 @@ __device__ __forceinline__ void bwd_step(const double (&col)[NY], const double (
     if constexpr (I > 0) bwd_step<I - 1>(col, invd, b, lane);
 }
 
+// phase stamps (PROF variant only): cycles of lane 0 spent per phase, accumulated per agent
+enum { PH_SETUP = 0, PH_LSC, PH_INIT, PH_P1, PH_REDUCE, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_P2, PH_P3, PH_P45, PH_OUT, PH_COUNT };
+
+template <bool PROF>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void lsc_plan_kernel(PlanArgs a)
 {
+    long long t_last = 0;
+    long long t_acc[PH_COUNT];
+    if constexpr (PROF) {
+#pragma unroll
+        for (int i = 0; i < PH_COUNT; i++) t_acc[i] = 0;
+        t_last = wall_clock64();
+    }
+    auto stamp = [&](int ph) {
+        if constexpr (PROF) {
+            long long now = wall_clock64();
+            t_acc[ph] += now - t_last;
+            t_last = now;
+        }
+    };
     extern __shared__ __align__(16) unsigned char smem_raw[];
     Smem &S = *reinterpret_cast<Smem *>(smem_raw);
     const Model &md = *a.model;
@@ -349,6 +367,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         kconst[e] = v;
     }
 
+    stamp(PH_SETUP);
     // ------------------------------------------------------------------ phase B: LSC rows
     // unit = (obstacle oi, segment m); rows that cannot be active inside the reachable box are dropped
     // (redundant constraints: removing them does not change the feasible set, hence not the optimum).
@@ -446,6 +465,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
     }
     if (tid < NCP && S.cnt[tid] > CAP) S.cnt[tid] = CAP;
+    stamp(PH_LSC);
 
     // ------------------------------------------------------------------ phase C: interior point
     for (int sl = tid; sl < AXROWS; sl += NT) {
@@ -688,6 +708,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
             __syncthreads();
 
+            stamp(PH_INIT);
             // ---------------- Mehrotra predictor-corrector iterations
             const int max_iters = md.max_iters;
             const double hmax = fmax(1.0, fmax(fabs((double)md.world_max[0]), fabs((double)md.world_min[0])));
@@ -725,22 +746,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 block_reduce3(objp, 0.0, 0.0, 0, 0, 0);
                 obj = S.sc[0];
                 const double mu = gap / nrow;
+                stamp(PH_P1);
 
                 reduce_rows(true, false);
+                stamp(PH_REDUCE);
                 assemble(true);
+                stamp(PH_ASSEMBLE);
                 double rdn = (tid < NY) ? fabs(S.dy[tid]) : 0.0;
                 block_reduce3(rdn, 0.0, 0.0, 1, 0, 0);
                 rdn = S.sc[0];
+                if (tid == 0) { S.sc[3] = gap; S.sc[4] = rpmax; S.sc[5] = rdn; S.sc[6] = obj; }
                 const bool gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
                 if (rpmax <= 1e-9 * hmax && rdn <= 1e-5 * (1.0 + fabs(obj)) && gap_ok) { status = LSC_STATUS_OK_K; break; }
                 if (!(gap == gap) || !(rpmax == rpmax)) break;
 
-                if (!factor()) {
+                const bool fok = factor();
+                stamp(PH_FACTOR);
+                if (!fok) {
                     // K lost definiteness to round-off: accept only if already within 1e-7 relative gap
                     if (rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) status = LSC_STATUS_OK_K;
                     break;
                 }
                 solve();  // affine direction in dy / dx
+                stamp(PH_SOLVE);
+                {
+                    // Newton-step test: with gap and primal residual at tolerance, the affine (pure Newton) step
+                    // measures the distance to the optimum; the stationarity residual can stall at the round-off
+                    // level of the ill-conditioned normal equations when z/s is huge.
+                    double dxa = (tid < NV) ? fabs(S.dx[tid]) : 0.0, xa = (tid < NV) ? fabs(S.x[tid]) : 0.0;
+                    block_reduce3(dxa, xa, 0.0, 1, 1, 0);
+                    if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-9 * fmax(1.0, S.sc[1])) { status = LSC_STATUS_OK_K; break; }
+                }
 
                 // P2: affine step length and centring statistics
                 double amin = 1.0, s1 = 0.0, s2 = 0.0;
@@ -774,6 +810,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
                 sigma = sigma * sigma * sigma;
                 const double smu = sigma * mu;
+                stamp(PH_P2);
 
                 // P3: corrector right-hand side  v = w rp - (ds dz - sigma mu)/s
                 for (int sl = tid; sl < AXROWS; sl += NT) {
@@ -791,9 +828,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     rt2[r] = zv * is * rp - (rt2[r] - smu) * is;
                 }
                 __syncthreads();
+                stamp(PH_P3);
                 reduce_rows(false, false);
+                stamp(PH_REDUCE);
                 assemble(false);
+                stamp(PH_ASSEMBLE);
                 solve();  // combined direction
+                stamp(PH_SOLVE);
 
                 // P4: step length (ds = -rp - a.dx ; dz = -z + v + w a.dx)
                 amin = 1e300;
@@ -844,6 +885,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 __syncthreads();
                 compute_x(S.y, S.x, true);
                 __syncthreads();
+                stamp(PH_P45);
             }
         }
     }
@@ -865,10 +907,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (status == LSC_STATUS_OK_K) a.cost[qi] = obj;
         a.status[qi] = status;
         a.iters[qi] = iters;
+        if (a.iters_acc) a.iters_acc[qi] += iters;
         if (a.nrows) {
             int tot = 0;
             for (int c = 0; c < NCP; c++) tot += S.cnt[c];
             a.nrows[qi] = tot;
+        }
+        if (a.dbg) { a.dbg[4 * qi] = S.sc[3]; a.dbg[4 * qi + 1] = S.sc[4]; a.dbg[4 * qi + 2] = S.sc[5]; a.dbg[4 * qi + 3] = S.sc[6]; }
+        if constexpr (PROF) {
+            stamp(PH_OUT);
+            if (a.prof)
+                for (int i = 0; i < PH_COUNT; i++) a.prof[(size_t)qi * PH_COUNT + i] += t_acc[i];
         }
     }
 }
@@ -896,12 +945,16 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_plan_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_plan_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_plan_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(lsc_plan_kernel, dim3(a.count), dim3(NT), smem, st, a);
+    if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, a);
+    else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, a);
     return hipGetLastError();
 }
 

@@ -160,6 +160,24 @@ class SwarmPlanner:
         self._check(self.L.lsc_sweep_device(self.ctx, state.data_ptr(), traj_prev.data_ptr(), planner_seq, normal.data_ptr(),
                                             d.data_ptr(), stream))
 
+    PHASES = ("setup", "lsc_build", "ip_init", "residual_pass", "row_reduce", "assemble", "cholesky", "tri_solves",
+              "affine_pass", "corrector_pass", "step_update", "output")
+
+    def phase_profile(self, enable=-1):
+        out = np.zeros((self.N, 12), np.int64)
+        self._check(self.L.lsc_phase_profile(self.ctx, enable, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
+        return out
+
+    def solver_residuals(self):
+        out = np.zeros((self.N, 4))
+        self._check(self.L.lsc_solver_residuals(self.ctx, _dp(out)))
+        return out
+
+    def iterations_total(self, reset=False):
+        t = ctypes.c_longlong()
+        self._check(self.L.lsc_iterations_total(self.ctx, ctypes.byref(t), int(reset)))
+        return t.value
+
     def set_timing(self, on):
         self._check(self.L.lsc_set_timing(self.ctx, int(on)))
 

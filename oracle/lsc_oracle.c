@@ -940,6 +940,14 @@ int orc_qp_solve(const double *P, const double *c, double cst, const double *lo,
         for (int a = 0; a < ny; a++) rhs[a] = -rd[a] - rhs[a];
         chol_solve(K, ny, rhs);
         X_FROM_Y(dy, dx, 0);
+        {
+            /* Newton-step test: with the gap and the primal residual at tolerance, the affine (pure Newton)
+             * step measures the distance to the optimum; the stationarity residual itself can stall at the
+             * round-off level of the ill-conditioned normal equations when z/s is huge. */
+            double dxn = 0, xn = 1.0;
+            for (int i = 0; i < NV; i++) { if (fabs(dx[i]) > dxn) dxn = fabs(dx[i]); if (fabs(xx[i]) > xn) xn = fabs(xx[i]); }
+            if (rpn <= 1e-9 * hmax && gap_ok && dxn <= 1e-9 * xn) { status = 0; break; }
+        }
         double alpha = 1.0;
         for (int r = 0; r < R; r++) {
             double adx = ROWDOT(r, dx);

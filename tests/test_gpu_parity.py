@@ -1,0 +1,144 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle and the committed golden fixtures.
+
+Tolerances (stated once): LSC normals / margins are integer-like geometry -> bit-exact.  QP optimum: the oracle
+and the kernel are two different interior-point codes converging to the same unique optimum, so
+  cost: |dcost| <= 1e-6 * |cost|   (north_star allows 1e-3),   control points: |dx| <= 2e-5 m (float32 storage).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_mission, oracle_swarm
+
+pytestmark = pytest.mark.gpu
+
+COST_RTOL = 1e-6
+TRAJ_ATOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lsc_planner_amd as L
+    L.load_library()          # fails loudly if liblsc_hip.so is missing on a GPU box
+    return L
+
+
+def test_gjk_kernel_bitwise_vs_reference_golden(L, gjk_golden):
+    pl = L.SwarmPlanner(L.circle_swap(4, 1.0))
+    v, d = pl.gjk_batch(gjk_golden["pts"].astype(np.float64))
+    assert np.array_equal(d, gjk_golden["dist"])
+    assert np.array_equal(v, gjk_golden["v"])
+    pl.close()
+
+
+def test_gjk_kernel_bitwise_vs_oracle_random(L, oracle):
+    rng = np.random.default_rng(99)
+    pts = (rng.normal(size=(20000, 6, 3)) * rng.uniform(0.05, 3.0, size=(20000, 1, 1))
+           + rng.normal(size=(20000, 1, 3))).astype(np.float32).astype(np.float64)
+    pl = L.SwarmPlanner(L.circle_swap(4, 1.0))
+    v, d = pl.gjk_batch(pts)
+    for i in range(0, 20000, 7):
+        do, vo, _, _ = oracle.gjk_origin(pts[i])
+        assert do == d[i] and np.array_equal(vo, v[i])
+    pl.close()
+
+
+@pytest.mark.parametrize("name,keep", [("multi_simple4", (1, 2, 3, 20)), ("multi_circle20", (1, 15))])
+@pytest.mark.parametrize("prune", [True, False])
+def test_tick_matches_golden_snapshots(L, ticks, name, keep, prune):
+    ms = golden_mission(ticks, name)
+    for tick in keep:
+        pl = L.SwarmPlanner(ms, L.PlannerConfig(prune=prune))
+        pl.planner_seq = tick - 1
+        g = pl.plan(ticks[f"{name}/tick{tick}/state"], ms.goal, ticks[f"{name}/tick{tick}/prev"], want_constraints=True)
+        assert (g["status"] == 0).all()
+        assert np.array_equal(g["normal"], ticks[f"{name}/tick{tick}/normal"])
+        assert np.array_equal(g["d"], ticks[f"{name}/tick{tick}/d"])
+        ref_cost = ticks[f"{name}/tick{tick}/cost"]
+        assert (np.abs(g["cost"] - ref_cost) <= COST_RTOL * np.abs(ref_cost)).all()
+        assert np.abs(g["traj"] - ticks[f"{name}/tick{tick}/traj"]).max() <= TRAJ_ATOL
+        pl.close()
+
+
+def _run_vs_oracle(L, O, ms, n_ticks, prune=True, every=1):
+    from lsc_planner_amd.planner import next_state_host
+    N = ms.qn
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(prune=prune))
+    sw = oracle_swarm(O, ms)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    for tick in range(1, n_ticks + 1):
+        check = tick % every == 0 or tick <= 2
+        g = pl.plan(state, ms.goal, traj, want_constraints=check)
+        if check:
+            sw.stale[:] = traj
+            o = sw.tick(state, ms.goal, traj, tick, want_lsc=True, nthreads=8)
+            assert np.array_equal(g["normal"], o["normal"]), tick
+            assert np.array_equal(g["d"], o["d"]), tick
+            assert np.array_equal(g["status"], o["status"]), tick
+            ok = o["status"] == 0
+            assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok]).all(), tick
+            assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL, tick
+        traj = g["traj"]
+        state = next_state_host(traj)
+    pl.close()
+
+
+def test_circle20_mission_ticks_vs_oracle(L, oracle):
+    _run_vs_oracle(L, oracle, L.circle_swap(20, 8.0), 40, prune=True, every=4)
+
+
+def test_circle64_headline_config_vs_oracle(L, oracle):
+    """BASELINE configs[2]: the 64-agent circle swap; a few ticks checked against the oracle at full size."""
+    _run_vs_oracle(L, oracle, L.circle_swap(64, 8.0), 24, prune=True, every=8)
+
+
+def test_pruned_and_unpruned_rows_give_the_same_plan(L):
+    """Dropping provably redundant LSC rows must not move the optimum."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(32, 4.0)
+    a, b = L.SwarmPlanner(ms, L.PlannerConfig(prune=True)), L.SwarmPlanner(ms, L.PlannerConfig(prune=False))
+    state = np.zeros((32, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((32, 3, 30), np.float32)
+    for tick in range(1, 31):
+        ga, gb = a.plan(state, ms.goal, traj), b.plan(state, ms.goal, traj)
+        assert (ga["status"] == 0).all() and (gb["status"] == 0).all()
+        assert (np.abs(ga["cost"] - gb["cost"]) <= COST_RTOL * np.abs(gb["cost"])).all()
+        assert np.abs(ga["traj"] - gb["traj"]).max() <= TRAJ_ATOL
+        assert (b.row_counts() == 27 * 31).all() and (a.row_counts() <= 27 * 31).all()
+        traj = gb["traj"]
+        state = next_state_host(traj)
+    assert a.row_counts().mean() < 0.7 * 27 * 31
+    a.close(); b.close()
+
+
+def test_infeasible_qp_keeps_stale_trajectory_like_the_reference(L, oracle):
+    """The scene of log/QPmodel.lp: agent 3's QP is infeasible; the reference swallows the failure and keeps the
+    optimiser's previous trajectory (zeros on the first tick), src/traj_planner.cpp:1553-1584."""
+    import json, os
+    from conftest import GOLDEN
+    sc = json.load(open(os.path.join(GOLDEN, "qpmodel_lp.json")))["scene"]
+    starts = np.array(sc["starts_xy_z07"], np.float32)
+    N = len(starts)
+    goal = starts.copy(); goal[:, :2] *= -0.5
+    ms = L.Mission(starts, goal, np.asarray(sc["world"][:3], np.float32), np.asarray(sc["world"][3:], np.float32),
+                   np.full(N, sc["radius"]), np.full(N, sc["downwash"]), np.tile(sc["max_vel"], (N, 1)).astype(float),
+                   np.tile(sc["max_acc"], (N, 1)).astype(float), np.full(N, sc["nominal_velocity"]))
+    pl = L.SwarmPlanner(ms)
+    sw = oracle_swarm(oracle, ms)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = starts
+    g = pl.plan(state, goal, np.zeros((N, 3, 30), np.float32))
+    o = sw.tick(state, goal, np.zeros((N, 3, 30), np.float32), 1)
+    assert np.array_equal(g["status"], o["status"]) and g["status"][sc["agent"]] == 1
+    bad = g["status"] != 0
+    assert (g["traj"][bad] == 0).all()
+    assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL
+    pl.close()
+
+
+def test_row_capacity_overflow_is_reported_not_hidden(L):
+    ms = L.circle_swap(12, 0.9)          # dense ring: every neighbour is active
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=2, prune=False))
+    state = np.zeros((12, 9), np.float32); state[:, :3] = ms.start
+    g = pl.plan(state, ms.goal, np.zeros((12, 3, 30), np.float32))
+    assert (g["status"] == 3).all()
+    pl.close()

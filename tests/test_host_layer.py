@@ -1,0 +1,159 @@
+"""Host-side logic that needs no GPU: ABI surface, device-GJK header arithmetic on the host, missions, sharding."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from lsc_planner_amd import _lib
+    L = _lib.load_library()                       # loads without a GPU; compute calls are not made here
+    hdr = open(os.path.join(ROOT, "include", "lsc_planner_amd.h")).read()
+    declared = set(re.findall(r"\b(lsc_[a-z_]+)\s*\(", hdr)) - {"lsc_ctx"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name)
+
+
+def test_create_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import lsc_planner_amd as L
+    with pytest.raises(L.LscError):
+        L.SwarmPlanner(L.circle_swap(4, 1.0))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "lsc_planner_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("oracle's", "").lower() or f == "sharded.py" or f == "__init__.py", f
+
+
+def test_device_gjk_header_matches_oracle_on_host(oracle, gjk_golden):
+    so = os.path.join(ROOT, "tests", "native", "libgjk_host_check.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.dirname(so)])
+    H = ctypes.CDLL(so)
+    dp, ip, fp = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)
+    pts = np.ascontiguousarray(gjk_golden["pts"].astype(np.float64))
+    n = len(pts)
+    v = np.zeros((n, 3)); d = np.zeros(n); nv = np.zeros(n, np.int32)
+    H.gjkhdr_batch(pts.ctypes.data_as(dp), n, v.ctypes.data_as(dp), d.ctypes.data_as(dp), nv.ctypes.data_as(ip))
+    assert np.array_equal(d, gjk_golden["dist"]) and np.array_equal(v, gjk_golden["v"]) and np.array_equal(nv, gjk_golden["nvrtx"])
+    rng = np.random.default_rng(2)
+    for t in range(300):
+        a = rng.normal(size=3) * 3
+        init = (a[:, None] + np.outer(rng.normal(size=3), np.linspace(0, 1, 30)) + rng.normal(size=(3, 30)) * 0.02).astype(np.float32)
+        obs = ((a + rng.normal(size=3) * 1.5)[:, None] + np.outer(rng.normal(size=3), np.linspace(0, 1, 30))).astype(np.float32)
+        ra, ro = 0.15, float(np.float32(0.15))
+        dw = (2.0 * ra + 2.0 * ro) / (ra + ro)
+        nrm, dd = oracle.lsc_pair(init, obs, ra, ro, 2.0, 2.0)
+        for m in range(5):
+            pa = np.ascontiguousarray(init[:, m * 6:(m + 1) * 6].T); po = np.ascontiguousarray(obs[:, m * 6:(m + 1) * 6].T)
+            n2 = np.zeros(3, np.float32); d2 = np.zeros(6)
+            H.lschdr_segment(pa.ctypes.data_as(fp), po.ctypes.data_as(fp), ctypes.c_double(dw), ctypes.c_double(ro + ra),
+                             n2.ctypes.data_as(fp), d2.ctypes.data_as(dp))
+            assert np.array_equal(n2, nrm[m]) and np.array_equal(d2, dd[m])
+
+
+def test_mission_loader_and_generators(tmp_path):
+    import json
+    import lsc_planner_amd as L
+    doc = {"quadrotors": {"crazyflie": {"max_vel": [1, 1, 1], "max_acc": [2, 2, 1], "radius": 0.15, "nominal_velocity": 1.0, "downwash": 2.0}},
+           "world": [{"dimension": [-5, -5, 0, 5, 5, 2.5]}],
+           "agents": [{"type": "crazyflie", "cid": 1, "start": [1.0, 0.1, 0.4], "goal": [-1, 0, 0.4]},
+                      {"type": "crazyflie", "cid": 2, "start": [-1, 0, 0.4], "goal": [1, 0, 0.4]}], "obstacles": []}
+    p = tmp_path / "m.json"
+    p.write_text(json.dumps(doc))
+    ms = L.load_mission(str(p))
+    assert ms.qn == 2 and ms.start.dtype == np.float32 and ms.start[0, 1] == np.float32(0.1)
+    assert ms.max_acc[0, 2] == 1.0 and ms.world_max[2] == np.float32(2.5)
+    doc["world"].append(doc["world"][0])
+    p.write_text(json.dumps(doc))
+    with pytest.raises(ValueError):
+        L.load_mission(str(p))
+    c = L.circle_swap(64)
+    assert c.qn == 64 and np.allclose(c.goal[:, :2], -c.start[:, :2]) and (c.goal[:, 2] == 1).all()
+    assert abs(np.linalg.norm(c.start[5, :2]) - 8.0) < 1e-5
+    r1, r2 = L.random_swarm(40, seed=7), L.random_swarm(40, seed=7)
+    assert np.array_equal(r1.start, r2.start) and np.array_equal(r1.goal, r2.goal)
+    q = r1.start.astype(np.float64).copy(); q[:, 2] /= 2
+    D = np.linalg.norm(q[:, None] - q[None], axis=2) + np.eye(40) * 9
+    assert D.min() >= 0.6 - 1e-6
+
+
+def test_shard_bounds_cover_all_agents():
+    from lsc_planner_amd.sharded import shard_bounds
+    for n in (1, 4, 20, 64, 65, 1024):
+        for w in (1, 2, 3, 8):
+            if w > n:
+                continue
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle as O
+import lsc_planner_amd as L
+from lsc_planner_amd.sharded import ShardedSwarm
+from lsc_planner_amd.planner import next_state_host
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[4]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ms = L.circle_swap(5, circle_radius=1.5, world=(-5, -5, 0, 5, 5, 2.5))       # 5 agents over 2 ranks: ragged shards
+prm = O.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+sw = O.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+def tick_fn(state, goal, prev, nxt, seq, first, count):
+    r = sw.tick(state.numpy(), goal.numpy(), prev.numpy().reshape(-1, 3, 30), seq)      # CPU stand-in for the HIP tick
+    nxt[first:first + count] = torch.from_numpy(r["traj"].reshape(-1, 90))[first:first + count]
+def prop_fn(traj, state):
+    state.copy_(torch.from_numpy(next_state_host(traj.numpy())))
+sh = ShardedSwarm(dist, ms.qn, tick_fn, prop_fn)
+state = torch.zeros((ms.qn, 9)); state[:, :3] = torch.from_numpy(ms.start)
+goal = torch.from_numpy(ms.goal)
+a, b = torch.zeros((ms.qn, 90)), torch.zeros((ms.qn, 90))
+for _ in range(4):
+    b.zero_()
+    sh.step(state, goal, a, b)
+    a, b = b, a
+np.save(sys.argv[5] + f"/rank{rank}.npy", a.numpy())
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_stepping_world2_gloo_equals_single_process(oracle, tmp_path):
+    """world_size-2 gloo run of the sharded loop (ragged 3+2 shards) == the unsharded oracle run."""
+    import socket
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import next_state_host
+    from conftest import oracle_swarm
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    w = tmp_path / "worker.py"
+    w.write_text(_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(w), ROOT, str(r), "2", str(port), str(tmp_path)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    ms = L.circle_swap(5, circle_radius=1.5, world=(-5, -5, 0, 5, 5, 2.5))
+    sw = oracle_swarm(oracle, ms)
+    state = np.zeros((5, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((5, 3, 30), np.float32)
+    for tick in range(1, 5):
+        traj = sw.tick(state, ms.goal, traj, tick)["traj"]
+        state = next_state_host(traj)
+    r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(r0, r1)
+    assert np.array_equal(r0.reshape(5, 3, 30), traj)
