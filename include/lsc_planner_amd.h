@@ -144,6 +144,9 @@ int lsc_iterations_total(lsc_ctx *ctx, long long *total, int reset);
  * primal residual, stationarity residual, objective. */
 int lsc_phase_profile(lsc_ctx *ctx, int enable, long long *out);
 int lsc_solver_residuals(lsc_ctx *ctx, double *out);
+/* Reads the [64][8] per-iteration trace recorded for the agent selected by the PREVIOUS call (out may be NULL),
+ * then selects `agent` (-1: off): gap, |rp|, objective, affine step, sigma, step, |dx_aff|, mu. */
+int lsc_solver_trace(lsc_ctx *ctx, int agent, double *out);
 
 #ifdef __cplusplus
 }

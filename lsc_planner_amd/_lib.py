@@ -38,7 +38,7 @@ class LscConfig(ctypes.Structure):
 EXPORTS = [
     "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_propagate_device", "lsc_sweep_device",
-    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals",
+    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace",
 ]
 
 
@@ -78,6 +78,7 @@ def load_library():
     L.lsc_last_row_counts.argtypes = [vp, ip]
     L.lsc_phase_profile.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]
     L.lsc_solver_residuals.argtypes = [vp, dp]
+    L.lsc_solver_trace.argtypes = [vp, ctypes.c_int, dp]
     L.lsc_iterations_total.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
     for name in EXPORTS:
         fn = getattr(L, name)

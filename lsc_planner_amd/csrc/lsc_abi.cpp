@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -124,8 +125,13 @@ void build_model(const lsc_config &cfg, HostModel &H)
                 }
             bool any = false;
             for (auto &kv : acc) if (kv.second != 0) any = true;
-            if (!any && !(k == kk && m.Hc[a * NYA + b] != 0.0)) continue;
-            if (gi - gj > BAND) { std::fprintf(stderr, "lsc: band violated (%d,%d)\n", gi, gj); std::abort(); }
+            const bool structural = any || (k == kk && m.Hc[a * NYA + b] != 0.0);
+            if (gi - gj > BAND) {
+                if (structural) { std::fprintf(stderr, "lsc: band violated (%d,%d)\n", gi, gj); std::abort(); }
+                continue;
+            }
+            // every position of the band gets an entry, also the structurally zero ones: the Cholesky factor is
+            // published in place and fills the band, so each assembly must rewrite all of it
             H.entries.push_back(((uint32_t)gi << 16) | (uint32_t)gj);
             H.entries.push_back((uint32_t)H.terms.size());
             for (auto &kv : acc) {
@@ -143,6 +149,15 @@ void build_model(const lsc_config &cfg, HostModel &H)
     m.use_sfc = cfg.use_octomap;
     m.prune = cfg.prune;
     m.max_iters = cfg.max_iters > 0 ? cfg.max_iters : 50;
+    m.dx_tol = 2e-8;
+    int n = 0;
+    for (int sl = 0; sl < AXROWS; sl++) {
+        const int type = sl / NV, t = (sl % NV) % SEGV, mm = t / NC, i = t % NC;
+        const bool valid = type < 2 ? !(mm == 0 && i < 3) : (type < 4 ? (i <= 4 && !(mm == 0 && i < 2)) : (i <= 3 && !(mm == 0 && i == 0)));
+        if (valid) m.amap[n++] = (unsigned short)sl;
+    }
+    if (n != 414) { std::fprintf(stderr, "lsc: axis row count %d != 414\n", n); std::abort(); }
+    if (const char *e = std::getenv("LSC_DX_TOL")) m.dx_tol = std::atof(e);
 }
 
 }  // namespace
@@ -163,6 +178,8 @@ struct lsc_ctx {
     long long *d_iters_acc = nullptr;
     long long *d_prof = nullptr;
     double *d_dbg = nullptr;
+    double *d_trace = nullptr;
+    int trace_agent = -1;
     bool profiling = false;
     // buffers of the host-pointer tick
     float *d_state = nullptr, *d_goal = nullptr, *d_prev = nullptr, *d_next = nullptr;
@@ -246,6 +263,7 @@ void lsc_destroy(lsc_ctx *c)
 {
     if (!c) return;
     free_agents(c);
+    if (c->d_trace) (void)hipFree(c->d_trace);
     if (c->d_model) (void)hipFree(c->d_model);
     if (c->d_terms) (void)hipFree(c->d_terms);
     if (c->d_entries) (void)hipFree(c->d_entries);
@@ -337,6 +355,7 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.stale = c->d_stale; a.sfc = c->cfg.use_octomap ? c->d_sfc : nullptr;
     a.out_normal = nullptr; a.out_d = nullptr;
     a.dbg = c->d_dbg; a.prof = c->profiling ? c->d_prof : nullptr;
+    a.trace = c->trace_agent >= 0 ? c->d_trace : nullptr; a.trace_agent = c->trace_agent;
     return LSC_OK;
 }
 
@@ -473,6 +492,18 @@ int lsc_phase_profile(lsc_ctx *c, int enable, long long *out)
         c->profiling = enable != 0;
         HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * PROF_PHASES * (size_t)c->N));
     }
+    return LSC_OK;
+}
+
+// per-iteration solver trace of one agent: [64][8] = gap, |rp|, objective, affine step, sigma, step, |dx_aff|, mu
+int lsc_solver_trace(lsc_ctx *c, int agent, double *out)
+{
+    if (!c || c->N == 0) return LSC_EINVAL;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (!c->d_trace) { HIPCHK(c, hipMalloc(&c->d_trace, sizeof(double) * (64 * 8 + 39 * 41 + 450 + 512))); }
+    if (out) HIPCHK(c, hipMemcpy(out, c->d_trace, sizeof(double) * (64 * 8 + 39 * 41 + 450 + 512), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->d_trace, 0, sizeof(double) * (64 * 8 + 39 * 41 + 450 + 512)));
+    c->trace_agent = agent;
     return LSC_OK;
 }
 

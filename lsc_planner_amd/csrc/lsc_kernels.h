@@ -33,6 +33,8 @@ struct PlanArgs {
     double *out_d;             // optional dense dump [count][N-1][M][6]
     double *dbg;               // optional [N][4]: last (gap, |rp|, |rd|, objective) seen by the solver
     long long *prof;           // optional [N][12] phase cycle counters (selects the instrumented kernel)
+    double *trace;             // optional [64][8] per-iteration trace of agent trace_agent (diagnostics)
+    int trace_agent;
 };
 constexpr int PROF_PHASES = 12;
 

@@ -51,6 +51,7 @@ __device__ __forceinline__ double wave_min(double v)
 __device__ __forceinline__ void load_segment(const float *__restrict__ state, const float *__restrict__ traj_prev, int q,
                                              int m, int planner_seq, float dtf, F3 out[6])
 {
+#pragma clang fp contract(off)   // float32 semantics of octomath::Vector3: no fused multiply-add
     if (planner_seq < 2) {
         const float *s = state + 9 * q;
 #pragma unroll
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void lsc_gjk_kernel(const double *__restrict__
 // getStateFromControlPoints at t = dt (include/polynomial.hpp:63-97): segment 1, local time 0.
 __global__ void lsc_propagate_kernel(const float *__restrict__ traj, float *__restrict__ state, int N, float finv)
 {
+#pragma clang fp contract(off)   // the reference evaluates these float32 expressions without fusing
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * 3) return;
     int q = idx / 3, k = idx % 3;
@@ -140,20 +142,22 @@ __global__ void lsc_propagate_kernel(const float *__restrict__ traj, float *__re
 // ---------------------------------------------------------------------------------------------------
 // The per-agent planning kernel
 // ---------------------------------------------------------------------------------------------------
-constexpr int NB = 27;  // control points that carry LSC rows: all but (m=0, i<3)
+constexpr int NB = 27;        // control points that carry LSC rows: all but (m=0, i<3)
+constexpr int AXVALID = 414;  // 162 bound + 138 velocity + 114 acceleration rows (src/traj_optimizer.cpp:274-303, 468-525)
 
 struct Smem {
     // PDIP vectors
     double x[96], dx[96];       // control points (axis-major, 90 used) and their step
-    double gx[96], gz[96];      // x-space gradients: cost + sum a_r v_r ; cost + sum a_r z_r
+    double gx[96];              // x-space gradient: cost + sum a_r v_r
     double y[40], dy[40], rhs[40];
     double W[W_SIZE];           // x-space Hessian weights (see lsc_model.hpp)
-    double Tv[NCP * 3], Tz[NCP * 3];
-    double K[NY * KLD];         // reduced Hessian (lower band), overwritten by its Cholesky factor
-    double red[3][NWAVE];
+    double Tv[NCP * 3];         // per control point: -sum v n over its LSC rows
+    double K[NY * KLD];         // reduced Hessian (lower band); rows of its Cholesky factor after factor()
+    double red[6][NWAVE];
     double sc[8];               // broadcast scalars
     // axis rows: slot = type*90 + k*30 + t ; type 0 x<=hi, 1 -x<=-lo, 2/3 +-velocity, 4/5 +-acceleration
     double as_[AXROWS], az[AXROWS], at1[AXROWS], at2[AXROWS], ah[AXROWS];
+    unsigned short amap[AXVALID + 2];   // valid slots, compact
     unsigned char avalid[AXROWS];
     // agent constants
     double s0[3][3];            // c_{0,0..2} per axis
@@ -161,10 +165,12 @@ struct Smem {
     double goal[3];
     float pinit[NV];            // own initial trajectory (float32)
     int cnt[32];                // rows per control-point bucket
+    int offs[32];               // exclusive prefix of cnt over the 27 buckets
     int wcnt[NWAVE][32];
     int tseg;                   // terminal segments
     int flag;                   // capacity overflow
-    alignas(8) uint32_t dyn[2]; // dynamic part starts here: terms, entry table, kconst, LSC rows
+    int nact;                   // active LSC rows
+    alignas(8) uint32_t dyn[2]; // dynamic part starts here: terms, entry table, kconst, LSC rows, row map
 };
 
 __device__ __forceinline__ double ax_row(const double *x, int type, int k, int t)
@@ -190,33 +196,43 @@ __device__ __forceinline__ double bcast_lane(double v)
     return __hiloint2double(hi, lo);
 }
 
-// Banded Cholesky of the 39x39 matrix in LDS (lower band, leading dimension KLD), executed by wave 0:
-// lane i owns row i in registers; finished columns are published through LDS and re-read as broadcasts.
-template <int J>
-__device__ __forceinline__ void chol_column(double *K, double (&row)[NY], double (&invd)[NY], int lane, bool act, bool &ok)
+// 1/sqrt(d): hardware seed (v_rsq_f64) + two Newton steps -> full double precision, no sqrt / divide sequence
+__device__ __forceinline__ double rsqrt_nr(double d)
 {
-    constexpr int k0 = (J - BAND) > 0 ? (J - BAND) : 0;
-    double acc = row[J];
-    double dj = K[J * KLD + J];
-#pragma unroll
-    for (int k = k0; k < J; k++) {
-        double ljk = K[J * KLD + k];
-        acc -= row[k] * ljk;
-        dj -= ljk * ljk;
-    }
-    if (!(dj > 0.0)) ok = false;
-    double inv = 1.0 / sqrt(dj);
-    invd[J] = inv;
-    double l = acc * inv;
-    if (lane == J) l = dj * inv;
-    if (lane < J) l = 0.0;
-    row[J] = l;
-    if (act && lane >= J) K[lane * KLD + J] = l;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if constexpr (J + 1 < NY) chol_column<J + 1>(K, row, invd, lane, act, ok);
+    double y = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-d * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
 }
 
+template <int J, int K, int K1>
+__device__ __forceinline__ void chol_update(double (&row)[NY], double l)
+{
+    const double lk = bcast_lane<K>(l);
+    row[K] = fma(-l, lk, row[K]);
+    if constexpr (K < K1) chol_update<J, K + 1, K1>(row, l);
+}
+
+// Right-looking banded Cholesky of the 39x39 reduced Hessian, entirely in registers of wave 0: lane i owns row i
+// (column index = register index), the pivot and the column entries travel by v_readlane; only the next column's
+// single update sits on the dependency chain.
+template <int J>
+__device__ __forceinline__ void chol_step(double (&row)[NY], double (&invd)[NY], bool &ok)
+{
+    const double dj = bcast_lane<J>(row[J]);
+    if (!(dj > 0.0)) ok = false;
+    const double inv = rsqrt_nr(dj);
+    invd[J] = inv;
+    const double l = row[J] * inv;      // L[i][J] in lane i (lane J: sqrt(dj))
+    row[J] = l;
+    constexpr int K1 = (J + BAND) < (NY - 1) ? (J + BAND) : (NY - 1);
+    if constexpr (J + 1 <= K1) {
+        chol_update<J, J + 1, K1>(row, l);
+    }
+    if constexpr (J + 1 < NY) chol_step<J + 1>(row, invd, ok);
+}
 template <int J>
 __device__ __forceinline__ void fwd_step(const double (&row)[NY], const double (&invd)[NY], double &b, int lane)
 {
@@ -268,10 +284,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     uint32_t *terms = S.dyn;                                        // [n_terms]
     uint32_t *ent = terms + ((n_terms + 1) & ~1);                   // [n_entries+1][2] : (gi<<16|gj), first term
     double *kconst = reinterpret_cast<double *>(ent + 2 * n_entries + 2);
-    double *rrhs = kconst + n_entries;
-    double *rs = rrhs + R, *rz = rs + R, *rt1 = rz + R, *rt2 = rt1 + R;
-    float *rn = reinterpret_cast<float *>(rt2 + R);                 // [3][R]
-    unsigned char *rcp = reinterpret_cast<unsigned char *>(rn + 3 * R);  // control point of the row, 255 = empty
+    double *__restrict__ rrhs = kconst + n_entries;
+    double *__restrict__ rs = rrhs + R;
+    double *__restrict__ rz = rs + R;
+    double *__restrict__ rt1 = rz + R;
+    double *__restrict__ rt2 = rt1 + R;
+    float *__restrict__ rn = reinterpret_cast<float *>(rt2 + R);     // [3][R]
+    uint32_t *__restrict__ cmap = reinterpret_cast<uint32_t *>(rn + 3 * R);  // compact row map: slot | cp << 16
+    unsigned char *rcp = reinterpret_cast<unsigned char *>(cmap + R);        // control point of a slot, 255 = empty
 
     // ------------------------------------------------------------------ phase A: agent constants
     for (int i = tid; i < n_terms; i += NT) terms[i] = a.terms[i];
@@ -281,6 +301,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (tid == 0) S.flag = 0;
     const float dtf = (float)md.dt;
     if (tid < NV) {
+#pragma clang fp contract(off)
         const int k = tid / SEGV, c = tid % SEGV, m = c / NC, i = c % NC;
         float val;
         if (a.planner_seq < 2) {
@@ -312,6 +333,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
     }
     if (tid == 0) {
+#pragma clang fp contract(off)
         // getTerminalSegments (src/traj_optimizer.cpp:541-548), float32 norm like octomath
         const float *s = a.state + 9 * qi;
         const float *g = a.goal + 3 * qi;
@@ -321,11 +343,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         int T = (int)((M * md.dt - flight + 1e-9) / md.dt);
         S.tseg = T > 1 ? T : 1;
     }
+    for (int i = tid; i < AXVALID; i += NT) S.amap[i] = md.amap[i];
     // per-lane constants kept in registers for the whole solve
     int xk = 0, xt = 0, xn = 0, xg0 = 0, xg1 = 0, xg2 = 0;     // lanes < 90: x_t = sum xc*y[xg]
     double xc0 = 0, xc1 = 0, xc2 = 0, qr[NC] = {0, 0, 0, 0, 0, 0};
-    if (tid < NV) {
-        xk = tid / SEGV; xt = tid % SEGV;
+    const int vq = tid < NV ? tid : (tid >= NT - NV ? tid - (NT - NV) : -1);  // lanes 0..89 (x / objective) and 166..255 (row gather)
+    if (vq >= 0) {
+        xk = vq / SEGV; xt = vq % SEGV;
         xn = md.x_n[xt];
         xg0 = yglob(xk, md.x_i[xt][0]); xg1 = yglob(xk, md.x_i[xt][1]); xg2 = yglob(xk, md.x_i[xt][2]);
         xc0 = md.x_c[xt][0]; xc1 = md.x_c[xt][1]; xc2 = md.x_c[xt][2];
@@ -366,8 +390,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
         kconst[e] = v;
     }
-
     stamp(PH_SETUP);
+
     // ------------------------------------------------------------------ phase B: LSC rows
     // unit = (obstacle oi, segment m); rows that cannot be active inside the reachable box are dropped
     // (redundant constraints: removing them does not change the feasible set, hence not the optimum).
@@ -465,6 +489,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
     }
     if (tid < NCP && S.cnt[tid] > CAP) S.cnt[tid] = CAP;
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0;
+        for (int b = 0; b < NB; b++) { S.offs[b] = o; o += S.cnt[b + 3]; }
+        S.nact = o;
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += NT) {
+        const int cp = rcp[r];
+        if (cp == 255) continue;
+        const int b = cp - 3;
+        cmap[S.offs[b] + (r - b * CS)] = (uint32_t)r | ((uint32_t)cp << 16);
+    }
     stamp(PH_LSC);
 
     // ------------------------------------------------------------------ phase C: interior point
@@ -481,10 +518,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     if (tid < 40) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
     for (int i = tid; i < NY * KLD; i += NT) S.K[i] = 0.0;
-    for (int i = tid; i < NCP * 3; i += NT) { S.Tv[i] = 0.0; S.Tz[i] = 0.0; }
+    for (int i = tid; i < NCP * 3; i += NT) S.Tv[i] = 0.0;
     for (int i = tid; i < W_SIZE; i += NT) S.W[i] = 0.0;
     __syncthreads();
     const bool overflow = S.flag != 0;
+    const int nact = S.nact;
+    const double nrow = (double)(AXVALID + nact);
 
     // x from y : x_t = sum coef * y_glob  (+ state constants for t < 3)
     auto compute_x = [&](const double *yv, double *xv, bool with_const) {
@@ -495,7 +534,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             xv[tid] = v;
         }
     };
-    // cost gradient in x-space for this lane's variable: 2 w_c Q x within the segment + terminal term
+    // cost gradient in x-space for this lane's variable: 2 w_c Q x within the segment (terminal term added by caller)
     auto cost_grad = [&]() -> double {
         const double *xs = S.x + xk * SEGV + (xt / NC) * NC;
         double g = 0.0;
@@ -503,29 +542,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int j = 0; j < NC; j++) g += qr[j] * xs[j];
         return g;
     };
-    // block reductions: op 0 sum, 1 max, 2 min ; results in S.sc[0..2]
-    auto block_reduce3 = [&](double v0, double v1, double v2, int op0, int op1, int op2) {
-        double r0 = op0 == 0 ? wave_sum(v0) : (op0 == 1 ? wave_max(v0) : wave_min(v0));
-        double r1 = op1 == 0 ? wave_sum(v1) : (op1 == 1 ? wave_max(v1) : wave_min(v1));
-        double r2 = op2 == 0 ? wave_sum(v2) : (op2 == 1 ? wave_max(v2) : wave_min(v2));
-        if (lane == 0) { S.red[0][wave] = r0; S.red[1][wave] = r1; S.red[2][wave] = r2; }
+    // block reduction of up to 6 values: op 0 sum, 1 max, 2 min ; results in S.sc[0..5]
+    auto block_reduce = [&](double v0, double v1, double v2, double v3, double v4, int op0, int op1, int op2, int op3, int op4) {
+        auto wr = [&](double v, int op) { return op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v)); };
+        double r0 = wr(v0, op0), r1 = wr(v1, op1), r2 = wr(v2, op2), r3 = wr(v3, op3), r4 = wr(v4, op4);
+        if (lane == 0) { S.red[0][wave] = r0; S.red[1][wave] = r1; S.red[2][wave] = r2; S.red[3][wave] = r3; S.red[4][wave] = r4; }
         __syncthreads();
-        if (tid == 0) {
-            double t0 = S.red[0][0], t1 = S.red[1][0], t2 = S.red[2][0];
-            for (int w = 1; w < NWAVE; w++) {
-                t0 = op0 == 0 ? t0 + S.red[0][w] : (op0 == 1 ? fmax(t0, S.red[0][w]) : fmin(t0, S.red[0][w]));
-                t1 = op1 == 0 ? t1 + S.red[1][w] : (op1 == 1 ? fmax(t1, S.red[1][w]) : fmin(t1, S.red[1][w]));
-                t2 = op2 == 0 ? t2 + S.red[2][w] : (op2 == 1 ? fmax(t2, S.red[2][w]) : fmin(t2, S.red[2][w]));
-            }
-            S.sc[0] = t0; S.sc[1] = t1; S.sc[2] = t2;
+        if (tid < 5) {
+            const int op = tid == 0 ? op0 : (tid == 1 ? op1 : (tid == 2 ? op2 : (tid == 3 ? op3 : op4)));
+            double t = S.red[tid][0];
+            for (int w = 1; w < NWAVE; w++) t = op == 0 ? t + S.red[tid][w] : (op == 1 ? fmax(t, S.red[tid][w]) : fmin(t, S.red[tid][w]));
+            S.sc[tid] = t;
         }
         __syncthreads();
     };
 
     // Reduction of the per-row values (w = z*t1 or 1, v = t2) into x-space weights and gradients.
+    // Axis rows are gathered by the last 90 lanes, LSC buckets by units (bucket, component) from lane 0 up.
     auto reduce_rows = [&](bool with_w, bool unit_w) {
-        if (tid < NV) {
-            const int k = xk, t = xt, i = t % NC;
+        if (tid >= NT - NV) {
+            const int q = tid - (NT - NV);
+            const int k = q / SEGV, t = q % SEGV, i = t % NC;
             const int b = k * SEGV + t;
             auto wof = [&](int type, int tt) -> double {
                 int sl = type * NV + k * SEGV + tt;
@@ -533,26 +570,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 return unit_w ? 1.0 : S.az[sl] * S.at1[sl];
             };
             auto vof = [&](int type, int tt) -> double { int sl = type * NV + k * SEGV + tt; return S.avalid[sl] ? S.at2[sl] : 0.0; };
-            auto zof = [&](int type, int tt) -> double { int sl = type * NV + k * SEGV + tt; return S.avalid[sl] ? S.az[sl] : 0.0; };
-            double g = 0.0, gzv = 0.0;
+            double g = 0.0;
             g += vof(0, t) - vof(1, t);
-            gzv += zof(0, t) - zof(1, t);
             g += -vof(2, t) + vof(3, t);
-            gzv += -zof(2, t) + zof(3, t);
             g += vof(4, t) - vof(5, t);
-            gzv += zof(4, t) - zof(5, t);
-            if (i >= 1) {
-                g += vof(2, t - 1) - vof(3, t - 1) - 2.0 * (vof(4, t - 1) - vof(5, t - 1));
-                gzv += zof(2, t - 1) - zof(3, t - 1) - 2.0 * (zof(4, t - 1) - zof(5, t - 1));
-            }
-            if (i >= 2) {
-                g += vof(4, t - 2) - vof(5, t - 2);
-                gzv += zof(4, t - 2) - zof(5, t - 2);
-            }
-            double cg = cost_grad();
-            if (xterm) cg += 2.0 * md.w_t * (S.x[b] - S.goal[k]);
+            if (i >= 1) g += vof(2, t - 1) - vof(3, t - 1) - 2.0 * (vof(4, t - 1) - vof(5, t - 1));
+            if (i >= 2) g += vof(4, t - 2) - vof(5, t - 2);
+            double cg = cost_grad();   // this lane's (xk, xt) equal (k, t)
+            if (i == DEG && t / NC >= M - S.tseg) cg += 2.0 * md.w_t * (S.x[b] - S.goal[k]);
             S.gx[b] = cg + g;
-            S.gz[b] = cg + gzv;
             if (with_w) {
                 double wB = wof(0, t) + wof(1, t);
                 double wV0 = wof(2, t) + wof(3, t);
@@ -565,34 +591,47 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 S.W[W_2 + b] = wA0;
             }
         }
-        // LSC buckets: unit (bucket, c): c 0..5 -> sum w n n^T, 6..8 -> -sum v n, 9..11 -> -sum z n  (a_r = -n)
-        for (int u = tid; u < NB * 12; u += NT) {
-            const int bkt = u / 12, c = u % 12, cp = bkt + 3;
+        // LSC buckets: unit (bucket, c): c 0..5 -> sum w n n^T, 6..8 -> -sum v n   (row vector a_r = -n)
+        const int nunits = with_w ? NB * 9 : NB * 3;
+        if (tid < nunits) {
+            const int bkt = with_w ? tid / 9 : tid / 3, c = with_w ? tid % 9 : 6 + tid % 3, cp = bkt + 3;
             const int cnt = S.cnt[cp];
-            if (c < 6 && !with_w) continue;
-            double acc = 0.0;
             const int r0 = bkt * CS;
-            int ia = 0, ib = 0;
-            if (c < 6) { ia = c < 3 ? 0 : (c < 5 ? 1 : 2); ib = c < 3 ? c : (c < 5 ? c - 2 : 2); }
-            const float *na = rn + ia * R + r0, *nb = rn + ib * R + r0, *nc = rn + ((c >= 9 ? c - 9 : (c >= 6 ? c - 6 : 0))) * R + r0;
+            double acc0 = 0.0, acc1 = 0.0;
             if (c < 6) {
-                for (int j = 0; j < cnt; j++) {
-                    double w = unit_w ? 1.0 : rz[r0 + j] * rt1[r0 + j];
-                    acc += w * (double)na[j] * (double)nb[j];
+                const int ia = c < 3 ? 0 : (c < 5 ? 1 : 2), ib = c < 3 ? c : (c < 5 ? c - 2 : 2);
+                const float *na = rn + ia * R + r0, *nb = rn + ib * R + r0;
+                const double *pz = rz + r0, *pi = rt1 + r0;
+                int j = 0;
+                for (; j + 4 <= cnt; j += 4) {
+                    double z0 = pz[j], z1 = pz[j + 1], z2 = pz[j + 2], z3 = pz[j + 3];
+                    double i0 = pi[j], i1 = pi[j + 1], i2 = pi[j + 2], i3 = pi[j + 3];
+                    double a0 = (double)na[j] * (double)nb[j], a1 = (double)na[j + 1] * (double)nb[j + 1];
+                    double a2 = (double)na[j + 2] * (double)nb[j + 2], a3 = (double)na[j + 3] * (double)nb[j + 3];
+                    if (unit_w) { acc0 += a0 + a2; acc1 += a1 + a3; }
+                    else { acc0 += z0 * i0 * a0 + z2 * i2 * a2; acc1 += z1 * i1 * a1 + z3 * i3 * a3; }
                 }
-                S.W[W_S + cp * 6 + c] = acc;
-            } else if (c < 9) {
-                for (int j = 0; j < cnt; j++) acc += rt2[r0 + j] * (double)nc[j];
-                S.Tv[cp * 3 + (c - 6)] = -acc;
+                for (; j < cnt; j++) {
+                    double w = unit_w ? 1.0 : pz[j] * pi[j];
+                    acc0 += w * (double)na[j] * (double)nb[j];
+                }
+                S.W[W_S + cp * 6 + c] = acc0 + acc1;
             } else {
-                for (int j = 0; j < cnt; j++) acc += rz[r0 + j] * (double)nc[j];
-                S.Tz[cp * 3 + (c - 9)] = -acc;
+                const float *nc = rn + (c - 6) * R + r0;
+                const double *pv = rt2 + r0;
+                int j = 0;
+                for (; j + 4 <= cnt; j += 4) {
+                    acc0 += pv[j] * (double)nc[j] + pv[j + 2] * (double)nc[j + 2];
+                    acc1 += pv[j + 1] * (double)nc[j + 1] + pv[j + 3] * (double)nc[j + 3];
+                }
+                for (; j < cnt; j++) acc0 += pv[j] * (double)nc[j];
+                S.Tv[cp * 3 + (c - 6)] = -(acc0 + acc1);
             }
         }
         __syncthreads();
     };
 
-    // K (lower band) from W ;  rhs = -Z^T (gx + Tv) ;  stationarity residual Z^T (gz + Tz) -> S.dy (scratch)
+    // K (lower band) from W ;  rhs = -Z^T (gx + Tv)
     auto assemble = [&](bool with_k) {
         if (with_k) {
             for (int e = tid; e < n_entries; e += NT) {
@@ -608,10 +647,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (tid < NY) {
             double r = yc0 * (S.gx[yo0] + S.Tv[yp0]) + yc1 * (S.gx[yo1] + S.Tv[yp1]) + yc2 * (S.gx[yo2] + S.Tv[yp2]) +
                        yc3 * (S.gx[yo3] + S.Tv[yp3]);
-            double rd = yc0 * (S.gz[yo0] + S.Tz[yp0]) + yc1 * (S.gz[yo1] + S.Tz[yp1]) + yc2 * (S.gz[yo2] + S.Tz[yp2]) +
-                        yc3 * (S.gz[yo3] + S.Tz[yp3]);
             S.rhs[tid] = -r;
-            S.dy[tid] = rd;
         }
         __syncthreads();
     };
@@ -624,10 +660,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (wave == 0) {
             const bool act = lane < NY;
 #pragma unroll
-            for (int j = 0; j < NY; j++) lrow[j] = (act && j <= lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
+            for (int j = 0; j < NY; j++) {
+                lrow[j] = (act && j <= lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
+            }
+            // (updates run on whole register rows; only the part left of the diagonal is meaningful afterwards)
             bool ok = true;
-            chol_column<0>(S.K, lrow, linvd, lane, act, ok);
-            // column of L owned by this lane (L[i][lane], i >= lane) for the backward sweep
+            chol_step<0>(lrow, linvd, ok);
+            // publish the factor rows, then gather the column owned by this lane for the backward sweep
+#pragma unroll
+            for (int j = 0; j < NY; j++)
+                if (act && j <= lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < NY; i++) lcol[i] = (act && i >= lane && i - lane <= BAND) ? S.K[i * KLD + lane] : 0.0;
             if (lane == 0) S.sc[7] = ok ? 1.0 : 0.0;
@@ -661,14 +705,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // ---------------- initial point: (H + A^T A) y = -grad(x0) + A^T (h - A x0)
         compute_x(S.y, S.x, true);
         __syncthreads();
-        for (int sl = tid; sl < AXROWS; sl += NT) {
-            if (!S.avalid[sl]) continue;
-            const int type = sl / NV, kt = sl % NV;
+        for (int c = tid; c < AXVALID; c += NT) {
+            const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
             S.at2[sl] = ax_row(S.x, type, kt / SEGV, kt % SEGV) - S.ah[sl];
         }
-        for (int r = tid; r < R; r += NT) {
-            const int cp = rcp[r];
-            if (cp == 255) continue;
+        for (int c = tid; c < nact; c += NT) {
+            const uint32_t e = cmap[c];
+            const int r = e & 0xffff, cp = e >> 16;
             rt2[r] = lsc_ax(S.x, r, cp) + rrhs[r];
         }
         __syncthreads();
@@ -681,59 +724,57 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             compute_x(S.y, S.x, true);
             __syncthreads();
             double mins = 1e300, minz = 1e300;
-            for (int sl = tid; sl < AXROWS; sl += NT) {
-                if (!S.avalid[sl]) continue;
-                const int type = sl / NV, kt = sl % NV;
+            for (int c = tid; c < AXVALID; c += NT) {
+                const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
                 double sv = S.ah[sl] - ax_row(S.x, type, kt / SEGV, kt % SEGV);
                 S.as_[sl] = sv; S.az[sl] = -sv;
                 mins = fmin(mins, sv); minz = fmin(minz, -sv);
             }
-            for (int r = tid; r < R; r += NT) {
-                const int cp = rcp[r];
-                if (cp == 255) continue;
+            for (int c = tid; c < nact; c += NT) {
+                const uint32_t e = cmap[c];
+                const int r = e & 0xffff, cp = e >> 16;
                 double sv = -rrhs[r] - lsc_ax(S.x, r, cp);
                 rs[r] = sv; rz[r] = -sv;
                 mins = fmin(mins, sv); minz = fmin(minz, -sv);
             }
-            block_reduce3(mins, minz, 0.0, 2, 2, 0);
+            block_reduce(mins, minz, 0.0, 0.0, 0.0, 2, 2, 0, 0, 0);
             const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0;
             const double shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
-            for (int sl = tid; sl < AXROWS; sl += NT) {
-                if (!S.avalid[sl]) continue;
-                S.as_[sl] += shs; S.az[sl] += shz;
-            }
-            for (int r = tid; r < R; r += NT) {
-                if (rcp[r] == 255) continue;
-                rs[r] += shs; rz[r] += shz;
-            }
+            // the shifted point enters the loop as a "step" of length 1 from (s - shs, z - shz): the first fused
+            // update/residual pass then applies it (t1 = ds, t2 = dz)
+            for (int c = tid; c < AXVALID; c += NT) { const int sl = S.amap[c]; S.at1[sl] = shs; S.at2[sl] = shz; }
+            for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & 0xffff; rt1[r] = shs; rt2[r] = shz; }
             __syncthreads();
-
             stamp(PH_INIT);
+
             // ---------------- Mehrotra predictor-corrector iterations
             const int max_iters = md.max_iters;
             const double hmax = fmax(1.0, fmax(fabs((double)md.world_max[0]), fabs((double)md.world_min[0])));
+            double alpha = 1.0;
             for (iters = 0; iters < max_iters; iters++) {
-                // P1: residuals, 1/s, v = w rp
-                double gap = 0.0, rpmax = 0.0, nrow = 0.0;
-                for (int sl = tid; sl < AXROWS; sl += NT) {
-                    if (!S.avalid[sl]) continue;
-                    const int type = sl / NV, kt = sl % NV;
-                    double sv = S.as_[sl], zv = S.az[sl];
+                // P1 (fused with the previous iteration's update): s += alpha ds, z += alpha dz, then residuals,
+                // 1/s and v = w rp at the new point
+                double gap = 0.0, rpmax = 0.0;
+                for (int c = tid; c < AXVALID; c += NT) {
+                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
+                    double sv = S.as_[sl] + alpha * S.at1[sl], zv = S.az[sl] + alpha * S.at2[sl];
                     double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - S.ah[sl];
                     double is = 1.0 / sv;
+                    S.as_[sl] = sv; S.az[sl] = zv;
                     S.at1[sl] = is;
                     S.at2[sl] = zv * is * rp;
-                    gap += sv * zv; rpmax = fmax(rpmax, fabs(rp)); nrow += 1.0;
+                    gap += sv * zv; rpmax = fmax(rpmax, fabs(rp));
                 }
-                for (int r = tid; r < R; r += NT) {
-                    const int cp = rcp[r];
-                    if (cp == 255) continue;
-                    double sv = rs[r], zv = rz[r];
+                for (int c = tid; c < nact; c += NT) {
+                    const uint32_t e = cmap[c];
+                    const int r = e & 0xffff, cp = e >> 16;
+                    double sv = rs[r] + alpha * rt1[r], zv = rz[r] + alpha * rt2[r];
                     double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
                     double is = 1.0 / sv;
+                    rs[r] = sv; rz[r] = zv;
                     rt1[r] = is;
                     rt2[r] = zv * is * rp;
-                    gap += sv * zv; rpmax = fmax(rpmax, fabs(rp)); nrow += 1.0;
+                    gap += sv * zv; rpmax = fmax(rpmax, fabs(rp));
                 }
                 // objective: sum x'(w_c Q)x + w_t sum |c - g|^2  (src/traj_optimizer.cpp:329-372)
                 double objp = 0.0;
@@ -741,48 +782,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     objp = 0.5 * cost_grad() * S.x[tid];
                     if (xterm) { double e = S.x[tid] - S.goal[xk]; objp += md.w_t * e * e; }
                 }
-                block_reduce3(gap, rpmax, nrow, 0, 1, 0);
-                gap = S.sc[0]; rpmax = S.sc[1]; nrow = S.sc[2];
-                block_reduce3(objp, 0.0, 0.0, 0, 0, 0);
-                obj = S.sc[0];
+                block_reduce(gap, rpmax, objp, 0.0, 0.0, 0, 1, 0, 0, 0);
+                gap = S.sc[0]; rpmax = S.sc[1]; obj = S.sc[2];
                 const double mu = gap / nrow;
+                if (tid == 0) { S.sc[5] = gap; S.sc[6] = rpmax; }
                 stamp(PH_P1);
+                if (!(gap == gap) || !(rpmax == rpmax)) break;
 
                 reduce_rows(true, false);
                 stamp(PH_REDUCE);
                 assemble(true);
                 stamp(PH_ASSEMBLE);
-                double rdn = (tid < NY) ? fabs(S.dy[tid]) : 0.0;
-                block_reduce3(rdn, 0.0, 0.0, 1, 0, 0);
-                rdn = S.sc[0];
-                if (tid == 0) { S.sc[3] = gap; S.sc[4] = rpmax; S.sc[5] = rdn; S.sc[6] = obj; }
                 const bool gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
-                if (rpmax <= 1e-9 * hmax && rdn <= 1e-5 * (1.0 + fabs(obj)) && gap_ok) { status = LSC_STATUS_OK_K; break; }
-                if (!(gap == gap) || !(rpmax == rpmax)) break;
-
                 const bool fok = factor();
                 stamp(PH_FACTOR);
                 if (!fok) {
+                    if (a.trace && qi == a.trace_agent) {
+                        // K's band in LDS is stale only where the factor was published: dump W/kconst-based K again
+                        assemble(true);
+                        for (int i = tid; i < NY * KLD; i += NT) a.trace[512 + i] = S.K[i];
+                        for (int i = tid; i < W_SIZE; i += NT) a.trace[512 + NY * KLD + i] = S.W[i];
+                        for (int i = tid; i < n_entries; i += NT) a.trace[512 + NY * KLD + W_SIZE + i] = kconst[i];
+                    }
+                    if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) { double *tr = a.trace + iters * 8; tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = -1; tr[4] = S.sc[5]; tr[5] = -1; tr[6] = 0; tr[7] = mu; }
                     // K lost definiteness to round-off: accept only if already within 1e-7 relative gap
                     if (rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) status = LSC_STATUS_OK_K;
                     break;
                 }
                 solve();  // affine direction in dy / dx
                 stamp(PH_SOLVE);
-                {
-                    // Newton-step test: with gap and primal residual at tolerance, the affine (pure Newton) step
-                    // measures the distance to the optimum; the stationarity residual can stall at the round-off
-                    // level of the ill-conditioned normal equations when z/s is huge.
-                    double dxa = (tid < NV) ? fabs(S.dx[tid]) : 0.0, xa = (tid < NV) ? fabs(S.x[tid]) : 0.0;
-                    block_reduce3(dxa, xa, 0.0, 1, 1, 0);
-                    if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-9 * fmax(1.0, S.sc[1])) { status = LSC_STATUS_OK_K; break; }
-                }
 
-                // P2: affine step length and centring statistics
+                // P2: affine step length and centring statistics (+ the Newton-step convergence test)
                 double amin = 1.0, s1 = 0.0, s2 = 0.0;
-                for (int sl = tid; sl < AXROWS; sl += NT) {
-                    if (!S.avalid[sl]) continue;
-                    const int type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
+                for (int c = tid; c < AXVALID; c += NT) {
+                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
                     double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
                     double rp = ax_row(S.x, type, k, t) + sv - S.ah[sl];
                     double adx = ax_row(S.dx, type, k, t);
@@ -792,9 +825,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     s1 += sv * dz + zv * ds; s2 += ds * dz;
                     S.at2[sl] = ds * dz;
                 }
-                for (int r = tid; r < R; r += NT) {
-                    const int cp = rcp[r];
-                    if (cp == 255) continue;
+                for (int c = tid; c < nact; c += NT) {
+                    const uint32_t e = cmap[c];
+                    const int r = e & 0xffff, cp = e >> 16;
                     double sv = rs[r], zv = rz[r], w = zv * rt1[r];
                     double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
                     double adx = lsc_ax(S.dx, r, cp);
@@ -804,8 +837,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     s1 += sv * dz + zv * ds; s2 += ds * dz;
                     rt2[r] = ds * dz;
                 }
-                block_reduce3(amin, s1, s2, 2, 0, 0);
+                const double dxa = (tid < NV) ? fabs(S.dx[tid]) : 0.0, xa = (tid < NV) ? fabs(S.x[tid]) : 0.0;
+                block_reduce(amin, s1, s2, dxa, xa, 2, 0, 0, 1, 1);
+                // Newton-step test: with gap and primal residual at tolerance, the affine (pure Newton) step
+                // measures the distance to the optimum (the stationarity residual itself can stall at the
+                // round-off level of the ill-conditioned normal equations when z/s is huge).
+                if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[3] <= md.dx_tol * fmax(1.0, S.sc[4])) { status = LSC_STATUS_OK_K; break; }
                 const double aaff = S.sc[0];
+                const double dxn_dbg = S.sc[3];
                 const double mu_aff = (gap + aaff * S.sc[1] + aaff * aaff * S.sc[2]) / nrow;
                 double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
                 sigma = sigma * sigma * sigma;
@@ -813,16 +852,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 stamp(PH_P2);
 
                 // P3: corrector right-hand side  v = w rp - (ds dz - sigma mu)/s
-                for (int sl = tid; sl < AXROWS; sl += NT) {
-                    if (!S.avalid[sl]) continue;
-                    const int type = sl / NV, kt = sl % NV;
+                for (int c = tid; c < AXVALID; c += NT) {
+                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
                     double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl];
                     double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - S.ah[sl];
                     S.at2[sl] = zv * is * rp - (S.at2[sl] - smu) * is;
                 }
-                for (int r = tid; r < R; r += NT) {
-                    const int cp = rcp[r];
-                    if (cp == 255) continue;
+                for (int c = tid; c < nact; c += NT) {
+                    const uint32_t e = cmap[c];
+                    const int r = e & 0xffff, cp = e >> 16;
                     double sv = rs[r], zv = rz[r], is = rt1[r];
                     double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
                     rt2[r] = zv * is * rp - (rt2[r] - smu) * is;
@@ -836,51 +874,35 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 solve();  // combined direction
                 stamp(PH_SOLVE);
 
-                // P4: step length (ds = -rp - a.dx ; dz = -z + v + w a.dx)
+                // P4: step length; the step itself is left in t1 = ds, t2 = dz for the fused pass of the next round
                 amin = 1e300;
-                for (int sl = tid; sl < AXROWS; sl += NT) {
-                    if (!S.avalid[sl]) continue;
-                    const int type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
+                for (int c = tid; c < AXVALID; c += NT) {
+                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
                     double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
                     double rp = ax_row(S.x, type, k, t) + sv - S.ah[sl];
                     double adx = ax_row(S.dx, type, k, t);
                     double ds = -rp - adx, dz = -zv + S.at2[sl] + w * adx;
                     if (ds < 0.0) amin = fmin(amin, -sv / ds);
                     if (dz < 0.0) amin = fmin(amin, -zv / dz);
+                    S.at1[sl] = ds; S.at2[sl] = dz;
                 }
-                for (int r = tid; r < R; r += NT) {
-                    const int cp = rcp[r];
-                    if (cp == 255) continue;
+                for (int c = tid; c < nact; c += NT) {
+                    const uint32_t e = cmap[c];
+                    const int r = e & 0xffff, cp = e >> 16;
                     double sv = rs[r], zv = rz[r], w = zv * rt1[r];
                     double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
                     double adx = lsc_ax(S.dx, r, cp);
                     double ds = -rp - adx, dz = -zv + rt2[r] + w * adx;
                     if (ds < 0.0) amin = fmin(amin, -sv / ds);
                     if (dz < 0.0) amin = fmin(amin, -zv / dz);
+                    rt1[r] = ds; rt2[r] = dz;
                 }
-                block_reduce3(amin, 0.0, 0.0, 2, 0, 0);
-                const double alpha = fmin(1.0, 0.99 * S.sc[0]);
-
-                // P5: update (recomputes ds, dz; nothing else is stored per row)
-                for (int sl = tid; sl < AXROWS; sl += NT) {
-                    if (!S.avalid[sl]) continue;
-                    const int type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
-                    double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
-                    double rp = ax_row(S.x, type, k, t) + sv - S.ah[sl];
-                    double adx = ax_row(S.dx, type, k, t);
-                    double ds = -rp - adx, dz = -zv + S.at2[sl] + w * adx;
-                    S.as_[sl] = sv + alpha * ds; S.az[sl] = zv + alpha * dz;
+                block_reduce(amin, 0.0, 0.0, 0.0, 0.0, 2, 0, 0, 0, 0);
+                alpha = fmin(1.0, 0.99 * S.sc[0]);
+                if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) {
+                    double *tr = a.trace + iters * 8;
+                    tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = aaff; tr[4] = sigma; tr[5] = alpha; tr[6] = dxn_dbg; tr[7] = mu;
                 }
-                for (int r = tid; r < R; r += NT) {
-                    const int cp = rcp[r];
-                    if (cp == 255) continue;
-                    double sv = rs[r], zv = rz[r], w = zv * rt1[r];
-                    double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
-                    double adx = lsc_ax(S.dx, r, cp);
-                    double ds = -rp - adx, dz = -zv + rt2[r] + w * adx;
-                    rs[r] = sv + alpha * ds; rz[r] = zv + alpha * dz;
-                }
-                __syncthreads();
                 if (tid < NY) S.y[tid] += alpha * S.dy[tid];
                 __syncthreads();
                 compute_x(S.y, S.x, true);
@@ -908,12 +930,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         a.status[qi] = status;
         a.iters[qi] = iters;
         if (a.iters_acc) a.iters_acc[qi] += iters;
-        if (a.nrows) {
-            int tot = 0;
-            for (int c = 0; c < NCP; c++) tot += S.cnt[c];
-            a.nrows[qi] = tot;
-        }
-        if (a.dbg) { a.dbg[4 * qi] = S.sc[3]; a.dbg[4 * qi + 1] = S.sc[4]; a.dbg[4 * qi + 2] = S.sc[5]; a.dbg[4 * qi + 3] = S.sc[6]; }
+        if (a.nrows) a.nrows[qi] = S.nact;
+        if (a.dbg) { a.dbg[4 * qi] = S.sc[5]; a.dbg[4 * qi + 1] = S.sc[6]; a.dbg[4 * qi + 2] = S.sc[3]; a.dbg[4 * qi + 3] = obj; }
         if constexpr (PROF) {
             stamp(PH_OUT);
             if (a.prof)
@@ -937,7 +955,7 @@ size_t plan_smem_bytes(int n_terms, int n_entries, int cap)
     b += sizeof(double) * (size_t)n_entries;
     const int cs = (cap & 1) ? cap : cap + 1;
     size_t R = (size_t)NB * cs;
-    b += R * (5 * sizeof(double) + 3 * sizeof(float) + 1);
+    b += R * (5 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t) + 1);
     return (b + 15) & ~(size_t)15;
 }
 

@@ -46,6 +46,8 @@ struct Model {
     int    n_terms;
     float  world_min[3], world_max[3];
     int    use_sfc, prune, max_iters, cap;
+    double dx_tol;            // Newton-step convergence tolerance (relative to max(1, |x|_inf))
+    unsigned short amap[416]; // compact list of the valid axis-row slots (414)
 };
 
 // offsets inside the x-space weight array W that the assembly terms read from

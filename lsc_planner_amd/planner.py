@@ -173,6 +173,14 @@ class SwarmPlanner:
         self._check(self.L.lsc_solver_residuals(self.ctx, _dp(out)))
         return out
 
+    def solver_trace(self, agent, read=False):
+        out = np.zeros(64 * 8 + 39 * 41 + 450 + 512)
+        self._check(self.L.lsc_solver_trace(self.ctx, agent, _dp(out) if read else None))
+        self.trace_K = out[512:512 + 39 * 41].reshape(39, 41)[:, :39]
+        self.trace_W = out[512 + 39 * 41:512 + 39 * 41 + 450]
+        self.trace_kconst = out[512 + 39 * 41 + 450:]
+        return out[:512].reshape(64, 8)
+
     def iterations_total(self, reset=False):
         t = ctypes.c_longlong()
         self._check(self.L.lsc_iterations_total(self.ctx, ctypes.byref(t), int(reset)))

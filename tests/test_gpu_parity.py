@@ -142,3 +142,24 @@ def test_row_capacity_overflow_is_reported_not_hidden(L):
     g = pl.plan(state, ms.goal, np.zeros((12, 3, 30), np.float32))
     assert (g["status"] == 3).all()
     pl.close()
+
+
+def test_first_tick_with_moving_agents_uses_float32_constant_velocity_model(L, oracle):
+    """planner_seq < 2: prediction = pos + vel * m_intp * dt in float32 (src/traj_planner.cpp:699-712) -- needs
+    unfused float32 arithmetic on the device to stay bit-exact."""
+    rng = np.random.default_rng(8)
+    ms = L.circle_swap(16, 3.0)
+    state = np.zeros((16, 9), np.float32)
+    state[:, :3] = ms.start
+    state[:, 3:6] = rng.normal(size=(16, 3)).astype(np.float32) * np.float32(0.3)
+    state[:, 6:9] = rng.normal(size=(16, 3)).astype(np.float32) * np.float32(0.2)
+    pl = L.SwarmPlanner(ms)
+    sw = oracle_swarm(oracle, ms)
+    g = pl.plan(state, ms.goal, np.zeros((16, 3, 30), np.float32), want_constraints=True)
+    o = sw.tick(state, ms.goal, np.zeros((16, 3, 30), np.float32), 1, want_lsc=True)
+    assert np.array_equal(g["normal"], o["normal"]) and np.array_equal(g["d"], o["d"])
+    assert np.array_equal(g["status"], o["status"])
+    ok = o["status"] == 0
+    assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok]).all()
+    assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL
+    pl.close()
