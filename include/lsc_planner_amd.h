@@ -52,6 +52,8 @@ extern "C" {
 #define LSC_STATUS_INFEASIBLE 1  /* solver failed: optimiser's previous trajectory kept, like the reference
                                     (exception swallowed, src/traj_planner.cpp:1553-1584)                */
 #define LSC_STATUS_CAPACITY 3    /* more active LSC rows than the configured LDS row capacity            */
+#define LSC_STATUS_SFC_BLOCKED 4 /* seed box of the corridor touches an obstacle (the reference throws
+                                    std::invalid_argument, corridor_constructor.hpp:35-38): stale trajectory kept */
 
 typedef struct lsc_ctx lsc_ctx;
 
@@ -91,6 +93,14 @@ int lsc_set_shard(lsc_ctx *ctx, int first, int count);
 /* TrajPlanner::setDistMap (src/traj_planner.cpp:168): dense EDT, metres, [nx][ny][nz], copied to HBM.
  * key_min = octomap key of cell (0,0,0).  Only used when use_octomap. */
 int lsc_set_distmap(lsc_ctx *ctx, const float *edt, int nx, int ny, int nz, const int key_min[3], double res);
+
+/* Map input formats: reads an octomap binary tree (.bt) and builds the distance field that
+ * MultiSyncSimulator::setOctomap creates with DynamicEDTOctomap(maxdist, tree, world_min, world_max, false)
+ * (src/multi_sync_simulator.cpp:153-167).  *edt is malloc'ed [dims0][dims1][dims2] float metres: release it with
+ * lsc_free_host.  Pure host code (no GPU needed). */
+int lsc_edt_from_bt(const char *path, const float world_min[3], const float world_max[3], double maxdist, float **edt,
+                    int dims[3], int key_min[3], double *res);
+void lsc_free_host(void *p);
 
 /* One replan tick, host buffers in and out (H2D + kernels + D2H inside).
  *   planner_seq : TrajPlanner::planner_seq AFTER its increment in plan() (1 on the first tick):

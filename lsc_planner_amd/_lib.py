@@ -11,7 +11,7 @@ _LIB = None
 
 M, DEG, NC, SEGV, NV = 5, 5, 6, 30, 90
 
-STATUS_OK, STATUS_INFEASIBLE, STATUS_CAPACITY = 0, 1, 3
+STATUS_OK, STATUS_INFEASIBLE, STATUS_CAPACITY, STATUS_SFC_BLOCKED = 0, 1, 3, 4
 
 
 class LscError(RuntimeError):
@@ -38,7 +38,7 @@ class LscConfig(ctypes.Structure):
 EXPORTS = [
     "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_propagate_device", "lsc_sweep_device",
-    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace",
+    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host",
 ]
 
 
@@ -79,10 +79,13 @@ def load_library():
     L.lsc_phase_profile.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]
     L.lsc_solver_residuals.argtypes = [vp, dp]
     L.lsc_solver_trace.argtypes = [vp, ctypes.c_int, dp]
+    L.lsc_edt_from_bt.argtypes = [ctypes.c_char_p, fp, fp, ctypes.c_double, ctypes.POINTER(fp), ip, ip, dp]
+    L.lsc_free_host.argtypes = [vp]
+    L.lsc_free_host.restype = None
     L.lsc_iterations_total.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if fn.restype is ctypes.c_int or name not in ("lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error"):
+        if fn.restype is ctypes.c_int or name not in ("lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_free_host"):
             fn.restype = ctypes.c_int
     _LIB = L
     return L

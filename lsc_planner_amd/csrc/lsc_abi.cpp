@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -174,6 +175,11 @@ struct lsc_ctx {
     double *d_radius = nullptr, *d_radius_obs = nullptr, *d_downwash = nullptr, *d_downwash_obs = nullptr;
     double *d_vmax = nullptr, *d_amax = nullptr, *d_vnom = nullptr;
     float *d_stale = nullptr, *d_sfc = nullptr;
+    int *d_sfc_init = nullptr, *d_sfc_err = nullptr, *d_img_of_agent = nullptr, *d_integral = nullptr;
+    std::vector<float> h_edt;   // host copy of the distance field (integral images are rebuilt when agents change)
+    int edt_dims[3] = {0, 0, 0}, edt_kmin[3] = {0, 0, 0};
+    double edt_res = 0.0;
+    std::vector<double> h_radius;
     int *d_nrows = nullptr;
     long long *d_iters_acc = nullptr;
     long long *d_prof = nullptr;
@@ -214,6 +220,8 @@ static int timing_begin(lsc_ctx *c, int which, hipStream_t st, hipEvent_t *e1)
         }                                                                                     \
     } while (0)
 
+static int build_integrals(lsc_ctx *c);
+
 extern "C" {
 
 void lsc_default_config(lsc_config *cfg)
@@ -251,12 +259,13 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
 static void free_agents(lsc_ctx *c)
 {
     void *ptrs[] = {c->d_radius, c->d_radius_obs, c->d_downwash, c->d_downwash_obs, c->d_vmax, c->d_amax, c->d_vnom,
-                    c->d_stale, c->d_sfc, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_goal, c->d_prev, c->d_next, c->d_cost, c->d_status,
+                    c->d_stale, c->d_sfc, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_goal, c->d_prev, c->d_next, c->d_cost, c->d_status,
                     c->d_iters, c->d_onormal, c->d_od};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->d_radius = c->d_radius_obs = c->d_downwash = c->d_downwash_obs = c->d_vmax = c->d_amax = c->d_vnom = nullptr;
     c->d_stale = c->d_sfc = c->d_state = c->d_goal = c->d_prev = c->d_next = nullptr;
-    c->d_cost = nullptr; c->d_status = c->d_iters = c->d_nrows = nullptr; c->d_iters_acc = nullptr; c->d_prof = nullptr; c->d_dbg = nullptr; c->d_onormal = nullptr; c->d_od = nullptr;
+    c->d_cost = nullptr; c->d_status = c->d_iters = c->d_nrows = nullptr; c->d_iters_acc = nullptr; c->d_prof = nullptr; c->d_dbg = nullptr;
+    c->d_sfc_init = c->d_sfc_err = c->d_img_of_agent = c->d_integral = nullptr; c->d_onormal = nullptr; c->d_od = nullptr;
 }
 
 void lsc_destroy(lsc_ctx *c)
@@ -308,6 +317,14 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMemset(c->d_stale, 0, sizeof(float) * NV * (size_t)N));   // TrajOptimizer::trajectory starts at (0,0,0)
     HIPCHK(c, hipMalloc(&c->d_sfc, sizeof(float) * M * 6 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_sfc, 0, sizeof(float) * M * 6 * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_sfc_init, sizeof(int) * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_sfc_err, sizeof(int) * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_sfc_err, 0, sizeof(int) * (size_t)N));
+    {
+        std::vector<int> ones(N, 1);                        // flag_initialize_sfc = true (src/traj_planner.cpp:48)
+        HIPCHK(c, hipMemcpy(c->d_sfc_init, ones.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice));
+    }
+    c->h_radius.assign(radius, radius + N);
     HIPCHK(c, hipMalloc(&c->d_nrows, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (size_t)N));
@@ -324,7 +341,7 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMemset(c->d_cost, 0, sizeof(double) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_status, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_iters, sizeof(int) * (size_t)N));
-    return LSC_OK;
+    return build_integrals(c);
 }
 
 int lsc_set_shard(lsc_ctx *c, int first, int count)
@@ -335,11 +352,67 @@ int lsc_set_shard(lsc_ctx *c, int first, int count)
     return LSC_OK;
 }
 
-int lsc_set_distmap(lsc_ctx *c, const float *, int, int, int, const int *, double)
+// blocked-cell integral images, one per distinct agent radius:  blocked = EDT < r + res/2 - 1e-5
+// (include/corridor_constructor.hpp:114)
+static int build_integrals(lsc_ctx *c)
 {
-    if (!c) return LSC_EINVAL;
-    c->err = "lsc_set_distmap: SFC path not built yet";
-    return LSC_ESTATE;
+    if (c->h_edt.empty() || c->N == 0) return LSC_OK;
+    const int nx = c->edt_dims[0], ny = c->edt_dims[1], nz = c->edt_dims[2];
+    std::vector<double> radii;
+    std::vector<int> img(c->N);
+    for (int q = 0; q < c->N; q++) {
+        auto it = std::find(radii.begin(), radii.end(), c->h_radius[q]);
+        if (it == radii.end()) { radii.push_back(c->h_radius[q]); img[q] = (int)radii.size() - 1; }
+        else img[q] = (int)(it - radii.begin());
+    }
+    const size_t isz = (size_t)(nx + 1) * (ny + 1) * (nz + 1);
+    std::vector<int> I(isz * radii.size(), 0);
+    for (size_t r = 0; r < radii.size(); r++) {
+        const double thr = radii[r] + 0.5 * c->cfg.world_resolution - 1e-5;
+        int *J = I.data() + r * isz;
+        auto at = [&](int x, int y, int z) -> int & { return J[((size_t)x * (ny + 1) + y) * (nz + 1) + z]; };
+        for (int x = 1; x <= nx; x++)
+            for (int y = 1; y <= ny; y++)
+                for (int z = 1; z <= nz; z++) {
+                    const int b = (double)c->h_edt[((size_t)(x - 1) * ny + (y - 1)) * nz + (z - 1)] < thr ? 1 : 0;
+                    at(x, y, z) = b + at(x - 1, y, z) + at(x, y - 1, z) + at(x, y, z - 1) - at(x - 1, y - 1, z) - at(x - 1, y, z - 1) -
+                                  at(x, y - 1, z - 1) + at(x - 1, y - 1, z - 1);
+                }
+    }
+    if (c->d_integral) { (void)hipFree(c->d_integral); c->d_integral = nullptr; }
+    if (c->d_img_of_agent) { (void)hipFree(c->d_img_of_agent); c->d_img_of_agent = nullptr; }
+    HIPCHK(c, hipMalloc(&c->d_integral, sizeof(int) * I.size()));
+    HIPCHK(c, hipMemcpy(c->d_integral, I.data(), sizeof(int) * I.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_img_of_agent, sizeof(int) * (size_t)c->N));
+    HIPCHK(c, hipMemcpy(c->d_img_of_agent, img.data(), sizeof(int) * (size_t)c->N, hipMemcpyHostToDevice));
+    return LSC_OK;
+}
+
+int lsc_set_distmap(lsc_ctx *c, const float *edt, int nx, int ny, int nz, const int key_min[3], double res)
+{
+    if (!c || !edt || nx < 1 || ny < 1 || nz < 1 || !key_min || !(res > 0)) return LSC_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->h_edt.assign(edt, edt + (size_t)nx * ny * nz);
+    c->edt_dims[0] = nx; c->edt_dims[1] = ny; c->edt_dims[2] = nz;
+    for (int k = 0; k < 3; k++) c->edt_kmin[k] = key_min[k];
+    c->edt_res = res;
+    return build_integrals(c);
+}
+
+static int run_sfc(lsc_ctx *c, const float *d_state, const float *d_goal, const float *d_prev, hipStream_t st)
+{
+    if (!c->cfg.use_octomap) return LSC_OK;
+    if (!c->d_integral) { c->err = "use_octomap is set but lsc_set_distmap was not called"; return LSC_ESTATE; }
+    SfcArgs s;
+    s.N = c->N; s.first = c->first; s.count = c->count;
+    s.state = d_state; s.goal = d_goal; s.traj_prev = d_prev;
+    s.radius = c->d_radius; s.img_of_agent = c->d_img_of_agent; s.integral = c->d_integral;
+    s.nx = c->edt_dims[0]; s.ny = c->edt_dims[1]; s.nz = c->edt_dims[2];
+    for (int k = 0; k < 3; k++) { s.key_min[k] = c->edt_kmin[k]; s.world_min[k] = c->cfg.world_min[k]; s.world_max[k] = c->cfg.world_max[k]; }
+    s.rf = 1.0 / c->edt_res; s.wres = c->cfg.world_resolution;
+    s.sfc = c->d_sfc; s.init_flag = c->d_sfc_init; s.err = c->d_sfc_err;
+    HIPCHK(c, launch_sfc(s, st));
+    return LSC_OK;
 }
 
 static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const float *d_goal, const float *d_prev, int seq,
@@ -353,6 +426,7 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.vmax = c->d_vmax; a.amax = c->d_amax; a.vnom = c->d_vnom;
     a.traj_next = d_next; a.cost = d_cost; a.status = d_status; a.iters = d_iters; a.nrows = c->d_nrows; a.iters_acc = c->d_iters_acc;
     a.stale = c->d_stale; a.sfc = c->cfg.use_octomap ? c->d_sfc : nullptr;
+    a.sfc_err = c->cfg.use_octomap ? c->d_sfc_err : nullptr;
     a.out_normal = nullptr; a.out_d = nullptr;
     a.dbg = c->d_dbg; a.prof = c->profiling ? c->d_prof : nullptr;
     a.trace = c->trace_agent >= 0 ? c->d_trace : nullptr; a.trace_agent = c->trace_agent;
@@ -375,6 +449,8 @@ int lsc_tick_device(lsc_ctx *c, const float *d_state, const float *d_goal, const
     if (!c || !d_state || !d_goal || !d_traj_prev || !d_traj_next || !d_cost || !d_status || !d_iters) return LSC_EINVAL;
     PlanArgs a;
     int rc = fill_plan_args(c, a, d_state, d_goal, d_traj_prev, planner_seq, d_traj_next, d_cost, d_status, d_iters);
+    if (rc) return rc;
+    rc = run_sfc(c, d_state, d_goal, d_traj_prev, (hipStream_t)hip_stream);
     if (rc) return rc;
     return run_plan(c, a, (hipStream_t)hip_stream);
 }
@@ -401,6 +477,8 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
         }
         a.out_normal = c->d_onormal; a.out_d = c->d_od;
     }
+    rc = run_sfc(c, c->d_state, c->d_goal, c->d_prev, st);
+    if (rc) return rc;
     rc = run_plan(c, a, st);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(out_traj, c->d_next + first * NV, sizeof(float) * NV * cnt, hipMemcpyDeviceToHost, st));

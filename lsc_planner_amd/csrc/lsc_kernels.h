@@ -9,6 +9,7 @@
 #define LSC_STATUS_OK_K 0
 #define LSC_STATUS_INFEASIBLE_K 1
 #define LSC_STATUS_CAPACITY_K 3
+#define LSC_STATUS_SFC_K 4
 
 namespace lsc {
 
@@ -29,6 +30,7 @@ struct PlanArgs {
     long long *iters_acc;      // [N] running sum of interior-point iterations (bench accounting), may be null
     float *stale;              // [N][90] optimiser's last good trajectory (persistent)
     const float *sfc;          // [N][M][6] or null
+    const int *sfc_err;        // [N] or null: seed box blocked -> status 4
     float *out_normal;         // optional dense dump [count][N-1][M][3]
     double *out_d;             // optional dense dump [count][N-1][M][6]
     double *dbg;               // optional [N][4]: last (gap, |rp|, |rd|, objective) seen by the solver
@@ -46,6 +48,24 @@ struct SweepArgs {
     float *out_normal;
     double *out_d;
 };
+
+// Safe Flight Corridor update (TrajPlanner::generateFeasibleSFC), one lane per agent
+struct SfcArgs {
+    int N, first, count;
+    const float *state, *goal, *traj_prev;
+    const double *radius;
+    const int *img_of_agent;    // [N] index of the blocked-cell integral image matching the agent's margin
+    const int *integral;        // [n_img][(nx+1)(ny+1)(nz+1)] inclusive 3-D prefix sums of "EDT < r + res/2 - 1e-5"
+    int nx, ny, nz;
+    int key_min[3];
+    double rf;                  // 1 / tree resolution (OcTreeBaseImpl::resolution_factor)
+    double wres;                // world/resolution
+    float world_min[3], world_max[3];
+    float *sfc;                 // [N][M][6] persistent boxes (box_min, box_max as float)
+    int *init_flag;             // [N] flag_initialize_sfc
+    int *err;                   // [N] 1 when the seed box already touches an obstacle
+};
+hipError_t launch_sfc(const SfcArgs &a, hipStream_t st);
 
 size_t plan_smem_bytes(int n_terms, int n_entries, int cap);
 hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st);

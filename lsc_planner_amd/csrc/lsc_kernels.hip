@@ -139,6 +139,157 @@ __global__ void lsc_propagate_kernel(const float *__restrict__ traj, float *__re
     state[9 * q + 6 + k] = a0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Safe Flight Corridor: CorridorConstructor::expandBoxFromPoint (include/corridor_constructor.hpp:18-245) driven by
+// TrajPlanner::generateFeasibleSFC (src/traj_planner.cpp:1451-1491).  The reference tests every lattice point of a
+// slab against the distance field; here "distance < margin" is pre-thresholded into a 3-D integral image, so a slab
+// test is 8 loads.  One lane per agent (the growth loop is inherently sequential, a few hundred steps).
+// ---------------------------------------------------------------------------------------------------
+struct SfcGrid {
+    const int *I;
+    int nx, ny, nz;
+    int kmin[3];
+    double rf, wres;
+    double wmin[3], wmax[3];
+};
+
+__device__ __forceinline__ int sfc_cell(const SfcGrid &g, int axis, float sp)
+{
+    return (int)floor(g.rf * (double)sp) + 32768 - g.kmin[axis];
+}
+
+// isObstacleInBox (:81-122).  Per axis the reference visits the lattice points lo, lo+res, ..., each nudged by a
+// float 1e-5: the first one downwards (unless the box sits on the world boundary), all others upwards.  In cells that
+// is {a0} u [b0, b1] per axis -- note that the cell just above `lo` is skipped by the reference, so the tested set is
+// the product of those per-axis sets: 8 sub-boxes, each answered by the integral image.
+__device__ bool sfc_blocked(const SfcGrid &g, const double *box)
+{
+#pragma clang fp contract(off)
+    int a0[3], b0[3], b1[3];
+    const int dims[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int size = (int)round((box[i + 3] - box[i]) / g.wres) + 1;
+        const int last = (size > 2 ? size : 2) - 1;
+        const float d0 = (box[i] > g.wmin[i] + 1e-5) ? (float)-1e-5 : (float)1e-5;
+        const float p0 = (float)box[i] + d0;
+        const float p1 = ((size == 1) ? (float)box[i] : (float)(box[i] + 1 * g.wres)) + (float)1e-5;
+        const float pl = ((size == 1) ? (float)box[i] : (float)(box[i] + last * g.wres)) + (float)1e-5;
+        a0[i] = sfc_cell(g, i, p0);
+        b0[i] = sfc_cell(g, i, p1);
+        b1[i] = sfc_cell(g, i, pl);
+        if (b1[i] < b0[i]) { const int t = b0[i]; b0[i] = b1[i]; b1[i] = t; }
+        if (a0[i] < 0 || a0[i] >= dims[i] || b0[i] < 0 || b1[i] >= dims[i]) return true;   // getDistance() = -1 outside
+    }
+    const int sy = g.nz + 1, sx = (g.ny + 1) * (g.nz + 1);
+    int cnt = 0;
+#pragma unroll
+    for (int sel = 0; sel < 8; sel++) {
+        const int x0 = (sel & 1) ? b0[0] : a0[0], x1 = ((sel & 1) ? b1[0] : a0[0]) + 1;
+        const int y0 = (sel & 2) ? b0[1] : a0[1], y1 = ((sel & 2) ? b1[1] : a0[1]) + 1;
+        const int z0 = (sel & 4) ? b0[2] : a0[2], z1 = ((sel & 4) ? b1[2] : a0[2]) + 1;
+        const int *I = g.I;
+        cnt += I[x1 * sx + y1 * sy + z1] - I[x0 * sx + y1 * sy + z1] - I[x1 * sx + y0 * sy + z1] - I[x1 * sx + y1 * sy + z0] +
+               I[x0 * sx + y0 * sy + z1] + I[x0 * sx + y1 * sy + z0] + I[x1 * sx + y0 * sy + z0] - I[x0 * sx + y0 * sy + z0];
+    }
+    return cnt > 0;
+}
+
+__device__ bool sfc_in_boundary(const SfcGrid &g, const double *b)
+{
+    return b[0] > g.wmin[0] - 1e-9 && b[1] > g.wmin[1] - 1e-9 && b[2] > g.wmin[2] - 1e-9 && b[3] < g.wmax[0] + 1e-9 &&
+           b[4] < g.wmax[1] + 1e-9 && b[5] < g.wmax[2] + 1e-9;
+}
+
+// returns 0 ok, 1 seed box blocked, 2 seed outside the world
+__device__ int sfc_expand(const SfcGrid &g, const float point[3], const float goal[3], double out[6])
+{
+#pragma clang fp contract(off)
+    double cur[6], cnd[6], upd[6];
+    for (int i = 0; i < 3; i++) {
+        const double p = (double)point[i];
+        const double rp = round(p / g.wres) * g.wres;
+        if (fabs(p - rp) < 0.01) { cur[i] = rp; cur[i + 3] = rp; }
+        else { cur[i] = floor(p / g.wres) * g.wres; cur[i + 3] = ceil(p / g.wres) * g.wres; }
+    }
+    if (sfc_blocked(g, cur)) return 1;
+    // setAxisCand (:142-182): axes ordered by |goal - centre|, goal-ward direction first, opposite directions reversed
+    int cand[6], ncand = 6;
+    {
+        float delta[3];
+        double val[3];
+        int offs[3], order[3], n = 0;
+        for (int k = 0; k < 3; k++) {
+            const float mid = (float)(0.5 * (cur[k] + cur[k + 3]));
+            delta[k] = goal[k] - mid;
+            offs[k] = delta[k] > 0 ? 3 : 0;
+            val[k] = fabs((double)delta[k]);
+        }
+        double maxv = -1.0, minv = 1e9;
+        for (int i = 0; i < 3; i++) {
+            if (val[i] > maxv) { for (int j = n; j > 0; j--) order[j] = order[j - 1]; order[0] = i; n++; maxv = val[i]; }
+            else if (val[i] < minv) { order[n++] = i; minv = val[i]; }
+            else { for (int j = n; j > 1; j--) order[j] = order[j - 1]; order[1] = i; n++; }
+        }
+        for (int i = 0; i < 3; i++) { cand[i] = order[i] + offs[order[i]]; cand[5 - i] = order[i] + (3 - offs[order[i]]); }
+    }
+    int i = -1;
+    while (ncand > 0) {
+        for (int j = 0; j < 6; j++) { cnd[j] = cur[j]; upd[j] = cur[j]; }
+        while (!sfc_blocked(g, upd) && sfc_in_boundary(g, upd)) {
+            i++;
+            if (i >= ncand) i = 0;
+            const int axis = cand[i];
+            for (int j = 0; j < 6; j++) { cur[j] = cnd[j]; upd[j] = cnd[j]; }
+            if (axis < 3) { upd[axis + 3] = cnd[axis]; cnd[axis] = cnd[axis] - g.wres; upd[axis] = cnd[axis]; }
+            else { upd[axis - 3] = cnd[axis]; cnd[axis] = cnd[axis] + g.wres; upd[axis] = cnd[axis]; }
+        }
+        if (i < 0) return 2;
+        for (int j = i; j < ncand - 1; j++) cand[j] = cand[j + 1];
+        ncand--;
+        if (i > 0) i--;
+        else i = ncand - 1;
+    }
+    for (int j = 0; j < 6; j++) out[j] = cur[j];
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void lsc_sfc_kernel(SfcArgs a)
+{
+    const int al = blockIdx.x * blockDim.x + threadIdx.x;
+    if (al >= a.count) return;
+    const int qi = a.first + al;
+    SfcGrid g;
+    g.I = a.integral + (size_t)a.img_of_agent[qi] * (size_t)(a.nx + 1) * (a.ny + 1) * (a.nz + 1);
+    g.nx = a.nx; g.ny = a.ny; g.nz = a.nz;
+    for (int k = 0; k < 3; k++) { g.kmin[k] = a.key_min[k]; g.wmin[k] = (double)a.world_min[k]; g.wmax[k] = (double)a.world_max[k]; }
+    g.rf = a.rf; g.wres = a.wres;
+    float *sfc = a.sfc + (size_t)qi * M * 6;
+    const float *goal = a.goal + 3 * qi;
+    double box[6];
+    int rc;
+    if (a.init_flag[qi]) {
+        rc = sfc_expand(g, a.state + 9 * qi, goal, box);
+        if (rc == 0) {
+            for (int m = 0; m < M; m++)
+                for (int j = 0; j < 6; j++) sfc[m * 6 + j] = (float)box[j];
+            a.init_flag[qi] = 0;
+        }
+    } else {
+        const float *t = a.traj_prev + (size_t)qi * NV;
+        const int c = (M - 1) * NC + DEG;
+        const float last[3] = {t[c], t[SEGV + c], t[2 * SEGV + c]};
+        rc = sfc_expand(g, last, goal, box);
+        if (rc == 0) {
+            for (int m = 1; m < M; m++)
+                for (int j = 0; j < 6; j++) sfc[(m - 1) * 6 + j] = sfc[m * 6 + j];
+            for (int j = 0; j < 6; j++) sfc[(M - 1) * 6 + j] = (float)box[j];
+        }
+    }
+    a.err[qi] = rc;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The per-agent planning kernel
 // ---------------------------------------------------------------------------------------------------
@@ -699,7 +850,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int iters = 0;
     double obj = 0.0;
 
-    if (overflow) {
+    if (a.sfc_err && a.sfc_err[qi] != 0) {
+        status = LSC_STATUS_SFC_K;   // seed box of the corridor blocked (the reference throws out of plan())
+    } else if (overflow) {
         status = LSC_STATUS_CAPACITY_K;
     } else {
         // ---------------- initial point: (H + A^T A) y = -grad(x0) + A^T (h - A x0)
@@ -973,6 +1126,12 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     }
     if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, a);
     else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sfc(const SfcArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(lsc_sfc_kernel, dim3((a.count + 63) / 64), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 

@@ -74,8 +74,10 @@ def circle_swap(n, circle_radius=8.0, z=1.0, world=(-10, -10, 0, 10, 10, 2.5)):
                    np.asarray(world[3:], np.float32), r, dw, vm, am, vn, name=f"circle_swap{n}_R{circle_radius}")
 
 
-def random_swarm(n, world=(-20, -20, 0, 20, 20, 5), seed=20260929, min_sep=0.6, shrink=0.5, downwash=2.0):
-    """Uniform starts / goals in the world box shrunk by `shrink`, pairwise (downwash-scaled) distance >= min_sep."""
+def random_swarm(n, world=(-20, -20, 0, 20, 20, 5), seed=20260929, min_sep=0.6, shrink=0.5, downwash=2.0, edt=None,
+                 edt_key_min=None, edt_res=0.1, min_clearance=0.45):
+    """Uniform starts / goals in the world box shrunk by `shrink`, pairwise (downwash-scaled) distance >= min_sep;
+    with a distance field, samples closer than `min_clearance` to an obstacle are rejected."""
     rng = np.random.default_rng(seed)
     lo = np.asarray(world[:3], float) + shrink
     hi = np.asarray(world[3:], float) - shrink
@@ -85,6 +87,10 @@ def random_swarm(n, world=(-20, -20, 0, 20, 20, 5), seed=20260929, min_sep=0.6, 
         while len(pts) < n:
             p = rng.uniform(lo, hi)
             ok = True
+            if edt is not None:
+                c = np.floor(p / edt_res).astype(int) + 32768 - np.asarray(edt_key_min)
+                if (c < 0).any() or (c >= np.asarray(edt.shape)).any() or edt[c[0], c[1], c[2]] < min_clearance:
+                    continue
             for q in pts:
                 d = p - q
                 d[2] /= downwash

@@ -91,6 +91,19 @@ class SwarmPlanner:
         except Exception:
             pass
 
+    # ---- TrajPlanner::setDistMap --------------------------------------------------------------------------
+    def set_distmap(self, dist, key_min, res):
+        """dist: float32 [nx][ny][nz] metres (DynamicEDTOctomap semantics), key_min: octomap key of cell (0,0,0)."""
+        dist = np.ascontiguousarray(dist, np.float32)
+        km = np.ascontiguousarray(key_min, np.int32)
+        self._check(self.L.lsc_set_distmap(self.ctx, _fp(dist), dist.shape[0], dist.shape[1], dist.shape[2], _ip(km), float(res)))
+
+    def load_octomap(self, bt_path, maxdist=1.0):
+        """MultiSyncSimulator::setOctomap (src/multi_sync_simulator.cpp:153-167): .bt -> distance field -> every agent."""
+        dist, key_min, res = edt_from_bt(bt_path, self.mission.world_min, self.mission.world_max, maxdist)
+        self.set_distmap(dist, key_min, res)
+        return dist, key_min, res
+
     def set_shard(self, first, count):
         self._check(self.L.lsc_set_shard(self.ctx, first, count))
         self.first, self.count = first, count
@@ -110,15 +123,18 @@ class SwarmPlanner:
         iters = np.zeros(cnt, np.int32)
         nrm = np.zeros((cnt, max(N - 1, 1), M, 3), np.float32) if want_constraints else None
         dd = np.zeros((cnt, max(N - 1, 1), M, NC), np.float64) if want_constraints else None
+        sfc = np.zeros((cnt, M, 6), np.float32) if self.cfg.use_octomap else None
         self._check(self.L.lsc_replan_tick(self.ctx, _fp(state), _fp(goal), _fp(prev), self.planner_seq, _fp(out), _dp(cost),
                                            _ip(status), _ip(iters), _fp(nrm) if want_constraints else None,
-                                           _dp(dd) if want_constraints else None, None))
+                                           _dp(dd) if want_constraints else None, _fp(sfc) if sfc is not None else None))
         sl = slice(self.first, self.first + cnt)
         self.traj_curr[sl] = out
         self.qp_cost[sl] = cost
         self.planning_report[sl] = status
         self.iters[sl] = iters
         res = {"traj": out, "cost": cost, "status": status, "iters": iters}
+        if sfc is not None:
+            res["sfc"] = sfc
         if want_constraints:
             res["normal"], res["d"] = nrm, dd
         return res
@@ -194,6 +210,24 @@ class SwarmPlanner:
         n = ctypes.c_long()
         self._check(self.L.lsc_kernel_time_ms(self.ctx, which, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+
+def edt_from_bt(bt_path, world_min, world_max, maxdist=1.0):
+    """Host-only: octomap .bt -> (dist float32 [nx][ny][nz], key_min int32[3], res).  No GPU needed."""
+    L = _lib.load_library()
+    fpp = ctypes.POINTER(ctypes.c_float)
+    wm = np.ascontiguousarray(world_min, np.float32)
+    wM = np.ascontiguousarray(world_max, np.float32)
+    edt = fpp()
+    dims = (ctypes.c_int * 3)()
+    kmin = (ctypes.c_int * 3)()
+    res = ctypes.c_double()
+    rc = L.lsc_edt_from_bt(str(bt_path).encode(), _fp(wm), _fp(wM), float(maxdist), ctypes.byref(edt), dims, kmin, ctypes.byref(res))
+    if rc != 0:
+        raise LscError(f"lsc_edt_from_bt({bt_path}) failed: {rc}")
+    arr = np.ctypeslib.as_array(edt, shape=tuple(dims)).copy()
+    L.lsc_free_host(edt)
+    return arr, np.array(list(kmin), np.int32), res.value
 
 
 def next_state_host(traj, dt=0.2):

@@ -1052,6 +1052,14 @@ void orc_next_state(const float *traj, double dt, float state[9])
 /* ------------------------------------------------------------------------------------------
  * One synchronous tick (src/multi_sync_simulator.cpp:249-337 + src/traj_planner.cpp:344-425)
  * ---------------------------------------------------------------------------------------- */
+static const orc_edt *g_edt = NULL;
+static double g_wres = 0.1;
+static int *g_sfc_init = NULL;
+void orc_tick_set_map(const void *edt, double world_res, int *sfc_init_flags)
+{
+    g_edt = (const orc_edt *)edt; g_wres = world_res; g_sfc_init = sfc_init_flags;
+}
+
 int orc_tick(const orc_params *prm, int N, const float *state, const float *goal, const float *prev_traj,
              int planner_seq, const double *radius, const double *downwash, const double *vmax,
              const double *amax, const double *vnom, float *stale_traj, float *sfc_io, float *out_traj,
@@ -1091,11 +1099,16 @@ int orc_tick(const orc_params *prm, int N, const float *state, const float *goal
         if (out_d) memcpy(out_d + (size_t)qi * n_obs * ORC_M * ORC_NC, dd, sizeof(double) * ORC_NC * ORC_M * (size_t)n_obs);
 
         const float *sfc = (prm->use_sfc && sfc_io) ? sfc_io + (size_t)qi * ORC_M * 6 : NULL;
+        int sfc_rc = 0;
+        if (sfc && g_edt && g_sfc_init)   /* generateSFC, src/traj_planner.cpp:1242-1250 */
+            sfc_rc = orc_update_sfc(prm, g_edt, g_wres, state + 9 * qi, goal + 3 * qi, prev_traj + (size_t)qi * ORC_NV,
+                                    radius[qi], sfc_io + (size_t)qi * ORC_M * 6, &g_sfc_init[qi]);
         int nr = orc_qp_assemble(prm, state + 9 * qi, goal + 3 * qi, vnom[qi], vmax + 3 * qi, amax + 3 * qi, n_obs,
                                  obs_traj, nrm, dd, sfc, P, c, &cst, lo, hi, rows);
         double cost;
         int iters = 0;
         int st = orc_qp_solve(P, c, cst, lo, hi, rows, nr, x, &cost, &iters, NULL);
+        if (sfc_rc) st = 4;   /* seed box blocked: the reference throws out of plan(); reported, stale trajectory kept */
         float *o = out_traj + (size_t)qi * ORC_NV;
         float *stale = stale_traj + (size_t)qi * ORC_NV;
         if (st == 0) {

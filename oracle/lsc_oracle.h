@@ -105,6 +105,8 @@ int  orc_tick(const orc_params *prm, int N, const float *state, const float *goa
               float *stale_traj, float *sfc_io,
               float *out_traj, double *out_cost, int *out_status, int *out_iters,
               float *out_normal, double *out_d, int nthreads);
+/* SFC inputs of the next orc_tick calls (use_sfc): distance field, world/resolution, per-agent flag_initialize_sfc [N] */
+void orc_tick_set_map(const void *edt, double world_res, int *sfc_init_flags);
 
 /* ---- EDT + SFC (include/corridor_constructor.hpp:18-245; dynamicEDT3D restated) ---- */
 typedef struct {
@@ -113,8 +115,13 @@ typedef struct {
     int key_min[3];      /* octomap key of cell (0,0,0)            */
     double res;
 } orc_edt;
+int  orc_bt_read(const char *path, double *res, int **leaves /*[n][4] min key + cube edge*/, int *n);
+int  orc_edt_build(const int *leaves, int n, double res, const float world_min[3], const float world_max[3],
+                   double maxdist, orc_edt *edt);
 int  orc_expand_box(const orc_params *prm, const orc_edt *edt, double world_res,
                     const float point[3], const float goal[3], double radius, double box[6]);
+int  orc_update_sfc(const orc_params *prm, const orc_edt *edt, double world_res, const float pos[3], const float goal[3],
+                    const float *prev_traj, double radius, float *sfc /*[M][6]*/, int *init_flag);
 
 #ifdef __cplusplus
 }

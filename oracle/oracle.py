@@ -85,9 +85,14 @@ def lib():
         L.orc_tick.restype = ctypes.c_int
         L.orc_tick.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp,
                                _fp, _fp, _fp, _dp, _ip, _ip, _fp, _dp, ctypes.c_int]
-        if hasattr(L, "orc_expand_box"):
-            L.orc_expand_box.restype = ctypes.c_int
-            L.orc_expand_box.argtypes = [ctypes.POINTER(OrcParams), ctypes.POINTER(OrcEdt), ctypes.c_double, _fp, _fp, ctypes.c_double, _dp]
+        L.orc_expand_box.restype = ctypes.c_int
+        L.orc_expand_box.argtypes = [ctypes.POINTER(OrcParams), ctypes.POINTER(OrcEdt), ctypes.c_double, _fp, _fp, ctypes.c_double, _dp]
+        L.orc_bt_read.restype = ctypes.c_int
+        L.orc_bt_read.argtypes = [ctypes.c_char_p, _dp, ctypes.POINTER(_ip), _ip]
+        L.orc_edt_build.restype = ctypes.c_int
+        L.orc_edt_build.argtypes = [_ip, ctypes.c_int, ctypes.c_double, _fp, _fp, ctypes.c_double, ctypes.POINTER(OrcEdt)]
+        L.orc_tick_set_map.restype = None
+        L.orc_tick_set_map.argtypes = [ctypes.c_void_p, ctypes.c_double, _ip]
         _lib = L
     return _lib
 
@@ -241,6 +246,12 @@ class Swarm:
         self.stale = np.zeros((self.N, 3, SEGV), np.float32)
         self.cost = np.zeros(self.N)
         self.sfc = np.zeros((self.N, M, 6), np.float32)
+        self.sfc_init = np.ones(self.N, np.int32)       # flag_initialize_sfc (src/traj_planner.cpp:48)
+        self.distmap = None
+        self.world_res = 0.1
+
+    def set_distmap(self, distmap, world_res=0.1):
+        self.distmap, self.world_res = distmap, world_res
 
     def tick(self, state, goal, prev_traj, planner_seq, want_lsc=False, nthreads=1):
         N = self.N
@@ -252,14 +263,56 @@ class Swarm:
         iters = np.zeros(N, np.int32)
         nrm = np.zeros((N, max(N - 1, 1), M, 3), np.float32) if want_lsc else None
         dd = np.zeros((N, max(N - 1, 1), M, NC)) if want_lsc else None
+        if self.prm.use_sfc:
+            lib().orc_tick_set_map(ctypes.addressof(self.distmap.edt), self.world_res, _i(self.sfc_init))
+        else:
+            lib().orc_tick_set_map(None, 0.1, None)
         lib().orc_tick(ctypes.byref(self.prm), N, _f(state), _f(goal), _f(prev), planner_seq, _d(self.radius),
                        _d(self.downwash), _d(self.vmax), _d(self.amax), _d(self.vnom), _f(self.stale),
                        _f(self.sfc) if self.prm.use_sfc else None, _f(out), _d(self.cost), _i(status), _i(iters),
                        _f(nrm) if want_lsc else None, _d(dd) if want_lsc else None, nthreads)
-        res = {"traj": out, "cost": self.cost.copy(), "status": status, "iters": iters}
+        res = {"traj": out, "cost": self.cost.copy(), "status": status, "iters": iters, "sfc": self.sfc.copy()}
         if want_lsc:
             res["normal"], res["d"] = nrm, dd
         return res
+
+
+def bt_read(path):
+    """Occupied leaves of an octomap .bt file: (res, int[n][4] = min key x,y,z + cube edge in cells)."""
+    res = ctypes.c_double()
+    keys = _ip()
+    n = ctypes.c_int()
+    rc = lib().orc_bt_read(path.encode(), ctypes.byref(res), ctypes.byref(keys), ctypes.byref(n))
+    if rc:
+        raise IOError(f"orc_bt_read({path}) -> {rc}")
+    arr = np.ctypeslib.as_array(keys, shape=(n.value, 4)).copy()
+    ctypes.CDLL(None).free(keys)
+    return res.value, arr
+
+
+class DistMap:
+    """Dense distance field as DynamicEDTOctomap holds it (restated): dist [nx][ny][nz] float32 metres."""
+
+    def __init__(self, leaves, res, world_min, world_max, maxdist=1.0):
+        self.edt = OrcEdt()
+        wmin = np.ascontiguousarray(world_min, np.float32)
+        wmax = np.ascontiguousarray(world_max, np.float32)
+        leaves = np.ascontiguousarray(leaves, np.int32)
+        rc = lib().orc_edt_build(_i(leaves), len(leaves), res, _f(wmin), _f(wmax), maxdist, ctypes.byref(self.edt))
+        if rc:
+            raise ValueError("orc_edt_build failed")
+        e = self.edt
+        self.dist = np.ctypeslib.as_array(e.dist, shape=(e.nx, e.ny, e.nz)).copy()
+        ctypes.CDLL(None).free(e.dist)
+        e.dist = _f(self.dist)
+        self.key_min = np.array([e.key_min[0], e.key_min[1], e.key_min[2]], np.int32)
+        self.res = res
+
+    def expand_box(self, prm, point, goal, radius, world_res=0.1):
+        box = np.zeros(6)
+        rc = lib().orc_expand_box(ctypes.byref(prm), ctypes.byref(self.edt), world_res, _f(np.ascontiguousarray(point, np.float32)),
+                                  _f(np.ascontiguousarray(goal, np.float32)), radius, _d(box))
+        return rc, box
 
 
 def ref_gjk_lib():

@@ -163,3 +163,65 @@ def test_first_tick_with_moving_agents_uses_float32_constant_velocity_model(L, o
     assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok]).all()
     assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL
     pl.close()
+
+
+def test_sfc_boxes_and_ticks_match_oracle_on_forest(L, oracle):
+    """use_octomap: corridor boxes bit-exact vs the oracle's literal restatement of corridor_constructor.hpp, and the
+    QP with SFC rows within the stated tolerances (BASELINE configs[3] map, smaller swarm)."""
+    from maputil import forest_leaves
+    from lsc_planner_amd.planner import next_state_host
+    leaves, res = forest_leaves()
+    dm = oracle.DistMap(leaves, res, [-5, -5, 0], [5, 5, 2.5])
+    ms = L.random_swarm(48, world=(-5, -5, 0, 5, 5, 2.5), seed=11, edt=dm.dist, edt_key_min=dm.key_min)
+    N = ms.qn
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True))
+    pl.set_distmap(dm.dist, dm.key_min, res)
+    prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, use_sfc=True, obs_f32=True)
+    sw = oracle.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+    sw.set_distmap(dm)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    for tick in range(1, 13):
+        g = pl.plan(state, ms.goal, traj, want_constraints=True)
+        sw.stale[:] = traj if tick > 1 else 0
+        o = sw.tick(state, ms.goal, traj, tick, want_lsc=True, nthreads=8)
+        assert np.array_equal(g["sfc"], o["sfc"]), tick
+        assert np.array_equal(g["normal"], o["normal"]) and np.array_equal(g["d"], o["d"])
+        assert np.array_equal(g["status"], o["status"]), (tick, g["status"], o["status"])
+        ok = o["status"] == 0
+        assert ok.sum() >= N - 4
+        assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok]).all()
+        assert np.abs(g["traj"][ok] - o["traj"][ok]).max() <= TRAJ_ATOL
+        traj = g["traj"]
+        state = next_state_host(traj)
+    pl.close()
+
+
+def test_sfc_box_growth_bitwise_on_random_seeds(L, oracle):
+    """Many independent expandBoxFromPoint calls (first-tick boxes) on the forest map: GPU integral-image growth ==
+    oracle's per-lattice-point loops, including seeds that are rejected (status 4)."""
+    from maputil import forest_leaves
+    leaves, res = forest_leaves()
+    dm = oracle.DistMap(leaves, res, [-5, -5, 0], [5, 5, 2.5])
+    rng = np.random.default_rng(5)
+    N = 256
+    start = rng.uniform([-4.8, -4.8, 0.1], [4.8, 4.8, 2.4], size=(N, 3)).astype(np.float32)
+    goal = rng.uniform([-4.8, -4.8, 0.1], [4.8, 4.8, 2.4], size=(N, 3)).astype(np.float32)
+    ms = L.Mission(start, goal, np.array([-5, -5, 0], np.float32), np.array([5, 5, 2.5], np.float32), np.full(N, 0.15),
+                   np.full(N, 2.0), np.ones((N, 3)), np.full((N, 3), 2.0), np.ones(N))
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True))
+    pl.set_distmap(dm.dist, dm.key_min, res)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = start
+    g = pl.plan(state, goal, np.zeros((N, 3, 30), np.float32))
+    prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, use_sfc=True, obs_f32=True)
+    n_blocked = 0
+    for q in range(N):
+        rc, box = dm.expand_box(prm, start[q], goal[q], 0.15)
+        if rc:
+            n_blocked += 1
+            assert g["status"][q] == 4
+        else:
+            assert np.array_equal(g["sfc"][q, 0], box.astype(np.float32)), (q, g["sfc"][q, 0], box)
+            assert np.array_equal(g["sfc"][q, 4], g["sfc"][q, 0])
+    assert 0 < n_blocked < N // 2
+    pl.close()

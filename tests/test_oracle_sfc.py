@@ -1,0 +1,103 @@
+"""Map side on the CPU: .bt reader, distance field (oracle brute force vs product separable transform), box growth."""
+import numpy as np
+import pytest
+
+from maputil import forest_leaves, write_bt
+
+
+@pytest.fixture(scope="module")
+def forest(oracle):
+    leaves, res = forest_leaves()
+    dm = oracle.DistMap(leaves, res, [-5, -5, 0], [5, 5, 2.5])
+    return leaves, res, dm
+
+
+def test_bt_roundtrip_oracle_reader(oracle, tmp_path):
+    leaves, res = forest_leaves()
+    p = tmp_path / "forest.bt"
+    write_bt(str(p), leaves, res)
+    res2, leaves2 = oracle.bt_read(str(p))
+    assert res2 == res
+    assert sorted(map(tuple, leaves2)) == sorted(map(tuple, leaves))
+    assert (leaves2[:, 3] ** 3).sum() == 4384          # 4384 occupied 0.1 m voxels
+
+
+def test_product_bt_reader_and_edt_match_oracle(oracle, tmp_path):
+    """lsc_edt_from_bt (host C++, separable exact transform) == oracle (brute-force stamping), bitwise."""
+    from lsc_planner_amd.planner import edt_from_bt
+    leaves, res = forest_leaves()
+    p = tmp_path / "forest.bt"
+    write_bt(str(p), leaves, res)
+    for wmin, wmax in (([-5, -5, 0], [5, 5, 2.5]), ([-2.05, -1.3, 0.2], [1.5, 3.33, 2.2])):
+        dm = oracle.DistMap(leaves, res, wmin, wmax)
+        dist, kmin, r = edt_from_bt(str(p), wmin, wmax)
+        assert r == res and np.array_equal(kmin, dm.key_min)
+        assert np.array_equal(dist, dm.dist)
+    dm = oracle.DistMap(leaves, res, [-5, -5, 0], [5, 5, 2.5])
+    assert dm.dist.shape == (101, 101, 26) and (dm.dist == 0).sum() == 4384
+    assert abs(dm.dist.max() - 1.1) < 1e-6               # truncated at (int)(1.0/0.1 + 1) = 11 cells
+
+
+def test_edt_is_exact_on_a_sample(oracle, forest):
+    leaves, res, dm = forest
+    vox = []
+    for x, y, z, s in leaves:
+        for dx in range(s):
+            for dy in range(s):
+                for dz in range(s):
+                    vox.append((x + dx, y + dy, z + dz))
+    vox = np.array(vox) - dm.key_min
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        c = rng.integers(0, dm.dist.shape)
+        d2 = ((vox - c) ** 2).sum(1).min()
+        want = np.float32(np.float64(np.float32(np.sqrt(min(d2, 121)))) * res)
+        assert dm.dist[tuple(c)] == want
+
+
+def test_box_growth_properties(oracle, forest):
+    """Grown boxes are obstacle-free (every cell whose centre lies inside keeps the margin) and maximal in the sense
+    of the reference: no face can move one more step without touching a blocked cell or leaving the world."""
+    leaves, res, dm = forest
+    prm = oracle.make_params(world_min=[-5, -5, 0], world_max=[5, 5, 2.5], use_sfc=True, obs_f32=True)
+    rng = np.random.default_rng(1)
+    n_ok = 0
+    blocked = dm.dist < 0.15 + 0.05 - 1e-5
+    for _ in range(300):
+        p = rng.uniform([-4.5, -4.5, 0.3], [4.5, 4.5, 2.2]).astype(np.float32)
+        g = rng.uniform([-4.5, -4.5, 0.3], [4.5, 4.5, 2.2]).astype(np.float32)
+        rc, box = dm.expand_box(prm, p, g, 0.15)
+        if rc:
+            continue
+        n_ok += 1
+        assert (box[:3] <= p + 0.0101).all() and (box[3:] >= p - 0.0101).all()      # seed snapped by < 0.01 (reference TODO)
+        assert (box[:3] >= -5 - 1e-9).all() and (box[3:] <= np.array([5, 5, 2.5]) + 1e-9).all()
+        lo = np.round(box[:3] / 0.1).astype(int) + 32768 - dm.key_min
+        hi = np.round(box[3:] / 0.1).astype(int) + 32768 - dm.key_min
+        inner = blocked[lo[0] + 1:hi[0], lo[1] + 1:hi[1], lo[2] + 1:hi[2]]
+        assert not inner.any()
+    assert n_ok > 150
+
+
+def test_tick_with_sfc_rows_on_forest(oracle, forest):
+    """Oracle tick with SFC rows on the forest map: trajectories stay inside their corridor boxes."""
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import next_state_host
+    leaves, res, dm = forest
+    ms = L.random_swarm(12, world=(-5, -5, 0, 5, 5, 2.5), seed=3, edt=dm.dist, edt_key_min=dm.key_min)
+    prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, use_sfc=True, obs_f32=True)
+    sw = oracle.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+    sw.set_distmap(dm)
+    state = np.zeros((12, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((12, 3, 30), np.float32)
+    for tick in range(1, 8):
+        r = sw.tick(state, ms.goal, traj, tick, nthreads=4)
+        ok = r["status"] == 0
+        assert ok.sum() >= 10
+        t = r["traj"].reshape(12, 3, 5, 6)
+        for q in np.nonzero(ok)[0]:
+            for m in range(5):
+                lo, hi = r["sfc"][q, m, :3], r["sfc"][q, m, 3:]
+                pts = t[q, :, m, :] if m > 0 else t[q, :, m, 3:]
+                assert (pts >= lo[:, None] - 1e-5).all() and (pts <= hi[:, None] + 1e-5).all()
+        traj = r["traj"]; state = next_state_host(traj)
