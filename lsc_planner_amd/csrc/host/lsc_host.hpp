@@ -1,0 +1,262 @@
+// lsc_host.hpp -- C++ host side above the C ABI: the reference's own class surface, headless (no ROS).
+//
+//   Mission / Param           src/mission.cpp:20-132, src/param.cpp:4-144 (only what reaches the hot path)
+//   TrajPlanner               include/traj_planner.hpp:51-101  (per-agent view onto the batched GPU context)
+//   MultiSyncSimulator        src/multi_sync_simulator.cpp: run :83-147, update :190-318, plan :320-337,
+//                             isFinished :358-380, savePlanningResult :408-510, CSV writers :513-633
+// The per-agent objects keep their names and argument meaning, but TrajPlanner::plan() does not compute: the
+// simulator plans ALL agents with one lsc_replan_tick() (the inputs are frozen by update() before anybody plans).
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/lsc_planner_amd.h"
+
+namespace DynamicPlanning {
+
+constexpr double SP_EPSILON = 1e-9, SP_EPSILON_FLOAT = 1e-5, SP_INFINITY = 1e9;
+
+// ---------------------------------------------------------------------------------------------- tiny JSON reader
+// (the reference vendors rapidjson; the mission files only need objects, arrays, numbers and strings)
+struct Json {
+    enum Kind { Null, Num, Str, Arr, Obj } kind = Null;
+    double num = 0;
+    std::string str;
+    std::vector<Json> arr;
+    std::vector<std::pair<std::string, Json>> obj;
+    const Json &operator[](const std::string &k) const {
+        for (auto &kv : obj) if (kv.first == k) return kv.second;
+        throw std::invalid_argument("[Mission] missing key " + k);
+    }
+    bool has(const std::string &k) const { for (auto &kv : obj) if (kv.first == k) return true; return false; }
+    const Json &operator[](size_t i) const { return arr.at(i); }
+};
+
+class JsonParser {
+  public:
+    explicit JsonParser(const std::string &s) : s_(s) {}
+    Json parse() { Json j = value(); ws(); return j; }
+  private:
+    const std::string &s_;
+    size_t p_ = 0;
+    void ws() { while (p_ < s_.size() && (isspace((unsigned char)s_[p_]))) p_++; }
+    Json value() {
+        ws();
+        if (p_ >= s_.size()) throw std::invalid_argument("[Mission] unexpected end of JSON");
+        char c = s_[p_];
+        Json j;
+        if (c == '{') {
+            j.kind = Json::Obj; p_++; ws();
+            if (s_[p_] == '}') { p_++; return j; }
+            for (;;) {
+                ws(); Json k = value(); ws();
+                if (s_[p_] != ':') throw std::invalid_argument("[Mission] JSON: ':' expected");
+                p_++;
+                j.obj.emplace_back(k.str, value()); ws();
+                if (s_[p_] == ',') { p_++; continue; }
+                if (s_[p_] == '}') { p_++; break; }
+                throw std::invalid_argument("[Mission] JSON: ',' or '}' expected");
+            }
+        } else if (c == '[') {
+            j.kind = Json::Arr; p_++; ws();
+            if (s_[p_] == ']') { p_++; return j; }
+            for (;;) {
+                j.arr.push_back(value()); ws();
+                if (s_[p_] == ',') { p_++; continue; }
+                if (s_[p_] == ']') { p_++; break; }
+                throw std::invalid_argument("[Mission] JSON: ',' or ']' expected");
+            }
+        } else if (c == '"') {
+            j.kind = Json::Str; p_++;
+            while (p_ < s_.size() && s_[p_] != '"') { if (s_[p_] == '\\') p_++; j.str += s_[p_++]; }
+            p_++;
+        } else {
+            size_t e = p_;
+            while (e < s_.size() && (isdigit((unsigned char)s_[e]) || strchr("+-.eE", s_[e]))) e++;
+            if (e == p_) throw std::invalid_argument("[Mission] JSON: value expected");
+            j.kind = Json::Num; j.num = std::stod(s_.substr(p_, e - p_)); p_ = e;
+        }
+        return j;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- data model
+struct point3d {   // octomap::point3d: float storage, float arithmetic
+    float v[3] = {0, 0, 0};
+    point3d() = default;
+    point3d(double x, double y, double z) { v[0] = (float)x; v[1] = (float)y; v[2] = (float)z; }
+    float x() const { return v[0]; } float y() const { return v[1]; } float z() const { return v[2]; }
+    float &operator()(int i) { return v[i]; } float operator()(int i) const { return v[i]; }
+    point3d operator-(const point3d &o) const { point3d r; for (int i = 0; i < 3; i++) r.v[i] = v[i] - o.v[i]; return r; }
+    point3d operator+(const point3d &o) const { point3d r; for (int i = 0; i < 3; i++) r.v[i] = v[i] + o.v[i]; return r; }
+    point3d operator*(float s) const { point3d r; for (int i = 0; i < 3; i++) r.v[i] = v[i] * s; return r; }
+    double norm() const { float n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; return std::sqrt((double)n2); }
+};
+typedef std::vector<std::vector<point3d>> traj_t;   // [m][control point]
+
+struct State { point3d position, velocity, acceleration; int planner_seq = 0; };
+
+struct Agent {
+    int id = 0, cid = 0;
+    State current_state;
+    point3d start_position, desired_goal_position, current_goal_position;
+    std::vector<double> max_vel, max_acc;
+    double radius = 0.15, downwash = 2.0, nominal_velocity = 1.0;
+};
+
+enum class PlanningReport { Initialized = 0, INITTRAJGENERATIONFAILED, CONSTRAINTGENERATIONFAILED, QPFAILED, WAITFORROSMSG, SUCCESS };
+
+struct Param {   // defaults = launch/testall_empty.launch
+    double dt = 0.2, horizon = 1.0;
+    int n = 5, phi = 3;
+    double control_input_weight = 0.01, terminal_weight = 1.0;
+    double multisim_time_step = 0.2, multisim_record_time_step = 0.1, multisim_reset_threshold = 0.15;
+    int multisim_max_planner_iteration = 300;
+    bool multisim_save_result = false;
+    double goal_threshold = 0.1;
+    bool world_use_octomap = false;
+    double world_resolution = 0.1;
+    std::string log_dir = ".";
+    int device = 0;
+    std::string getPlannerModeStr() const { return "LSC"; }
+};
+
+class Mission {
+  public:
+    int qn = 0, on = 0;
+    std::vector<Agent> agents;
+    point3d world_min, world_max;
+    std::string mission_file_name, world_file_name;
+
+    bool initialize(const std::string &mission_file, const std::string &world_file = "") {
+        mission_file_name = mission_file; world_file_name = world_file;
+        std::ifstream ifs(mission_file);
+        if (!ifs) throw std::invalid_argument("There is no such mission file " + mission_file + "\n");
+        std::stringstream ss; ss << ifs.rdbuf();
+        const std::string txt = ss.str();
+        Json doc = JsonParser(txt).parse();
+        const Json &world = doc["world"];
+        if (world.arr.size() != 1) throw std::invalid_argument("[Mission] World must have one element");
+        const Json &dim = world[0]["dimension"];
+        world_min = point3d(dim[0].num, dim[1].num, dim[2].num);
+        world_max = point3d(dim[3].num, dim[4].num, dim[5].num);
+        std::map<std::string, Agent> quad;
+        for (auto &kv : doc["quadrotors"].obj) {
+            Agent q;
+            for (int i = 0; i < 3; i++) { q.max_vel.push_back(kv.second["max_vel"][i].num); q.max_acc.push_back(kv.second["max_acc"][i].num); }
+            q.radius = kv.second["radius"].num; q.downwash = kv.second["downwash"].num; q.nominal_velocity = kv.second["nominal_velocity"].num;
+            quad[kv.first] = q;
+        }
+        const Json &al = doc["agents"];
+        qn = (int)al.arr.size();
+        agents.resize(qn);
+        for (int qi = 0; qi < qn; qi++) {
+            const Json &a = al[qi];
+            if (!a.has("type") || !a.has("start") || !a.has("goal")) throw std::invalid_argument("[Mission] Agent must have type, start and goal");
+            agents[qi] = quad.at(a["type"].str);
+            agents[qi].id = qi;
+            agents[qi].cid = a.has("cid") ? (int)a["cid"].num : qi;
+            agents[qi].start_position = point3d(a["start"][0].num, a["start"][1].num, a["start"][2].num);
+            agents[qi].desired_goal_position = point3d(a["goal"][0].num, a["goal"][1].num, a["goal"][2].num);
+            if (a.has("downwash")) agents[qi].downwash = a["downwash"].num;
+            if (a.has("nominal_velocity")) agents[qi].nominal_velocity = a["nominal_velocity"].num;
+        }
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- polynomial.hpp:9-121
+inline int nChoosek(int n, int k) {
+    if (k > n) return 0;
+    if (k * 2 > n) k = n - k;
+    if (k == 0) return 1;
+    int r = n;
+    for (int i = 2; i <= k; i++) { r *= (n - i + 1); r /= i; }
+    return r;
+}
+inline point3d getPointFromControlPoints(const std::vector<point3d> &cp, double t) {
+    const int n = (int)cp.size() - 1;
+    double x = 0, y = 0, z = 0;
+    for (int i = 0; i <= n; i++) {
+        double b = nChoosek(n, i) * std::pow(t, i) * std::pow(1 - t, n - i);
+        x += cp[i].x() * b; y += cp[i].y() * b; z += cp[i].z() * b;
+    }
+    return point3d((float)x, (float)y, (float)z);
+}
+inline State getStateFromControlPoints(const traj_t &cps, double current_time, int M, int n, double dt) {
+    int m = (int)(current_time / dt);
+    if (m == M && current_time < M * dt + SP_EPSILON) m = M - 1;
+    else if (m >= M) throw std::invalid_argument("[Polynomial] Input of getOdom is out of bound");
+    State s;
+    const double tl = current_time / dt - m;
+    s.position = getPointFromControlPoints(cps[m], tl);
+    std::vector<point3d> vp(n), ap(n - 1);
+    for (int i = 0; i < n; i++) vp[i] = ((cps[m][i + 1] - cps[m][i]) * (float)n) * (float)std::pow(dt, -1);
+    s.velocity = getPointFromControlPoints(vp, tl);
+    for (int i = 0; i < n - 1; i++) ap[i] = ((vp[i + 1] - vp[i]) * (float)(n - 1)) * (float)std::pow(dt, -1);
+    s.acceleration = getPointFromControlPoints(ap, tl);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------- TrajPlanner facade
+class TrajPlanner {
+  public:
+    TrajPlanner(int agent_id, const Param &p, const Mission &m) : param(p), mission(m) {
+        agent = mission.agents[agent_id];
+        agent.current_state.position = agent.start_position;
+        agent.current_goal_position = agent.desired_goal_position;
+        M = (int)((param.horizon + SP_EPSILON) / param.dt);
+        n = param.n;
+        traj_curr.assign(M, std::vector<point3d>(n + 1));
+    }
+    // --- surface used by MultiSyncSimulator (include/traj_planner.hpp:51-101) ---
+    void setCurrentState(const State &s) { agent.current_state = s; current_state_seq = s.planner_seq; state_updated = true; }
+    void setObsPrevTrajs(const std::vector<traj_t> &) { obstacles_updated = true; }   // the GPU context holds the table
+    void setStart(const point3d &p) { agent.start_position = p; }
+    void setDesiredGoal(const point3d &p) { agent.desired_goal_position = p; }
+    State getCurrentStateMsg() const { State s = agent.current_state; s.planner_seq = planner_seq; return s; }
+    State getFutureStateMsg(double t) const { State s = getStateFromControlPoints(traj_curr, t, M, n, param.dt); s.planner_seq = planner_seq; return s; }
+    traj_t getTraj() const { return traj_curr; }
+    double getQPCost() const { return current_qp_cost; }
+    PlanningReport getPlanningReport() const { return planning_report; }
+    double getPlanningTime() const { return planning_time; }
+    point3d getCurrentPosition() const { return agent.current_state.position; }
+    point3d getDesiredGoalPosition() const { return agent.desired_goal_position; }
+    point3d getCurrentGoalPosition() const { return agent.current_goal_position; }
+    int getPlannerSeq() const { return planner_seq; }
+    // goal_mode = static (src/traj_planner.cpp:511-513); the grid/A* modes are SURVEY 8(f)#1
+    void goalPlanning() { agent.current_goal_position = agent.desired_goal_position; }
+    // TrajPlanner::plan's bookkeeping (:99-145); the QP itself was solved by the batched tick
+    bool inputsFresh() const { return state_updated && obstacles_updated && current_state_seq == planner_seq; }
+    void acceptPlan(const float *traj90, double cost, int status, double seconds) {
+        planner_seq++;
+        for (int m = 0; m < M; m++)
+            for (int i = 0; i <= n; i++)
+                traj_curr[m][i] = point3d(traj90[m * (n + 1) + i], traj90[30 + m * (n + 1) + i], traj90[60 + m * (n + 1) + i]);
+        if (status == LSC_STATUS_OK) current_qp_cost = cost;
+        planning_report = PlanningReport::SUCCESS;   // QP failures are swallowed (src/traj_planner.cpp:1556-1584)
+        last_status = status;
+        planning_time = seconds;
+        state_updated = obstacles_updated = false;
+    }
+    Agent agent;
+    int last_status = 0;
+  private:
+    Param param;
+    Mission mission;
+    int M, n;
+    traj_t traj_curr;
+    int planner_seq = 0, current_state_seq = 0;
+    bool state_updated = false, obstacles_updated = false;
+    double current_qp_cost = 0, planning_time = 0;
+    PlanningReport planning_report = PlanningReport::Initialized;
+};
+
+}  // namespace DynamicPlanning

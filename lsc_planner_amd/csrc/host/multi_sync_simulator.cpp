@@ -1,0 +1,249 @@
+// multi_sync_simulator.cpp -- headless MultiSyncSimulator (src/multi_sync_simulator.cpp) over the C ABI.
+//   lsc_sim --mission m.json [--world map.bt] [--max-iter 300] [--csv DIR] [--device 0] [--quiet]
+// Loop: isFinished -> doStep -> update (ideal next state of every agent) -> plan (one lsc_replan_tick for the
+// swarm) -> savePlanningResult (safety ratio / collision accounting) -> optional result / summary CSV in the
+// reference's column layout, so that its replayer can read our runs.
+#include <chrono>
+#include <cstring>
+#include <iostream>
+
+#include "lsc_host.hpp"
+
+namespace DynamicPlanning {
+
+class MultiSyncSimulator {
+  public:
+    MultiSyncSimulator(const Param &p, const Mission &m) : param(p), mission(m) {
+        for (int qi = 0; qi < mission.qn; qi++) agents.emplace_back(new TrajPlanner(qi, param, mission));
+        lsc_config cfg;
+        lsc_default_config(&cfg);
+        cfg.dt = param.dt; cfg.control_weight = param.control_input_weight; cfg.terminal_weight = param.terminal_weight;
+        for (int k = 0; k < 3; k++) { cfg.world_min[k] = mission.world_min(k); cfg.world_max[k] = mission.world_max(k); }
+        cfg.use_octomap = param.world_use_octomap; cfg.world_resolution = param.world_resolution; cfg.device = param.device;
+        ctx = lsc_create(&cfg);
+        if (!ctx) throw std::runtime_error("[MultiSyncSimulator] lsc_create failed: no usable MI355X (there is no CPU path)");
+        const int N = mission.qn;
+        std::vector<double> r(N), dw(N), vm(3 * N), am(3 * N), vn(N);
+        for (int qi = 0; qi < N; qi++) {
+            const Agent &a = mission.agents[qi];
+            r[qi] = a.radius; dw[qi] = a.downwash; vn[qi] = a.nominal_velocity;
+            for (int k = 0; k < 3; k++) { vm[3 * qi + k] = a.max_vel[k]; am[3 * qi + k] = a.max_acc[k]; }
+        }
+        check(lsc_set_agents(ctx, N, r.data(), dw.data(), vm.data(), am.data(), vn.data()));
+        if (param.world_use_octomap) setOctomap(mission.world_file_name);
+        h_state.resize(9 * N); h_goal.resize(3 * N); h_prev.assign(90 * N, 0.f); h_next.resize(90 * N);
+        h_cost.assign(N, 0.0); h_status.assign(N, 0); h_iters.assign(N, 0);
+        points.resize(N);
+        file_name_param = param.getPlannerModeStr() + "_" + std::to_string(N) + "agents";
+    }
+    ~MultiSyncSimulator() { lsc_destroy(ctx); }
+
+    // src/multi_sync_simulator.cpp:153-167
+    void setOctomap(const std::string &file) {
+        float *edt = nullptr; int dims[3], kmin[3]; double res;
+        const float wmin[3] = {mission.world_min(0), mission.world_min(1), mission.world_min(2)};
+        const float wmax[3] = {mission.world_max(0), mission.world_max(1), mission.world_max(2)};
+        if (lsc_edt_from_bt(file.c_str(), wmin, wmax, 1.0, &edt, dims, kmin, &res) != LSC_OK)
+            throw std::invalid_argument("[MultiSyncSimulator] Fail to read octomap file " + file);
+        check(lsc_set_distmap(ctx, edt, dims[0], dims[1], dims[2], kmin, res));
+        lsc_free_host(edt);
+    }
+
+    // :83-147 (simulation branch)
+    void run(bool quiet) {
+        for (int iter = 0; iter < param.multisim_max_planner_iteration; iter++) {
+            if (isFinished() || iter == param.multisim_max_planner_iteration - 1) { summarizeResult(); break; }
+            if (initial_update) { sim_start_time = sim_current_time = param.multisim_time_step; }
+            else sim_current_time += param.multisim_time_step;
+            update();
+            if (!plan()) break;
+            if (!quiet && iter % 10 == 0) {
+                double worst = 0; int failed = 0;
+                for (int qi = 0; qi < mission.qn; qi++) {
+                    worst = std::max(worst, (agents[qi]->getCurrentPosition() - mission.agents[qi].desired_goal_position).norm());
+                    failed += agents[qi]->last_status != 0;
+                }
+                std::printf("[MultiSyncSimulator] iter %d t=%.1f max dist to goal %.3f safety ratio %.4f qp failures %d tick %.3f ms\n",
+                            iter, sim_current_time - sim_start_time, worst, safety_ratio_agent, failed, last_tick_ms);
+            }
+        }
+    }
+
+    // :190-318 (no tf: ideal states; no dynamic obstacles)
+    void update() {
+        const int N = mission.qn;
+        std::vector<State> next(N);
+        for (int qi = 0; qi < N; qi++)
+            next[qi] = initial_update ? agents[qi]->getCurrentStateMsg() : agents[qi]->getFutureStateMsg(param.multisim_time_step);
+        for (int qi = 0; qi < N; qi++) {
+            next[qi].planner_seq = agents[qi]->getPlannerSeq();
+            agents[qi]->setCurrentState(next[qi]);
+        }
+        // obstacle list of agent qi = every other agent's next state + previous trajectory: one shared table
+        for (int qi = 0; qi < N; qi++) {
+            const traj_t t = agents[qi]->getTraj();
+            for (int m = 0; m < 5; m++) for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) h_prev[90 * qi + 30 * k + 6 * m + i] = t[m][i](k);
+            agents[qi]->setObsPrevTrajs({});
+        }
+        initial_update = false;
+    }
+
+    // :320-337
+    bool plan() {
+        const int N = mission.qn;
+        for (int qi = 0; qi < N; qi++) {
+            if (!agents[qi]->inputsFresh()) return false;
+            agents[qi]->goalPlanning();
+            const State &s = agents[qi]->agent.current_state;
+            for (int k = 0; k < 3; k++) {
+                h_state[9 * qi + k] = s.position(k); h_state[9 * qi + 3 + k] = s.velocity(k); h_state[9 * qi + 6 + k] = s.acceleration(k);
+                h_goal[3 * qi + k] = agents[qi]->getCurrentGoalPosition()(k);
+            }
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        check(lsc_replan_tick(ctx, h_state.data(), h_goal.data(), h_prev.data(), agents[0]->getPlannerSeq() + 1, h_next.data(),
+                              h_cost.data(), h_status.data(), h_iters.data(), nullptr, nullptr, nullptr));
+        last_tick_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        for (int qi = 0; qi < N; qi++) agents[qi]->acceptPlan(h_next.data() + 90 * qi, h_cost[qi], h_status[qi], last_tick_ms * 1e-3 / N);
+        total_ticks++; total_tick_ms += last_tick_ms;
+        savePlanningResult();
+        if (param.multisim_save_result) savePlanningResultAsCSV();
+        return true;
+    }
+
+    // :358-380 (GOTO)
+    bool isFinished() {
+        for (int qi = 0; qi < mission.qn; qi++)
+            if ((agents[qi]->getCurrentPosition() - mission.agents[qi].desired_goal_position).norm() > param.goal_threshold) return false;
+        total_flight_time = sim_current_time - sim_start_time;
+        return true;
+    }
+
+    // :408-510
+    void savePlanningResult() {
+        const int N = mission.qn;
+        for (double ft = 0; ft < param.multisim_time_step - SP_EPSILON_FLOAT; ft += param.multisim_record_time_step) {
+            std::vector<point3d> pos(N);
+            for (int qi = 0; qi < N; qi++) { pos[qi] = agents[qi]->getFutureStateMsg(ft).position; points[qi].push_back(pos[qi]); }
+            for (int qi = 0; qi < N; qi++) {
+                double current = SP_INFINITY; int min_qj = -1;
+                for (int qj = 0; qj < N; qj++) {
+                    if (qi == qj) continue;
+                    const Agent &a = mission.agents[qi], &b = mission.agents[qj];
+                    const double downwash = (a.downwash * a.radius + b.downwash * b.radius) / (a.radius + b.radius);
+                    point3d d = pos[qi] - pos[qj];
+                    d(2) = (float)(d.z() / downwash);             // distBetweenAgents, include/util.hpp:225-229
+                    const double ratio = d.norm() / (a.radius + b.radius);
+                    if (ratio < current) { current = ratio; min_qj = qj; }
+                    if (ratio < safety_ratio_agent) safety_ratio_agent = ratio;
+                }
+                if (current < 1) {
+                    std::fprintf(stderr, "[MultiSyncSimulator] collision with agents, agent_id: (%d,%d), safety_ratio:%g\n", qi, min_qj, current);
+                    is_collided = true;
+                }
+            }
+        }
+        for (int qi = 0; qi < N; qi++) { N_average++; planning_time_sum += agents[qi]->getPlanningTime(); }
+    }
+
+    // :513-587 : 15 columns per agent per record step
+    void savePlanningResultAsCSV() {
+        const std::string fn = param.log_dir + "/result_" + file_name_param + ".csv";
+        std::ofstream csv(fn, sim_current_time == sim_start_time ? std::ios_base::trunc : std::ios_base::app);
+        const int N = mission.qn;
+        if (sim_current_time == sim_start_time)
+            for (int qi = 0; qi < N; qi++) csv << "id,t,px,py,pz,vx,vy,vz,ax,ay,az,planning_time,qp_cost,planning_report,size" << (qi < N - 1 ? "," : "\n");
+        double t = sim_current_time - sim_start_time;
+        for (double ft = 0; ft < param.multisim_time_step; ft += param.multisim_record_time_step, t += param.multisim_record_time_step)
+            for (int qi = 0; qi < N; qi++) {
+                const State s = agents[qi]->getFutureStateMsg(ft);
+                csv << qi << "," << t << "," << s.position.x() << "," << s.position.y() << "," << s.position.z() << "," << s.velocity.x() << ","
+                    << s.velocity.y() << "," << s.velocity.z() << "," << s.acceleration.x() << "," << s.acceleration.y() << "," << s.acceleration.z()
+                    << "," << agents[qi]->getPlanningTime() << "," << agents[qi]->getQPCost() << "," << (int)agents[qi]->getPlanningReport() << ","
+                    << mission.agents[qi].radius << (qi < N - 1 ? "," : "\n");
+            }
+    }
+
+    // :671-680
+    double getTotalDistance() const {
+        double d = 0;
+        for (auto &p : points) for (size_t i = 0; i + 1 < p.size(); i++) d += (p[i + 1] - p[i]).norm();
+        return d;
+    }
+
+    // :382-402 + :589-633 (25 columns; per-phase times that do not exist separately on the GPU are written as 0)
+    void summarizeResult() {
+        total_distance = getTotalDistance();
+        const double avg = N_average ? planning_time_sum / N_average : 0.0;
+        std::printf("[MultiSyncSimulator] total flight time: %g\n[MultiSyncSimulator] total distance: %g\n"
+                    "[MultiSyncSimulator] planning time per agent: %g\n[MultiSyncSimulator] safety ratio between agent: %g\n"
+                    "[MultiSyncSimulator] collided: %d, ticks: %d, mean tick %.3f ms -> %.1f agent-replans/s (host-buffer ABI)\n",
+                    total_flight_time, total_distance, avg, safety_ratio_agent, (int)is_collided, total_ticks,
+                    total_ticks ? total_tick_ms / total_ticks : 0.0, total_tick_ms > 0 ? mission.qn * total_ticks / (total_tick_ms * 1e-3) : 0.0);
+        if (!param.multisim_save_result) return;
+        const std::string fn = param.log_dir + "/summary_" + file_name_param + ".csv";
+        std::ifstream in(fn);
+        const bool header = !in || in.peek() == std::ifstream::traits_type::eof();
+        std::ofstream out(fn, std::ios_base::app);
+        if (header)
+            out << "start_time,total_flight_time,total_flight_distance,is_collided,safety_ratio_agent,average_planning_time,min_planning_time,"
+                   "max_planning_time,initial_traj_planning_time,obstacle_prediction_time,goal_planning_time,lsc_generation_time,"
+                   "sfc_generation_time,traj_optimization_time,mission_file_name,world_file_name,planner_mode,prediction_mode,"
+                   "initial_traj_mode,slack_mode,goal_mode,world_dimension,dt,horizon,N_constraint_segments\n";
+        out << sim_start_time << "," << total_flight_time << "," << total_distance << "," << is_collided << "," << safety_ratio_agent << "," << avg
+            << "," << avg << "," << avg << ",0,0,0,0,0," << avg << "," << mission.mission_file_name << "," << mission.world_file_name
+            << ",LSC,previous_solution,previous_solution,none,static,3," << param.dt << "," << param.horizon << ",-1\n";
+    }
+
+    bool is_collided = false;
+    double safety_ratio_agent = SP_INFINITY, total_flight_time = 0, total_distance = 0;
+    int total_ticks = 0;
+    double total_tick_ms = 0, last_tick_ms = 0;
+
+  private:
+    void check(int rc) { if (rc != LSC_OK) throw std::runtime_error(std::string("[MultiSyncSimulator] ") + lsc_last_error(ctx)); }
+    Param param;
+    Mission mission;
+    std::vector<std::unique_ptr<TrajPlanner>> agents;
+    lsc_ctx *ctx = nullptr;
+    std::vector<float> h_state, h_goal, h_prev, h_next;
+    std::vector<double> h_cost;
+    std::vector<int> h_status, h_iters;
+    std::vector<std::vector<point3d>> points;
+    bool initial_update = true;
+    double sim_start_time = 0, sim_current_time = 0, planning_time_sum = 0;
+    long N_average = 0;
+    std::string file_name_param;
+};
+
+}  // namespace DynamicPlanning
+
+int main(int argc, char **argv)
+{
+    using namespace DynamicPlanning;
+    Param param;
+    std::string mission_file, world_file;
+    bool quiet = false;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&]() -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+        if (a == "--mission") mission_file = next();
+        else if (a == "--world") { world_file = next(); param.world_use_octomap = true; }
+        else if (a == "--max-iter") param.multisim_max_planner_iteration = std::stoi(next());
+        else if (a == "--csv") { param.log_dir = next(); param.multisim_save_result = true; }
+        else if (a == "--device") param.device = std::stoi(next());
+        else if (a == "--quiet") quiet = true;
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--quiet]\n"); return 2; }
+    }
+    if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
+    try {
+        Mission mission;
+        mission.initialize(mission_file, world_file);
+        MultiSyncSimulator sim(param, mission);
+        sim.run(quiet);
+        return sim.is_collided ? 1 : 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 3;
+    }
+}

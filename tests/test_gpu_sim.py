@@ -1,0 +1,68 @@
+"""-m gpu: the C++ host side (TrajPlanner facade + headless MultiSyncSimulator, csrc/host) driving the C ABI."""
+import csv
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_mission
+
+pytestmark = pytest.mark.gpu
+
+SIM = os.path.join(ROOT, "lsc_planner_amd", "lsc_sim")
+
+
+def _write_mission(path, ms):
+    doc = {"quadrotors": {"crazyflie": {"max_vel": list(map(float, ms.max_vel[0])), "max_acc": list(map(float, ms.max_acc[0])),
+                                        "radius": float(ms.radius[0]), "nominal_velocity": float(ms.nominal_velocity[0]),
+                                        "downwash": float(ms.downwash[0])}},
+           "world": [{"dimension": [float(v) for v in list(ms.world_min) + list(ms.world_max)]}],
+           "agents": [{"type": "crazyflie", "cid": i + 1, "start": [float(v) for v in ms.start[i]], "goal": [float(v) for v in ms.goal[i]]}
+                      for i in range(ms.qn)], "obstacles": []}
+    json.dump(doc, open(path, "w"))
+
+
+def test_headless_simulator_runs_the_reference_mission(ticks, tmp_path):
+    assert os.path.exists(SIM), "lsc_sim not built (python -c 'import __graft_entry__ as g; g.build()')"
+    ms = golden_mission(ticks, "multi_simple4")
+    mp = tmp_path / "multi_simple4.json"
+    _write_mission(str(mp), ms)
+    r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(tmp_path), "--quiet"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr                 # 0 = finished without collision
+    out = r.stdout
+    t = float(out.split("total flight time:")[1].split()[0])
+    assert 5.0 < t < 16.0                                          # oracle mission: 55 ticks = 10.8 s
+    ratio = float(out.split("safety ratio between agent:")[1].split()[0])
+    assert ratio >= 1.0 - 1e-3
+    # result CSV in the reference's schema: 15 columns per agent, 2 record steps per tick
+    rows = list(csv.reader(open(tmp_path / "result_LSC_4agents.csv")))
+    assert rows[0][:15] == "id,t,px,py,pz,vx,vy,vz,ax,ay,az,planning_time,qp_cost,planning_report,size".split(",")
+    assert all(len(r_) == 60 for r_ in rows)
+    assert abs(float(rows[1][2]) - 1.0) < 1e-6 and float(rows[1][14]) == 0.15
+    summ = list(csv.reader(open(tmp_path / "summary_LSC_4agents.csv")))
+    assert len(summ[0]) == 25 and summ[1][3] == "0"
+
+
+def test_simulator_trajectory_equals_python_host_layer(ticks, tmp_path):
+    """Same mission through the Python harness: the C++ and Python host layers feed the ABI identically."""
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import next_state_host
+    ms = golden_mission(ticks, "multi_simple4")
+    mp = tmp_path / "m.json"
+    _write_mission(str(mp), ms)
+    subprocess.run([SIM, "--mission", str(mp), "--csv", str(tmp_path), "--quiet", "--max-iter", "12"], check=False, timeout=300)
+    rows = list(csv.reader(open(tmp_path / "result_LSC_4agents.csv")))[1:]
+    pl = L.SwarmPlanner(ms)
+    state = np.zeros((4, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((4, 3, 30), np.float32)
+    for tick in range(10):
+        g = pl.plan(state, ms.goal, traj)
+        traj = g["traj"]
+        row = rows[2 * tick]                                      # record step at future_time = 0 of this tick
+        for q in range(4):
+            p = [float(row[15 * q + 2 + k]) for k in range(3)]
+            assert np.allclose(p, traj[q, :, 0], atol=2e-6), (tick, q)
+        state = next_state_host(traj)
+    pl.close()
