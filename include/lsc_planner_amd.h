@@ -71,6 +71,9 @@ typedef struct {
     int    max_iters;          /* interior-point iteration cap; 0 = 50                 */
     int    prune;              /* 1 (default via lsc_default_config): drop LSC rows that are provably
                                   redundant inside the reachable box; 0: keep all 27(N-1) rows  */
+    double warm_start_mu;      /* interior-point start: > 0 warm start from the shifted previous plan, every row
+                                  centred on this complementarity value (default 0.1), with the cold (Mehrotra)
+                                  start as fallback; 0 = always cold start */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);

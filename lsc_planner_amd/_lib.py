@@ -31,6 +31,7 @@ class LscConfig(ctypes.Structure):
         ("max_rows_per_cp", ctypes.c_int),
         ("max_iters", ctypes.c_int),
         ("prune", ctypes.c_int),
+        ("warm_start_mu", ctypes.c_double),
     ]
 
 

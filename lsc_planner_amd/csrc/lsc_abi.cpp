@@ -151,6 +151,7 @@ void build_model(const lsc_config &cfg, HostModel &H)
     m.prune = cfg.prune;
     m.max_iters = cfg.max_iters > 0 ? cfg.max_iters : 50;
     m.dx_tol = 2e-8;
+    m.ws_mu0 = cfg.warm_start_mu >= 0.0 ? cfg.warm_start_mu : 0.1;
     int n = 0;
     for (int sl = 0; sl < AXROWS; sl++) {
         const int type = sl / NV, t = (sl % NV) % SEGV, mm = t / NC, i = t % NC;
@@ -159,6 +160,7 @@ void build_model(const lsc_config &cfg, HostModel &H)
     }
     if (n != 414) { std::fprintf(stderr, "lsc: axis row count %d != 414\n", n); std::abort(); }
     if (const char *e = std::getenv("LSC_DX_TOL")) m.dx_tol = std::atof(e);
+    if (const char *e = std::getenv("LSC_WS_MU0")) m.ws_mu0 = std::atof(e);
 }
 
 }  // namespace
@@ -231,7 +233,7 @@ void lsc_default_config(lsc_config *cfg)
     cfg->world_min[0] = -10; cfg->world_min[1] = -10; cfg->world_min[2] = 0;
     cfg->world_max[0] = 10; cfg->world_max[1] = 10; cfg->world_max[2] = 2.5f;
     cfg->use_octomap = 0; cfg->world_resolution = 0.1; cfg->device = 0;
-    cfg->max_rows_per_cp = 0; cfg->max_iters = 50; cfg->prune = 1;
+    cfg->max_rows_per_cp = 0; cfg->max_iters = 50; cfg->prune = 1; cfg->warm_start_mu = 0.1;
 }
 
 lsc_ctx *lsc_create(const lsc_config *cfg)

@@ -849,13 +849,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int status = LSC_STATUS_INFEASIBLE_K;
     int iters = 0;
     double obj = 0.0;
+    const double hmax = fmax(1.0, fmax(fabs((double)md.world_max[0]), fabs((double)md.world_min[0])));
 
-    if (a.sfc_err && a.sfc_err[qi] != 0) {
-        status = LSC_STATUS_SFC_K;   // seed box of the corridor blocked (the reference throws out of plan())
-    } else if (overflow) {
-        status = LSC_STATUS_CAPACITY_K;
-    } else {
-        // ---------------- initial point: (H + A^T A) y = -grad(x0) + A^T (h - A x0)
+    // The solver is a small state machine so that the (fully unrolled, register-heavy) factorisation and triangular
+    // solves exist at exactly one place in the code:
+    //   ST_COLD : cold start  (H + A^T A) y = -grad(x0) + A^T (h - A x0), then s, z shifted into the interior
+    //   ST_PRED : residuals at the current point, Hessian, factorisation, affine (predictor) direction
+    //   ST_CORR : corrector right-hand side, same factor, combined direction, step
+    // Start: warm (y = free control points of the shifted previous plan, every row centred on mu0) when enabled,
+    // with the cold start as fallback; cold only otherwise.
+    enum { ST_COLD = 0, ST_PRED = 1, ST_CORR = 2 };
+    int phase = ST_PRED, attempt = md.ws_mu0 > 0.0 ? 0 : 1, spent = 0;
+    double alpha = 1.0, gap = 0.0, rpmax = 0.0, mu = 0.0, smu = 0.0;
+    bool gap_ok = false;
+    const int max_iters = md.max_iters;
+
+    auto prepare_cold = [&]() {
+        if (tid < 40) S.y[tid] = 0.0;
+        __syncthreads();
         compute_x(S.y, S.x, true);
         __syncthreads();
         for (int c = tid; c < AXVALID; c += NT) {
@@ -868,46 +879,58 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             rt2[r] = lsc_ax(S.x, r, cp) + rrhs[r];
         }
         __syncthreads();
-        reduce_rows(true, true);
-        assemble(true);
-        if (factor()) {
-            solve();
-            if (tid < NY) S.y[tid] = S.dy[tid];
-            __syncthreads();
-            compute_x(S.y, S.x, true);
-            __syncthreads();
-            double mins = 1e300, minz = 1e300;
-            for (int c = tid; c < AXVALID; c += NT) {
-                const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
-                double sv = S.ah[sl] - ax_row(S.x, type, kt / SEGV, kt % SEGV);
-                S.as_[sl] = sv; S.az[sl] = -sv;
-                mins = fmin(mins, sv); minz = fmin(minz, -sv);
-            }
-            for (int c = tid; c < nact; c += NT) {
-                const uint32_t e = cmap[c];
-                const int r = e & 0xffff, cp = e >> 16;
-                double sv = -rrhs[r] - lsc_ax(S.x, r, cp);
-                rs[r] = sv; rz[r] = -sv;
-                mins = fmin(mins, sv); minz = fmin(minz, -sv);
-            }
-            block_reduce(mins, minz, 0.0, 0.0, 0.0, 2, 2, 0, 0, 0);
-            const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0;
-            const double shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
-            // the shifted point enters the loop as a "step" of length 1 from (s - shs, z - shz): the first fused
-            // update/residual pass then applies it (t1 = ds, t2 = dz)
-            for (int c = tid; c < AXVALID; c += NT) { const int sl = S.amap[c]; S.at1[sl] = shs; S.at2[sl] = shz; }
-            for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & 0xffff; rt1[r] = shs; rt2[r] = shz; }
-            __syncthreads();
-            stamp(PH_INIT);
+    };
+    auto prepare_warm = [&](double mu0) {
+        if (tid < NY) {
+            const int g = tid, k = g < 36 ? (g % 9) / 3 : g - 36, va = g < 36 ? (g / 9) * 3 + (g % 3) : 12;
+            const int t = va < 12 ? (va / 3) * NC + 3 + (va % 3) : (M - 1) * NC + 3;
+            S.y[g] = (double)S.pinit[k * SEGV + t];
+        }
+        __syncthreads();
+        compute_x(S.y, S.x, true);
+        __syncthreads();
+        const double smin = sqrt(mu0);
+        for (int c = tid; c < AXVALID; c += NT) {
+            const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
+            // velocity / acceleration rows are stored divided by n/dt and n(n-1)/dt^2: scale the floor with them so that
+            // the start equals the one of the reference's row scaling
+            const double floor_s = type < 2 ? smin : (type < 4 ? smin * md.hv_scale : smin * md.ha_scale);
+            const double sv = fmax(S.ah[sl] - ax_row(S.x, type, kt / SEGV, kt % SEGV), floor_s);
+            S.as_[sl] = sv; S.az[sl] = mu0 / sv; S.at1[sl] = 0.0; S.at2[sl] = 0.0;
+        }
+        for (int c = tid; c < nact; c += NT) {
+            const uint32_t e = cmap[c];
+            const int r = e & 0xffff, cp = e >> 16;
+            const double sv = fmax(-rrhs[r] - lsc_ax(S.x, r, cp), smin);
+            rs[r] = sv; rz[r] = mu0 / sv; rt1[r] = 0.0; rt2[r] = 0.0;
+        }
+        __syncthreads();
+    };
 
-            // ---------------- Mehrotra predictor-corrector iterations
-            const int max_iters = md.max_iters;
-            const double hmax = fmax(1.0, fmax(fabs((double)md.world_max[0]), fabs((double)md.world_min[0])));
-            double alpha = 1.0;
-            for (iters = 0; iters < max_iters; iters++) {
-                // P1 (fused with the previous iteration's update): s += alpha ds, z += alpha dz, then residuals,
-                // 1/s and v = w rp at the new point
-                double gap = 0.0, rpmax = 0.0;
+    bool run = true;
+    if (a.sfc_err && a.sfc_err[qi] != 0) {
+        status = LSC_STATUS_SFC_K;   // seed box of the corridor blocked (the reference throws out of plan())
+        run = false;
+    } else if (overflow) {
+        status = LSC_STATUS_CAPACITY_K;
+        run = false;
+    } else if (attempt == 0) {
+        prepare_warm(md.ws_mu0);
+        phase = ST_PRED;
+    } else {
+        prepare_cold();
+        phase = ST_COLD;
+    }
+    stamp(PH_INIT);
+
+    while (run) {
+        bool failed = false;
+        // ---------------------------------------------------------------- before the linear solve
+        if (phase == ST_PRED) {
+            if (iters >= max_iters) failed = true;
+            else {
+                // P1 (fused with the previous step): s += alpha ds, z += alpha dz, then residuals, 1/s, v = w rp
+                double gp = 0.0, rpm = 0.0;
                 for (int c = tid; c < AXVALID; c += NT) {
                     const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
                     double sv = S.as_[sl] + alpha * S.at1[sl], zv = S.az[sl] + alpha * S.at2[sl];
@@ -916,7 +939,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     S.as_[sl] = sv; S.az[sl] = zv;
                     S.at1[sl] = is;
                     S.at2[sl] = zv * is * rp;
-                    gap += sv * zv; rpmax = fmax(rpmax, fabs(rp));
+                    gp += sv * zv; rpm = fmax(rpm, fabs(rp));
                 }
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
@@ -927,7 +950,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     rs[r] = sv; rz[r] = zv;
                     rt1[r] = is;
                     rt2[r] = zv * is * rp;
-                    gap += sv * zv; rpmax = fmax(rpmax, fabs(rp));
+                    gp += sv * zv; rpm = fmax(rpm, fabs(rp));
                 }
                 // objective: sum x'(w_c Q)x + w_t sum |c - g|^2  (src/traj_optimizer.cpp:329-372)
                 double objp = 0.0;
@@ -935,36 +958,83 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     objp = 0.5 * cost_grad() * S.x[tid];
                     if (xterm) { double e = S.x[tid] - S.goal[xk]; objp += md.w_t * e * e; }
                 }
-                block_reduce(gap, rpmax, objp, 0.0, 0.0, 0, 1, 0, 0, 0);
+                block_reduce(gp, rpm, objp, 0.0, 0.0, 0, 1, 0, 0, 0);
                 gap = S.sc[0]; rpmax = S.sc[1]; obj = S.sc[2];
-                const double mu = gap / nrow;
+                mu = gap / nrow;
+                gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
                 if (tid == 0) { S.sc[5] = gap; S.sc[6] = rpmax; }
                 stamp(PH_P1);
-                if (!(gap == gap) || !(rpmax == rpmax)) break;
-
-                reduce_rows(true, false);
-                stamp(PH_REDUCE);
-                assemble(true);
-                stamp(PH_ASSEMBLE);
-                const bool gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
+                if (!(gap == gap) || !(rpmax == rpmax)) failed = true;
+            }
+        } else if (phase == ST_CORR) {
+            // P3: corrector right-hand side  v = w rp - (ds dz - sigma mu)/s
+            for (int c = tid; c < AXVALID; c += NT) {
+                const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
+                double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl];
+                double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - S.ah[sl];
+                S.at2[sl] = zv * is * rp - (S.at2[sl] - smu) * is;
+            }
+            for (int c = tid; c < nact; c += NT) {
+                const uint32_t e = cmap[c];
+                const int r = e & 0xffff, cp = e >> 16;
+                double sv = rs[r], zv = rz[r], is = rt1[r];
+                double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
+                rt2[r] = zv * is * rp - (rt2[r] - smu) * is;
+            }
+            __syncthreads();
+            stamp(PH_P3);
+        }
+        if (!failed) {
+            const bool with_w = phase != ST_CORR;
+            reduce_rows(with_w, phase == ST_COLD);
+            stamp(PH_REDUCE);
+            assemble(with_w);
+            stamp(PH_ASSEMBLE);
+            if (with_w) {
                 const bool fok = factor();
                 stamp(PH_FACTOR);
                 if (!fok) {
-                    if (a.trace && qi == a.trace_agent) {
-                        // K's band in LDS is stale only where the factor was published: dump W/kconst-based K again
-                        assemble(true);
-                        for (int i = tid; i < NY * KLD; i += NT) a.trace[512 + i] = S.K[i];
-                        for (int i = tid; i < W_SIZE; i += NT) a.trace[512 + NY * KLD + i] = S.W[i];
-                        for (int i = tid; i < n_entries; i += NT) a.trace[512 + NY * KLD + W_SIZE + i] = kconst[i];
-                    }
-                    if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) { double *tr = a.trace + iters * 8; tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = -1; tr[4] = S.sc[5]; tr[5] = -1; tr[6] = 0; tr[7] = mu; }
+                    if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) { double *tr = a.trace + iters * 8; tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = -1; tr[5] = -1; tr[7] = mu; }
                     // K lost definiteness to round-off: accept only if already within 1e-7 relative gap
-                    if (rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) status = LSC_STATUS_OK_K;
-                    break;
+                    if (phase == ST_PRED && rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
+                    failed = true;
                 }
-                solve();  // affine direction in dy / dx
-                stamp(PH_SOLVE);
-
+            }
+        }
+        if (!failed) {
+            solve();
+            stamp(PH_SOLVE);
+            // ------------------------------------------------------------ after the linear solve
+            if (phase == ST_COLD) {
+                if (tid < NY) S.y[tid] = S.dy[tid];
+                __syncthreads();
+                compute_x(S.y, S.x, true);
+                __syncthreads();
+                double mins = 1e300, minz = 1e300;
+                for (int c = tid; c < AXVALID; c += NT) {
+                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
+                    double sv = S.ah[sl] - ax_row(S.x, type, kt / SEGV, kt % SEGV);
+                    S.as_[sl] = sv; S.az[sl] = -sv;
+                    mins = fmin(mins, sv); minz = fmin(minz, -sv);
+                }
+                for (int c = tid; c < nact; c += NT) {
+                    const uint32_t e = cmap[c];
+                    const int r = e & 0xffff, cp = e >> 16;
+                    double sv = -rrhs[r] - lsc_ax(S.x, r, cp);
+                    rs[r] = sv; rz[r] = -sv;
+                    mins = fmin(mins, sv); minz = fmin(minz, -sv);
+                }
+                block_reduce(mins, minz, 0.0, 0.0, 0.0, 2, 2, 0, 0, 0);
+                const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0;
+                const double shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
+                // the shift enters the loop as a "step" of length 1 (t1 = ds, t2 = dz) applied by the first fused pass
+                for (int c = tid; c < AXVALID; c += NT) { const int sl = S.amap[c]; S.at1[sl] = shs; S.at2[sl] = shz; }
+                for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & 0xffff; rt1[r] = shs; rt2[r] = shz; }
+                __syncthreads();
+                alpha = 1.0;
+                phase = ST_PRED;
+                stamp(PH_INIT);
+            } else if (phase == ST_PRED) {
                 // P2: affine step length and centring statistics (+ the Newton-step convergence test)
                 double amin = 1.0, s1 = 0.0, s2 = 0.0;
                 for (int c = tid; c < AXVALID; c += NT) {
@@ -992,43 +1062,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 const double dxa = (tid < NV) ? fabs(S.dx[tid]) : 0.0, xa = (tid < NV) ? fabs(S.x[tid]) : 0.0;
                 block_reduce(amin, s1, s2, dxa, xa, 2, 0, 0, 1, 1);
-                // Newton-step test: with gap and primal residual at tolerance, the affine (pure Newton) step
-                // measures the distance to the optimum (the stationarity residual itself can stall at the
-                // round-off level of the ill-conditioned normal equations when z/s is huge).
+                // Newton-step test: with gap and primal residual at tolerance, the affine (pure Newton) step measures
+                // the distance to the optimum (the stationarity residual itself can stall at the round-off level of
+                // the ill-conditioned normal equations when z/s is huge).
                 if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[3] <= md.dx_tol * fmax(1.0, S.sc[4])) { status = LSC_STATUS_OK_K; break; }
                 const double aaff = S.sc[0];
-                const double dxn_dbg = S.sc[3];
                 const double mu_aff = (gap + aaff * S.sc[1] + aaff * aaff * S.sc[2]) / nrow;
                 double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
                 sigma = sigma * sigma * sigma;
-                const double smu = sigma * mu;
+                smu = sigma * mu;
+                if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) {
+                    double *tr = a.trace + iters * 8;
+                    tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = aaff; tr[4] = sigma; tr[6] = S.sc[3]; tr[7] = mu;
+                }
+                phase = ST_CORR;
                 stamp(PH_P2);
-
-                // P3: corrector right-hand side  v = w rp - (ds dz - sigma mu)/s
-                for (int c = tid; c < AXVALID; c += NT) {
-                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
-                    double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl];
-                    double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - S.ah[sl];
-                    S.at2[sl] = zv * is * rp - (S.at2[sl] - smu) * is;
-                }
-                for (int c = tid; c < nact; c += NT) {
-                    const uint32_t e = cmap[c];
-                    const int r = e & 0xffff, cp = e >> 16;
-                    double sv = rs[r], zv = rz[r], is = rt1[r];
-                    double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
-                    rt2[r] = zv * is * rp - (rt2[r] - smu) * is;
-                }
-                __syncthreads();
-                stamp(PH_P3);
-                reduce_rows(false, false);
-                stamp(PH_REDUCE);
-                assemble(false);
-                stamp(PH_ASSEMBLE);
-                solve();  // combined direction
-                stamp(PH_SOLVE);
-
-                // P4: step length; the step itself is left in t1 = ds, t2 = dz for the fused pass of the next round
-                amin = 1e300;
+            } else {
+                // P4: step length; the step itself stays in t1 = ds, t2 = dz for the fused pass of the next round
+                double amin = 1e300;
                 for (int c = tid; c < AXVALID; c += NT) {
                     const int sl = S.amap[c], type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
                     double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
@@ -1052,18 +1103,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 block_reduce(amin, 0.0, 0.0, 0.0, 0.0, 2, 0, 0, 0, 0);
                 alpha = fmin(1.0, 0.99 * S.sc[0]);
-                if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) {
-                    double *tr = a.trace + iters * 8;
-                    tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = aaff; tr[4] = sigma; tr[5] = alpha; tr[6] = dxn_dbg; tr[7] = mu;
-                }
+                if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) a.trace[iters * 8 + 5] = alpha;
                 if (tid < NY) S.y[tid] += alpha * S.dy[tid];
                 __syncthreads();
                 compute_x(S.y, S.x, true);
                 __syncthreads();
+                iters++;
+                phase = ST_PRED;
                 stamp(PH_P45);
             }
         }
+        if (failed) {
+            if (attempt == 0) {
+                // warm start did not converge: fall back to the cold start
+                attempt = 1;
+                spent += iters;
+                if (tid == 0) S.sc[3] = 1000.0 + (double)spent;   // diagnostics
+                iters = 0;
+                prepare_cold();
+                phase = ST_COLD;
+            } else {
+                break;
+            }
+        }
     }
+    iters += spent;
 
     // ------------------------------------------------------------------ output
     // success: float32 rounding of the optimum (src/traj_optimizer.cpp:79-96); failure: the optimiser's

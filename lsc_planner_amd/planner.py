@@ -25,6 +25,7 @@ class PlannerConfig:
     max_rows_per_cp: int = 0
     max_iters: int = 50
     prune: bool = True
+    warm_start_mu: float = 0.1     # 0 = cold (Mehrotra) start only
 
 
 def _fp(a):
@@ -58,6 +59,7 @@ class SwarmPlanner:
         c.max_rows_per_cp = self.cfg.max_rows_per_cp
         c.max_iters = self.cfg.max_iters
         c.prune = int(self.cfg.prune)
+        c.warm_start_mu = float(self.cfg.warm_start_mu)
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:
