@@ -300,9 +300,11 @@ struct Smem {
     // PDIP vectors
     double x[96], dx[96];       // control points (axis-major, 90 used) and their step
     double gx[96];              // x-space gradient: cost + sum a_r v_r
+    double gz[96];              // cost + sum a_r z_r  (stationarity residual before projection)
     double y[40], dy[40], rhs[40];
     double W[W_SIZE];           // x-space Hessian weights (see lsc_model.hpp)
     double Tv[NCP * 3];         // per control point: -sum v n over its LSC rows
+    double Tz[NCP * 3];         // per control point: -sum z n
     double K[NY * KLD];         // reduced Hessian (lower band); rows of its Cholesky factor after factor()
     double red[6][NWAVE];
     double sc[8];               // broadcast scalars
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     if (tid < 40) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
     for (int i = tid; i < NY * KLD; i += NT) S.K[i] = 0.0;
-    for (int i = tid; i < NCP * 3; i += NT) S.Tv[i] = 0.0;
+    for (int i = tid; i < NCP * 3; i += NT) { S.Tv[i] = 0.0; S.Tz[i] = 0.0; }
     for (int i = tid; i < W_SIZE; i += NT) S.W[i] = 0.0;
     __syncthreads();
     const bool overflow = S.flag != 0;
@@ -727,9 +729,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             g += vof(4, t) - vof(5, t);
             if (i >= 1) g += vof(2, t - 1) - vof(3, t - 1) - 2.0 * (vof(4, t - 1) - vof(5, t - 1));
             if (i >= 2) g += vof(4, t - 2) - vof(5, t - 2);
+            double gzv = 0.0;
+            if (with_w && !unit_w) {   // stationarity residual (only on predictor passes)
+                auto zof = [&](int type, int tt) -> double { int sl = type * NV + k * SEGV + tt; return S.avalid[sl] ? S.az[sl] : 0.0; };
+                gzv += zof(0, t) - zof(1, t) - zof(2, t) + zof(3, t) + zof(4, t) - zof(5, t);
+                if (i >= 1) gzv += zof(2, t - 1) - zof(3, t - 1) - 2.0 * (zof(4, t - 1) - zof(5, t - 1));
+                if (i >= 2) gzv += zof(4, t - 2) - zof(5, t - 2);
+            }
             double cg = cost_grad();   // this lane's (xk, xt) equal (k, t)
             if (i == DEG && t / NC >= M - S.tseg) cg += 2.0 * md.w_t * (S.x[b] - S.goal[k]);
             S.gx[b] = cg + g;
+            S.gz[b] = cg + gzv;
             if (with_w) {
                 double wB = wof(0, t) + wof(1, t);
                 double wV0 = wof(2, t) + wof(3, t);
@@ -769,14 +779,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 S.W[W_S + cp * 6 + c] = acc0 + acc1;
             } else {
                 const float *nc = rn + (c - 6) * R + r0;
-                const double *pv = rt2 + r0;
+                const double *pv = rt2 + r0, *pz = rz + r0;
+                double az0 = 0.0, az1 = 0.0;
                 int j = 0;
                 for (; j + 4 <= cnt; j += 4) {
-                    acc0 += pv[j] * (double)nc[j] + pv[j + 2] * (double)nc[j + 2];
-                    acc1 += pv[j + 1] * (double)nc[j + 1] + pv[j + 3] * (double)nc[j + 3];
+                    const double n0 = (double)nc[j], n1 = (double)nc[j + 1], n2 = (double)nc[j + 2], n3 = (double)nc[j + 3];
+                    acc0 += pv[j] * n0 + pv[j + 2] * n2;
+                    acc1 += pv[j + 1] * n1 + pv[j + 3] * n3;
+                    az0 += pz[j] * n0 + pz[j + 2] * n2;
+                    az1 += pz[j + 1] * n1 + pz[j + 3] * n3;
                 }
-                for (; j < cnt; j++) acc0 += pv[j] * (double)nc[j];
+                for (; j < cnt; j++) { acc0 += pv[j] * (double)nc[j]; az0 += pz[j] * (double)nc[j]; }
                 S.Tv[cp * 3 + (c - 6)] = -(acc0 + acc1);
+                S.Tz[cp * 3 + (c - 6)] = -(az0 + az1);
             }
         }
         __syncthreads();
@@ -799,6 +814,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             double r = yc0 * (S.gx[yo0] + S.Tv[yp0]) + yc1 * (S.gx[yo1] + S.Tv[yp1]) + yc2 * (S.gx[yo2] + S.Tv[yp2]) +
                        yc3 * (S.gx[yo3] + S.Tv[yp3]);
             S.rhs[tid] = -r;
+            // projected stationarity residual Z^T (grad + A^T z), parked in dy (free until the solve)
+            S.dy[tid] = yc0 * (S.gz[yo0] + S.Tz[yp0]) + yc1 * (S.gz[yo1] + S.Tz[yp1]) + yc2 * (S.gz[yo2] + S.Tz[yp2]) +
+                        yc3 * (S.gz[yo3] + S.Tz[yp3]);
         }
         __syncthreads();
     };
@@ -990,6 +1008,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             stamp(PH_REDUCE);
             assemble(with_w);
             stamp(PH_ASSEMBLE);
+            if (phase == ST_PRED) {
+                // cheap exit before the factorisation: primal residual, gap and stationarity all at tolerance
+                const double rda = (tid < NY) ? fabs(S.dy[tid]) : 0.0;
+                block_reduce(rda, 0.0, 0.0, 0.0, 0.0, 1, 0, 0, 0, 0);
+                if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
+            }
             if (with_w) {
                 const bool fok = factor();
                 stamp(PH_FACTOR);

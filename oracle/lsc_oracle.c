@@ -688,6 +688,9 @@ static void chol_solve(const double *L, int n, double *b)
  * onto the equality subspace, s = max(slack, sqrt(mu0)), z = mu0 / s.  Disabled when mu0 <= 0. */
 static __thread const double *g_ws_x0 = NULL;
 static __thread double g_ws_mu0 = 0.0;
+static __thread const double *g_ws_z0 = NULL;   /* experimental: dual warm start, [R] in G order (or NULL) */
+static __thread double *g_zout = NULL;          /* experimental: duals out */
+void orc_set_dual_io(const double *z0, double *zout) { g_ws_z0 = z0; g_zout = zout; }
 void orc_set_warm_start(const double *x0, double mu0) { g_ws_x0 = x0; g_ws_mu0 = mu0; }
 
 int orc_qp_solve(const double *P, const double *c, double cst, const double *lo, const double *hi,
@@ -887,6 +890,7 @@ int orc_qp_solve(const double *P, const double *c, double cst, const double *lo,
             double sl = G[r].rhs - ROWDOT(r, xx);
             s[r] = sl > smin ? sl : smin;
             z[r] = g_ws_mu0 / s[r];
+            if (g_ws_z0 && g_ws_z0[r] > z[r]) z[r] = g_ws_z0[r];
         }
         goto iterate;
     }
@@ -1011,6 +1015,7 @@ iterate:
     }
 
 done:
+    if (g_zout) memcpy(g_zout, z, sizeof(double) * (size_t)R);
     X_FROM_Y(y, xx, 1);
     memcpy(x, xx, sizeof(double) * NV);
     {
