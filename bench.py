@@ -32,6 +32,16 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (guide: half the 157.3 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def pmc_traffic(key):
+    """HBM-side traffic per launch (bytes) from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json):
+    FETCH_SIZE + WRITE_SIZE, raw counter values (see the file for the calibration caveat).  None when absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[key]
+        return int((d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024)
+    except Exception:
+        return None
+
+
 def algorithmic_flops(n_agents, iters_total):
     """per interior-point iteration per agent ~ (N-1)*1.0 kflop + 0.3 Mflop (fp64)."""
     return float(iters_total) * ((n_agents - 1) * 1.0e3 + 0.3e6)
@@ -80,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-leg", action="store_true")
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--sweep-agents", type=int, default=1024,
+                    help="extra leg: dense LSC sweep at this swarm size (HBM-meaningful working set); 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -180,7 +192,8 @@ def main():
                    "reference_rows_per_agent": 27 * (n_agents - 1)},
             "roofline": {"kernel": "lsc_plan_kernel", "bound": "valu_fp64", "achieved": round(ach, 5),
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_VALU_PEAK_TFLOPS, 7),
-                         "traffic": None, "avg_launch_ms": round(k_ms, 5), "launches": k_n,
+                         "traffic": pmc_traffic("lsc_plan_kernel_N64") if n_agents == 64 else None,
+                         "avg_launch_ms": round(k_ms, 5), "launches": k_n,
                          "note": "latency-bound: one 256-lane workgroup per agent; algorithmic flops = IP iterations x "
                                  "((N-1) kflop + 0.3 Mflop) per SURVEY 8(d); neither HBM nor MFMA bounds this kernel"},
         }
@@ -204,11 +217,48 @@ def main():
         alg = count * nobs * 180 + n_agents * 404
         result["roofline_sweep"] = {"kernel": "lsc_sweep_kernel", "bound": "hbm",
                                     "achieved": round(alg / (s_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                                    "frac": round(alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                    "traffic": pmc_traffic("lsc_sweep_kernel_N64") if n_agents == 64 else None,
                                     "avg_launch_ms": round(s_ms, 5), "bytes_written_per_launch": wr,
                                     "algorithmic_bytes_per_launch": alg,
                                     "note": "N(N-1)*180 B + N*404 B per SURVEY 8(d); at this N the working set is "
                                             "L2/Infinity-Cache resident and the launch is latency-bound"}
+
+    # ---- the same sweep at a swarm size whose output does not fit the caches (only N = 1024 is a
+    # meaningful HBM measurement): 1024-agent seeded random swarm, tick-2 inputs (shifted previous plans)
+    if args.sweep_agents > 1 and rank == 0 and G == 1:
+        from lsc_planner_amd.planner import next_state_host
+        n2 = args.sweep_agents
+        ms2 = L.random_swarm(n2, seed=20260929) if n2 >= 512 else L.circle_swap(n2, 8.0 * n2 / 64)
+        p2 = L.SwarmPlanner(ms2, L.PlannerConfig(device=local_rank))
+        st2 = np.zeros((n2, 9), np.float32)
+        st2[:, :3] = ms2.start
+        g2 = p2.plan(st2, ms2.goal, np.zeros((n2, 3, 30), np.float32))
+        tj2 = torch.from_numpy(g2["traj"].reshape(n2, 90)).to(dev)
+        s2 = torch.from_numpy(next_state_host(g2["traj"])).to(dev)
+        nrm2 = torch.empty((n2, n2 - 1, 5, 3), **f32)
+        dd2 = torch.empty((n2, n2 - 1, 5, 6), dtype=torch.float64, device=dev)
+        for _ in range(2):
+            p2.sweep_device(s2, tj2, 2, nrm2, dd2, stream)
+        torch.cuda.synchronize()
+        p2.set_timing(True)
+        for _ in range(10):
+            p2.sweep_device(s2, tj2, 2, nrm2, dd2, stream)
+        torch.cuda.synchronize()
+        ms_l, _ = p2.kernel_time_ms(1)
+        p2.set_timing(False)
+        alg2 = n2 * (n2 - 1) * 180 + n2 * 404
+        wr2 = n2 * (n2 - 1) * 5 * 60
+        result["roofline_sweep_large"] = {"kernel": "lsc_sweep_kernel", "agents": n2, "bound": "hbm",
+                                          "achieved": round(alg2 / (ms_l * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(alg2 / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                          "traffic": pmc_traffic("lsc_sweep_kernel_N1024") if n2 == 1024 else None,
+                                          "avg_launch_ms": round(ms_l, 4), "algorithmic_bytes_per_launch": alg2,
+                                          "bytes_written_per_launch": wr2,
+                                          "written_GBps": round(wr2 / (ms_l * 1e-3) / 1e9, 2),
+                                          "gjk_per_s": round(n2 * (n2 - 1) * 5 / (ms_l * 1e-3), 0)}
+        p2.close()
+        del nrm2, dd2
 
     # ---- per-tick latency through the host-buffer ABI (H2D + kernel + D2H, PCIe-inclusive): p50 / p99
     if not args.no_latency_leg and rank == 0 and G == 1:
