@@ -20,30 +20,46 @@
 
 namespace lsc {
 
-constexpr int NT = 256;
+constexpr int NT = 512;      // lanes per agent workgroup: 8 waves, 2 per SIMD (register budget 256 per lane)
 constexpr int NWAVE = NT / 64;
 
 // ---------------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
+// Wave-wide reductions without LDS traffic: four DPP row_shr steps inside each 16-lane row, then the four row
+// results (lanes 15/31/47/63) are combined through v_readlane.  (__shfl_xor on a double costs two ds_bpermute
+// round trips per step; six dependent steps were ~1000 cycles per value.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v, double identity)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    const int ilo = __double2loint(identity), ihi = __double2hiint(identity);
+    lo = __builtin_amdgcn_update_dpp(ilo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(ihi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v)
+__device__ __forceinline__ double lane_value(double v, int lane_const)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_const);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_const);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_min(double v)
+// OP: 0 sum, 1 max, 2 min
+template <int OP>
+__device__ __forceinline__ double red_op(double a, double b) { return OP == 0 ? a + b : (OP == 1 ? fmax(a, b) : fmin(a, b)); }
+template <int OP>
+__device__ __forceinline__ double wave_reduce(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
+    const double id = OP == 0 ? 0.0 : (OP == 1 ? -1.7976931348623157e308 : 1.7976931348623157e308);
+    v = red_op<OP>(v, dpp_move<0x111>(v, id));   // row_shr:1
+    v = red_op<OP>(v, dpp_move<0x112>(v, id));   // row_shr:2
+    v = red_op<OP>(v, dpp_move<0x114>(v, id));   // row_shr:4
+    v = red_op<OP>(v, dpp_move<0x118>(v, id));   // row_shr:8  -> lane 15 of every row holds the row result
+    return red_op<OP>(red_op<OP>(lane_value(v, 15), lane_value(v, 31)), red_op<OP>(lane_value(v, 47), lane_value(v, 63)));
 }
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce<0>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<1>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<2>(v); }
 
 // Predicted / initial control points of agent q for segment m.
 //   planner_seq < 2 : pos + vel * m_intp * dt   (float32, src/traj_planner.cpp:699-712, 1030-1037)
@@ -372,42 +388,59 @@ __device__ __forceinline__ void chol_update(double (&row)[NY], double l)
 // (column index = register index), the pivot and the column entries travel by v_readlane; only the next column's
 // single update sits on the dependency chain.
 template <int J>
-__device__ __forceinline__ void chol_step(double (&row)[NY], double (&invd)[NY], bool &ok)
+__device__ __forceinline__ void chol_step(double (&row)[NY], double &dinv_own, int lane, bool &ok)
 {
     const double dj = bcast_lane<J>(row[J]);
     if (!(dj > 0.0)) ok = false;
-    const double inv = rsqrt_nr(dj);
-    invd[J] = inv;
-    const double l = row[J] * inv;      // L[i][J] in lane i (lane J: sqrt(dj))
-    row[J] = l;
+    const double inv = rsqrt_nr(dj);      // 1 / L[J][J], uniform over the wave
+    if (lane == J) dinv_own = inv;
+    const double l = row[J] * inv;        // L[i][J] in lane i (lane J: sqrt(dj))
     constexpr int K1 = (J + BAND) < (NY - 1) ? (J + BAND) : (NY - 1);
     if constexpr (J + 1 <= K1) {
         chol_update<J, J + 1, K1>(row, l);
     }
-    if constexpr (J + 1 < NY) chol_step<J + 1>(row, invd, ok);
+    row[J] = l * inv;                     // keep the unit-diagonal factor M[i][J] = L[i][J] / L[J][J]
+    if constexpr (J + 1 < NY) chol_step<J + 1>(row, dinv_own, lane, ok);
 }
+
+// Triangular solves with the factor scaled to unit diagonal (M = L D^-1, D = diag L): the dependent chain of a
+// substitution step is one v_readlane pair and one fma, no multiply by the inverse pivot.
+//   forward : M u = b            (rowS[J] = L[lane][J] / L[J][J])
+//   backward: M^T x = D^-2 u     (colS[I] = L[I][lane] / L[lane][lane])
 template <int J>
-__device__ __forceinline__ void fwd_step(const double (&row)[NY], const double (&invd)[NY], double &b, int lane)
+__device__ __forceinline__ void fwd_step(const double (&rowS)[NY], double &b, int lane)
 {
-    double bj = bcast_lane<J>(b) * invd[J];
-    if (lane == J) b = bj;
-    else if (lane > J) b -= row[J] * bj;
-    if constexpr (J + 1 < NY) fwd_step<J + 1>(row, invd, b, lane);
+    const double bj = bcast_lane<J>(b);
+    if (lane > J) b = fma(-rowS[J], bj, b);
+    if constexpr (J + 1 < NY) fwd_step<J + 1>(rowS, b, lane);
 }
-template <int I>
-__device__ __forceinline__ void bwd_step(const double (&col)[NY], const double (&invd)[NY], double &b, int lane)
+// Backward sweep: lane j needs column j of M = row j of M^T.  Keeping all 39 entries in registers would cost 78
+// VGPRs per lane for the whole kernel, so they are fetched from the published factor in LDS in three chunks of 13
+// (the loads of a chunk are independent of the dependency chain and are issued together).
+template <int I, int LO>
+__device__ __forceinline__ void bwd_chunk_steps(const double (&c)[13], double &b, int lane)
 {
-    double xi = bcast_lane<I>(b) * invd[I];
-    if (lane == I) b = xi;
-    else if (lane < I) b -= col[I] * xi;
-    if constexpr (I > 0) bwd_step<I - 1>(col, invd, b, lane);
+    const double xi = bcast_lane<I>(b);
+    if (lane < I) b = fma(-c[I - LO], xi, b);
+    if constexpr (I > LO) bwd_chunk_steps<I - 1, LO>(c, b, lane);
+}
+template <int LO>
+__device__ __forceinline__ void bwd_chunk(const double *K, double &b, int lane)
+{
+    double c[13];
+#pragma unroll
+    for (int q = 0; q < 13; q++) {
+        const int i = LO + q;
+        c[q] = (lane < NY && i >= lane && i - lane <= BAND) ? K[i * KLD + lane] : 0.0;   // M[i][lane] = L[i][lane] / L[lane][lane]
+    }
+    bwd_chunk_steps<LO + 12, LO>(c, b, lane);
 }
 
 // phase stamps (PROF variant only): cycles of lane 0 spent per phase, accumulated per agent
 enum { PH_SETUP = 0, PH_LSC, PH_INIT, PH_P1, PH_REDUCE, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_P2, PH_P3, PH_P45, PH_OUT, PH_COUNT };
 
 template <bool PROF>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void lsc_plan_kernel(PlanArgs a)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_kernel(PlanArgs a)
 {
     long long t_last = 0;
     long long t_acc[PH_COUNT];
@@ -695,7 +728,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int j = 0; j < NC; j++) g += qr[j] * xs[j];
         return g;
     };
-    // block reduction of up to 6 values: op 0 sum, 1 max, 2 min ; results in S.sc[0..5]
+    // block reduction of up to 5 values: op 0 sum, 1 max, 2 min ; results in S.sc[0..4] (one barrier pair; the
+    // per-wave partials are combined by five lanes)
     auto block_reduce = [&](double v0, double v1, double v2, double v3, double v4, int op0, int op1, int op2, int op3, int op4) {
         auto wr = [&](double v, int op) { return op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v)); };
         double r0 = wr(v0, op0), r1 = wr(v1, op1), r2 = wr(v2, op2), r3 = wr(v3, op3), r4 = wr(v4, op4);
@@ -704,6 +738,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (tid < 5) {
             const int op = tid == 0 ? op0 : (tid == 1 ? op1 : (tid == 2 ? op2 : (tid == 3 ? op3 : op4)));
             double t = S.red[tid][0];
+#pragma unroll
             for (int w = 1; w < NWAVE; w++) t = op == 0 ? t + S.red[tid][w] : (op == 1 ? fmax(t, S.red[tid][w]) : fmin(t, S.red[tid][w]));
             S.sc[tid] = t;
         }
@@ -752,46 +787,47 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 S.W[W_2 + b] = wA0;
             }
         }
-        // LSC buckets: unit (bucket, c): c 0..5 -> sum w n n^T, 6..8 -> -sum v n   (row vector a_r = -n)
+        // LSC buckets: unit (bucket, c): c 0..5 -> sum w n n^T, 6..8 -> -sum v n and -sum z n  (row vector a_r = -n).
+        // Two lanes per unit take the even / odd rows of the bucket and combine through a lane-pair shuffle.
         const int nunits = with_w ? NB * 9 : NB * 3;
-        if (tid < nunits) {
-            const int bkt = with_w ? tid / 9 : tid / 3, c = with_w ? tid % 9 : 6 + tid % 3, cp = bkt + 3;
-            const int cnt = S.cnt[cp];
+        {
+            const int u = tid >> 1, half = tid & 1;
+            const bool live = u < nunits;
+            const int bkt = live ? (with_w ? u / 9 : u / 3) : 0, c = live ? (with_w ? u % 9 : 6 + u % 3) : 6, cp = bkt + 3;
+            const int cnt = live ? S.cnt[cp] : 0;
             const int r0 = bkt * CS;
-            double acc0 = 0.0, acc1 = 0.0;
+            double acc0 = 0.0, acc1 = 0.0, az0 = 0.0, az1 = 0.0;
             if (c < 6) {
                 const int ia = c < 3 ? 0 : (c < 5 ? 1 : 2), ib = c < 3 ? c : (c < 5 ? c - 2 : 2);
                 const float *na = rn + ia * R + r0, *nb = rn + ib * R + r0;
                 const double *pz = rz + r0, *pi = rt1 + r0;
-                int j = 0;
-                for (; j + 4 <= cnt; j += 4) {
-                    double z0 = pz[j], z1 = pz[j + 1], z2 = pz[j + 2], z3 = pz[j + 3];
-                    double i0 = pi[j], i1 = pi[j + 1], i2 = pi[j + 2], i3 = pi[j + 3];
-                    double a0 = (double)na[j] * (double)nb[j], a1 = (double)na[j + 1] * (double)nb[j + 1];
-                    double a2 = (double)na[j + 2] * (double)nb[j + 2], a3 = (double)na[j + 3] * (double)nb[j + 3];
-                    if (unit_w) { acc0 += a0 + a2; acc1 += a1 + a3; }
-                    else { acc0 += z0 * i0 * a0 + z2 * i2 * a2; acc1 += z1 * i1 * a1 + z3 * i3 * a3; }
+                int j = half;
+                for (; j + 2 < cnt; j += 4) {
+                    const double a0 = (double)na[j] * (double)nb[j], a1 = (double)na[j + 2] * (double)nb[j + 2];
+                    if (unit_w) { acc0 += a0; acc1 += a1; }
+                    else { acc0 += pz[j] * pi[j] * a0; acc1 += pz[j + 2] * pi[j + 2] * a1; }
                 }
-                for (; j < cnt; j++) {
-                    double w = unit_w ? 1.0 : pz[j] * pi[j];
+                for (; j < cnt; j += 2) {
+                    const double w = unit_w ? 1.0 : pz[j] * pi[j];
                     acc0 += w * (double)na[j] * (double)nb[j];
                 }
-                S.W[W_S + cp * 6 + c] = acc0 + acc1;
             } else {
                 const float *nc = rn + (c - 6) * R + r0;
                 const double *pv = rt2 + r0, *pz = rz + r0;
-                double az0 = 0.0, az1 = 0.0;
-                int j = 0;
-                for (; j + 4 <= cnt; j += 4) {
-                    const double n0 = (double)nc[j], n1 = (double)nc[j + 1], n2 = (double)nc[j + 2], n3 = (double)nc[j + 3];
-                    acc0 += pv[j] * n0 + pv[j + 2] * n2;
-                    acc1 += pv[j + 1] * n1 + pv[j + 3] * n3;
-                    az0 += pz[j] * n0 + pz[j + 2] * n2;
-                    az1 += pz[j + 1] * n1 + pz[j + 3] * n3;
+                int j = half;
+                for (; j + 2 < cnt; j += 4) {
+                    const double n0 = (double)nc[j], n1 = (double)nc[j + 2];
+                    acc0 += pv[j] * n0; acc1 += pv[j + 2] * n1;
+                    az0 += pz[j] * n0; az1 += pz[j + 2] * n1;
                 }
-                for (; j < cnt; j++) { acc0 += pv[j] * (double)nc[j]; az0 += pz[j] * (double)nc[j]; }
-                S.Tv[cp * 3 + (c - 6)] = -(acc0 + acc1);
-                S.Tz[cp * 3 + (c - 6)] = -(az0 + az1);
+                for (; j < cnt; j += 2) { acc0 += pv[j] * (double)nc[j]; az0 += pz[j] * (double)nc[j]; }
+            }
+            double sa = acc0 + acc1, sz = az0 + az1;
+            sa += __shfl_xor(sa, 1, 64);
+            sz += __shfl_xor(sz, 1, 64);
+            if (live && half == 0) {
+                if (c < 6) S.W[W_S + cp * 6 + c] = sa;
+                else { S.Tv[cp * 3 + (c - 6)] = -sa; S.Tz[cp * 3 + (c - 6)] = -sz; }
             }
         }
         __syncthreads();
@@ -821,9 +857,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __syncthreads();
     };
 
-    double lrow[NY], lcol[NY], linvd[NY];  // wave 0: Cholesky factor rows / columns / inverse pivots
+    double lrow[NY];            // wave 0: unit-diagonal factor M = L D^-1, lane = row, register = column
+    double dinv_own = 0.0;      // 1 / L[lane][lane]
 #pragma unroll
-    for (int j = 0; j < NY; j++) { lrow[j] = 0.0; lcol[j] = 0.0; linvd[j] = 0.0; }
+    for (int j = 0; j < NY; j++) lrow[j] = 0.0;
 
     auto factor = [&]() -> bool {
         if (wave == 0) {
@@ -834,15 +871,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
             // (updates run on whole register rows; only the part left of the diagonal is meaningful afterwards)
             bool ok = true;
-            chol_step<0>(lrow, linvd, ok);
-            // publish the factor rows, then gather the column owned by this lane for the backward sweep
+            dinv_own = 0.0;
+            chol_step<0>(lrow, dinv_own, lane, ok);
+            // publish the unit-diagonal rows M[i][j] = L[i][j] / L[j][j] for the backward sweep
 #pragma unroll
             for (int j = 0; j < NY; j++)
                 if (act && j <= lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < NY; i++) lcol[i] = (act && i >= lane && i - lane <= BAND) ? S.K[i * KLD + lane] : 0.0;
             if (lane == 0) S.sc[7] = ok ? 1.0 : 0.0;
         }
         __syncthreads();
@@ -851,8 +885,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     auto solve = [&]() {
         if (wave == 0) {
             double b = lane < NY ? S.rhs[lane] : 0.0;
-            fwd_step<0>(lrow, linvd, b, lane);
-            bwd_step<NY - 1>(lcol, linvd, b, lane);
+            fwd_step<0>(lrow, b, lane);
+            b *= dinv_own * dinv_own;
+            bwd_chunk<26>(S.K, b, lane);
+            bwd_chunk<13>(S.K, b, lane);
+            bwd_chunk<0>(S.K, b, lane);
             if (lane < NY) S.dy[lane] = b;
         }
         __syncthreads();
