@@ -407,22 +407,24 @@ __device__ __forceinline__ void chol_step(double (&row)[NY], double &dinv_own, i
 // substitution step is one v_readlane pair and one fma, no multiply by the inverse pivot.
 //   forward : M u = b            (rowS[J] = L[lane][J] / L[J][J])
 //   backward: M^T x = D^-2 u     (colS[I] = L[I][lane] / L[lane][lane])
+// (rowS / the column chunks are zero on and above the diagonal, so a step is readlane + fma with no lane predicate)
 template <int J>
-__device__ __forceinline__ void fwd_step(const double (&rowS)[NY], double &b, int lane)
+__device__ __forceinline__ void fwd_step(const double (&rowS)[NY], double &b)
 {
     const double bj = bcast_lane<J>(b);
-    if (lane > J) b = fma(-rowS[J], bj, b);
-    if constexpr (J + 1 < NY) fwd_step<J + 1>(rowS, b, lane);
+    b = fma(-rowS[J], bj, b);
+    if constexpr (J + 1 < NY) fwd_step<J + 1>(rowS, b);
 }
+
 // Backward sweep: lane j needs column j of M = row j of M^T.  Keeping all 39 entries in registers would cost 78
 // VGPRs per lane for the whole kernel, so they are fetched from the published factor in LDS in three chunks of 13
 // (the loads of a chunk are independent of the dependency chain and are issued together).
 template <int I, int LO>
-__device__ __forceinline__ void bwd_chunk_steps(const double (&c)[13], double &b, int lane)
+__device__ __forceinline__ void bwd_chunk_steps(const double (&c)[13], double &b)
 {
     const double xi = bcast_lane<I>(b);
-    if (lane < I) b = fma(-c[I - LO], xi, b);
-    if constexpr (I > LO) bwd_chunk_steps<I - 1, LO>(c, b, lane);
+    b = fma(-c[I - LO], xi, b);
+    if constexpr (I > LO) bwd_chunk_steps<I - 1, LO>(c, b);
 }
 template <int LO>
 __device__ __forceinline__ void bwd_chunk(const double *K, double &b, int lane)
@@ -431,9 +433,9 @@ __device__ __forceinline__ void bwd_chunk(const double *K, double &b, int lane)
 #pragma unroll
     for (int q = 0; q < 13; q++) {
         const int i = LO + q;
-        c[q] = (lane < NY && i >= lane && i - lane <= BAND) ? K[i * KLD + lane] : 0.0;   // M[i][lane] = L[i][lane] / L[lane][lane]
+        c[q] = (lane < NY && i > lane && i - lane <= BAND) ? K[i * KLD + lane] : 0.0;   // M[i][lane], strictly below the diagonal
     }
-    bwd_chunk_steps<LO + 12, LO>(c, b, lane);
+    bwd_chunk_steps<LO + 12, LO>(c, b);
 }
 
 // phase stamps (PROF variant only): cycles of lane 0 spent per phase, accumulated per agent
@@ -749,43 +751,50 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // Axis rows are gathered by the last 90 lanes, LSC buckets by units (bucket, component) from lane 0 up.
     auto reduce_rows = [&](bool with_w, bool unit_w) {
         if (tid >= NT - NV) {
-            const int q = tid - (NT - NV);
-            const int k = q / SEGV, t = q % SEGV, i = t % NC;
+            // Gather of the bound / velocity / acceleration rows that touch variable (k, t).  Slots that do not exist
+            // (first control points, segment ends) keep s = 1, z = 0, t1 = t2 = 0 for the whole solve, so every load
+            // below is unconditional and independent (no validity branches between them).
+            const int k = xk, t = xt, i = t % NC;
             const int b = k * SEGV + t;
-            auto wof = [&](int type, int tt) -> double {
-                int sl = type * NV + k * SEGV + tt;
-                if (!S.avalid[sl]) return 0.0;
-                return unit_w ? 1.0 : S.az[sl] * S.at1[sl];
-            };
-            auto vof = [&](int type, int tt) -> double { int sl = type * NV + k * SEGV + tt; return S.avalid[sl] ? S.at2[sl] : 0.0; };
-            double g = 0.0;
-            g += vof(0, t) - vof(1, t);
-            g += -vof(2, t) + vof(3, t);
-            g += vof(4, t) - vof(5, t);
-            if (i >= 1) g += vof(2, t - 1) - vof(3, t - 1) - 2.0 * (vof(4, t - 1) - vof(5, t - 1));
-            if (i >= 2) g += vof(4, t - 2) - vof(5, t - 2);
+            const int t1i = t >= 1 ? t - 1 : 0, t2i = t >= 2 ? t - 2 : 0;
+            const int o0 = k * SEGV + t, o1 = k * SEGV + t1i, o2 = k * SEGV + t2i;
+            const double v0 = S.at2[0 * NV + o0], v1 = S.at2[1 * NV + o0], v2 = S.at2[2 * NV + o0], v3 = S.at2[3 * NV + o0];
+            const double v4 = S.at2[4 * NV + o0], v5 = S.at2[5 * NV + o0];
+            const double v2m = S.at2[2 * NV + o1], v3m = S.at2[3 * NV + o1], v4m = S.at2[4 * NV + o1], v5m = S.at2[5 * NV + o1];
+            const double v4mm = S.at2[4 * NV + o2], v5mm = S.at2[5 * NV + o2];
+            const double m1 = t >= 1 ? 1.0 : 0.0, m2 = t >= 2 ? 1.0 : 0.0;
+            double g = (v0 - v1) + (v3 - v2) + (v4 - v5) + m1 * ((v2m - v3m) - 2.0 * (v4m - v5m)) + m2 * (v4mm - v5mm);
             double gzv = 0.0;
-            if (with_w && !unit_w) {   // stationarity residual (only on predictor passes)
-                auto zof = [&](int type, int tt) -> double { int sl = type * NV + k * SEGV + tt; return S.avalid[sl] ? S.az[sl] : 0.0; };
-                gzv += zof(0, t) - zof(1, t) - zof(2, t) + zof(3, t) + zof(4, t) - zof(5, t);
-                if (i >= 1) gzv += zof(2, t - 1) - zof(3, t - 1) - 2.0 * (zof(4, t - 1) - zof(5, t - 1));
-                if (i >= 2) gzv += zof(4, t - 2) - zof(5, t - 2);
-            }
             double cg = cost_grad();   // this lane's (xk, xt) equal (k, t)
             if (i == DEG && t / NC >= M - S.tseg) cg += 2.0 * md.w_t * (S.x[b] - S.goal[k]);
-            S.gx[b] = cg + g;
-            S.gz[b] = cg + gzv;
             if (with_w) {
-                double wB = wof(0, t) + wof(1, t);
-                double wV0 = wof(2, t) + wof(3, t);
-                double wA0 = wof(4, t) + wof(5, t);
-                double wV1 = i >= 1 ? wof(2, t - 1) + wof(3, t - 1) : 0.0;
-                double wA1 = i >= 1 ? wof(4, t - 1) + wof(5, t - 1) : 0.0;
-                double wA2 = i >= 2 ? wof(4, t - 2) + wof(5, t - 2) : 0.0;
+                double w0, w1, w2, w3, w4, w5, w2m, w3m, w4m, w5m, w4mm, w5mm;
+                if (unit_w) {
+                    // cold start: weight 1 on every existing row
+                    w0 = S.avalid[0 * NV + o0]; w1 = S.avalid[1 * NV + o0]; w2 = S.avalid[2 * NV + o0]; w3 = S.avalid[3 * NV + o0];
+                    w4 = S.avalid[4 * NV + o0]; w5 = S.avalid[5 * NV + o0];
+                    w2m = S.avalid[2 * NV + o1]; w3m = S.avalid[3 * NV + o1]; w4m = S.avalid[4 * NV + o1]; w5m = S.avalid[5 * NV + o1];
+                    w4mm = S.avalid[4 * NV + o2]; w5mm = S.avalid[5 * NV + o2];
+                } else {
+                    const double z0 = S.az[0 * NV + o0], z1 = S.az[1 * NV + o0], z2 = S.az[2 * NV + o0], z3 = S.az[3 * NV + o0];
+                    const double z4 = S.az[4 * NV + o0], z5 = S.az[5 * NV + o0];
+                    const double z2m = S.az[2 * NV + o1], z3m = S.az[3 * NV + o1], z4m = S.az[4 * NV + o1], z5m = S.az[5 * NV + o1];
+                    const double z4mm = S.az[4 * NV + o2], z5mm = S.az[5 * NV + o2];
+                    w0 = z0 * S.at1[0 * NV + o0]; w1 = z1 * S.at1[1 * NV + o0]; w2 = z2 * S.at1[2 * NV + o0]; w3 = z3 * S.at1[3 * NV + o0];
+                    w4 = z4 * S.at1[4 * NV + o0]; w5 = z5 * S.at1[5 * NV + o0];
+                    w2m = z2m * S.at1[2 * NV + o1]; w3m = z3m * S.at1[3 * NV + o1]; w4m = z4m * S.at1[4 * NV + o1]; w5m = z5m * S.at1[5 * NV + o1];
+                    w4mm = z4mm * S.at1[4 * NV + o2]; w5mm = z5mm * S.at1[5 * NV + o2];
+                    // stationarity residual (predictor passes only)
+                    gzv = (z0 - z1) + (z3 - z2) + (z4 - z5) + m1 * ((z2m - z3m) - 2.0 * (z4m - z5m)) + m2 * (z4mm - z5mm);
+                }
+                const double wB = w0 + w1, wV0 = w2 + w3, wA0 = w4 + w5;
+                const double wV1 = m1 * (w2m + w3m), wA1 = m1 * (w4m + w5m), wA2 = m2 * (w4mm + w5mm);
                 S.W[W_D + b] = wB + wV0 + wV1 + wA0 + 4.0 * wA1 + wA2;
                 S.W[W_1 + b] = -wV0 - 2.0 * wA0 - 2.0 * wA1;
                 S.W[W_2 + b] = wA0;
             }
+            S.gx[b] = cg + g;
+            S.gz[b] = cg + gzv;
         }
         // LSC buckets: unit (bucket, c): c 0..5 -> sum w n n^T, 6..8 -> -sum v n and -sum z n  (row vector a_r = -n).
         // Two lanes per unit take the even / odd rows of the bucket and combine through a lane-pair shuffle.
@@ -857,23 +866,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __syncthreads();
     };
 
-    double lrow[NY];            // wave 0: unit-diagonal factor M = L D^-1, lane = row, register = column
-    double dinv_own = 0.0;      // 1 / L[lane][lane]
-#pragma unroll
-    for (int j = 0; j < NY; j++) lrow[j] = 0.0;
+    double dinv_own = 0.0;      // wave 0: 1 / L[lane][lane] of the current factor
 
+    // The factor lives in LDS (S.K, unit-diagonal M = L D^-1, lower band) between phases; registers hold it only inside
+    // factor() and solve(), so the row passes and reductions in between keep the whole register budget.
     auto factor = [&]() -> bool {
         if (wave == 0) {
             const bool act = lane < NY;
+            double lrow[NY];      // lane = row, register = column
 #pragma unroll
-            for (int j = 0; j < NY; j++) {
-                lrow[j] = (act && j <= lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
-            }
+            for (int j = 0; j < NY; j++) lrow[j] = (act && j <= lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
             // (updates run on whole register rows; only the part left of the diagonal is meaningful afterwards)
             bool ok = true;
             dinv_own = 0.0;
             chol_step<0>(lrow, dinv_own, lane, ok);
-            // publish the unit-diagonal rows M[i][j] = L[i][j] / L[j][j] for the backward sweep
 #pragma unroll
             for (int j = 0; j < NY; j++)
                 if (act && j <= lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
@@ -884,8 +890,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
     auto solve = [&]() {
         if (wave == 0) {
+            double rowS[NY];      // strictly lower part of M, zeros elsewhere: substitution steps need no lane predicate
+#pragma unroll
+            for (int j = 0; j < NY; j++) rowS[j] = (lane < NY && j < lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
             double b = lane < NY ? S.rhs[lane] : 0.0;
-            fwd_step<0>(lrow, b, lane);
+            fwd_step<0>(rowS, b);
             b *= dinv_own * dinv_own;
             bwd_chunk<26>(S.K, b, lane);
             bwd_chunk<13>(S.K, b, lane);

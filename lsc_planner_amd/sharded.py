@@ -23,7 +23,7 @@ def all_gather_rows(dist, full, first, count, counts=None):
     world = dist.get_world_size()
     if world == 1:
         return
-    mine = full[first:first + count].contiguous()
+    mine = full[first:first + count].clone()      # own rows, detached from the receive buffer
     if counts is None or len(set(counts)) == 1:
         dist.all_gather_into_tensor(full.view(-1), mine.view(-1))
         return
