@@ -225,3 +225,61 @@ def test_sfc_box_growth_bitwise_on_random_seeds(L, oracle):
             assert np.array_equal(g["sfc"][q, 4], g["sfc"][q, 0])
     assert 0 < n_blocked < N // 2
     pl.close()
+
+
+def test_heterogeneous_agents_match_oracle(L, oracle):
+    """Per-agent radius / downwash / velocity and acceleration limits / nominal speed (Mission::agents, src/mission.cpp:60-130):
+    the pair downwash, the float32-rounded obstacle radius and the per-axis limits must all follow the agent."""
+    from lsc_planner_amd.planner import next_state_host
+    rng = np.random.default_rng(21)
+    N = 18
+    base = L.circle_swap(N, 3.0, world=(-6, -6, 0, 6, 6, 3.0))
+    ms = L.Mission(base.start, base.goal, base.world_min, base.world_max,
+                   rng.uniform(0.10, 0.22, N), rng.uniform(1.5, 2.5, N), rng.uniform(0.8, 1.5, (N, 3)), rng.uniform(1.0, 2.5, (N, 3)),
+                   rng.uniform(0.7, 1.3, N))
+    pl = L.SwarmPlanner(ms)
+    sw = oracle_swarm(oracle, ms)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    for tick in range(1, 21):
+        g = pl.plan(state, ms.goal, traj, want_constraints=True)
+        sw.stale[:] = traj if tick > 1 else 0
+        o = sw.tick(state, ms.goal, traj, tick, want_lsc=True, nthreads=8)
+        assert np.array_equal(g["normal"], o["normal"]) and np.array_equal(g["d"], o["d"]), tick
+        assert np.array_equal(g["status"], o["status"]), tick
+        ok = o["status"] == 0
+        assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok]).all(), tick
+        assert np.abs(g["traj"][ok] - o["traj"][ok]).max() <= TRAJ_ATOL, tick
+        traj = g["traj"]
+        state = next_state_host(traj)
+    pl.close()
+
+
+def test_heterogeneous_radii_use_their_own_corridor_margin(L, oracle):
+    """SFC margin = r + res/2 - 1e-5 per agent: two radius classes -> two blocked-cell integral images."""
+    from maputil import forest_leaves
+    leaves, res = forest_leaves()
+    dm = oracle.DistMap(leaves, res, [-5, -5, 0], [5, 5, 2.5])
+    rng = np.random.default_rng(9)
+    N = 64
+    start = rng.uniform([-4.5, -4.5, 0.3], [4.5, 4.5, 2.2], size=(N, 3)).astype(np.float32)
+    goal = rng.uniform([-4.5, -4.5, 0.3], [4.5, 4.5, 2.2], size=(N, 3)).astype(np.float32)
+    radius = np.where(np.arange(N) % 2 == 0, 0.15, 0.25)
+    ms = L.Mission(start, goal, np.array([-5, -5, 0], np.float32), np.array([5, 5, 2.5], np.float32), radius, np.full(N, 2.0),
+                   np.ones((N, 3)), np.full((N, 3), 2.0), np.ones(N))
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True))
+    pl.set_distmap(dm.dist, dm.key_min, res)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = start
+    g = pl.plan(state, goal, np.zeros((N, 3, 30), np.float32))
+    prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, use_sfc=True, obs_f32=True)
+    differ = 0
+    for q in range(N):
+        rc, box = dm.expand_box(prm, start[q], goal[q], radius[q])
+        if rc:
+            assert g["status"][q] == 4
+            continue
+        assert np.array_equal(g["sfc"][q, 0], box.astype(np.float32)), q
+        rc2, box2 = dm.expand_box(prm, start[q], goal[q], 0.4 - radius[q])
+        differ += int(rc2 != 0 or not np.array_equal(box, box2))
+    assert differ > 5           # the two margins really give different corridors on this map
+    pl.close()
