@@ -9,8 +9,9 @@ every agent (the reference's MultiSyncSimulator::plan loop), followed by the ide
 next tick.  Everything stays resident in HBM during the timed region (no host round trip inside a tick).
 
 Workload (config.workload): BASELINE.json configs[2], the 64-agent circle swap on the empty map
-(matlab/mission_generator.m geometry, R = 8 m, z = 1 m, testall_empty.launch parameters), goal input =
-desired goal (goal_mode=static; the reference's grid/A* goal planner is SURVEY 8(f)#1, outside this path).
+(matlab/mission_generator.m geometry, R = 8 m, z = 1 m, testall_empty.launch parameters incl. mode/goal =
+prior_based: goalPlanningWithPriority runs on the device; on maps without a distance field the reference's grid A*
+has no observable effect on the planned goal).
 With --gpus G the swarm is 64*G agents on a circle of radius 8*G (same spacing), agent-sharded 64 per GPU with one
 all-gather of the new trajectories per tick: weak scaling.
 
@@ -47,7 +48,7 @@ def algorithmic_flops(n_agents, iters_total):
     return float(iters_total) * ((n_agents - 1) * 1.0e3 + 0.3e6)
 
 
-def cpu_baseline(ms, seconds_target=12.0, max_ticks=120):
+def cpu_baseline(ms, seconds_target=12.0, max_ticks=120, static_goal=False):
     """Oracle (CPU restatement of the reference path) on the same mission from its start, sequential over agents
     like the reference, then once more with OpenMP over agents on all cores."""
     from oracle import oracle as O
@@ -64,7 +65,8 @@ def cpu_baseline(ms, seconds_target=12.0, max_ticks=120):
         ticks = 0
         budget = seconds_target if threads == 1 else seconds_target / 3
         while ticks < max_ticks and (time.perf_counter() - t0) < budget:
-            r = sw.tick(state, ms.goal, traj, ticks + 1, nthreads=threads)
+            goal = ms.goal if static_goal else O.goal_prior_based(state, ms.goal, traj, ticks + 1)
+            r = sw.tick(state, goal, traj, ticks + 1, nthreads=threads)
             traj = r["traj"]
             state = next_state_host(traj)
             ticks += 1
@@ -90,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-leg", action="store_true")
     ap.add_argument("--no-prune", action="store_true")
+    ap.add_argument("--static-goal", action="store_true", help="mode/goal=static instead of the reference default prior_based")
     ap.add_argument("--sweep-agents", type=int, default=1024,
                     help="extra leg: dense LSC sweep at this swarm size (HBM-meaningful working set); 0 = skip")
     args = ap.parse_args()
@@ -116,7 +119,8 @@ def main():
     n_agents = args.agents_per_gpu * G
     R = 8.0 * n_agents / 64.0
     ms = L.circle_swap(n_agents, circle_radius=R, z=1.0, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
-    pl = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune))
+    goal_mode = "static" if args.static_goal else "prior_based"
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode))
     first, count = shard_bounds(n_agents, G, rank)
     counts = [shard_bounds(n_agents, G, r)[1] for r in range(G)]
     pl.set_shard(first, count)
@@ -183,8 +187,8 @@ def main():
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n_agents}-agent generated circle swap (R={R:g} m, z=1 m), empty map, LSC mode, "
-                                   f"dt 0.2 s, M=5 n=5, goal_mode=static, {args.agents_per_gpu} agents per GPU, "
-                                   "device-resident ticks (plan kernel + state propagation"
+                                   f"dt 0.2 s, M=5 n=5, mode/goal={goal_mode}, {args.agents_per_gpu} agents per GPU, "
+                                   "device-resident ticks (goal planning + plan kernel + state propagation"
                                    + (", RCCL all-gather of trajectories per tick)" if G > 1 else ")"),
                        "agents": n_agents, "parallelism": f"agent-shard x{G}", "prune_redundant_rows": not args.no_prune},
             "qp": {"mean_ip_iterations": round(iters_total / (n_agents * args.steps), 2), "failed_agents_last_tick": bad,
@@ -263,7 +267,7 @@ def main():
     # ---- per-tick latency through the host-buffer ABI (H2D + kernel + D2H, PCIe-inclusive): p50 / p99
     if not args.no_latency_leg and rank == 0 and G == 1:
         from lsc_planner_amd.planner import next_state_host
-        pl2 = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune))
+        pl2 = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode))
         st = np.zeros((n_agents, 9), np.float32)
         st[:, :3] = ms.start
         tj = np.zeros((n_agents, 3, 30), np.float32)
@@ -281,7 +285,7 @@ def main():
         pl2.close()
 
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(ms)
+        result["cpu_baseline"] = cpu_baseline(ms, static_goal=args.static_goal)
     elif rank == 0:
         result["cpu_baseline"] = None
 

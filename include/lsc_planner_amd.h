@@ -71,6 +71,13 @@ typedef struct {
     int    max_iters;          /* interior-point iteration cap; 0 = 50                 */
     int    prune;              /* 1 (default via lsc_default_config): drop LSC rows that are provably
                                   redundant inside the reachable box; 0: keep all 27(N-1) rows  */
+    int    goal_mode;          /* mode/goal: 0 static (the goal input IS current_goal_position), 1 prior_based: the goal
+                                  input is the desired goal and TrajPlanner::goalPlanningWithPriority runs on the
+                                  device (exact on maps without a distance field; with use_octomap the grid A* of
+                                  SURVEY 8(f)#1 would be needed -> LSC_ESTATE) */
+    double goal_threshold;     /* plan/goal_threshold          0.1 */
+    double priority_dist_threshold; /* plan/priority_dist_threshold 0.4 */
+    double goal_radius;        /* plan/goal_radius             2.0 */
     double warm_start_mu;      /* interior-point start: > 0 warm start from the shifted previous plan, every row
                                   centred on this complementarity value (default 0.1), with the cold (Mehrotra)
                                   start as fallback; 0 = always cold start */
@@ -143,6 +150,9 @@ int lsc_gjk_batch(lsc_ctx *ctx, const double *pts, int count, double *v, double 
  * the last reset.  which: 0 = plan kernel, 1 = dense sweep kernel. */
 int lsc_kernel_time_ms(lsc_ctx *ctx, int which, double *avg_ms, long *launches);
 int lsc_set_timing(lsc_ctx *ctx, int enabled);
+
+/* current_goal_position of every agent as used by the last tick, float [N][3] (goal_mode 1: planned on the device). */
+int lsc_last_goals(lsc_ctx *ctx, float *goals);
 
 /* Active (non-redundant) LSC rows each agent's QP carried in the last tick, [N] (diagnostics). */
 int lsc_last_row_counts(lsc_ctx *ctx, int *rows);

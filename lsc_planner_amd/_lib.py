@@ -31,6 +31,10 @@ class LscConfig(ctypes.Structure):
         ("max_rows_per_cp", ctypes.c_int),
         ("max_iters", ctypes.c_int),
         ("prune", ctypes.c_int),
+        ("goal_mode", ctypes.c_int),
+        ("goal_threshold", ctypes.c_double),
+        ("priority_dist_threshold", ctypes.c_double),
+        ("goal_radius", ctypes.c_double),
         ("warm_start_mu", ctypes.c_double),
     ]
 
@@ -39,7 +43,7 @@ class LscConfig(ctypes.Structure):
 EXPORTS = [
     "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_propagate_device", "lsc_sweep_device",
-    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host",
+    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals",
 ]
 
 
@@ -81,6 +85,7 @@ def load_library():
     L.lsc_solver_residuals.argtypes = [vp, dp]
     L.lsc_solver_trace.argtypes = [vp, ctypes.c_int, dp]
     L.lsc_edt_from_bt.argtypes = [ctypes.c_char_p, fp, fp, ctypes.c_double, ctypes.POINTER(fp), ip, ip, dp]
+    L.lsc_last_goals.argtypes = [vp, fp]
     L.lsc_free_host.argtypes = [vp]
     L.lsc_free_host.restype = None
     L.lsc_iterations_total.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]

@@ -121,6 +121,7 @@ struct Param {   // defaults = launch/testall_empty.launch
     int multisim_max_planner_iteration = 300;
     bool multisim_save_result = false;
     double goal_threshold = 0.1;
+    bool goal_mode_prior_based = true;   // mode/goal (launch/*.launch: prior_based)
     bool world_use_octomap = false;
     double world_resolution = 0.1;
     std::string log_dir = ".";
@@ -231,8 +232,9 @@ class TrajPlanner {
     point3d getDesiredGoalPosition() const { return agent.desired_goal_position; }
     point3d getCurrentGoalPosition() const { return agent.current_goal_position; }
     int getPlannerSeq() const { return planner_seq; }
-    // goal_mode = static (src/traj_planner.cpp:511-513); the grid/A* modes are SURVEY 8(f)#1
-    void goalPlanning() { agent.current_goal_position = agent.desired_goal_position; }
+    // goalPlanning() itself runs behind the C ABI (lsc_config.goal_mode); the simulator copies the result back into
+    // agent.current_goal_position after the tick
+    void goalPlanning() {}
     // TrajPlanner::plan's bookkeeping (:99-145); the QP itself was solved by the batched tick
     bool inputsFresh() const { return state_updated && obstacles_updated && current_state_seq == planner_seq; }
     void acceptPlan(const float *traj90, double cost, int status, double seconds) {

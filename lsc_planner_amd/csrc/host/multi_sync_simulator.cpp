@@ -20,6 +20,9 @@ class MultiSyncSimulator {
         cfg.dt = param.dt; cfg.control_weight = param.control_input_weight; cfg.terminal_weight = param.terminal_weight;
         for (int k = 0; k < 3; k++) { cfg.world_min[k] = mission.world_min(k); cfg.world_max[k] = mission.world_max(k); }
         cfg.use_octomap = param.world_use_octomap; cfg.world_resolution = param.world_resolution; cfg.device = param.device;
+        // mode/goal: prior_based like every shipped launch file; on octomap worlds the grid A* is not built yet -> static
+        cfg.goal_mode = (param.goal_mode_prior_based && !param.world_use_octomap) ? 1 : 0;
+        cfg.goal_threshold = param.goal_threshold;
         ctx = lsc_create(&cfg);
         if (!ctx) throw std::runtime_error("[MultiSyncSimulator] lsc_create failed: no usable MI355X (there is no CPU path)");
         const int N = mission.qn;
@@ -97,14 +100,19 @@ class MultiSyncSimulator {
             const State &s = agents[qi]->agent.current_state;
             for (int k = 0; k < 3; k++) {
                 h_state[9 * qi + k] = s.position(k); h_state[9 * qi + 3 + k] = s.velocity(k); h_state[9 * qi + 6 + k] = s.acceleration(k);
-                h_goal[3 * qi + k] = agents[qi]->getCurrentGoalPosition()(k);
+                h_goal[3 * qi + k] = agents[qi]->getDesiredGoalPosition()(k);   // goalPlanning() runs behind the ABI (cfg.goal_mode)
             }
         }
         const auto t0 = std::chrono::steady_clock::now();
         check(lsc_replan_tick(ctx, h_state.data(), h_goal.data(), h_prev.data(), agents[0]->getPlannerSeq() + 1, h_next.data(),
                               h_cost.data(), h_status.data(), h_iters.data(), nullptr, nullptr, nullptr));
         last_tick_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        for (int qi = 0; qi < N; qi++) agents[qi]->acceptPlan(h_next.data() + 90 * qi, h_cost[qi], h_status[qi], last_tick_ms * 1e-3 / N);
+        std::vector<float> goals(3 * N);
+        check(lsc_last_goals(ctx, goals.data()));
+        for (int qi = 0; qi < N; qi++) {
+            agents[qi]->agent.current_goal_position = point3d(goals[3 * qi], goals[3 * qi + 1], goals[3 * qi + 2]);
+            agents[qi]->acceptPlan(h_next.data() + 90 * qi, h_cost[qi], h_status[qi], last_tick_ms * 1e-3 / N);
+        }
         total_ticks++; total_tick_ms += last_tick_ms;
         savePlanningResult();
         if (param.multisim_save_result) savePlanningResultAsCSV();
@@ -233,7 +241,8 @@ int main(int argc, char **argv)
         else if (a == "--csv") { param.log_dir = next(); param.multisim_save_result = true; }
         else if (a == "--device") param.device = std::stoi(next());
         else if (a == "--quiet") quiet = true;
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--quiet]\n"); return 2; }
+        else if (a == "--static-goal") param.goal_mode_prior_based = false;
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet]\n"); return 2; }
     }
     if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
     try {

@@ -177,6 +177,7 @@ struct lsc_ctx {
     double *d_radius = nullptr, *d_radius_obs = nullptr, *d_downwash = nullptr, *d_downwash_obs = nullptr;
     double *d_vmax = nullptr, *d_amax = nullptr, *d_vnom = nullptr;
     float *d_stale = nullptr, *d_sfc = nullptr;
+    float *d_goal_cur = nullptr;
     int *d_sfc_init = nullptr, *d_sfc_err = nullptr, *d_img_of_agent = nullptr, *d_integral = nullptr;
     std::vector<float> h_edt;   // host copy of the distance field (integral images are rebuilt when agents change)
     int edt_dims[3] = {0, 0, 0}, edt_kmin[3] = {0, 0, 0};
@@ -234,6 +235,7 @@ void lsc_default_config(lsc_config *cfg)
     cfg->world_max[0] = 10; cfg->world_max[1] = 10; cfg->world_max[2] = 2.5f;
     cfg->use_octomap = 0; cfg->world_resolution = 0.1; cfg->device = 0;
     cfg->max_rows_per_cp = 0; cfg->max_iters = 50; cfg->prune = 1; cfg->warm_start_mu = 0.1;
+    cfg->goal_mode = 0; cfg->goal_threshold = 0.1; cfg->priority_dist_threshold = 0.4; cfg->goal_radius = 2.0;
 }
 
 lsc_ctx *lsc_create(const lsc_config *cfg)
@@ -261,13 +263,14 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
 static void free_agents(lsc_ctx *c)
 {
     void *ptrs[] = {c->d_radius, c->d_radius_obs, c->d_downwash, c->d_downwash_obs, c->d_vmax, c->d_amax, c->d_vnom,
-                    c->d_stale, c->d_sfc, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_goal, c->d_prev, c->d_next, c->d_cost, c->d_status,
+                    c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_goal, c->d_prev, c->d_next, c->d_cost, c->d_status,
                     c->d_iters, c->d_onormal, c->d_od};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->d_radius = c->d_radius_obs = c->d_downwash = c->d_downwash_obs = c->d_vmax = c->d_amax = c->d_vnom = nullptr;
     c->d_stale = c->d_sfc = c->d_state = c->d_goal = c->d_prev = c->d_next = nullptr;
     c->d_cost = nullptr; c->d_status = c->d_iters = c->d_nrows = nullptr; c->d_iters_acc = nullptr; c->d_prof = nullptr; c->d_dbg = nullptr;
-    c->d_sfc_init = c->d_sfc_err = c->d_img_of_agent = c->d_integral = nullptr; c->d_onormal = nullptr; c->d_od = nullptr;
+    c->d_sfc_init = c->d_sfc_err = c->d_img_of_agent = c->d_integral = nullptr;
+    c->d_goal_cur = nullptr; c->d_onormal = nullptr; c->d_od = nullptr;
 }
 
 void lsc_destroy(lsc_ctx *c)
@@ -319,6 +322,8 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMemset(c->d_stale, 0, sizeof(float) * NV * (size_t)N));   // TrajOptimizer::trajectory starts at (0,0,0)
     HIPCHK(c, hipMalloc(&c->d_sfc, sizeof(float) * M * 6 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_sfc, 0, sizeof(float) * M * 6 * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_goal_cur, sizeof(float) * 3 * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_goal_cur, 0, sizeof(float) * 3 * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_sfc_init, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_sfc_err, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMemset(c->d_sfc_err, 0, sizeof(int) * (size_t)N));
@@ -401,6 +406,30 @@ int lsc_set_distmap(lsc_ctx *c, const float *edt, int nx, int ny, int nz, const 
     return build_integrals(c);
 }
 
+// goalPlanning(): returns the device pointer holding current_goal_position for this tick
+static int run_goal(lsc_ctx *c, const float *d_state, const float *d_goal, const float *d_prev, int seq, hipStream_t st,
+                    const float **d_goal_used)
+{
+    if (c->cfg.goal_mode == 0) {
+        *d_goal_used = d_goal;
+        // keep a copy so that lsc_last_goals answers in both modes
+        HIPCHK(c, hipMemcpyAsync(c->d_goal_cur, d_goal, sizeof(float) * 3 * (size_t)c->N, hipMemcpyDeviceToDevice, st));
+        return LSC_OK;
+    }
+    if (c->cfg.use_octomap) {
+        c->err = "goal_mode prior_based with use_octomap needs the grid A* goal planner (not built yet); use goal_mode 0";
+        return LSC_ESTATE;
+    }
+    GoalArgs g;
+    g.N = c->N; g.planner_seq = seq; g.dtf = (float)c->cfg.dt;
+    g.state = d_state; g.desired_goal = d_goal; g.traj_prev = d_prev;
+    g.goal_threshold = c->cfg.goal_threshold; g.priority_dist_threshold = c->cfg.priority_dist_threshold; g.goal_radius = c->cfg.goal_radius;
+    g.current_goal = c->d_goal_cur;
+    HIPCHK(c, launch_goal(g, st));
+    *d_goal_used = c->d_goal_cur;
+    return LSC_OK;
+}
+
 static int run_sfc(lsc_ctx *c, const float *d_state, const float *d_goal, const float *d_prev, hipStream_t st)
 {
     if (!c->cfg.use_octomap) return LSC_OK;
@@ -450,7 +479,12 @@ int lsc_tick_device(lsc_ctx *c, const float *d_state, const float *d_goal, const
 {
     if (!c || !d_state || !d_goal || !d_traj_prev || !d_traj_next || !d_cost || !d_status || !d_iters) return LSC_EINVAL;
     PlanArgs a;
-    int rc = fill_plan_args(c, a, d_state, d_goal, d_traj_prev, planner_seq, d_traj_next, d_cost, d_status, d_iters);
+    if (c->N == 0) return LSC_ESTATE;
+    const float *d_goal_used = nullptr;
+    int rc = run_goal(c, d_state, d_goal, d_traj_prev, planner_seq, (hipStream_t)hip_stream, &d_goal_used);
+    if (rc) return rc;
+    d_goal = d_goal_used;
+    rc = fill_plan_args(c, a, d_state, d_goal, d_traj_prev, planner_seq, d_traj_next, d_cost, d_status, d_iters);
     if (rc) return rc;
     rc = run_sfc(c, d_state, d_goal, d_traj_prev, (hipStream_t)hip_stream);
     if (rc) return rc;
@@ -470,7 +504,10 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
     HIPCHK(c, hipMemcpyAsync(c->d_goal, goal, sizeof(float) * 3 * N, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->d_prev, prev_traj, sizeof(float) * NV * N, hipMemcpyHostToDevice, st));
     PlanArgs a;
-    int rc = fill_plan_args(c, a, c->d_state, c->d_goal, c->d_prev, planner_seq, c->d_next, c->d_cost, c->d_status, c->d_iters);
+    const float *d_goal_used = nullptr;
+    int rc = run_goal(c, c->d_state, c->d_goal, c->d_prev, planner_seq, st, &d_goal_used);
+    if (rc) return rc;
+    rc = fill_plan_args(c, a, c->d_state, d_goal_used, c->d_prev, planner_seq, c->d_next, c->d_cost, c->d_status, c->d_iters);
     if (rc) return rc;
     if (out_lsc_normal || out_lsc_d) {
         if (!c->d_onormal) {
@@ -479,7 +516,7 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
         }
         a.out_normal = c->d_onormal; a.out_d = c->d_od;
     }
-    rc = run_sfc(c, c->d_state, c->d_goal, c->d_prev, st);
+    rc = run_sfc(c, c->d_state, d_goal_used, c->d_prev, st);
     if (rc) return rc;
     rc = run_plan(c, a, st);
     if (rc) return rc;
@@ -607,6 +644,14 @@ int lsc_iterations_total(lsc_ctx *c, long long *total, int reset)
     for (long long v : h) t += v;
     *total = t;
     if (reset) HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (size_t)c->N));
+    return LSC_OK;
+}
+
+int lsc_last_goals(lsc_ctx *c, float *goals)
+{
+    if (!c || !goals || c->N == 0) return LSC_EINVAL;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(goals, c->d_goal_cur, sizeof(float) * 3 * (size_t)c->N, hipMemcpyDeviceToHost));
     return LSC_OK;
 }
 

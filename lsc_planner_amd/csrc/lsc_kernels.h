@@ -49,6 +49,16 @@ struct SweepArgs {
     double *out_d;
 };
 
+// Goal planning, mode/goal = prior_based on a map without a distance field (one lane per agent)
+struct GoalArgs {
+    int N, planner_seq;
+    float dtf;
+    const float *state, *desired_goal, *traj_prev;
+    double goal_threshold, priority_dist_threshold, goal_radius;
+    float *current_goal;       // [N][3]
+};
+hipError_t launch_goal(const GoalArgs &a, hipStream_t st);
+
 // Safe Flight Corridor update (TrajPlanner::generateFeasibleSFC), one lane per agent
 struct SfcArgs {
     int N, first, count;

@@ -157,6 +157,71 @@ __global__ void lsc_propagate_kernel(const float *__restrict__ traj, float *__re
 
 
 // ---------------------------------------------------------------------------------------------------
+// Goal planning, mode/goal = prior_based (TrajPlanner::goalPlanningWithPriority, src/traj_planner.cpp:540-608) on a
+// map without a distance field.  There the grid A* (src/grid_based_planner.cpp) has no observable effect: its path
+// only feeds findLOSFreeGoal (:350-407), whose line-of-sight test passes for every point when there are neither
+// static obstacles nor a distmap, so the result is the desired goal clamped to goal_radius from the end of the
+// initial trajectory -- unless a higher-priority agent is closer than priority_dist_threshold (retreat rule).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
+{
+#pragma clang fp contract(off)   // octomath float32 semantics
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= a.N) return;
+    auto dist = [](const float *p, const float *q) {
+        float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+        float n2 = dx * dx + dy * dy + dz * dz;
+        return sqrt((double)n2);
+    };
+    const float *pos = a.state + 9 * qi;
+    const float *goal_i = a.desired_goal + 3 * qi;
+    const double dist_to_goal = dist(pos, goal_i);
+    double min_dist_to_obs = 1e9;
+    int closest = -1;
+    const int cl = (M - 1) * NC + DEG, cf = DEG;   // control points [M-1][n] and [0][n]
+    for (int qj = 0; qj < a.N; qj++) {
+        if (qj == qi) continue;
+        const float *opos = a.state + 9 * qj, *ogoal = a.desired_goal + 3 * qj;
+        const double obs_dist_to_goal = dist(opos, ogoal);
+        const double dist_to_obs = dist(opos, pos);
+        if (obs_dist_to_goal < a.goal_threshold) continue;
+        const float *pt = a.traj_prev + (size_t)qj * NV;
+        const float ax = pt[cl] - pt[cf], ay = pt[SEGV + cl] - pt[SEGV + cf], az = pt[2 * SEGV + cl] - pt[2 * SEGV + cf];
+        const float bx = pt[cf] - pos[0], by = pt[SEGV + cf] - pos[1], bz = pt[2 * SEGV + cf] - pos[2];
+        const float dp = ax * bx + ay * by + az * bz;
+        if (dist_to_goal > a.goal_threshold && (double)dp > 0.0) continue;
+        if (dist_to_goal < a.goal_threshold || obs_dist_to_goal < dist_to_goal) {
+            if (dist_to_obs < min_dist_to_obs) { min_dist_to_obs = dist_to_obs; closest = qj; }
+        }
+    }
+    float *out = a.current_goal + 3 * qi;
+    if (min_dist_to_obs < a.priority_dist_threshold) {
+        const float *opos = a.state + 9 * closest;
+        F3 dir = normalized_f32(F3{opos[0] - pos[0], opos[1] - pos[1], opos[2] - pos[2]});
+        const float keep = (float)(a.priority_dist_threshold + 0.1);
+        out[0] = pos[0] - dir.x * keep; out[1] = pos[1] - dir.y * keep; out[2] = pos[2] - dir.z * keep;
+        return;
+    }
+    float ex, ey, ez;
+    if (a.planner_seq < 2) {
+        const float mi = (float)((double)(M - 1) + (double)DEG / (double)DEG);
+        ex = pos[0] + (pos[3] * mi) * a.dtf; ey = pos[1] + (pos[4] * mi) * a.dtf; ez = pos[2] + (pos[5] * mi) * a.dtf;
+    } else {
+        const float *pt = a.traj_prev + (size_t)qi * NV;
+        ex = pt[cl]; ey = pt[SEGV + cl]; ez = pt[2 * SEGV + cl];
+    }
+    F3 delta = F3{goal_i[0] - ex, goal_i[1] - ey, goal_i[2] - ez};
+    const float n2 = delta.x * delta.x + delta.y * delta.y + delta.z * delta.z;
+    if (sqrt((double)n2) > a.goal_radius) {
+        delta = normalized_f32(delta);
+        const float r = (float)a.goal_radius;
+        out[0] = ex + delta.x * r; out[1] = ey + delta.y * r; out[2] = ez + delta.z * r;
+    } else {
+        out[0] = goal_i[0]; out[1] = goal_i[1]; out[2] = goal_i[2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Safe Flight Corridor: CorridorConstructor::expandBoxFromPoint (include/corridor_constructor.hpp:18-245) driven by
 // TrajPlanner::generateFeasibleSFC (src/traj_planner.cpp:1451-1491).  The reference tests every lattice point of a
 // slab against the distance field; here "distance < margin" is pre-thresholded into a 3-D integral image, so a slab
@@ -1260,6 +1325,12 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     }
     if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, a);
     else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_goal(const GoalArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(lsc_goal_kernel, dim3((a.N + 63) / 64), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 

@@ -26,6 +26,10 @@ class PlannerConfig:
     max_iters: int = 50
     prune: bool = True
     warm_start_mu: float = 0.1     # 0 = cold (Mehrotra) start only
+    goal_mode: str = "static"       # mode/goal: "static" or "prior_based" (the latter: goal input = desired goal)
+    goal_threshold: float = 0.1
+    priority_dist_threshold: float = 0.4
+    goal_radius: float = 2.0
 
 
 def _fp(a):
@@ -60,6 +64,9 @@ class SwarmPlanner:
         c.max_iters = self.cfg.max_iters
         c.prune = int(self.cfg.prune)
         c.warm_start_mu = float(self.cfg.warm_start_mu)
+        c.goal_mode = {"static": 0, "prior_based": 1}[self.cfg.goal_mode]
+        c.goal_threshold, c.priority_dist_threshold, c.goal_radius = (self.cfg.goal_threshold, self.cfg.priority_dist_threshold,
+                                                                       self.cfg.goal_radius)
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:
@@ -153,6 +160,12 @@ class SwarmPlanner:
 
     def get_planner_seq(self):
         return self.planner_seq
+
+    def last_goals(self):
+        """current_goal_position used by the last tick (getCurrentGoalPosition of every agent)."""
+        g = np.zeros((self.N, 3), np.float32)
+        self._check(self.L.lsc_last_goals(self.ctx, _fp(g)))
+        return g
 
     def row_counts(self):
         rows = np.zeros(self.N, np.int32)

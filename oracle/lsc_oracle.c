@@ -1078,6 +1078,70 @@ void orc_next_state(const float *traj, double dt, float state[9])
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Goal planning, mode/goal = prior_based, on a map WITHOUT a distance field
+ * (TrajPlanner::goalPlanningWithPriority src/traj_planner.cpp:540-608).  The grid A* result
+ * (src/grid_based_planner.cpp:53-70) only enters through findLOSFreeGoal (:350-407), whose line-of-sight
+ * test passes for every path point when there are neither static obstacles nor a distmap: the LOS goal
+ * is then the desired goal clamped to goal_radius from the end of the initial trajectory, so the A*
+ * search has no observable effect on empty maps and is not restated here.
+ * ---------------------------------------------------------------------------------------- */
+void orc_goal_prior_based(int N, int qi, const float *state, const float *desired_goal, const float *prev_traj,
+                          int planner_seq, double dt, double goal_threshold, double priority_dist_threshold,
+                          double goal_radius, float out_goal[3])
+{
+    const float *pos = state + 9 * qi;
+    const float *goal_i = desired_goal + 3 * qi;
+    const double dist_to_goal = f32_dist(pos, goal_i);
+    double min_dist_to_obs = 1e9;
+    int closest = -1;
+    for (int qj = 0; qj < N; qj++) {
+        if (qj == qi) continue;
+        const float *opos = state + 9 * qj;                       /* obstacle.pose = ideal next state of qj */
+        const float *ogoal = desired_goal + 3 * qj;               /* obstacle.goal_point = getDesiredGoalPosition() */
+        const double obs_dist_to_goal = f32_dist(opos, ogoal);
+        const double dist_to_obs = f32_dist(opos, pos);
+        if (obs_dist_to_goal < goal_threshold) continue;          /* :560-562 */
+        const float *pt = prev_traj + (size_t)qj * ORC_NV;        /* obs_prev_trajs[oi] = qj's previous plan (unshifted) */
+        float a[3], b[3];
+        for (int k = 0; k < 3; k++) {
+            float last = pt[k * ORC_SEGV + (ORC_M - 1) * ORC_NC + ORC_N], first = pt[k * ORC_SEGV + ORC_N];
+            a[k] = last - first;
+            b[k] = first - pos[k];
+        }
+        if (dist_to_goal > goal_threshold && (double)f32_dot(a, b) > 0) continue;   /* same direction :564-566 */
+        if (dist_to_goal < goal_threshold || obs_dist_to_goal < dist_to_goal) {      /* :569-575 */
+            if (dist_to_obs < min_dist_to_obs) { min_dist_to_obs = dist_to_obs; closest = qj; }
+        }
+    }
+    const double dist_keep = priority_dist_threshold + 0.1;
+    if (min_dist_to_obs < priority_dist_threshold) {              /* retreat :580-587 */
+        const float *opos = state + 9 * closest;
+        float dir[3] = {opos[0] - pos[0], opos[1] - pos[1], opos[2] - pos[2]};
+        f32_normalize(dir);
+        for (int k = 0; k < 3; k++) { float s = dir[k] * (float)dist_keep; out_goal[k] = pos[k] - s; }
+        return;
+    }
+    /* findLOSFreeGoal(initial_traj[M-1][n], desired_goal, ...) on an empty map */
+    float end[3];
+    if (planner_seq < 2) {
+        float tmp[ORC_NV];
+        orc_const_vel_traj(pos, pos + 3, dt, tmp);
+        for (int k = 0; k < 3; k++) end[k] = tmp[k * ORC_SEGV + (ORC_M - 1) * ORC_NC + ORC_N];
+    } else {
+        const float *pt = prev_traj + (size_t)qi * ORC_NV;
+        for (int k = 0; k < 3; k++) end[k] = pt[k * ORC_SEGV + (ORC_M - 1) * ORC_NC + ORC_N];
+    }
+    float delta[3] = {goal_i[0] - end[0], goal_i[1] - end[1], goal_i[2] - end[2]};
+    float n2 = delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2];
+    if (sqrt((double)n2) > goal_radius) {
+        f32_normalize(delta);
+        for (int k = 0; k < 3; k++) { float s = delta[k] * (float)goal_radius; out_goal[k] = end[k] + s; }
+    } else {
+        for (int k = 0; k < 3; k++) out_goal[k] = goal_i[k];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * One synchronous tick (src/multi_sync_simulator.cpp:249-337 + src/traj_planner.cpp:344-425)
  * ---------------------------------------------------------------------------------------- */
 static const orc_edt *g_edt = NULL;

@@ -91,6 +91,11 @@ int  orc_qp_assemble(const orc_params *prm, const float state[9], const float go
 int  orc_qp_solve(const double *P, const double *c, double cst, const double *lo, const double *hi,
                   const orc_row *rows, int nrows, double *x, double *cost, int *iters, double *kkt);
 
+/* ---- goal planning, prior_based, empty map (src/traj_planner.cpp:540-608; see the .c file) ---- */
+void orc_goal_prior_based(int N, int qi, const float *state, const float *desired_goal, const float *prev_traj,
+                          int planner_seq, double dt, double goal_threshold, double priority_dist_threshold,
+                          double goal_radius, float out_goal[3]);
+
 /* ---- state propagation (include/polynomial.hpp:63-97 at t = dt; multi_sync_simulator.cpp:190-247) ---- */
 void orc_next_state(const float *traj /*[3][30]*/, double dt, float state[9]);
 

@@ -91,6 +91,9 @@ def lib():
         L.orc_bt_read.argtypes = [ctypes.c_char_p, _dp, ctypes.POINTER(_ip), _ip]
         L.orc_edt_build.restype = ctypes.c_int
         L.orc_edt_build.argtypes = [_ip, ctypes.c_int, ctypes.c_double, _fp, _fp, ctypes.c_double, ctypes.POINTER(OrcEdt)]
+        L.orc_goal_prior_based.restype = None
+        L.orc_goal_prior_based.argtypes = [ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_double, _fp]
         L.orc_tick_set_map.restype = None
         L.orc_tick_set_map.argtypes = [ctypes.c_void_p, ctypes.c_double, _ip]
         _lib = L
@@ -275,6 +278,20 @@ class Swarm:
         if want_lsc:
             res["normal"], res["d"] = nrm, dd
         return res
+
+
+def goal_prior_based(state, desired_goal, prev_traj, planner_seq, dt=0.2, goal_threshold=0.1, priority_dist_threshold=0.4,
+                     goal_radius=2.0):
+    """current_goal_position of every agent, mode/goal = prior_based on an empty map."""
+    state = np.ascontiguousarray(state, np.float32)
+    N = len(state)
+    dg = np.ascontiguousarray(desired_goal, np.float32).reshape(N, 3)
+    pt = np.ascontiguousarray(prev_traj, np.float32).reshape(N, NV)
+    out = np.zeros((N, 3), np.float32)
+    for qi in range(N):
+        lib().orc_goal_prior_based(N, qi, _f(state), _f(dg), _f(pt), planner_seq, dt, goal_threshold, priority_dist_threshold,
+                                   goal_radius, _f(out[qi]))
+    return out
 
 
 def bt_read(path):

@@ -283,3 +283,39 @@ def test_heterogeneous_radii_use_their_own_corridor_margin(L, oracle):
         differ += int(rc2 != 0 or not np.array_equal(box, box2))
     assert differ > 5           # the two margins really give different corridors on this map
     pl.close()
+
+
+def test_prior_based_goal_planning_bitwise_and_mission_completes(L, oracle):
+    """mode/goal = prior_based (the reference's default) on the empty map: device goals == oracle restatement of
+    goalPlanningWithPriority bit for bit, ticks match, and the 20-agent circle swap reaches its goals without collision
+    (with static goals it deadlocks in the centre)."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(20, 8.0)
+    N = 20
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))
+    sw = oracle_swarm(oracle, ms)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    saw_retreat = False
+    for tick in range(1, 260):
+        g = pl.plan(state, ms.goal, traj)
+        goals = pl.last_goals()
+        og = oracle.goal_prior_based(state, ms.goal, traj, tick)
+        assert np.array_equal(goals, og), tick
+        saw_retreat |= bool((np.linalg.norm(goals - state[:, :3], axis=1) < 0.6).any() and (np.linalg.norm(state[:, :3] - ms.goal, axis=1) > 1).all())
+        if tick % 10 == 0 or tick < 4:
+            sw.stale[:] = traj if tick > 1 else 0
+            o = sw.tick(state, og, traj, tick, nthreads=8)
+            assert np.array_equal(g["status"], o["status"])
+            assert (np.abs(g["cost"] - o["cost"]) <= COST_RTOL * np.abs(o["cost"]) + 1e-8).all(), (tick, g["cost"], o["cost"])   # costs -> 0 near the goal: absolute floor
+            assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL, tick
+        assert (g["status"] == 0).all()
+        traj = g["traj"]
+        state = next_state_host(traj)
+        p = state[:, :3].astype(np.float64).copy(); p[:, 2] /= 2.0
+        D = np.linalg.norm(p[:, None] - p[None], axis=2) + np.eye(N) * 9
+        assert D.min() >= 0.3 - 1e-4
+        if np.linalg.norm(state[:, :3] - ms.goal, axis=1).max() < 0.1:
+            break
+    assert tick < 220, "mission did not finish"
+    pl.close()

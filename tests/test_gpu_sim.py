@@ -54,7 +54,7 @@ def test_simulator_trajectory_equals_python_host_layer(ticks, tmp_path):
     _write_mission(str(mp), ms)
     subprocess.run([SIM, "--mission", str(mp), "--csv", str(tmp_path), "--quiet", "--max-iter", "12"], check=False, timeout=300)
     rows = list(csv.reader(open(tmp_path / "result_LSC_4agents.csv")))[1:]
-    pl = L.SwarmPlanner(ms)
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))   # lsc_sim defaults to mode/goal = prior_based
     state = np.zeros((4, 9), np.float32); state[:, :3] = ms.start
     traj = np.zeros((4, 3, 30), np.float32)
     for tick in range(10):

@@ -57,3 +57,20 @@ def test_mission_simple4_reaches_goals_without_collision(oracle, ticks):
         if np.linalg.norm(state[:, :3] - ms.goal, axis=1).max() < 0.1:
             break
     assert tick < 80
+
+
+def test_prior_based_goal_rules(oracle):
+    """goalPlanningWithPriority on an empty map: LOS goal = desired goal clamped to goal_radius from the end of the
+    initial trajectory; retreat by priority_dist_threshold + 0.1 from a closer higher-priority agent."""
+    state = np.zeros((2, 9), np.float32)
+    state[0, :3] = [0, 0, 1]; state[1, :3] = [5, 0, 1]
+    goal = np.array([[10, 0, 1], [5.5, 0, 1]], np.float32)
+    prev = np.zeros((2, 3, 30), np.float32)
+    g = oracle.goal_prior_based(state, goal, prev, 1)
+    assert np.allclose(g[0], [2, 0, 1]) and np.allclose(g[1], [5.5, 0, 1])          # clamp to 2 m / goal within reach
+    # agent 1 (closer to its goal -> higher priority) sits 0.3 m in front of agent 0: agent 0 retreats to 0.5 m
+    state[1, :3] = [0.3, 0, 1]; goal[1] = [0.9, 0, 1]
+    prev[:, 0, :] = state[:, 0:1]; prev[:, 2, :] = 1
+    g = oracle.goal_prior_based(state, goal, prev, 2)
+    assert np.allclose(g[0], [-0.5, 0, 1], atol=1e-6)
+    assert np.allclose(g[1], [0.9, 0, 1])
