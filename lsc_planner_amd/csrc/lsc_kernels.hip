@@ -388,6 +388,7 @@ struct Smem {
     double Tz[NCP * 3];         // per control point: -sum z n
     double K[NY * KLD];         // reduced Hessian (lower band); rows of its Cholesky factor after factor()
     double red[6][NWAVE];
+    double colbuf[2 * 64];      // Cholesky column broadcast buffer (double-buffered by column parity)
     double sc[8];               // broadcast scalars
     // axis rows: slot = type*90 + k*30 + t ; type 0 x<=hi, 1 -x<=-lo, 2/3 +-velocity, 4/5 +-acceleration
     double as_[AXROWS], az[AXROWS], at1[AXROWS], at2[AXROWS], ah[AXROWS];
@@ -441,37 +442,72 @@ __device__ __forceinline__ double rsqrt_nr(double d)
     return y;
 }
 
-template <int J, int K, int K1>
-__device__ __forceinline__ void chol_update(double (&row)[NY], double l)
+// Right-looking banded LDL^T of the 39x39 reduced Hessian (K = M D M^T, M unit lower triangular, D = diag(d)) in the
+// registers of wave 0: lane i owns row i (column index = register index).  No square roots: the dependency chain of
+// a column is  readlane(d_J) -> 1/d_J (v_rcp_f64 + 2 Newton steps) -> u = row[J]/d_J -> one fma into the next pivot.
+// Column J's (unscaled) entries reach the other lanes two ways:
+//   * k = J+1, J+2 (needed by the next two pivots): v_readlane, issued before the reciprocal is known;
+//   * k = J+3 .. J+11: the column is published once in LDS and read back as broadcast loads; those loads are issued
+//     at the start of step J and their updates are applied during step J+1, so the LDS latency is hidden behind the
+//     next pivot's chain (two columns of slack before the values are needed).
+constexpr int CHOL_NEAR = 2;
+__device__ __forceinline__ double rcp_nr(double d)
 {
-    const double lk = bcast_lane<K>(l);
-    row[K] = fma(-l, lk, row[K]);
-    if constexpr (K < K1) chol_update<J, K + 1, K1>(row, l);
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    return y;
 }
-
-// Right-looking banded Cholesky of the 39x39 reduced Hessian, entirely in registers of wave 0: lane i owns row i
-// (column index = register index), the pivot and the column entries travel by v_readlane; only the next column's
-// single update sits on the dependency chain.
 template <int J>
-__device__ __forceinline__ void chol_step(double (&row)[NY], double &dinv_own, int lane, bool &ok)
+__device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, double &dinv_own, int lane, bool &ok,
+                                          double u_prev, const double (&pend)[BAND])
 {
-    const double dj = bcast_lane<J>(row[J]);
-    if (!(dj > 0.0)) ok = false;
-    const double inv = rsqrt_nr(dj);      // 1 / L[J][J], uniform over the wave
-    if (lane == J) dinv_own = inv;
-    const double l = row[J] * inv;        // L[i][J] in lane i (lane J: sqrt(dj))
     constexpr int K1 = (J + BAND) < (NY - 1) ? (J + BAND) : (NY - 1);
-    if constexpr (J + 1 <= K1) {
-        chol_update<J, J + 1, K1>(row, l);
+    const double cj = row[J];             // A[i][J] after the updates of columns < J (lane J: the pivot d_J)
+    // publish the column and issue the loads for its far entries first: nothing below depends on them until step J+1
+    double nxt[BAND];
+#pragma unroll
+    for (int q = 0; q < BAND; q++) nxt[q] = 0.0;
+    if constexpr (J + 1 + CHOL_NEAR <= K1) {
+        double *buf = colbuf + (J & 1) * 64;
+        buf[lane] = cj;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < BAND; q++) {
+            const int k = J + 1 + CHOL_NEAR + q;
+            if (k <= K1) nxt[q] = buf[k];
+        }
     }
-    row[J] = l * inv;                     // keep the unit-diagonal factor M[i][J] = L[i][J] / L[J][J]
-    if constexpr (J + 1 < NY) chol_step<J + 1>(row, dinv_own, lane, ok);
+    // ---- critical part: pivot J and the updates the next two pivots depend on
+    const double dj = bcast_lane<J>(cj);
+    const double s1 = bcast_lane<(J + 1 < NY ? J + 1 : 0)>(cj);
+    const double s2 = bcast_lane<(J + 2 < NY ? J + 2 : 0)>(cj);
+    if (!(dj > 0.0)) ok = false;
+    const double r = rcp_nr(dj);          // 1 / d_J, uniform over the wave
+    if (lane == J) dinv_own = r;
+    const double u = cj * r;              // M[i][J] = A[i][J] / d_J  (unit-diagonal factor entry)
+    if constexpr (J + 1 <= K1) row[J + 1] = fma(-u, s1, row[J + 1]);
+    if constexpr (J + 2 <= K1) row[J + 2] = fma(-u, s2, row[J + 2]);
+    // ---- deferred part of the PREVIOUS column (its LDS loads were issued one step ago)
+    if constexpr (J >= 1) {
+        constexpr int P = J - 1;
+        constexpr int PK1 = (P + BAND) < (NY - 1) ? (P + BAND) : (NY - 1);
+#pragma unroll
+        for (int q = 0; q < BAND; q++) {
+            const int k = P + 1 + CHOL_NEAR + q;
+            if (k <= PK1) row[k] = fma(-u_prev, pend[q], row[k]);
+        }
+    }
+    row[J] = u;
+    if constexpr (J + 1 < NY) chol_step<J + 1>(row, colbuf, dinv_own, lane, ok, u, nxt);
 }
 
-// Triangular solves with the factor scaled to unit diagonal (M = L D^-1, D = diag L): the dependent chain of a
-// substitution step is one v_readlane pair and one fma, no multiply by the inverse pivot.
-//   forward : M u = b            (rowS[J] = L[lane][J] / L[J][J])
-//   backward: M^T x = D^-2 u     (colS[I] = L[I][lane] / L[lane][lane])
+// Triangular solves with the unit-diagonal factor (K = M D M^T): the dependent chain of a substitution step is one
+// v_readlane pair and one fma, no multiply by an inverse pivot.
+//   forward : M u = b ;   v = D^-1 u ;   backward: M^T x = v
 // (rowS / the column chunks are zero on and above the diagonal, so a step is readlane + fma with no lane predicate)
 template <int J>
 __device__ __forceinline__ void fwd_step(const double (&rowS)[NY], double &b)
@@ -931,7 +967,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         __syncthreads();
     };
 
-    double dinv_own = 0.0;      // wave 0: 1 / L[lane][lane] of the current factor
+    double dinv_own = 0.0;      // wave 0: 1 / d_lane of the current factor K = M D M^T
 
     // The factor lives in LDS (S.K, unit-diagonal M = L D^-1, lower band) between phases; registers hold it only inside
     // factor() and solve(), so the row passes and reductions in between keep the whole register budget.
@@ -944,7 +980,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // (updates run on whole register rows; only the part left of the diagonal is meaningful afterwards)
             bool ok = true;
             dinv_own = 0.0;
-            chol_step<0>(lrow, dinv_own, lane, ok);
+            const double pend0[BAND] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            chol_step<0>(lrow, S.colbuf, dinv_own, lane, ok, 0.0, pend0);
 #pragma unroll
             for (int j = 0; j < NY; j++)
                 if (act && j <= lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
@@ -960,7 +997,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int j = 0; j < NY; j++) rowS[j] = (lane < NY && j < lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
             double b = lane < NY ? S.rhs[lane] : 0.0;
             fwd_step<0>(rowS, b);
-            b *= dinv_own * dinv_own;
+            b *= dinv_own;      // D^-1
             bwd_chunk<26>(S.K, b, lane);
             bwd_chunk<13>(S.K, b, lane);
             bwd_chunk<0>(S.K, b, lane);
