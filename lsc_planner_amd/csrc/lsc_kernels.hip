@@ -444,29 +444,29 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 
 // Right-looking banded LDL^T of the 39x39 reduced Hessian (K = M D M^T, M unit lower triangular, D = diag(d)) in the
 // registers of wave 0: lane i owns row i (column index = register index).  No square roots: the dependency chain of
-// a column is  readlane(d_J) -> 1/d_J (v_rcp_f64 + 2 Newton steps) -> u = row[J]/d_J -> one fma into the next pivot.
+// a column is  readlane(d_J) -> 1/d_J (v_rcp_f64 + 1 Newton step) -> u = row[J]/d_J -> one fma into the next pivot.
 // Column J's (unscaled) entries reach the other lanes two ways:
-//   * k = J+1, J+2 (needed by the next two pivots): v_readlane, issued before the reciprocal is known;
-//   * k = J+3 .. J+11: the column is published once in LDS and read back as broadcast loads; those loads are issued
-//     at the start of step J and their updates are applied during step J+1, so the LDS latency is hidden behind the
-//     next pivot's chain (two columns of slack before the values are needed).
-constexpr int CHOL_NEAR = 2;
+//   * k = J+1 .. J+3 (needed by the next three pivots): v_readlane, issued before the reciprocal is known;
+//   * k = J+4 .. J+11: the column is published once in LDS and read back as broadcast loads; those loads are issued
+//     at the start of step J and their updates are applied during step J+2, so the LDS latency is hidden behind two
+//     pivot chains wherever the instruction scheduler places the uses.
+constexpr int CHOL_NEAR = 3;
 __device__ __forceinline__ double rcp_nr(double d)
 {
+    // v_rcp_f64 seed (~2^-26 relative) + one Newton step -> ~2^-51: as accurate as the factorisation needs (the compiler's
+    // correctly rounded division spends a second step and a fix-up on the last half ulp)
     double y = __builtin_amdgcn_rcp(d);
     double e = fma(-d, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-d, y, 1.0);
     y = fma(y, e, y);
     return y;
 }
 template <int J>
 __device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, double &dinv_own, int lane, bool &ok,
-                                          double u_prev, const double (&pend)[BAND])
+                                          double u_p1, const double (&pend_p1)[BAND], double u_p2, const double (&pend_p2)[BAND])
 {
     constexpr int K1 = (J + BAND) < (NY - 1) ? (J + BAND) : (NY - 1);
     const double cj = row[J];             // A[i][J] after the updates of columns < J (lane J: the pivot d_J)
-    // publish the column and issue the loads for its far entries first: nothing below depends on them until step J+1
+    // publish the column and issue the loads for its far entries first: nothing depends on them until step J+2
     double nxt[BAND];
 #pragma unroll
     for (int q = 0; q < BAND; q++) nxt[q] = 0.0;
@@ -481,28 +481,34 @@ __device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, dou
             if (k <= K1) nxt[q] = buf[k];
         }
     }
-    // ---- critical part: pivot J and the updates the next two pivots depend on
+    // ---- critical part: pivot J and the updates the next three pivots depend on
     const double dj = bcast_lane<J>(cj);
     const double s1 = bcast_lane<(J + 1 < NY ? J + 1 : 0)>(cj);
     const double s2 = bcast_lane<(J + 2 < NY ? J + 2 : 0)>(cj);
+    const double s3 = bcast_lane<(J + 3 < NY ? J + 3 : 0)>(cj);
     if (!(dj > 0.0)) ok = false;
     const double r = rcp_nr(dj);          // 1 / d_J, uniform over the wave
     if (lane == J) dinv_own = r;
     const double u = cj * r;              // M[i][J] = A[i][J] / d_J  (unit-diagonal factor entry)
     if constexpr (J + 1 <= K1) row[J + 1] = fma(-u, s1, row[J + 1]);
     if constexpr (J + 2 <= K1) row[J + 2] = fma(-u, s2, row[J + 2]);
-    // ---- deferred part of the PREVIOUS column (its LDS loads were issued one step ago)
-    if constexpr (J >= 1) {
-        constexpr int P = J - 1;
+    if constexpr (J + 3 <= K1) row[J + 3] = fma(-u, s3, row[J + 3]);
+    // ---- deferred part of column J-2 (its LDS loads were issued two steps ago)
+    if constexpr (J >= 2) {
+        constexpr int P = J - 2;
         constexpr int PK1 = (P + BAND) < (NY - 1) ? (P + BAND) : (NY - 1);
 #pragma unroll
         for (int q = 0; q < BAND; q++) {
             const int k = P + 1 + CHOL_NEAR + q;
-            if (k <= PK1) row[k] = fma(-u_prev, pend[q], row[k]);
+            if (k <= PK1) row[k] = fma(-u_p2, pend_p2[q], row[k]);
         }
     }
     row[J] = u;
-    if constexpr (J + 1 < NY) chol_step<J + 1>(row, colbuf, dinv_own, lane, ok, u, nxt);
+    if constexpr (J + 1 < NY) chol_step<J + 1>(row, colbuf, dinv_own, lane, ok, u, nxt, u_p1, pend_p1);
+    else {
+        // flush: column J-1 may still hold deferred updates (none in practice: its far range is empty at the end)
+        (void)u_p1;
+    }
 }
 
 // Triangular solves with the unit-diagonal factor (K = M D M^T): the dependent chain of a substitution step is one
@@ -981,7 +987,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             bool ok = true;
             dinv_own = 0.0;
             const double pend0[BAND] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            chol_step<0>(lrow, S.colbuf, dinv_own, lane, ok, 0.0, pend0);
+            chol_step<0>(lrow, S.colbuf, dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
 #pragma unroll
             for (int j = 0; j < NY; j++)
                 if (act && j <= lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
