@@ -137,13 +137,21 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     seq = 0
 
+    state_b = torch.zeros_like(state)
+    states = [state, state_b]
+
     def tick(prev, nxt):
+        # one GPU: a tick is ONE launch (goal planning, LSC, QP and the next ideal states fused);
+        # several GPUs: plan the shard, all-gather the new trajectories, then every rank propagates all states
         nonlocal seq
         seq += 1
-        pl.tick_device(state, goal, prev, nxt, cost, status, iters, seq, stream)
-        if G > 1:
+        if G == 1:
+            pl.tick_device_fused(states[0], goal, prev, nxt, states[1], cost, status, iters, seq, stream)
+            states.reverse()
+        else:
+            pl.tick_device(states[0], goal, prev, nxt, cost, status, iters, seq, stream)
             all_gather_rows(dist, nxt, first, count, counts)
-        pl.propagate_device(nxt, state, stream)
+            pl.propagate_device(nxt, states[0], stream)
 
     def sync():
         if G > 1:
@@ -188,7 +196,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n_agents}-agent generated circle swap (R={R:g} m, z=1 m), empty map, LSC mode, "
                                    f"dt 0.2 s, M=5 n=5, mode/goal={goal_mode}, {args.agents_per_gpu} agents per GPU, "
-                                   "device-resident ticks (goal planning + plan kernel + state propagation"
+                                   "device-resident ticks (one fused launch per tick: goal planning + LSC + QP + state propagation"
                                    + (", RCCL all-gather of trajectories per tick)" if G > 1 else ")"),
                        "agents": n_agents, "parallelism": f"agent-shard x{G}", "prune_redundant_rows": not args.no_prune},
             "qp": {"mean_ip_iterations": round(iters_total / (n_agents * args.steps), 2), "failed_agents_last_tick": bad,
@@ -207,11 +215,11 @@ def main():
     nrm = torch.empty((count, nobs, 5, 3), **f32)
     dd = torch.empty((count, nobs, 5, 6), dtype=torch.float64, device=dev)
     for _ in range(3):
-        pl.sweep_device(state, prev, seq + 1, nrm, dd, stream)
+        pl.sweep_device(states[0], prev, seq + 1, nrm, dd, stream)
     torch.cuda.synchronize()
     pl.set_timing(True)
     for _ in range(20):
-        pl.sweep_device(state, prev, seq + 1, nrm, dd, stream)
+        pl.sweep_device(states[0], prev, seq + 1, nrm, dd, stream)
     torch.cuda.synchronize()
     s_ms, s_n = pl.kernel_time_ms(1)
     pl.set_timing(False)

@@ -133,6 +133,14 @@ int lsc_tick_device(lsc_ctx *ctx, const float *d_state, const float *d_goal, con
                     int planner_seq, float *d_traj_next, double *d_cost, int *d_status, int *d_iters,
                     void *hip_stream);
 
+/* Same tick with MultiSyncSimulator::update()'s ideal-state step fused into the launch: additionally writes
+ * d_state_next [N][9] rows of the shard = the agent's state at t = dt on its new plan (what lsc_propagate_device
+ * computes).  With one GPU a whole tick is then a single kernel launch; d_state and d_state_next must be different
+ * buffers (every workgroup reads all current states). */
+int lsc_tick_device_fused(lsc_ctx *ctx, const float *d_state, const float *d_goal, const float *d_traj_prev,
+                          int planner_seq, float *d_traj_next, float *d_state_next, double *d_cost, int *d_status,
+                          int *d_iters, void *hip_stream);
+
 /* MultiSyncSimulator::update()'s ideal-state step on device: state[qi] = traj[qi] evaluated at t = dt
  * (getFutureStateMsg -> getStateFromControlPoints, include/polynomial.hpp:63-97).  All N agents. */
 int lsc_propagate_device(lsc_ctx *ctx, const float *d_traj, float *d_state, void *hip_stream);

@@ -42,7 +42,7 @@ class LscConfig(ctypes.Structure):
 # every symbol include/lsc_planner_amd.h declares
 EXPORTS = [
     "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
-    "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_propagate_device", "lsc_sweep_device",
+    "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_sweep_device",
     "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals",
 ]
 
@@ -75,6 +75,7 @@ def load_library():
     L.lsc_set_distmap.argtypes = [vp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ctypes.c_double]
     L.lsc_replan_tick.argtypes = [vp, fp, fp, fp, ctypes.c_int, fp, dp, ip, ip, fp, dp, fp]
     L.lsc_tick_device.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp]
+    L.lsc_tick_device_fused.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, vp]
     L.lsc_propagate_device.argtypes = [vp, vp, vp, vp]
     L.lsc_sweep_device.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]
     L.lsc_gjk_batch.argtypes = [vp, dp, ctypes.c_int, dp, dp]

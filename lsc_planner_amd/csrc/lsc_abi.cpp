@@ -178,6 +178,7 @@ struct lsc_ctx {
     double *d_vmax = nullptr, *d_amax = nullptr, *d_vnom = nullptr;
     float *d_stale = nullptr, *d_sfc = nullptr;
     float *d_goal_cur = nullptr;
+    float *fused_state_next = nullptr;   // set by lsc_tick_device_fused for one call
     int *d_sfc_init = nullptr, *d_sfc_err = nullptr, *d_img_of_agent = nullptr, *d_integral = nullptr;
     std::vector<float> h_edt;   // host copy of the distance field (integral images are rebuilt when agents change)
     int edt_dims[3] = {0, 0, 0}, edt_kmin[3] = {0, 0, 0};
@@ -406,27 +407,13 @@ int lsc_set_distmap(lsc_ctx *c, const float *edt, int nx, int ny, int nz, const 
     return build_integrals(c);
 }
 
-// goalPlanning(): returns the device pointer holding current_goal_position for this tick
-static int run_goal(lsc_ctx *c, const float *d_state, const float *d_goal, const float *d_prev, int seq, hipStream_t st,
-                    const float **d_goal_used)
+// goalPlanning() runs in phase A of the plan kernel; here only the mode check
+static int check_goal_mode(lsc_ctx *c)
 {
-    if (c->cfg.goal_mode == 0) {
-        *d_goal_used = d_goal;
-        // keep a copy so that lsc_last_goals answers in both modes
-        HIPCHK(c, hipMemcpyAsync(c->d_goal_cur, d_goal, sizeof(float) * 3 * (size_t)c->N, hipMemcpyDeviceToDevice, st));
-        return LSC_OK;
-    }
-    if (c->cfg.use_octomap) {
+    if (c->cfg.goal_mode == 1 && c->cfg.use_octomap) {
         c->err = "goal_mode prior_based with use_octomap needs the grid A* goal planner (not built yet); use goal_mode 0";
         return LSC_ESTATE;
     }
-    GoalArgs g;
-    g.N = c->N; g.planner_seq = seq; g.dtf = (float)c->cfg.dt;
-    g.state = d_state; g.desired_goal = d_goal; g.traj_prev = d_prev;
-    g.goal_threshold = c->cfg.goal_threshold; g.priority_dist_threshold = c->cfg.priority_dist_threshold; g.goal_radius = c->cfg.goal_radius;
-    g.current_goal = c->d_goal_cur;
-    HIPCHK(c, launch_goal(g, st));
-    *d_goal_used = c->d_goal_cur;
     return LSC_OK;
 }
 
@@ -459,6 +446,9 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.stale = c->d_stale; a.sfc = c->cfg.use_octomap ? c->d_sfc : nullptr;
     a.sfc_err = c->cfg.use_octomap ? c->d_sfc_err : nullptr;
     a.out_normal = nullptr; a.out_d = nullptr;
+    a.goal_mode = c->cfg.goal_mode; a.goal_threshold = c->cfg.goal_threshold;
+    a.priority_dist_threshold = c->cfg.priority_dist_threshold; a.goal_radius = c->cfg.goal_radius;
+    a.goal_out = c->d_goal_cur; a.state_next = nullptr; a.finv = (float)std::pow(c->cfg.dt, -1);
     a.dbg = c->d_dbg; a.prof = c->profiling ? c->d_prof : nullptr;
     a.trace = c->trace_agent >= 0 ? c->d_trace : nullptr; a.trace_agent = c->trace_agent;
     return LSC_OK;
@@ -480,15 +470,24 @@ int lsc_tick_device(lsc_ctx *c, const float *d_state, const float *d_goal, const
     if (!c || !d_state || !d_goal || !d_traj_prev || !d_traj_next || !d_cost || !d_status || !d_iters) return LSC_EINVAL;
     PlanArgs a;
     if (c->N == 0) return LSC_ESTATE;
-    const float *d_goal_used = nullptr;
-    int rc = run_goal(c, d_state, d_goal, d_traj_prev, planner_seq, (hipStream_t)hip_stream, &d_goal_used);
+    int rc = check_goal_mode(c);
     if (rc) return rc;
-    d_goal = d_goal_used;
     rc = fill_plan_args(c, a, d_state, d_goal, d_traj_prev, planner_seq, d_traj_next, d_cost, d_status, d_iters);
     if (rc) return rc;
+    a.state_next = c->fused_state_next;
     rc = run_sfc(c, d_state, d_goal, d_traj_prev, (hipStream_t)hip_stream);
     if (rc) return rc;
     return run_plan(c, a, (hipStream_t)hip_stream);
+}
+
+int lsc_tick_device_fused(lsc_ctx *c, const float *d_state, const float *d_goal, const float *d_traj_prev, int planner_seq,
+                          float *d_traj_next, float *d_state_next, double *d_cost, int *d_status, int *d_iters, void *hip_stream)
+{
+    if (!c || !d_state_next) return LSC_EINVAL;
+    c->fused_state_next = d_state_next;
+    const int rc = lsc_tick_device(c, d_state, d_goal, d_traj_prev, planner_seq, d_traj_next, d_cost, d_status, d_iters, hip_stream);
+    c->fused_state_next = nullptr;
+    return rc;
 }
 
 int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const float *prev_traj, int planner_seq,
@@ -504,10 +503,9 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
     HIPCHK(c, hipMemcpyAsync(c->d_goal, goal, sizeof(float) * 3 * N, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->d_prev, prev_traj, sizeof(float) * NV * N, hipMemcpyHostToDevice, st));
     PlanArgs a;
-    const float *d_goal_used = nullptr;
-    int rc = run_goal(c, c->d_state, c->d_goal, c->d_prev, planner_seq, st, &d_goal_used);
+    int rc = check_goal_mode(c);
     if (rc) return rc;
-    rc = fill_plan_args(c, a, c->d_state, d_goal_used, c->d_prev, planner_seq, c->d_next, c->d_cost, c->d_status, c->d_iters);
+    rc = fill_plan_args(c, a, c->d_state, c->d_goal, c->d_prev, planner_seq, c->d_next, c->d_cost, c->d_status, c->d_iters);
     if (rc) return rc;
     if (out_lsc_normal || out_lsc_d) {
         if (!c->d_onormal) {
@@ -516,7 +514,7 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
         }
         a.out_normal = c->d_onormal; a.out_d = c->d_od;
     }
-    rc = run_sfc(c, c->d_state, d_goal_used, c->d_prev, st);
+    rc = run_sfc(c, c->d_state, c->d_goal, c->d_prev, st);
     if (rc) return rc;
     rc = run_plan(c, a, st);
     if (rc) return rc;

@@ -19,7 +19,12 @@ struct PlanArgs {
     const uint32_t *entries;   // [n_entries+1][2] : (gi<<16|gj, first term)
     int N, first, count, planner_seq, cap;
     const float *state;        // [N][9]
-    const float *goal;         // [N][3]
+    const float *goal;         // [N][3] current goal (mode/goal static) or desired goal (prior_based)
+    int goal_mode;             // 0 static, 1 prior_based: goalPlanningWithPriority runs in phase A of the plan kernel
+    double goal_threshold, priority_dist_threshold, goal_radius;
+    float *goal_out;           // [N][3] current_goal_position actually used (diagnostics / getCurrentGoalPosition)
+    float *state_next;         // optional [N][9]: ideal state of the agent at t = dt on its NEW plan (fused propagation)
+    float finv;                // (float)pow(dt, -1)
     const float *traj_prev;    // [N][90]
     const double *radius, *radius_obs, *downwash, *downwash_obs;  // [N]; *_obs = value rounded through float32
     const double *vmax, *amax; // [N][3]
@@ -48,16 +53,6 @@ struct SweepArgs {
     float *out_normal;
     double *out_d;
 };
-
-// Goal planning, mode/goal = prior_based on a map without a distance field (one lane per agent)
-struct GoalArgs {
-    int N, planner_seq;
-    float dtf;
-    const float *state, *desired_goal, *traj_prev;
-    double goal_threshold, priority_dist_threshold, goal_radius;
-    float *current_goal;       // [N][3]
-};
-hipError_t launch_goal(const GoalArgs &a, hipStream_t st);
 
 // Safe Flight Corridor update (TrajPlanner::generateFeasibleSFC), one lane per agent
 struct SfcArgs {

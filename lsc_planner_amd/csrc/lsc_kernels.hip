@@ -157,71 +157,6 @@ __global__ void lsc_propagate_kernel(const float *__restrict__ traj, float *__re
 
 
 // ---------------------------------------------------------------------------------------------------
-// Goal planning, mode/goal = prior_based (TrajPlanner::goalPlanningWithPriority, src/traj_planner.cpp:540-608) on a
-// map without a distance field.  There the grid A* (src/grid_based_planner.cpp) has no observable effect: its path
-// only feeds findLOSFreeGoal (:350-407), whose line-of-sight test passes for every point when there are neither
-// static obstacles nor a distmap, so the result is the desired goal clamped to goal_radius from the end of the
-// initial trajectory -- unless a higher-priority agent is closer than priority_dist_threshold (retreat rule).
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
-{
-#pragma clang fp contract(off)   // octomath float32 semantics
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= a.N) return;
-    auto dist = [](const float *p, const float *q) {
-        float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
-        float n2 = dx * dx + dy * dy + dz * dz;
-        return sqrt((double)n2);
-    };
-    const float *pos = a.state + 9 * qi;
-    const float *goal_i = a.desired_goal + 3 * qi;
-    const double dist_to_goal = dist(pos, goal_i);
-    double min_dist_to_obs = 1e9;
-    int closest = -1;
-    const int cl = (M - 1) * NC + DEG, cf = DEG;   // control points [M-1][n] and [0][n]
-    for (int qj = 0; qj < a.N; qj++) {
-        if (qj == qi) continue;
-        const float *opos = a.state + 9 * qj, *ogoal = a.desired_goal + 3 * qj;
-        const double obs_dist_to_goal = dist(opos, ogoal);
-        const double dist_to_obs = dist(opos, pos);
-        if (obs_dist_to_goal < a.goal_threshold) continue;
-        const float *pt = a.traj_prev + (size_t)qj * NV;
-        const float ax = pt[cl] - pt[cf], ay = pt[SEGV + cl] - pt[SEGV + cf], az = pt[2 * SEGV + cl] - pt[2 * SEGV + cf];
-        const float bx = pt[cf] - pos[0], by = pt[SEGV + cf] - pos[1], bz = pt[2 * SEGV + cf] - pos[2];
-        const float dp = ax * bx + ay * by + az * bz;
-        if (dist_to_goal > a.goal_threshold && (double)dp > 0.0) continue;
-        if (dist_to_goal < a.goal_threshold || obs_dist_to_goal < dist_to_goal) {
-            if (dist_to_obs < min_dist_to_obs) { min_dist_to_obs = dist_to_obs; closest = qj; }
-        }
-    }
-    float *out = a.current_goal + 3 * qi;
-    if (min_dist_to_obs < a.priority_dist_threshold) {
-        const float *opos = a.state + 9 * closest;
-        F3 dir = normalized_f32(F3{opos[0] - pos[0], opos[1] - pos[1], opos[2] - pos[2]});
-        const float keep = (float)(a.priority_dist_threshold + 0.1);
-        out[0] = pos[0] - dir.x * keep; out[1] = pos[1] - dir.y * keep; out[2] = pos[2] - dir.z * keep;
-        return;
-    }
-    float ex, ey, ez;
-    if (a.planner_seq < 2) {
-        const float mi = (float)((double)(M - 1) + (double)DEG / (double)DEG);
-        ex = pos[0] + (pos[3] * mi) * a.dtf; ey = pos[1] + (pos[4] * mi) * a.dtf; ez = pos[2] + (pos[5] * mi) * a.dtf;
-    } else {
-        const float *pt = a.traj_prev + (size_t)qi * NV;
-        ex = pt[cl]; ey = pt[SEGV + cl]; ez = pt[2 * SEGV + cl];
-    }
-    F3 delta = F3{goal_i[0] - ex, goal_i[1] - ey, goal_i[2] - ez};
-    const float n2 = delta.x * delta.x + delta.y * delta.y + delta.z * delta.z;
-    if (sqrt((double)n2) > a.goal_radius) {
-        delta = normalized_f32(delta);
-        const float r = (float)a.goal_radius;
-        out[0] = ex + delta.x * r; out[1] = ey + delta.y * r; out[2] = ez + delta.z * r;
-    } else {
-        out[0] = goal_i[0]; out[1] = goal_i[1]; out[2] = goal_i[2];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Safe Flight Corridor: CorridorConstructor::expandBoxFromPoint (include/corridor_constructor.hpp:18-245) driven by
 // TrajPlanner::generateFeasibleSFC (src/traj_planner.cpp:1451-1491).  The reference tests every lattice point of a
 // slab against the distance field; here "distance < margin" is pre-thresholded into a 3-D integral image, so a slab
@@ -405,6 +340,8 @@ struct Smem {
     int tseg;                   // terminal segments
     int flag;                   // capacity overflow
     int nact;                   // active LSC rows
+    int itmp;                   // argmin scratch of the goal stage
+    float goalf[3];             // current goal (float32, as agent.current_goal_position)
     alignas(8) uint32_t dyn[2]; // dynamic part starts here: terms, entry table, kconst, LSC rows, row map
 };
 
@@ -609,6 +546,74 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         S.pinit[tid] = val;
     }
+    // ---- goal planning (TrajPlanner::goalPlanning, src/traj_planner.cpp:477-538)
+    //   static      : current goal = the goal input
+    //   prior_based : goalPlanningWithPriority (:540-608) on a map without a distance field.  There the grid A*
+    //                 (src/grid_based_planner.cpp) has no observable effect: its path only feeds findLOSFreeGoal
+    //                 (:350-407), whose line-of-sight test passes for every point when there are neither static
+    //                 obstacles nor a distmap, so the result is the desired goal clamped to goal_radius from the end of
+    //                 the initial trajectory -- unless a higher-priority agent is closer than priority_dist_threshold.
+    if (a.goal_mode == 1) {
+#pragma clang fp contract(off)   // octomath float32 semantics
+        auto distf = [](const float *p, const float *q) {
+            float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+            float n2 = dx * dx + dy * dy + dz * dz;
+            return sqrt((double)n2);
+        };
+        const float *pos = a.state + 9 * qi;
+        const float *goal_i = a.goal + 3 * qi;
+        const double dist_to_goal = distf(pos, goal_i);
+        const int cl = (M - 1) * NC + DEG, cf = DEG;   // control points [M-1][n] and [0][n]
+        double best = 1e9;
+        int bq = 0x7fffffff;
+        for (int qj = tid; qj < N; qj += NT) {
+            if (qj == qi) continue;
+            const float *opos = a.state + 9 * qj, *ogoal = a.goal + 3 * qj;
+            const double obs_dist_to_goal = distf(opos, ogoal);
+            const double dist_to_obs = distf(opos, pos);
+            if (obs_dist_to_goal < a.goal_threshold) continue;                 // :560-562
+            const float *pt = a.traj_prev + (size_t)qj * NV;                     // obs_prev_trajs (unshifted previous plan)
+            const float ax = pt[cl] - pt[cf], ay = pt[SEGV + cl] - pt[SEGV + cf], az = pt[2 * SEGV + cl] - pt[2 * SEGV + cf];
+            const float bx = pt[cf] - pos[0], by = pt[SEGV + cf] - pos[1], bz = pt[2 * SEGV + cf] - pos[2];
+            const float dp = ax * bx + ay * by + az * bz;
+            if (dist_to_goal > a.goal_threshold && (double)dp > 0.0) continue;   // same direction :564-566
+            if (dist_to_goal < a.goal_threshold || obs_dist_to_goal < dist_to_goal) {
+                if (dist_to_obs < best) { best = dist_to_obs; bq = qj; }        // :569-575 (first strict minimum)
+            }
+        }
+        // block argmin with the sequential loop's tie rule (lowest obstacle index among equal distances)
+        const double wmin = wave_min(best);
+        if (lane == 0) S.red[0][wave] = wmin;
+        if (tid == 0) S.itmp = 0x7fffffff;
+        __syncthreads();
+        double dmin = S.red[0][0];
+#pragma unroll
+        for (int w = 1; w < NWAVE; w++) dmin = fmin(dmin, S.red[0][w]);
+        if (bq != 0x7fffffff && best == dmin) atomicMin(&S.itmp, bq);
+        __syncthreads();
+        if (tid == 0) {
+            float gx, gy, gz;
+            if (dmin < a.priority_dist_threshold) {                               // retreat :580-587
+                const float *opos = a.state + 9 * S.itmp;
+                F3 dir = normalized_f32(F3{opos[0] - pos[0], opos[1] - pos[1], opos[2] - pos[2]});
+                const float keep = (float)(a.priority_dist_threshold + 0.1);
+                gx = pos[0] - dir.x * keep; gy = pos[1] - dir.y * keep; gz = pos[2] - dir.z * keep;
+            } else {                                                              // findLOSFreeGoal, empty map
+                const float ex = S.pinit[cl], ey = S.pinit[SEGV + cl], ez = S.pinit[2 * SEGV + cl];   // initial_traj[M-1][n]
+                F3 delta = F3{goal_i[0] - ex, goal_i[1] - ey, goal_i[2] - ez};
+                const float n2 = delta.x * delta.x + delta.y * delta.y + delta.z * delta.z;
+                if (sqrt((double)n2) > a.goal_radius) {
+                    delta = normalized_f32(delta);
+                    const float r = (float)a.goal_radius;
+                    gx = ex + delta.x * r; gy = ey + delta.y * r; gz = ez + delta.z * r;
+                } else { gx = goal_i[0]; gy = goal_i[1]; gz = goal_i[2]; }
+            }
+            S.goalf[0] = gx; S.goalf[1] = gy; S.goalf[2] = gz;
+        }
+    } else if (tid < 3) {
+        S.goalf[tid] = a.goal[3 * qi + tid];
+    }
+    __syncthreads();
     if (tid < 3) {
         const int k = tid;
         const float *s = a.state + 9 * qi;
@@ -616,7 +621,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         double c1 = c0 + (double)s[3 + k] * md.hv_scale;
         double c2 = (double)s[6 + k] * md.ha_scale + 2.0 * c1 - c0;
         S.s0[k][0] = c0; S.s0[k][1] = c1; S.s0[k][2] = c2;
-        S.goal[k] = (double)a.goal[3 * qi + k];
+        S.goal[k] = (double)S.goalf[k];
+        if (a.goal_out) a.goal_out[3 * qi + k] = S.goalf[k];
         for (int m = 0; m < M; m++) {
             double lo = (double)md.world_min[k], hi = (double)md.world_max[k];
             if (md.use_sfc && a.sfc) {
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma clang fp contract(off)
         // getTerminalSegments (src/traj_optimizer.cpp:541-548), float32 norm like octomath
         const float *s = a.state + 9 * qi;
-        const float *g = a.goal + 3 * qi;
+        const float *g = S.goalf;
         float dxg = g[0] - s[0], dyg = g[1] - s[1], dzg = g[2] - s[2];
         float n2 = dxg * dxg + dyg * dyg + dzg * dzg;
         double flight = sqrt((double)n2) / a.vnom[qi];
@@ -1320,6 +1326,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             out[tid] = stale[tid];
         }
     }
+    if (a.state_next && tid < 3) {
+#pragma clang fp contract(off)
+        // MultiSyncSimulator::update for the next tick, fused: ideal state at t = dt on the trajectory just written
+        // (getStateFromControlPoints, include/polynomial.hpp:63-97: segment 1, local time 0; float32, unfused)
+        const int k = tid;
+        float c0, c1, c2;
+        if (status == LSC_STATUS_OK_K) {
+            c0 = (float)S.x[k * SEGV + NC]; c1 = (float)S.x[k * SEGV + NC + 1]; c2 = (float)S.x[k * SEGV + NC + 2];
+        } else {
+            c0 = stale[k * SEGV + NC]; c1 = stale[k * SEGV + NC + 1]; c2 = stale[k * SEGV + NC + 2];
+        }
+        const float fn = (float)DEG, fn1 = (float)(DEG - 1), finv = a.finv;
+        const float v0 = ((c1 - c0) * fn) * finv;
+        const float v1 = ((c2 - c1) * fn) * finv;
+        const float a0 = ((v1 - v0) * fn1) * finv;
+        a.state_next[9 * qi + k] = c0;
+        a.state_next[9 * qi + 3 + k] = v0;
+        a.state_next[9 * qi + 6 + k] = a0;
+    }
     if (tid == 0) {
         if (status == LSC_STATUS_OK_K) a.cost[qi] = obj;
         a.status[qi] = status;
@@ -1368,12 +1393,6 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     }
     if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, a);
     else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_goal(const GoalArgs &a, hipStream_t st)
-{
-    hipLaunchKernelGGL(lsc_goal_kernel, dim3((a.N + 63) / 64), dim3(64), 0, st, a);
     return hipGetLastError();
 }
 

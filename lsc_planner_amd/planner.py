@@ -184,6 +184,12 @@ class SwarmPlanner:
         self._check(self.L.lsc_tick_device(self.ctx, state.data_ptr(), goal.data_ptr(), traj_prev.data_ptr(), planner_seq,
                                            traj_next.data_ptr(), cost.data_ptr(), status.data_ptr(), iters.data_ptr(), stream))
 
+    def tick_device_fused(self, state, goal, traj_prev, traj_next, state_next, cost, status, iters, planner_seq, stream=0):
+        """One launch per tick: goal planning + LSC + QP + next ideal state of every agent of the shard."""
+        self._check(self.L.lsc_tick_device_fused(self.ctx, state.data_ptr(), goal.data_ptr(), traj_prev.data_ptr(), planner_seq,
+                                                 traj_next.data_ptr(), state_next.data_ptr(), cost.data_ptr(), status.data_ptr(),
+                                                 iters.data_ptr(), stream))
+
     def propagate_device(self, traj, state, stream=0):
         self._check(self.L.lsc_propagate_device(self.ctx, traj.data_ptr(), state.data_ptr(), stream))
 

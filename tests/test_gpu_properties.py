@@ -173,3 +173,37 @@ def test_sharded_contexts_cover_the_swarm(L):
         assert np.array_equal(np.concatenate([g0["cost"], g1["cost"]]), g["cost"])
         traj = g["traj"]; state = next_state_host(traj)
     full.close(); s0.close(); s1.close()
+
+
+def test_fused_single_launch_tick_equals_host_buffer_ticks(L):
+    """lsc_tick_device_fused (goal planning + plan + next ideal state in ONE launch, what bench.py times on one GPU)
+    == lsc_replan_tick + host-side propagation, bitwise, in mode/goal = prior_based."""
+    import torch
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(64, 8.0)
+    N = 64
+    cfg = L.PlannerConfig(goal_mode="prior_based")
+    h, d = L.SwarmPlanner(ms, cfg), L.SwarmPlanner(ms, cfg)
+    dev = torch.device("cuda", 0)
+    state_h = np.zeros((N, 9), np.float32); state_h[:, :3] = ms.start
+    traj_h = np.zeros((N, 3, 30), np.float32)
+    s0 = torch.from_numpy(state_h.copy()).to(dev); s1 = torch.zeros_like(s0)
+    goal = torch.from_numpy(ms.goal).to(dev)
+    a, b = torch.zeros((N, 90), device=dev), torch.zeros((N, 90), device=dev)
+    cost = torch.zeros(N, dtype=torch.float64, device=dev)
+    status = torch.zeros(N, dtype=torch.int32, device=dev)
+    iters = torch.zeros(N, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for seq in range(1, 41):
+        g = h.plan(state_h, ms.goal, traj_h)
+        goals_h = h.last_goals()
+        traj_h = g["traj"]; state_h = next_state_host(traj_h)
+        d.tick_device_fused(s0, goal, a, b, s1, cost, status, iters, seq, st)
+        a, b = b, a
+        s0, s1 = s1, s0
+        torch.cuda.synchronize()
+        assert np.array_equal(d.last_goals(), goals_h), seq
+        assert np.array_equal(a.cpu().numpy().reshape(N, 3, 30), traj_h), seq
+        assert np.array_equal(s0.cpu().numpy(), state_h), seq
+        assert np.array_equal(cost.cpu().numpy(), g["cost"]), seq
+    h.close(); d.close()
