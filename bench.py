@@ -34,11 +34,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def pmc_traffic(key):
-    """HBM-side traffic per launch (bytes) from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary.json):
-    FETCH_SIZE + WRITE_SIZE, raw counter values (see the file for the calibration caveat).  None when absent."""
+    """HBM-side traffic per launch (bytes) from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary_v5.json,
+    made by profiles/summarize_rocpd.py): FETCH_SIZE + WRITE_SIZE, raw counter values in KB (see the file for the
+    calibration caveat and for what the plan kernel's write traffic consists of).  None when absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))[key]
-        return int((d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024)
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_v5.json")))["kernels"][key]
+        return int((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
     except Exception:
         return None
 
@@ -173,6 +174,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     k_ms, k_n = pl.kernel_time_ms(0)
+    k_all = pl.kernel_times_ms(0)
     iters_total = pl.iterations_total(reset=False)
     bad = int((status[first:first + count] != 0).sum().item())
     rows = pl.row_counts()[first:first + count]
@@ -194,6 +196,9 @@ def main():
             "metric": "agent-replans/sec (whole node)", "value": round(value, 1), "unit": "agent-replans/s",
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "tick_solve_ms": {"p50": round(float(np.percentile(k_all, 50)), 4), "p99": round(float(np.percentile(k_all, 99)), 4),
+                              "max": round(float(k_all.max()), 4),
+                              "note": "device time of the per-tick launch (HIP events, rank 0) over the timed steps"},
             "config": {"workload": f"{n_agents}-agent generated circle swap (R={R:g} m, z=1 m), empty map, LSC mode, "
                                    f"dt 0.2 s, M=5 n=5, mode/goal={goal_mode}, {args.agents_per_gpu} agents per GPU, "
                                    "device-resident ticks (one fused launch per tick: goal planning + LSC + QP + state propagation"
@@ -204,7 +209,7 @@ def main():
                    "reference_rows_per_agent": 27 * (n_agents - 1)},
             "roofline": {"kernel": "lsc_plan_kernel", "bound": "valu_fp64", "achieved": round(ach, 5),
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_VALU_PEAK_TFLOPS, 7),
-                         "traffic": pmc_traffic("lsc_plan_kernel_N64") if n_agents == 64 else None,
+                         "traffic": pmc_traffic("lsc_plan_kernel@grid32768") if n_agents == 64 else None,
                          "avg_launch_ms": round(k_ms, 5), "launches": k_n,
                          "note": "latency-bound: one 512-lane workgroup per agent; algorithmic flops = IP iterations x "
                                  "((N-1) kflop + 0.3 Mflop) per SURVEY 8(d); neither HBM nor MFMA bounds this kernel"},
@@ -230,7 +235,7 @@ def main():
         result["roofline_sweep"] = {"kernel": "lsc_sweep_kernel", "bound": "hbm",
                                     "achieved": round(alg / (s_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                    "traffic": pmc_traffic("lsc_sweep_kernel_N64") if n_agents == 64 else None,
+                                    "traffic": pmc_traffic("lsc_sweep_kernel@grid20224") if n_agents == 64 else None,
                                     "avg_launch_ms": round(s_ms, 5), "bytes_written_per_launch": wr,
                                     "algorithmic_bytes_per_launch": alg,
                                     "note": "N(N-1)*180 B + N*404 B per SURVEY 8(d); at this N the working set is "
@@ -264,7 +269,7 @@ def main():
         result["roofline_sweep_large"] = {"kernel": "lsc_sweep_kernel", "agents": n2, "bound": "hbm",
                                           "achieved": round(alg2 / (ms_l * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": round(alg2 / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                          "traffic": pmc_traffic("lsc_sweep_kernel_N1024") if n2 == 1024 else None,
+                                          "traffic": pmc_traffic("lsc_sweep_kernel@grid524288") if n2 == 1024 else None,
                                           "avg_launch_ms": round(ms_l, 4), "algorithmic_bytes_per_launch": alg2,
                                           "bytes_written_per_launch": wr2,
                                           "written_GBps": round(wr2 / (ms_l * 1e-3) / 1e9, 2),

@@ -158,6 +158,9 @@ int lsc_gjk_batch(lsc_ctx *ctx, const double *pts, int count, double *v, double 
  * the last reset.  which: 0 = plan kernel, 1 = dense sweep kernel. */
 int lsc_kernel_time_ms(lsc_ctx *ctx, int which, double *avg_ms, long *launches);
 int lsc_set_timing(lsc_ctx *ctx, int enabled);
+/* Per-launch device times (ms) of the launches timed since lsc_set_timing(ctx, 1): up to `capacity` values in launch
+ * order; *launches receives how many were timed (bench.py's p99 per-tick solve time). */
+int lsc_kernel_times_ms(lsc_ctx *ctx, int which, double *out_ms, long capacity, long *launches);
 
 /* current_goal_position of every agent as used by the last tick, float [N][3] (goal_mode 1: planned on the device). */
 int lsc_last_goals(lsc_ctx *ctx, float *goals);

@@ -43,7 +43,7 @@ class LscConfig(ctypes.Structure):
 EXPORTS = [
     "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_sweep_device",
-    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals",
+    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_kernel_times_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals",
 ]
 
 
@@ -80,6 +80,7 @@ def load_library():
     L.lsc_sweep_device.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]
     L.lsc_gjk_batch.argtypes = [vp, dp, ctypes.c_int, dp, dp]
     L.lsc_kernel_time_ms.argtypes = [vp, ctypes.c_int, dp, ctypes.POINTER(ctypes.c_long)]
+    L.lsc_kernel_times_ms.argtypes = [vp, ctypes.c_int, dp, ctypes.c_long, ctypes.POINTER(ctypes.c_long)]
     L.lsc_set_timing.argtypes = [vp, ctypes.c_int]
     L.lsc_last_row_counts.argtypes = [vp, ip]
     L.lsc_phase_profile.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]

@@ -596,6 +596,21 @@ int lsc_kernel_time_ms(lsc_ctx *c, int which, double *avg_ms, long *launches)
     return LSC_OK;
 }
 
+int lsc_kernel_times_ms(lsc_ctx *c, int which, double *out_ms, long capacity, long *launches)
+{
+    if (!c || which < 0 || which > 1 || (capacity > 0 && !out_ms)) return LSC_EINVAL;
+    const long n = (long)c->ev_used[which];
+    for (long i = 0; i < n && i < capacity; i++) {
+        auto &p = c->ev_pool[which][(size_t)i];
+        HIPCHK(c, hipEventSynchronize(p.second));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, p.first, p.second));
+        out_ms[i] = ms;
+    }
+    if (launches) *launches = n;
+    return LSC_OK;
+}
+
 // Diagnostics: phase profile of the plan kernel.  enable=1 switches to the instrumented kernel variant and clears
 // the counters; out (may be null) receives [N][12] cycle counts (100 MHz wall clock) accumulated since then.
 int lsc_phase_profile(lsc_ctx *c, int enable, long long *out)

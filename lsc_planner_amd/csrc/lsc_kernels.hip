@@ -328,6 +328,13 @@ struct Smem {
     // axis rows: slot = type*90 + k*30 + t ; type 0 x<=hi, 1 -x<=-lo, 2/3 +-velocity, 4/5 +-acceleration
     double as_[AXROWS], az[AXROWS], at1[AXROWS], at2[AXROWS], ah[AXROWS];
     unsigned short amap[AXVALID + 2];   // valid slots, compact
+    // solver constants addressed per lane (LDS tables instead of ~40 long-lived registers per lane, which the
+    // register allocator would otherwise park in scratch for the whole kernel)
+    double xtc[SEGV][3];        // x_t = sum xtc[t][j] * y[xgp byte j]   (zero beyond the stencil length)
+    double ytc[NY][4];          // gy = sum ytc[g][j] * gx[yop byte j]
+    double Qh6[NC * NC];        // 2 w_c Q_base (cost gradient stencil)
+    uint32_t xgp[NV];           // three global y indices per variable, one per byte
+    uint32_t yop[NY], ypp[NY];  // four x indices (axis-major / point-major) per unknown, one per byte
     unsigned char avalid[AXROWS];
     // agent constants
     double s0[3][3];            // c_{0,0..2} per axis
@@ -645,33 +652,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         S.tseg = T > 1 ? T : 1;
     }
     for (int i = tid; i < AXVALID; i += NT) S.amap[i] = md.amap[i];
-    // per-lane constants kept in registers for the whole solve
-    int xk = 0, xt = 0, xn = 0, xg0 = 0, xg1 = 0, xg2 = 0;     // lanes < 90: x_t = sum xc*y[xg]
-    double xc0 = 0, xc1 = 0, xc2 = 0, qr[NC] = {0, 0, 0, 0, 0, 0};
-    const int vq = tid < NV ? tid : (tid >= NT - NV ? tid - (NT - NV) : -1);  // lanes 0..89 (x / objective) and 166..255 (row gather)
-    if (vq >= 0) {
-        xk = vq / SEGV; xt = vq % SEGV;
-        xn = md.x_n[xt];
-        xg0 = yglob(xk, md.x_i[xt][0]); xg1 = yglob(xk, md.x_i[xt][1]); xg2 = yglob(xk, md.x_i[xt][2]);
-        xc0 = md.x_c[xt][0]; xc1 = md.x_c[xt][1]; xc2 = md.x_c[xt][2];
-        if (xn < 1) xc0 = 0; if (xn < 2) xc1 = 0; if (xn < 3) xc2 = 0;
-#pragma unroll
-        for (int j = 0; j < NC; j++) qr[j] = md.Qh[(xt % NC) * NC + j];
-    }
-    int yk = 0, yo0 = 0, yo1 = 0, yo2 = 0, yo3 = 0;            // lanes < 39: gy = sum yc * gx[yo]
-    int yp0 = 0, yp1 = 0, yp2 = 0, yp3 = 0;
-    double yc0 = 0, yc1 = 0, yc2 = 0, yc3 = 0;
-    if (tid < NY) {
-        const int g = tid;
-        yk = g < 36 ? (g % 9) / 3 : g - 36;
+    // per-lane solver constants -> LDS tables (see Smem)
+    const int vq = tid < NV ? tid : (tid >= NT - NV ? tid - (NT - NV) : -1);  // lanes 0..89 (x / objective) and the last 90 (row gather)
+    const int xk = vq >= 0 ? vq / SEGV : 0, xt = vq >= 0 ? vq % SEGV : 0;
+    if (tid < NV) {
+        const int xn = md.x_n[xt];
+        S.xgp[tid] = (uint32_t)yglob(xk, md.x_i[xt][0]) | ((uint32_t)yglob(xk, md.x_i[xt][1]) << 8) |
+                     ((uint32_t)yglob(xk, md.x_i[xt][2]) << 16);
+        if (xk == 0) {
+            S.xtc[xt][0] = xn < 1 ? 0.0 : md.x_c[xt][0];
+            S.xtc[xt][1] = xn < 2 ? 0.0 : md.x_c[xt][1];
+            S.xtc[xt][2] = xn < 3 ? 0.0 : md.x_c[xt][2];
+        }
+    } else if (tid >= 128 && tid < 128 + NC * NC) {
+        S.Qh6[tid - 128] = md.Qh[tid - 128];
+    } else if (tid >= 192 && tid < 192 + NY) {
+        const int g = tid - 192;
+        const int yk = g < 36 ? (g % 9) / 3 : g - 36;
         const int va = g < 36 ? (g / 9) * 3 + (g % 3) : 12;
         const int n = md.t_n[va];
-        yc0 = n > 0 ? md.t_c[va][0] : 0.0; yc1 = n > 1 ? md.t_c[va][1] : 0.0;
-        yc2 = n > 2 ? md.t_c[va][2] : 0.0; yc3 = n > 3 ? md.t_c[va][3] : 0.0;
+        S.ytc[g][0] = n > 0 ? md.t_c[va][0] : 0.0; S.ytc[g][1] = n > 1 ? md.t_c[va][1] : 0.0;
+        S.ytc[g][2] = n > 2 ? md.t_c[va][2] : 0.0; S.ytc[g][3] = n > 3 ? md.t_c[va][3] : 0.0;
         const int t0 = n > 0 ? md.t_t[va][0] : 0, t1 = n > 1 ? md.t_t[va][1] : 0;
         const int t2 = n > 2 ? md.t_t[va][2] : 0, t3 = n > 3 ? md.t_t[va][3] : 0;
-        yo0 = yk * SEGV + t0; yo1 = yk * SEGV + t1; yo2 = yk * SEGV + t2; yo3 = yk * SEGV + t3;
-        yp0 = t0 * 3 + yk; yp1 = t1 * 3 + yk; yp2 = t2 * 3 + yk; yp3 = t3 * 3 + yk;
+        S.yop[g] = (uint32_t)(yk * SEGV + t0) | ((uint32_t)(yk * SEGV + t1) << 8) | ((uint32_t)(yk * SEGV + t2) << 16) |
+                   ((uint32_t)(yk * SEGV + t3) << 24);
+        S.ypp[g] = (uint32_t)(t0 * 3 + yk) | ((uint32_t)(t1 * 3 + yk) << 8) | ((uint32_t)(t2 * 3 + yk) << 16) |
+                   ((uint32_t)(t3 * 3 + yk) << 24);
     }
     __syncthreads();
     const bool xterm = (tid < NV) && (xt % NC == DEG) && (xt / NC >= M - S.tseg);
@@ -831,7 +838,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (tid < NV) {
             double v;
             if (xt < 3) v = with_const ? S.s0[xk][xt] : 0.0;
-            else v = xc0 * yv[xg0] + xc1 * yv[xg1] + xc2 * yv[xg2];
+            else {
+                const uint32_t gp = S.xgp[tid];
+                const double *c = S.xtc[xt];
+                v = c[0] * yv[gp & 0xff] + c[1] * yv[(gp >> 8) & 0xff] + c[2] * yv[gp >> 16];
+            }
             xv[tid] = v;
         }
     };
@@ -840,7 +851,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const double *xs = S.x + xk * SEGV + (xt / NC) * NC;
         double g = 0.0;
 #pragma unroll
-        for (int j = 0; j < NC; j++) g += qr[j] * xs[j];
+        for (int j = 0; j < NC; j++) g += S.Qh6[(xt % NC) * NC + j] * xs[j];
         return g;
     };
     // block reduction of up to 5 values: op 0 sum, 1 max, 2 min ; results in S.sc[0..4] (one barrier pair; the
@@ -969,6 +980,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
         if (tid < NY) {
+            const uint32_t yo = S.yop[tid], yp = S.ypp[tid];
+            const int yo0 = yo & 0xff, yo1 = (yo >> 8) & 0xff, yo2 = (yo >> 16) & 0xff, yo3 = yo >> 24;
+            const int yp0 = yp & 0xff, yp1 = (yp >> 8) & 0xff, yp2 = (yp >> 16) & 0xff, yp3 = yp >> 24;
+            const double yc0 = S.ytc[tid][0], yc1 = S.ytc[tid][1], yc2 = S.ytc[tid][2], yc3 = S.ytc[tid][3];
             double r = yc0 * (S.gx[yo0] + S.Tv[yp0]) + yc1 * (S.gx[yo1] + S.Tv[yp1]) + yc2 * (S.gx[yo2] + S.Tv[yp2]) +
                        yc3 * (S.gx[yo3] + S.Tv[yp3]);
             S.rhs[tid] = -r;

@@ -232,6 +232,15 @@ class SwarmPlanner:
         self._check(self.L.lsc_kernel_time_ms(self.ctx, which, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+    def kernel_times_ms(self, which=0):
+        """Per-launch device times (ms, HIP events on the launch stream) since set_timing(True)."""
+        n = ctypes.c_long()
+        self._check(self.L.lsc_kernel_times_ms(self.ctx, which, None, 0, ctypes.byref(n)))
+        out = np.zeros(max(n.value, 1), np.float64)
+        self._check(self.L.lsc_kernel_times_ms(self.ctx, which, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n.value,
+                                               ctypes.byref(n)))
+        return out[:n.value]
+
 
 def edt_from_bt(bt_path, world_min, world_max, maxdist=1.0):
     """Host-only: octomap .bt -> (dist float32 [nx][ny][nz], key_min int32[3], res).  No GPU needed."""
