@@ -60,6 +60,13 @@ def load_library():
     if not os.path.exists(p):
         raise LscError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch wheels bundle their own HIP/HSA runtime.  Two runtimes in one process do not coexist (the second one
+    # finds "no HIP GPUs"), so when this harness runs next to torch, torch's runtime must be the one that is loaded
+    # first; liblsc_hip.so then binds to it.  Stand-alone C++ users (lsc_sim) link /opt/rocm's runtime directly.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(p)
     vp, ip, dp, fp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)
     L.lsc_default_config.argtypes = [ctypes.POINTER(LscConfig)]

@@ -429,6 +429,13 @@ static int run_sfc(lsc_ctx *c, const float *d_state, const float *d_goal, const 
     for (int k = 0; k < 3; k++) { s.key_min[k] = c->edt_kmin[k]; s.world_min[k] = c->cfg.world_min[k]; s.world_max[k] = c->cfg.world_max[k]; }
     s.rf = 1.0 / c->edt_res; s.wres = c->cfg.world_resolution;
     s.sfc = c->d_sfc; s.init_flag = c->d_sfc_init; s.err = c->d_sfc_err;
+    double ext = 0.0;
+    for (int k = 0; k < 3; k++) ext = std::max(ext, (double)c->cfg.world_max[k] - (double)c->cfg.world_min[k]);
+    s.table_len = (int)std::ceil(ext / c->cfg.world_resolution) + 8;
+    if (sizeof(double) * 6 * (size_t)s.table_len > 160 * 1024) {
+        c->err = "world extent / world_resolution too large for the SFC face tables (limit 3400 steps per axis)";
+        return LSC_EINVAL;
+    }
     HIPCHK(c, launch_sfc(s, st));
     return LSC_OK;
 }

@@ -69,6 +69,7 @@ struct SfcArgs {
     float *sfc;                 // [N][M][6] persistent boxes (box_min, box_max as float)
     int *init_flag;             // [N] flag_initialize_sfc
     int *err;                   // [N] 1 when the seed box already touches an obstacle
+    int table_len;              // entries per face table in LDS: steps a face can move inside the world + slack
 };
 hipError_t launch_sfc(const SfcArgs &a, hipStream_t st);
 

@@ -160,7 +160,7 @@ __global__ void lsc_propagate_kernel(const float *__restrict__ traj, float *__re
 // Safe Flight Corridor: CorridorConstructor::expandBoxFromPoint (include/corridor_constructor.hpp:18-245) driven by
 // TrajPlanner::generateFeasibleSFC (src/traj_planner.cpp:1451-1491).  The reference tests every lattice point of a
 // slab against the distance field; here "distance < margin" is pre-thresholded into a 3-D integral image, so a slab
-// test is 8 loads.  One lane per agent (the growth loop is inherently sequential, a few hundred steps).
+// test is 64 independent loads.  One wave per agent, speculative over the growth steps (see sfc_expand).
 // ---------------------------------------------------------------------------------------------------
 struct SfcGrid {
     const int *I;
@@ -218,11 +218,24 @@ __device__ bool sfc_in_boundary(const SfcGrid &g, const double *b)
            b[4] < g.wmax[1] + 1e-9 && b[5] < g.wmax[2] + 1e-9;
 }
 
-// returns 0 ok, 1 seed box blocked, 2 seed outside the world
-__device__ int sfc_expand(const SfcGrid &g, const float point[3], const float goal[3], double out[6])
+// returns 0 ok, 1 seed box blocked, 2 seed outside the world.  Executed by ONE WAVE per box (all 64 lanes call it
+// with the same arguments and return the same result).
+//
+// The reference grows the box one resolution step at a time, round-robin over the directions that are still free
+// (expand_box :184-232): inherently sequential, a few hundred dependent slab tests.  Here the wave speculates: lane
+// l assumes that the l-1 steps before it all pass, rebuilds the box the reference would hold at that point and tests
+// its own slab; the first failing lane (ballot) is exactly the reference's first failure, everything before it is
+// accepted at once, that direction is dropped and the next round starts.  A box costs ~10 rounds of independent
+// loads instead of hundreds of dependent ones.
+//
+// Box faces only ever take the values  seed -/+ res -/+ res ...  (repeated additions, which is what the reference
+// does and what makes the doubles bit-identical), independently per face, so the six sequences are tabulated once in
+// LDS (T[face][count]) and "the box after s steps" is six table reads at counts that follow from the round-robin.
+__device__ int sfc_expand(const SfcGrid &g, const float point[3], const float goal[3], double out[6], double *T, int TL)
 {
 #pragma clang fp contract(off)
-    double cur[6], cnd[6], upd[6];
+    const int lane = threadIdx.x & 63;
+    double cur[6];
     for (int i = 0; i < 3; i++) {
         const double p = (double)point[i];
         const double rp = round(p / g.wres) * g.wres;
@@ -231,8 +244,10 @@ __device__ int sfc_expand(const SfcGrid &g, const float point[3], const float go
     }
     if (sfc_blocked(g, cur)) return 1;
     // setAxisCand (:142-182): axes ordered by |goal - centre|, goal-ward direction first, opposite directions reversed
-    int cand[6], ncand = 6;
+    unsigned cpack = 0;          // direction list, 3 bits each
+    int ncand = 6;
     {
+        int cand[6];
         float delta[3];
         double val[3];
         int offs[3], order[3], n = 0;
@@ -249,32 +264,90 @@ __device__ int sfc_expand(const SfcGrid &g, const float point[3], const float go
             else { for (int j = n; j > 1; j--) order[j] = order[j - 1]; order[1] = i; n++; }
         }
         for (int i = 0; i < 3; i++) { cand[i] = order[i] + offs[order[i]]; cand[5 - i] = order[i] + (3 - offs[order[i]]); }
+        for (int j = 0; j < 6; j++) cpack |= (unsigned)cand[j] << (3 * j);
     }
+    // face tables: lanes 0..5 run the six chains of additions
+    if (lane < 6) {
+        double v = lane == 0 ? cur[0] : lane == 1 ? cur[1] : lane == 2 ? cur[2] : lane == 3 ? cur[3] : lane == 4 ? cur[4] : cur[5];
+        double *t = T + lane * TL;
+        const double step = lane < 3 ? -g.wres : g.wres;
+        for (int k = 0; k < TL; k++) { t[k] = v; v = v + step; }
+    }
+    __syncthreads();
+    int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt4 = 0, cnt5 = 0;   // accepted expansions per face (wave-uniform)
     int i = -1;
+    bool fresh = true;          // the inner loop of the reference starts with a test of the whole current box
+    // steps of a round-robin that starts after position i: how many of the steps 0 .. s-1 fall on list position p
+    auto hits = [&](int s, int p) {
+        int t0 = (p - i - 1) % ncand;
+        if (t0 < 0) t0 += ncand;
+        return s > t0 ? (s - t0 - 1) / ncand + 1 : 0;
+    };
     while (ncand > 0) {
-        for (int j = 0; j < 6; j++) { cnd[j] = cur[j]; upd[j] = cur[j]; }
-        while (!sfc_blocked(g, upd) && sfc_in_boundary(g, upd)) {
-            i++;
-            if (i >= ncand) i = 0;
-            const int axis = cand[i];
-            for (int j = 0; j < 6; j++) { cur[j] = cnd[j]; upd[j] = cnd[j]; }
-            if (axis < 3) { upd[axis + 3] = cnd[axis]; cnd[axis] = cnd[axis] - g.wres; upd[axis] = cnd[axis]; }
-            else { upd[axis - 3] = cnd[axis]; cnd[axis] = cnd[axis] + g.wres; upd[axis] = cnd[axis]; }
+        // lane 0 of a fresh round tests the current box itself; lane l tests step s = l - fresh of this round
+        const int s = lane - (fresh ? 1 : 0);
+        int c0 = cnt0, c1 = cnt1, c2 = cnt2, c3 = cnt3, c4 = cnt4, c5 = cnt5;
+        for (int p = 0; p < ncand; p++) {
+            const int axis = (cpack >> (3 * p)) & 7;          // uniform
+            const int h = hits(s, p);
+            c0 += axis == 0 ? h : 0; c1 += axis == 1 ? h : 0; c2 += axis == 2 ? h : 0;
+            c3 += axis == 3 ? h : 0; c4 += axis == 4 ? h : 0; c5 += axis == 5 ? h : 0;
         }
+        const int lim = TL - 2;
+        c0 = c0 < lim ? c0 : lim; c1 = c1 < lim ? c1 : lim; c2 = c2 < lim ? c2 : lim;
+        c3 = c3 < lim ? c3 : lim; c4 = c4 < lim ? c4 : lim; c5 = c5 < lim ? c5 : lim;
+        double upd[6];
+        upd[0] = T[0 * TL + c0]; upd[1] = T[1 * TL + c1]; upd[2] = T[2 * TL + c2];
+        upd[3] = T[3 * TL + c3]; upd[4] = T[4 * TL + c4]; upd[5] = T[5 * TL + c5];
+        if (s >= 0) {
+            int pos = (i + 1 + s) % ncand;
+            const int axis = (cpack >> (3 * pos)) & 7;        // this lane's direction; the slab is [new face, old face]
+            if (axis == 0) { upd[3] = upd[0]; upd[0] = T[0 * TL + c0 + 1]; }
+            else if (axis == 1) { upd[4] = upd[1]; upd[1] = T[1 * TL + c1 + 1]; }
+            else if (axis == 2) { upd[5] = upd[2]; upd[2] = T[2 * TL + c2 + 1]; }
+            else if (axis == 3) { upd[0] = upd[3]; upd[3] = T[3 * TL + c3 + 1]; }
+            else if (axis == 4) { upd[1] = upd[4]; upd[4] = T[4 * TL + c4 + 1]; }
+            else { upd[2] = upd[5]; upd[5] = T[5 * TL + c5 + 1]; }
+        }
+        const bool fail = sfc_blocked(g, upd) || !sfc_in_boundary(g, upd);
+        const unsigned long long fm = __ballot(fail);
+        int accepted;                                         // steps of this round that the reference accepts
+        if (fm == 0ull) accepted = 64 - (fresh ? 1 : 0);
+        else accepted = (__ffsll((long long)fm) - 1) - (fresh ? 1 : 0);   // -1: the whole-box test itself failed
+        if (accepted > 0) {
+            for (int p = 0; p < ncand; p++) {
+                const int axis = (cpack >> (3 * p)) & 7;
+                const int h = hits(accepted, p);
+                cnt0 += axis == 0 ? h : 0; cnt1 += axis == 1 ? h : 0; cnt2 += axis == 2 ? h : 0;
+                cnt3 += axis == 3 ? h : 0; cnt4 += axis == 4 ? h : 0; cnt5 += axis == 5 ? h : 0;
+            }
+        }
+        if (fm == 0ull) {
+            i = (i + accepted) % ncand;                       // position of the last accepted step
+            fresh = false;
+            continue;
+        }
+        if (accepted >= 0) i = (i + 1 + accepted) % ncand;    // position of the failing step
         if (i < 0) return 2;
-        for (int j = i; j < ncand - 1; j++) cand[j] = cand[j + 1];
+        // drop direction i
+        {
+            const unsigned lowmask = (1u << (3 * i)) - 1u;
+            cpack = (cpack & lowmask) | ((cpack >> (3 * (i + 1))) << (3 * i));
+        }
         ncand--;
         if (i > 0) i--;
         else i = ncand - 1;
+        fresh = true;
     }
-    for (int j = 0; j < 6; j++) out[j] = cur[j];
+    out[0] = T[0 * TL + cnt0]; out[1] = T[1 * TL + cnt1]; out[2] = T[2 * TL + cnt2];
+    out[3] = T[3 * TL + cnt3]; out[4] = T[4 * TL + cnt4]; out[5] = T[5 * TL + cnt5];
     return 0;
 }
 
 __global__ __launch_bounds__(64) void lsc_sfc_kernel(SfcArgs a)
 {
-    const int al = blockIdx.x * blockDim.x + threadIdx.x;
-    if (al >= a.count) return;
+    const int al = blockIdx.x;                 // one wave per agent
+    const int lane = threadIdx.x;
     const int qi = a.first + al;
     SfcGrid g;
     g.I = a.integral + (size_t)a.img_of_agent[qi] * (size_t)(a.nx + 1) * (a.ny + 1) * (a.nz + 1);
@@ -285,25 +358,33 @@ __global__ __launch_bounds__(64) void lsc_sfc_kernel(SfcArgs a)
     const float *goal = a.goal + 3 * qi;
     double box[6];
     int rc;
-    if (a.init_flag[qi]) {
-        rc = sfc_expand(g, a.state + 9 * qi, goal, box);
-        if (rc == 0) {
-            for (int m = 0; m < M; m++)
-                for (int j = 0; j < 6; j++) sfc[m * 6 + j] = (float)box[j];
-            a.init_flag[qi] = 0;
-        }
+    const bool init = a.init_flag[qi] != 0;
+    float seed[3];
+    if (init) {
+        for (int k = 0; k < 3; k++) seed[k] = a.state[9 * qi + k];
     } else {
         const float *t = a.traj_prev + (size_t)qi * NV;
         const int c = (M - 1) * NC + DEG;
-        const float last[3] = {t[c], t[SEGV + c], t[2 * SEGV + c]};
-        rc = sfc_expand(g, last, goal, box);
-        if (rc == 0) {
-            for (int m = 1; m < M; m++)
-                for (int j = 0; j < 6; j++) sfc[(m - 1) * 6 + j] = sfc[m * 6 + j];
-            for (int j = 0; j < 6; j++) sfc[(M - 1) * 6 + j] = (float)box[j];
-        }
+        seed[0] = t[c]; seed[1] = t[SEGV + c]; seed[2] = t[2 * SEGV + c];
     }
-    a.err[qi] = rc;
+    const float gl[3] = {goal[0], goal[1], goal[2]};
+    extern __shared__ __align__(16) unsigned char sfc_smem[];
+    rc = sfc_expand(g, seed, gl, box, reinterpret_cast<double *>(sfc_smem), a.table_len);
+    // the shift of the previous boxes reads what it overwrites: one lane does the bookkeeping
+    if (lane == 0) {
+        if (rc == 0) {
+            if (init) {
+                for (int m = 0; m < M; m++)
+                    for (int j = 0; j < 6; j++) sfc[m * 6 + j] = (float)box[j];
+                a.init_flag[qi] = 0;
+            } else {
+                for (int m = 1; m < M; m++)
+                    for (int j = 0; j < 6; j++) sfc[(m - 1) * 6 + j] = sfc[m * 6 + j];
+                for (int j = 0; j < 6; j++) sfc[(M - 1) * 6 + j] = (float)box[j];
+            }
+        }
+        a.err[qi] = rc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1413,7 +1494,16 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 
 hipError_t launch_sfc(const SfcArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(lsc_sfc_kernel, dim3((a.count + 63) / 64), dim3(64), 0, st, a);
+    const size_t smem = sizeof(double) * 6 * (size_t)a.table_len;
+    if (a.table_len < 8 || smem > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_sfc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(lsc_sfc_kernel, dim3(a.count), dim3(64), smem, st, a);
     return hipGetLastError();
 }
 
