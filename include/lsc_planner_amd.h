@@ -97,7 +97,8 @@ const char *lsc_last_error(const lsc_ctx *ctx);
 int lsc_set_agents(lsc_ctx *ctx, int N, const double *radius, const double *downwash,
                    const double *max_vel /*[N][3]*/, const double *max_acc /*[N][3]*/, const double *nominal_vel);
 
-/* Shard of agents [first, first+count) planned by this context (agent-sharded multi-GPU); default all. */
+/* Shard of agents [first, first+count) planned by this context (agent-sharded multi-GPU); default all.
+ * count may be 0 (a rank without agents: its ticks are no-ops). */
 int lsc_set_shard(lsc_ctx *ctx, int first, int count);
 
 /* TrajPlanner::setDistMap (src/traj_planner.cpp:168): dense EDT, metres, [nx][ny][nz], copied to HBM.

@@ -355,7 +355,7 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
 int lsc_set_shard(lsc_ctx *c, int first, int count)
 {
     if (!c || c->N == 0) return LSC_ESTATE;
-    if (first < 0 || count < 1 || first + count > c->N) return LSC_EINVAL;
+    if (first < 0 || count < 0 || first + count > c->N) return LSC_EINVAL;   // count 0: a rank without agents
     c->first = first; c->count = count;
     return LSC_OK;
 }

@@ -1477,6 +1477,7 @@ size_t plan_smem_bytes(int n_terms, int n_entries, int cap)
 
 hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 {
+    if (a.count == 0) return hipSuccess;          // empty shard (more ranks than agents): nothing to plan
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_plan_kernel<false>),
@@ -1494,6 +1495,7 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 
 hipError_t launch_sfc(const SfcArgs &a, hipStream_t st)
 {
+    if (a.count == 0) return hipSuccess;
     const size_t smem = sizeof(double) * 6 * (size_t)a.table_len;
     if (a.table_len < 8 || smem > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_done = false;
@@ -1509,6 +1511,7 @@ hipError_t launch_sfc(const SfcArgs &a, hipStream_t st)
 
 hipError_t launch_sweep(const SweepArgs &a, hipStream_t st)
 {
+    if (a.count == 0) return hipSuccess;
     long total = (long)a.count * (a.N - 1) * M;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 8) blocks = 256 * 8;
