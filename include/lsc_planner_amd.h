@@ -54,6 +54,8 @@ extern "C" {
 #define LSC_STATUS_CAPACITY 3    /* more active LSC rows than the configured LDS row capacity            */
 #define LSC_STATUS_SFC_BLOCKED 4 /* seed box of the corridor touches an obstacle (the reference throws
                                     std::invalid_argument, corridor_constructor.hpp:35-38): stale trajectory kept */
+#define LSC_STATUS_GOAL_CAPACITY 5 /* the goal planner's search outgrew its LDS capacity (OPEN row / path / ray stack):
+                                    nothing is guessed, the stale trajectory is kept                                */
 
 typedef struct lsc_ctx lsc_ctx;
 
@@ -73,14 +75,17 @@ typedef struct {
                                   redundant inside the reachable box; 0: keep all 27(N-1) rows  */
     int    goal_mode;          /* mode/goal: 0 static (the goal input IS current_goal_position), 1 prior_based: the goal
                                   input is the desired goal and TrajPlanner::goalPlanningWithPriority runs on the
-                                  device (exact on maps without a distance field; with use_octomap the grid A* of
-                                  SURVEY 8(f)#1 would be needed -> LSC_ESTATE) */
+                                  device: fused into the plan kernel on maps without a distance field (where the grid
+                                  search has no observable effect), a separate launch with use_octomap (priority rule,
+                                  GridBasedPlanner's A* with the reference's tie-breaking, line-of-sight goal) */
     double goal_threshold;     /* plan/goal_threshold          0.1 */
     double priority_dist_threshold; /* plan/priority_dist_threshold 0.4 */
     double goal_radius;        /* plan/goal_radius             2.0 */
     double warm_start_mu;      /* interior-point start: > 0 warm start from the shifted previous plan, every row
                                   centred on this complementarity value (default 0.1), with the cold (Mehrotra)
                                   start as fallback; 0 = always cold start */
+    double grid_resolution;    /* grid/resolution 0.3: cell of the goal planner's search grid (goal_mode 1 + use_octomap) */
+    double grid_margin;        /* grid/margin     0.2: a cell is occupied when EDT(centre) < radius + grid_margin        */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);
@@ -165,6 +170,16 @@ int lsc_kernel_times_ms(lsc_ctx *ctx, int which, double *out_ms, long capacity, 
 
 /* current_goal_position of every agent as used by the last tick, float [N][3] (goal_mode 1: planned on the device). */
 int lsc_last_goals(lsc_ctx *ctx, float *goals);
+
+/* Goal-planner introspection (goal_mode 1 + use_octomap; parity tests): lsc_set_goal_trace(ctx, path_cap > 0) makes
+ * the following ticks keep each agent's grid path; lsc_get_goal_trace returns, for the shard's agents, the path as
+ * grid cells (i, j, k) int [count][path_cap][3], its length [count] (GridBasedPlanner::plan_result.grid_path,
+ * src/grid_based_planner.cpp:66), flags [count] (bit 0 retreat rule fired, bit 1 the search without priorities was
+ * used) and the number of nodes the search popped [count].  grid_dims / grid_min (optional) describe the grid of
+ * GridBasedPlanner::updateGridInfo (src/grid_based_planner.cpp:72-93). */
+int lsc_set_goal_trace(lsc_ctx *ctx, int path_cap);
+int lsc_get_goal_trace(lsc_ctx *ctx, int *path_cells, int *path_len, int *flags, int *expansions, int grid_dims[3],
+                       double grid_min[3]);
 
 /* Active (non-redundant) LSC rows each agent's QP carried in the last tick, [N] (diagnostics). */
 int lsc_last_row_counts(lsc_ctx *ctx, int *rows);

@@ -36,6 +36,8 @@ class LscConfig(ctypes.Structure):
         ("priority_dist_threshold", ctypes.c_double),
         ("goal_radius", ctypes.c_double),
         ("warm_start_mu", ctypes.c_double),
+        ("grid_resolution", ctypes.c_double),
+        ("grid_margin", ctypes.c_double),
     ]
 
 
@@ -43,7 +45,7 @@ class LscConfig(ctypes.Structure):
 EXPORTS = [
     "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_sweep_device",
-    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_kernel_times_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals",
+    "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_kernel_times_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals", "lsc_set_goal_trace", "lsc_get_goal_trace",
 ]
 
 
@@ -95,6 +97,8 @@ def load_library():
     L.lsc_solver_trace.argtypes = [vp, ctypes.c_int, dp]
     L.lsc_edt_from_bt.argtypes = [ctypes.c_char_p, fp, fp, ctypes.c_double, ctypes.POINTER(fp), ip, ip, dp]
     L.lsc_last_goals.argtypes = [vp, fp]
+    L.lsc_set_goal_trace.argtypes = [vp, ctypes.c_int]
+    L.lsc_get_goal_trace.argtypes = [vp, ip, ip, ip, ip, ip, dp]
     L.lsc_free_host.argtypes = [vp]
     L.lsc_free_host.restype = None
     L.lsc_iterations_total.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]

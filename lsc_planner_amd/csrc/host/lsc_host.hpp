@@ -124,6 +124,7 @@ struct Param {   // defaults = launch/testall_empty.launch
     bool goal_mode_prior_based = true;   // mode/goal (launch/*.launch: prior_based)
     bool world_use_octomap = false;
     double world_resolution = 0.1;
+    double grid_resolution = 0.3, grid_margin = 0.2;   // grid/resolution, grid/margin (launch/testall_forest.launch:88-89)
     std::string log_dir = ".";
     int device = 0;
     std::string getPlannerModeStr() const { return "LSC"; }

@@ -20,9 +20,10 @@ class MultiSyncSimulator {
         cfg.dt = param.dt; cfg.control_weight = param.control_input_weight; cfg.terminal_weight = param.terminal_weight;
         for (int k = 0; k < 3; k++) { cfg.world_min[k] = mission.world_min(k); cfg.world_max[k] = mission.world_max(k); }
         cfg.use_octomap = param.world_use_octomap; cfg.world_resolution = param.world_resolution; cfg.device = param.device;
-        // mode/goal: prior_based like every shipped launch file; on octomap worlds the grid A* is not built yet -> static
-        cfg.goal_mode = (param.goal_mode_prior_based && !param.world_use_octomap) ? 1 : 0;
+        // mode/goal: prior_based like every shipped launch file (on octomap worlds that includes the grid search)
+        cfg.goal_mode = param.goal_mode_prior_based ? 1 : 0;
         cfg.goal_threshold = param.goal_threshold;
+        cfg.grid_resolution = param.grid_resolution; cfg.grid_margin = param.grid_margin;
         ctx = lsc_create(&cfg);
         if (!ctx) throw std::runtime_error("[MultiSyncSimulator] lsc_create failed: no usable MI355X (there is no CPU path)");
         const int N = mission.qn;

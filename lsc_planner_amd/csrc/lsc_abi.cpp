@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/lsc_planner_amd.h"
@@ -184,6 +185,14 @@ struct lsc_ctx {
     int edt_dims[3] = {0, 0, 0}, edt_kmin[3] = {0, 0, 0};
     double edt_res = 0.0;
     std::vector<double> h_radius;
+    // goal planner with a distance field (lsc_goal.hip)
+    float *d_edt = nullptr, *d_goal_planned = nullptr, *d_ray_stack = nullptr;
+    unsigned char *d_occ_static = nullptr;
+    int *d_goal_err = nullptr, *d_goal_flags = nullptr, *d_goal_exp = nullptr, *d_goal_path = nullptr, *d_goal_plen = nullptr;
+    int goal_path_cap = 0;
+    int grid_dims[3] = {0, 0, 0}, grid_row_cap = 0;
+    double grid_min[3] = {0, 0, 0};
+    std::vector<int> nb_seq;
     int *d_nrows = nullptr;
     long long *d_iters_acc = nullptr;
     long long *d_prof = nullptr;
@@ -225,6 +234,7 @@ static int timing_begin(lsc_ctx *c, int which, hipStream_t st, hipEvent_t *e1)
     } while (0)
 
 static int build_integrals(lsc_ctx *c);
+static int build_goal_grid(lsc_ctx *c, const std::vector<double> &radii);
 
 extern "C" {
 
@@ -237,6 +247,7 @@ void lsc_default_config(lsc_config *cfg)
     cfg->use_octomap = 0; cfg->world_resolution = 0.1; cfg->device = 0;
     cfg->max_rows_per_cp = 0; cfg->max_iters = 50; cfg->prune = 1; cfg->warm_start_mu = 0.1;
     cfg->goal_mode = 0; cfg->goal_threshold = 0.1; cfg->priority_dist_threshold = 0.4; cfg->goal_radius = 2.0;
+    cfg->grid_resolution = 0.3; cfg->grid_margin = 0.2;   // launch/testall_forest.launch:88-89
 }
 
 lsc_ctx *lsc_create(const lsc_config *cfg)
@@ -267,6 +278,11 @@ static void free_agents(lsc_ctx *c)
                     c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_goal, c->d_prev, c->d_next, c->d_cost, c->d_status,
                     c->d_iters, c->d_onormal, c->d_od};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
+                  c->d_goal_path, c->d_goal_plen};
+    for (void *p : gp) if (p) (void)hipFree(p);
+    c->d_edt = c->d_goal_planned = c->d_ray_stack = nullptr; c->d_occ_static = nullptr;
+    c->d_goal_err = c->d_goal_flags = c->d_goal_exp = c->d_goal_path = c->d_goal_plen = nullptr;
     c->d_radius = c->d_radius_obs = c->d_downwash = c->d_downwash_obs = c->d_vmax = c->d_amax = c->d_vnom = nullptr;
     c->d_stale = c->d_sfc = c->d_state = c->d_goal = c->d_prev = c->d_next = nullptr;
     c->d_cost = nullptr; c->d_status = c->d_iters = c->d_nrows = nullptr; c->d_iters_acc = nullptr; c->d_prof = nullptr; c->d_dbg = nullptr;
@@ -360,6 +376,79 @@ int lsc_set_shard(lsc_ctx *c, int first, int count)
     return LSC_OK;
 }
 
+// Goal planner inputs derived from the map (GridBasedPlanner::updateGridInfo / updateGridMap, distmap part,
+// src/grid_based_planner.cpp:72-130): grid geometry, one static occupancy grid per distinct radius (indexed by the
+// search key H*W*z + W*i + j), the distance field itself for castRay, and the bucket-count sequence of the
+// std::unordered_map this build's libstdc++ provides (the reference's OPEN rows are such maps; see lsc_goal.hip).
+static int build_goal_grid(lsc_ctx *c, const std::vector<double> &radii)
+{
+    if (c->cfg.goal_mode != 1 || !c->cfg.use_octomap) return LSC_OK;
+    const double res = c->cfg.grid_resolution;
+    if (!(res > 0)) { c->err = "grid_resolution must be positive"; return LSC_EINVAL; }
+    int dim[3];
+    for (int a = 0; a < 3; a++) {
+        c->grid_min[a] = -std::floor((-(double)c->cfg.world_min[a] + 1e-9) / res) * res;
+        const double gmax = std::floor(((double)c->cfg.world_max[a] + 1e-9) / res) * res;
+        dim[a] = (int)std::round((gmax - c->grid_min[a]) / res) + 1;
+        c->grid_dims[a] = dim[a];
+    }
+    const int H = dim[0], W = dim[1], A = dim[2];
+    const size_t C = (size_t)H * W * A;
+    if (C > 131071) { c->err = "goal planner: search grid has more than 131071 cells"; return LSC_EINVAL; }
+    // OPEN row capacity: what fits the 160 KiB of LDS next to the per-cell state
+    int cap = W * A;
+    while (cap > 16 && goal_smem_bytes(H, W, A, cap) > 158 * 1024) cap--;
+    if (goal_smem_bytes(H, W, A, cap) > 158 * 1024) { c->err = "goal planner: search grid does not fit LDS"; return LSC_EINVAL; }
+    c->grid_row_cap = cap;
+    // bucket counts of a growing std::unordered_map<uint_least32_t, T> (identity hash), from the container itself
+    {
+        std::unordered_map<uint_least32_t, int> probe;
+        c->nb_seq.clear();
+        size_t last = probe.bucket_count();
+        for (uint_least32_t k = 0; k < (uint_least32_t)cap + 1 && c->nb_seq.size() < 16; k++) {
+            probe[k] = 0;
+            if (probe.bucket_count() != last) { last = probe.bucket_count(); c->nb_seq.push_back((int)last); }
+        }
+    }
+    const int nx = c->edt_dims[0], ny = c->edt_dims[1], nz = c->edt_dims[2];
+    const double rf = 1.0 / c->edt_res;
+    auto edt_at = [&](const float p[3]) -> float {
+        int cc[3];
+        const int dims[3] = {nx, ny, nz};
+        for (int a = 0; a < 3; a++) {
+            cc[a] = (int)std::floor(rf * (double)p[a]) + 32768 - c->edt_kmin[a];
+            if (cc[a] < 0 || cc[a] >= dims[a]) return -1.0f;
+        }
+        return c->h_edt[((size_t)cc[0] * ny + cc[1]) * nz + cc[2]];
+    };
+    std::vector<unsigned char> occ(C * radii.size(), 0);
+    const float margin = (float)c->cfg.grid_margin;
+    for (size_t r = 0; r < radii.size(); r++)
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++)
+                for (int k = 0; k < A; k++) {
+                    const float p[3] = {(float)(c->grid_min[0] + i * res), (float)(c->grid_min[1] + j * res),
+                                        (float)(c->grid_min[2] + k * res)};
+                    if ((double)edt_at(p) < radii[r] + (double)margin) occ[r * C + (size_t)H * W * k + (size_t)W * i + j] = 1;
+                }
+    void *old[] = {c->d_edt, c->d_occ_static, c->d_goal_planned, c->d_goal_err, c->d_goal_flags, c->d_goal_exp, c->d_ray_stack};
+    for (void *p : old) if (p) (void)hipFree(p);
+    c->d_edt = c->d_goal_planned = c->d_ray_stack = nullptr; c->d_occ_static = nullptr;
+    c->d_goal_err = c->d_goal_flags = c->d_goal_exp = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_edt, sizeof(float) * c->h_edt.size()));
+    HIPCHK(c, hipMemcpy(c->d_edt, c->h_edt.data(), sizeof(float) * c->h_edt.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_occ_static, occ.size()));
+    HIPCHK(c, hipMemcpy(c->d_occ_static, occ.data(), occ.size(), hipMemcpyHostToDevice));
+    const size_t N = (size_t)c->N;
+    HIPCHK(c, hipMalloc(&c->d_goal_planned, sizeof(float) * 3 * N));
+    HIPCHK(c, hipMalloc(&c->d_goal_err, sizeof(int) * N));
+    HIPCHK(c, hipMalloc(&c->d_goal_flags, sizeof(int) * N));
+    HIPCHK(c, hipMalloc(&c->d_goal_exp, sizeof(int) * N));
+    HIPCHK(c, hipMemset(c->d_goal_err, 0, sizeof(int) * N));
+    HIPCHK(c, hipMalloc(&c->d_ray_stack, sizeof(float) * N * 64 * 24 * 6));
+    return LSC_OK;
+}
+
 // blocked-cell integral images, one per distinct agent radius:  blocked = EDT < r + res/2 - 1e-5
 // (include/corridor_constructor.hpp:114)
 static int build_integrals(lsc_ctx *c)
@@ -393,7 +482,7 @@ static int build_integrals(lsc_ctx *c)
     HIPCHK(c, hipMemcpy(c->d_integral, I.data(), sizeof(int) * I.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_img_of_agent, sizeof(int) * (size_t)c->N));
     HIPCHK(c, hipMemcpy(c->d_img_of_agent, img.data(), sizeof(int) * (size_t)c->N, hipMemcpyHostToDevice));
-    return LSC_OK;
+    return build_goal_grid(c, radii);
 }
 
 int lsc_set_distmap(lsc_ctx *c, const float *edt, int nx, int ny, int nz, const int key_min[3], double res)
@@ -407,13 +496,32 @@ int lsc_set_distmap(lsc_ctx *c, const float *edt, int nx, int ny, int nz, const 
     return build_integrals(c);
 }
 
-// goalPlanning() runs in phase A of the plan kernel; here only the mode check
-static int check_goal_mode(lsc_ctx *c)
+// goalPlanning(): fused into phase A of the plan kernel on maps without a distance field; with one it is a launch of
+// its own (lsc_goal.hip) whose output replaces the goal input of the SFC and plan kernels
+static int run_goal(lsc_ctx *c, const float *d_state, const float *&d_goal, const float *d_prev, int seq, hipStream_t st)
 {
-    if (c->cfg.goal_mode == 1 && c->cfg.use_octomap) {
-        c->err = "goal_mode prior_based with use_octomap needs the grid A* goal planner (not built yet); use goal_mode 0";
-        return LSC_ESTATE;
-    }
+    if (!(c->cfg.goal_mode == 1 && c->cfg.use_octomap)) return LSC_OK;
+    if (!c->d_occ_static) { c->err = "goal_mode prior_based with use_octomap: lsc_set_distmap was not called"; return LSC_ESTATE; }
+    GoalArgs g;
+    g.N = c->N; g.first = c->first; g.count = c->count; g.planner_seq = seq; g.dtf = (float)c->cfg.dt;
+    g.state = d_state; g.goal = d_goal; g.traj_prev = d_prev;
+    g.radius = c->d_radius; g.downwash = c->d_downwash; g.radius_obs = c->d_radius_obs; g.downwash_obs = c->d_downwash_obs;
+    g.goal_threshold = c->cfg.goal_threshold; g.priority_dist_threshold = c->cfg.priority_dist_threshold;
+    g.goal_radius = c->cfg.goal_radius;
+    g.H = c->grid_dims[0]; g.W = c->grid_dims[1]; g.A = c->grid_dims[2];
+    for (int k = 0; k < 3; k++) { g.gmin[k] = c->grid_min[k]; g.key_min[k] = c->edt_kmin[k]; }
+    g.gres = c->cfg.grid_resolution;
+    g.occ_static = c->d_occ_static; g.img_of_agent = c->d_img_of_agent;
+    g.edt = c->d_edt; g.nx = c->edt_dims[0]; g.ny = c->edt_dims[1]; g.nz = c->edt_dims[2];
+    g.rf = 1.0 / c->edt_res; g.wres = c->cfg.world_resolution;
+    g.n_nb = (int)c->nb_seq.size();
+    for (int k = 0; k < 16; k++) g.nb_seq[k] = k < g.n_nb ? c->nb_seq[k] : 0;
+    g.row_cap = c->grid_row_cap;
+    g.goal_out = c->d_goal_planned; g.err = c->d_goal_err; g.flags = c->d_goal_flags; g.expansions = c->d_goal_exp;
+    g.path_out = c->d_goal_path; g.path_cap = c->goal_path_cap; g.path_len = c->d_goal_plen;
+    g.ray_stack = c->d_ray_stack;
+    HIPCHK(c, launch_goal(g, st));
+    d_goal = c->d_goal_planned;
     return LSC_OK;
 }
 
@@ -452,8 +560,10 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.traj_next = d_next; a.cost = d_cost; a.status = d_status; a.iters = d_iters; a.nrows = c->d_nrows; a.iters_acc = c->d_iters_acc;
     a.stale = c->d_stale; a.sfc = c->cfg.use_octomap ? c->d_sfc : nullptr;
     a.sfc_err = c->cfg.use_octomap ? c->d_sfc_err : nullptr;
+    const bool planned = c->cfg.goal_mode == 1 && c->cfg.use_octomap;   // goals come from lsc_goal_kernel
+    a.goal_err = planned ? c->d_goal_err : nullptr;
     a.out_normal = nullptr; a.out_d = nullptr;
-    a.goal_mode = c->cfg.goal_mode; a.goal_threshold = c->cfg.goal_threshold;
+    a.goal_mode = planned ? 0 : c->cfg.goal_mode; a.goal_threshold = c->cfg.goal_threshold;
     a.priority_dist_threshold = c->cfg.priority_dist_threshold; a.goal_radius = c->cfg.goal_radius;
     a.goal_out = c->d_goal_cur; a.state_next = nullptr; a.finv = (float)std::pow(c->cfg.dt, -1);
     a.dbg = c->d_dbg; a.prof = c->profiling ? c->d_prof : nullptr;
@@ -477,7 +587,7 @@ int lsc_tick_device(lsc_ctx *c, const float *d_state, const float *d_goal, const
     if (!c || !d_state || !d_goal || !d_traj_prev || !d_traj_next || !d_cost || !d_status || !d_iters) return LSC_EINVAL;
     PlanArgs a;
     if (c->N == 0) return LSC_ESTATE;
-    int rc = check_goal_mode(c);
+    int rc = run_goal(c, d_state, d_goal, d_traj_prev, planner_seq, (hipStream_t)hip_stream);
     if (rc) return rc;
     rc = fill_plan_args(c, a, d_state, d_goal, d_traj_prev, planner_seq, d_traj_next, d_cost, d_status, d_iters);
     if (rc) return rc;
@@ -510,9 +620,10 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
     HIPCHK(c, hipMemcpyAsync(c->d_goal, goal, sizeof(float) * 3 * N, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(c->d_prev, prev_traj, sizeof(float) * NV * N, hipMemcpyHostToDevice, st));
     PlanArgs a;
-    int rc = check_goal_mode(c);
+    const float *d_goal_in = c->d_goal;
+    int rc = run_goal(c, c->d_state, d_goal_in, c->d_prev, planner_seq, st);
     if (rc) return rc;
-    rc = fill_plan_args(c, a, c->d_state, c->d_goal, c->d_prev, planner_seq, c->d_next, c->d_cost, c->d_status, c->d_iters);
+    rc = fill_plan_args(c, a, c->d_state, d_goal_in, c->d_prev, planner_seq, c->d_next, c->d_cost, c->d_status, c->d_iters);
     if (rc) return rc;
     if (out_lsc_normal || out_lsc_d) {
         if (!c->d_onormal) {
@@ -521,7 +632,7 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
         }
         a.out_normal = c->d_onormal; a.out_d = c->d_od;
     }
-    rc = run_sfc(c, c->d_state, c->d_goal, c->d_prev, st);
+    rc = run_sfc(c, c->d_state, d_goal_in, c->d_prev, st);
     if (rc) return rc;
     rc = run_plan(c, a, st);
     if (rc) return rc;
@@ -664,6 +775,51 @@ int lsc_iterations_total(lsc_ctx *c, long long *total, int reset)
     for (long long v : h) t += v;
     *total = t;
     if (reset) HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (size_t)c->N));
+    return LSC_OK;
+}
+
+int lsc_set_goal_trace(lsc_ctx *c, int path_cap)
+{
+    if (!c || c->N == 0 || path_cap < 0) return LSC_EINVAL;
+    if (c->d_goal_path) { (void)hipFree(c->d_goal_path); c->d_goal_path = nullptr; }
+    if (c->d_goal_plen) { (void)hipFree(c->d_goal_plen); c->d_goal_plen = nullptr; }
+    c->goal_path_cap = path_cap;
+    if (path_cap > 0) {
+        HIPCHK(c, hipMalloc(&c->d_goal_path, sizeof(int) * (size_t)c->N * path_cap));
+        HIPCHK(c, hipMalloc(&c->d_goal_plen, sizeof(int) * (size_t)c->N));
+        HIPCHK(c, hipMemset(c->d_goal_plen, 0, sizeof(int) * (size_t)c->N));
+    }
+    return LSC_OK;
+}
+
+int lsc_get_goal_trace(lsc_ctx *c, int *path_cells, int *path_len, int *flags, int *expansions, int grid_dims[3],
+                       double grid_min[3])
+{
+    if (!c || c->N == 0) return LSC_EINVAL;
+    if (!c->d_goal_flags) { c->err = "goal trace: the goal planner is not active (goal_mode 1 + use_octomap + distmap)"; return LSC_ESTATE; }
+    HIPCHK(c, hipDeviceSynchronize());
+    const size_t cnt = c->count, first = c->first;
+    if (flags) HIPCHK(c, hipMemcpy(flags, c->d_goal_flags + first, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+    if (expansions) HIPCHK(c, hipMemcpy(expansions, c->d_goal_exp + first, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+    if (grid_dims) for (int k = 0; k < 3; k++) grid_dims[k] = c->grid_dims[k];
+    if (grid_min) for (int k = 0; k < 3; k++) grid_min[k] = c->grid_min[k];
+    if (path_len || path_cells) {
+        if (!c->d_goal_path) { c->err = "goal trace: call lsc_set_goal_trace(ctx, path_cap) first"; return LSC_ESTATE; }
+        std::vector<int> len(cnt), keys(cnt * (size_t)c->goal_path_cap);
+        HIPCHK(c, hipMemcpy(len.data(), c->d_goal_plen, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(keys.data(), c->d_goal_path, sizeof(int) * keys.size(), hipMemcpyDeviceToHost));
+        const int H = c->grid_dims[0], W = c->grid_dims[1];
+        for (size_t q = 0; q < cnt; q++) {
+            if (path_len) path_len[q] = len[q];
+            if (!path_cells) continue;
+            for (int t = 0; t < len[q] && t < c->goal_path_cap; t++) {
+                const int key = keys[q * c->goal_path_cap + t];
+                const int z = key / (H * W), rem = key % (H * W);
+                int *o = path_cells + (q * c->goal_path_cap + t) * 3;
+                o[0] = rem / W; o[1] = rem % W; o[2] = z;
+            }
+        }
+    }
     return LSC_OK;
 }
 

@@ -10,6 +10,7 @@
 #define LSC_STATUS_INFEASIBLE_K 1
 #define LSC_STATUS_CAPACITY_K 3
 #define LSC_STATUS_SFC_K 4
+#define LSC_STATUS_GOAL_K 5
 
 namespace lsc {
 
@@ -36,6 +37,7 @@ struct PlanArgs {
     float *stale;              // [N][90] optimiser's last good trajectory (persistent)
     const float *sfc;          // [N][M][6] or null
     const int *sfc_err;        // [N] or null: seed box blocked -> status 4
+    const int *goal_err;       // [N] or null: goal planner capacity overflow -> status 5
     float *out_normal;         // optional dense dump [count][N-1][M][3]
     double *out_d;             // optional dense dump [count][N-1][M][6]
     double *dbg;               // optional [N][4]: last (gap, |rp|, |rd|, objective) seen by the solver
@@ -72,6 +74,38 @@ struct SfcArgs {
     int table_len;              // entries per face table in LDS: steps a face can move inside the world + slack
 };
 hipError_t launch_sfc(const SfcArgs &a, hipStream_t st);
+
+// Goal planning with a distance field (lsc_goal.hip): priority rule, grid A*, line-of-sight goal.  One wave per agent.
+struct GoalArgs {
+    int N, first, count, planner_seq;
+    float dtf;
+    const float *state, *goal, *traj_prev;     // goal = desired goals [N][3]
+    const double *radius, *downwash, *radius_obs, *downwash_obs;
+    double goal_threshold, priority_dist_threshold, goal_radius;
+    // planning grid (GridBasedPlanner::updateGridInfo): dims, origin, resolution; cells addressed by key = H*W*z + W*i + j
+    int H, W, A;
+    double gmin[3], gres;
+    const unsigned char *occ_static;            // [n_img][H*W*A] by key: EDT(cell centre) < radius + grid_margin
+    const int *img_of_agent;                    // [N]
+    // distance field (DynamicEDTOctomap::getDistance)
+    const float *edt;
+    int nx, ny, nz, key_min[3];
+    double rf, wres;
+    // libstdc++ unordered_map bucket-count sequence (13, 29, 59, ...), read from the real container on the host
+    int n_nb;
+    int nb_seq[16];
+    int row_cap;                                // LDS capacity of one OPEN row (entries)
+    float *goal_out;                            // [N][3] current_goal_position
+    int *err;                                   // [N] 0 ok, 1 capacity (row / path / g overflow), 2 ray stack overflow
+    int *flags;                                 // optional [N]: bit 0 retreat rule, bit 1 search without priorities used
+    int *expansions;                            // optional [N]: nodes popped
+    int *path_out;                              // optional [count][path_cap] keys of the grid path (start -> goal)
+    int path_cap;
+    int *path_len;                              // optional [count]
+    float *ray_stack;                           // [count][64][24][6] bisection stacks of castRay
+};
+size_t goal_smem_bytes(int H, int W, int A, int cap);
+hipError_t launch_goal(const GoalArgs &a, hipStream_t st);
 
 size_t plan_smem_bytes(int n_terms, int n_entries, int cap);
 hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st);

@@ -1182,7 +1182,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     };
 
     bool run = true;
-    if (a.sfc_err && a.sfc_err[qi] != 0) {
+    if (a.goal_err && a.goal_err[qi] != 0) {
+        status = LSC_STATUS_GOAL_K;  // the goal planner ran out of LDS capacity: no goal, no plan
+        run = false;
+    } else if (a.sfc_err && a.sfc_err[qi] != 0) {
         status = LSC_STATUS_SFC_K;   // seed box of the corridor blocked (the reference throws out of plan())
         run = false;
     } else if (overflow) {

@@ -30,6 +30,8 @@ class PlannerConfig:
     goal_threshold: float = 0.1
     priority_dist_threshold: float = 0.4
     goal_radius: float = 2.0
+    grid_resolution: float = 0.3    # grid/resolution (goal planner's search grid; goal_mode prior_based + use_octomap)
+    grid_margin: float = 0.2        # grid/margin
 
 
 def _fp(a):
@@ -67,6 +69,7 @@ class SwarmPlanner:
         c.goal_mode = {"static": 0, "prior_based": 1}[self.cfg.goal_mode]
         c.goal_threshold, c.priority_dist_threshold, c.goal_radius = (self.cfg.goal_threshold, self.cfg.priority_dist_threshold,
                                                                        self.cfg.goal_radius)
+        c.grid_resolution, c.grid_margin = self.cfg.grid_resolution, self.cfg.grid_margin
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:
@@ -166,6 +169,26 @@ class SwarmPlanner:
         g = np.zeros((self.N, 3), np.float32)
         self._check(self.L.lsc_last_goals(self.ctx, _fp(g)))
         return g
+
+    def set_goal_trace(self, path_cap=512):
+        """Keep every agent's grid path of the following ticks (goal_mode prior_based + use_octomap)."""
+        self._goal_path_cap = path_cap
+        self._check(self.L.lsc_set_goal_trace(self.ctx, path_cap))
+
+    def goal_trace(self):
+        """dict(paths = list of int[n][3] grid cells, flags, expansions, grid_dims, grid_min) of the last tick."""
+        cap = getattr(self, "_goal_path_cap", 0)
+        cnt = self.count
+        cells = np.zeros((cnt, max(cap, 1), 3), np.int32)
+        plen = np.zeros(cnt, np.int32)
+        flags = np.zeros(cnt, np.int32)
+        exp = np.zeros(cnt, np.int32)
+        dims = np.zeros(3, np.int32)
+        gmin = np.zeros(3)
+        self._check(self.L.lsc_get_goal_trace(self.ctx, _ip(cells) if cap else None, _ip(plen) if cap else None, _ip(flags), _ip(exp),
+                                              _ip(dims), _dp(gmin)))
+        return {"paths": [cells[q, :min(plen[q], cap)].copy() for q in range(cnt)], "path_len": plen, "flags": flags,
+                "expansions": exp, "grid_dims": dims, "grid_min": gmin}
 
     def row_counts(self):
         rows = np.zeros(self.N, np.int32)

@@ -128,6 +128,16 @@ int  orc_expand_box(const orc_params *prm, const orc_edt *edt, double world_res,
 int  orc_update_sfc(const orc_params *prm, const orc_edt *edt, double world_res, const float pos[3], const float goal[3],
                     const float *prev_traj, double radius, float *sfc /*[M][6]*/, int *init_flag);
 
+/* ---- goal planning with a distance field: grid A* + line-of-sight goal (lsc_oracle_goal.cpp) ---- */
+long orc_astar_last_expansions(void);
+void orc_grid_dims(const orc_params *prm, double grid_res, int dims[3], double gmin[3]);
+int  orc_astar(const unsigned char *occ, const int dims[3], const int start[3], const int goal[3], int *path_out, int max_len);
+void orc_goal_prior_based_map(const orc_params *prm, const orc_edt *edt, double world_res, double grid_res, double grid_margin,
+                              int N, int qi, const float *state, const float *desired_goal, const float *prev_traj,
+                              int planner_seq, double goal_threshold, double priority_dist_threshold, double goal_radius,
+                              const double *radius, const double *downwash, float out_goal[3], int *path_out, int max_path,
+                              int *path_len, int *flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,15 @@ def lib():
                                            ctypes.c_double, ctypes.c_double, _fp]
         L.orc_tick_set_map.restype = None
         L.orc_tick_set_map.argtypes = [ctypes.c_void_p, ctypes.c_double, _ip]
+        _ub = ctypes.POINTER(ctypes.c_ubyte)
+        L.orc_grid_dims.restype = None
+        L.orc_grid_dims.argtypes = [ctypes.POINTER(OrcParams), ctypes.c_double, _ip, _dp]
+        L.orc_astar.argtypes = [_ub, _ip, _ip, _ip, _ip, ctypes.c_int]
+        L.orc_goal_prior_based_map.restype = None
+        L.orc_goal_prior_based_map.argtypes = [ctypes.POINTER(OrcParams), ctypes.POINTER(OrcEdt), ctypes.c_double, ctypes.c_double,
+                                               ctypes.c_double, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,
+                                               ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp, _fp, _ip, ctypes.c_int,
+                                               _ip, _ip]
         _lib = L
     return _lib
 
@@ -294,6 +303,49 @@ def goal_prior_based(state, desired_goal, prev_traj, planner_seq, dt=0.2, goal_t
     return out
 
 
+def grid_dims(prm, grid_res=0.3):
+    """GridBasedPlanner::updateGridInfo: (dims int[3], grid_min double[3])."""
+    dims = np.zeros(3, np.int32)
+    gmin = np.zeros(3)
+    lib().orc_grid_dims(ctypes.byref(prm), grid_res, _i(dims), _d(gmin))
+    return dims, gmin
+
+
+def astar(occ, start, goal, max_len=100000):
+    """Astar-3D on an occupancy grid [ni][nj][nk] (0 free): int[n][3] path (empty when unreachable)."""
+    occ = np.ascontiguousarray(occ, np.uint8)
+    dims = np.asarray(occ.shape, np.int32)
+    s = np.ascontiguousarray(start, np.int32)
+    g = np.ascontiguousarray(goal, np.int32)
+    out = np.zeros((max_len, 3), np.int32)
+    n = lib().orc_astar(occ.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _i(dims), _i(s), _i(g), _i(out), max_len)
+    return out[:n].copy()
+
+
+def goal_prior_based_map(prm, dm, state, desired_goal, prev_traj, planner_seq, radius, downwash, world_res=0.1, grid_res=0.3,
+                         grid_margin=0.2, goal_threshold=0.1, priority_dist_threshold=0.4, goal_radius=2.0, want_paths=False):
+    """current_goal_position of every agent, mode/goal = prior_based WITH a distance field (grid A* + LOS goal).
+    Returns goals [N][3] float32 (and, with want_paths, the list of grid paths and the flag words)."""
+    state = np.ascontiguousarray(state, np.float32)
+    N = len(state)
+    dg = np.ascontiguousarray(desired_goal, np.float32).reshape(N, 3)
+    pt = np.ascontiguousarray(prev_traj, np.float32).reshape(N, NV)
+    r = np.ascontiguousarray(radius, np.float64)
+    dw = np.ascontiguousarray(downwash, np.float64)
+    out = np.zeros((N, 3), np.float32)
+    paths, flags = [], np.zeros(N, np.int32)
+    buf = np.zeros((8192, 3), np.int32)
+    for qi in range(N):
+        n, fl = ctypes.c_int(), ctypes.c_int()
+        lib().orc_goal_prior_based_map(ctypes.byref(prm), ctypes.byref(dm.edt), world_res, grid_res, grid_margin, N, qi, _f(state),
+                                       _f(dg), _f(pt), planner_seq, goal_threshold, priority_dist_threshold, goal_radius, _d(r),
+                                       _d(dw), _f(out[qi]), _i(buf), len(buf), ctypes.byref(n), ctypes.byref(fl))
+        flags[qi] = fl.value
+        if want_paths:
+            paths.append(buf[:n.value].copy())
+    return (out, paths, flags) if want_paths else out
+
+
 def bt_read(path):
     """Occupied leaves of an octomap .bt file: (res, int[n][4] = min key x,y,z + cube edge in cells)."""
     res = ctypes.c_double()
@@ -324,6 +376,21 @@ class DistMap:
         e.dist = _f(self.dist)
         self.key_min = np.array([e.key_min[0], e.key_min[1], e.key_min[2]], np.int32)
         self.res = res
+
+    @classmethod
+    def from_array(cls, dist, key_min, res):
+        """Wraps an existing dense field (tests with synthetic maps)."""
+        self = cls.__new__(cls)
+        self.edt = OrcEdt()
+        self.dist = np.ascontiguousarray(dist, np.float32)
+        self.edt.dist = _f(self.dist)
+        self.edt.nx, self.edt.ny, self.edt.nz = self.dist.shape
+        for k in range(3):
+            self.edt.key_min[k] = int(key_min[k])
+        self.edt.res = res
+        self.key_min = np.asarray(key_min, np.int32)
+        self.res = res
+        return self
 
     def expand_box(self, prm, point, goal, radius, world_res=0.1):
         box = np.zeros(6)

@@ -1,0 +1,82 @@
+"""-m gpu: goal planning with a distance field (mode/goal = prior_based on an octomap world) through the C ABI against
+the oracle: the grid path (cell by cell -- this is where the reference's hash-order tie-breaking shows), the flags and
+the resulting current_goal_position, bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import oracle_swarm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lsc_planner_amd as L
+    L.load_library()
+    return L
+
+
+def _compare_goal_stage(L, O, ms, dm, dist, key_min, res, state, traj, tick, pl, grid_margin=0.2):
+    prm = O.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+    ref, paths, flags = O.goal_prior_based_map(prm, dm, state, ms.goal, traj, tick, ms.radius, ms.downwash, grid_margin=grid_margin,
+                                               want_paths=True)
+    g = pl.plan(state, ms.goal, traj)
+    tr = pl.goal_trace()
+    assert (g["status"] != 5).all(), "goal planner capacity"
+    for qi in range(ms.qn):
+        assert tr["flags"][qi] == flags[qi], (tick, qi, tr["flags"][qi], flags[qi])
+        if not (flags[qi] & 1):
+            assert np.array_equal(tr["paths"][qi], paths[qi]), (tick, qi, len(tr["paths"][qi]), len(paths[qi]))
+    assert np.array_equal(pl.last_goals(), ref), tick
+    return g
+
+
+def test_forest_goal_planning_bitwise_over_a_mission(L, oracle):
+    from maputil import forest_leaves
+    from lsc_planner_amd.planner import next_state_host
+    leaves, res = forest_leaves()
+    wmin, wmax = (-5, -5, 0), (5, 5, 2.5)
+    dm = oracle.DistMap(leaves, res, wmin, wmax)
+    ms = L.random_swarm(24, world=wmin + wmax, seed=4, edt=dm.dist, edt_key_min=dm.key_min)
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True, goal_mode="prior_based"))
+    pl.set_distmap(dm.dist, dm.key_min, res)
+    pl.set_goal_trace(512)
+    N = ms.qn
+    state = np.zeros((N, 9), np.float32)
+    state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    longest, most = 0, 0
+    for tick in range(1, 41):
+        g = _compare_goal_stage(L, oracle, ms, dm, dm.dist, dm.key_min, res, state, traj, tick, pl)
+        tr = pl.goal_trace()
+        longest = max(longest, int(tr["path_len"].max()))
+        most = max(most, int(tr["expansions"].max()))
+        traj = g["traj"]
+        state = next_state_host(traj)
+    pl.close()
+    assert longest >= 20 and most >= 500, (longest, most)      # real searches happened
+    assert np.linalg.norm(state[:, :3] - ms.goal, axis=1).mean() < np.linalg.norm(ms.start - ms.goal, axis=1).mean()
+
+
+def test_random_mazes_tie_breaking(L, oracle):
+    """Synthetic 'distance fields' (0 inside random blocks, 1 m elsewhere) make dense mazes with many equal-cost paths:
+    the path must still be the reference's, cell for cell."""
+    rng = np.random.default_rng(11)
+    wmin, wmax = (-4, -4, 0), (4, 4, 2.0)
+    res = 0.1
+    for trial in range(6):
+        kmin = np.array([np.floor(wmin[k] / res) + 32768 for k in range(3)], np.int32)
+        dims = [int(np.floor(wmax[k] / res) + 32768 - kmin[k] + 1) for k in range(3)]
+        coarse = rng.random((dims[0] // 3 + 1, dims[1] // 3 + 1, dims[2] // 3 + 1)) < (0.12 + 0.05 * (trial % 3))
+        dist = np.where(np.kron(coarse, np.ones((3, 3, 3), bool))[:dims[0], :dims[1], :dims[2]], 0.0, 1.0).astype(np.float32)
+        dm = oracle.DistMap.from_array(dist, kmin, res)
+        n = 12
+        ms = L.random_swarm(n, world=wmin + wmax, seed=100 + trial, edt=dist, edt_key_min=kmin, min_clearance=0.5)
+        pl = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True, goal_mode="prior_based", grid_margin=0.05))
+        pl.set_distmap(dist, kmin, res)
+        pl.set_goal_trace(1024)
+        state = np.zeros((n, 9), np.float32)
+        state[:, :3] = ms.start
+        traj = np.zeros((n, 3, 30), np.float32)
+        _compare_goal_stage(L, oracle, ms, dm, dist, kmin, res, state, traj, 1, pl, grid_margin=0.05)
+        pl.close()

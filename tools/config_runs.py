@@ -7,7 +7,8 @@ bench lines): device-resident tick loop, one JSON line per configuration.
   circle20    20-agent circle swap, empty map, mode/goal prior_based           (BASELINE configs[1] geometry)
   circle64    the bench headline workload                                      (configs[2])
   forest256   256 agents, the simple_forest occupancy tiled 2 x 2 (20 x 20 x 2.5 m), EDT + SFC path, mode/goal static
-              (configs[3] on one GPU; prior_based on an octomap needs the grid A* of SURVEY 8(f)#1)
+              (configs[3] on one GPU, the goal mode of the reference's own logged forest runs)
+  forest256p  the same with mode/goal prior_based: priority rule + grid A* + line-of-sight goal on the device
   random1024  1024-agent random swarm, empty 40 x 40 x 5 m world               (configs[4] on one GPU)
 Needs a GPU; nothing here touches oracle/ or /root/reference.  The forest occupancy comes from the committed leaf
 fixture (tests/golden/simple_forest_leaves.npz) written out as a .bt file and read back by the product's own reader.
@@ -101,7 +102,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ticks", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--only", default="circle20,circle64,forest256,random1024")
+    ap.add_argument("--only", default="circle20,circle64,forest256,forest256p,random1024")
     a = ap.parse_args()
     import lsc_planner_amd as L
     from lsc_planner_amd.planner import PlannerConfig
@@ -116,6 +117,12 @@ def main():
         dist, kmin, res = L.edt_from_bt(bt, wmin, wmax)
         ms = L.random_swarm(256, world=world, seed=7, edt=dist, edt_key_min=kmin, edt_res=res)
         run("forest256", ms, PlannerConfig(goal_mode="static", use_octomap=True), a.ticks, a.warmup, bt=bt)
+    if "forest256p" in want:
+        bt, world = forest_tiles(2)
+        wmin, wmax = np.asarray(world[:3], np.float32), np.asarray(world[3:], np.float32)
+        dist, kmin, res = L.edt_from_bt(bt, wmin, wmax)
+        ms = L.random_swarm(256, world=world, seed=7, edt=dist, edt_key_min=kmin, edt_res=res)
+        run("forest256p", ms, PlannerConfig(goal_mode="prior_based", use_octomap=True), a.ticks, a.warmup, bt=bt)
     if "random1024" in want:
         run("random1024", L.random_swarm(1024), PlannerConfig(goal_mode="prior_based"), a.ticks, a.warmup)
 
