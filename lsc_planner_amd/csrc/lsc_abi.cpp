@@ -515,7 +515,10 @@ static int run_goal(lsc_ctx *c, const float *d_state, const float *&d_goal, cons
     g.edt = c->d_edt; g.nx = c->edt_dims[0]; g.ny = c->edt_dims[1]; g.nz = c->edt_dims[2];
     g.rf = 1.0 / c->edt_res; g.wres = c->cfg.world_resolution;
     g.n_nb = (int)c->nb_seq.size();
-    for (int k = 0; k < 16; k++) g.nb_seq[k] = k < g.n_nb ? c->nb_seq[k] : 0;
+    for (int k = 0; k < 16; k++) {
+        g.nb_seq[k] = k < g.n_nb ? c->nb_seq[k] : 0;
+        g.nb_magic[k] = k < g.n_nb ? (uint32_t)(0x100000000ull / (uint32_t)c->nb_seq[k]) : 0u;
+    }
     g.row_cap = c->grid_row_cap;
     g.goal_out = c->d_goal_planned; g.err = c->d_goal_err; g.flags = c->d_goal_flags; g.expansions = c->d_goal_exp;
     g.path_out = c->d_goal_path; g.path_cap = c->goal_path_cap; g.path_len = c->d_goal_plen;

@@ -34,27 +34,62 @@ constexpr int ST_OCC = 1, ST_OPEN = 2, ST_CLOSED = 4;    // + parent direction <
 constexpr int RAY_STACK = 24;
 
 
+// One wave per workgroup: LDS operations of a wave are performed in program order, so lanes only need the compiler
+// not to move or merge LDS accesses across a hand-over point -- a wavefront-scope fence, no s_barrier.
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// n / d for n < 2^32 with m = floor(2^32 / d): the estimate is at most one too small
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t d, uint32_t m)
+{
+    uint32_t q = __umulhi(n, m);
+    if (n - q * d >= d) q++;
+    return q;
+}
+
+// Wave reductions without LDS traffic: four DPP row_shr steps inside each 16-lane row, then the four row results are
+// combined through v_readlane (a __shfl_xor butterfly costs a ds_bpermute round trip per step).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v, int identity) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v, double identity)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(identity), lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_min_d(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o); v = t < v ? t : v; }
-    return v;
+    const double id = 1.7976931348623157e308;
+    v = fmin(v, dpp_d<0x111>(v, id)); v = fmin(v, dpp_d<0x112>(v, id)); v = fmin(v, dpp_d<0x114>(v, id)); v = fmin(v, dpp_d<0x118>(v, id));
+    auto rl = [&](int l) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l)); };
+    return fmin(fmin(rl(15), rl(31)), fmin(rl(47), rl(63)));
 }
-__device__ __forceinline__ uint32_t wave_max_u(uint32_t v)
+__device__ __forceinline__ uint32_t wave_max_u(uint32_t u)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, o); v = t > v ? t : v; }
-    return v;
+    // values stay below 2^31 here, so signed max is unsigned max
+    int v = (int)u;
+    v = max(v, dpp_i<0x111>(v, 0)); v = max(v, dpp_i<0x112>(v, 0)); v = max(v, dpp_i<0x114>(v, 0)); v = max(v, dpp_i<0x118>(v, 0));
+    return (uint32_t)max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+                         max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
 }
 __device__ __forceinline__ int wave_min_i(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o); v = t < v ? t : v; }
-    return v;
+    const int id = 0x7fffffff;
+    v = min(v, dpp_i<0x111>(v, id)); v = min(v, dpp_i<0x112>(v, id)); v = min(v, dpp_i<0x114>(v, id)); v = min(v, dpp_i<0x118>(v, id));
+    return min(min(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)),
+               min(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
 }
 
 struct Ctx {
     int H, W, A, HW, C, cap, lane;
+    uint32_t mW, mHW;                // floor(2^32 / W), floor(2^32 / HW)
+    const uint32_t *nb_magic;
     int gi, gj, gz;                  // goal cell
     uint8_t *st;                     // [C]
     double *rowF;                    // [H]  F of the registered row minimum
@@ -70,9 +105,9 @@ struct Ctx {
 
 __device__ __forceinline__ void decode(const Ctx &c, uint32_t key, int &i, int &j, int &z)
 {
-    z = (int)(key / (uint32_t)c.HW);
+    z = (int)div_magic(key, (uint32_t)c.HW, c.mHW);
     const uint32_t rem = key - (uint32_t)z * (uint32_t)c.HW;
-    i = (int)(rem / (uint32_t)c.W);
+    i = (int)div_magic(rem, (uint32_t)c.W, c.mW);
     j = (int)(rem - (uint32_t)i * (uint32_t)c.W);
 }
 
@@ -100,13 +135,14 @@ __device__ int row_find(const Ctx &c, const uint32_t *row, int cnt, uint32_t key
 }
 
 // libstdc++ _M_insert_bucket_begin on the array form: before the first entry of the same bucket, else at the front
-__device__ void row_place(const Ctx &c, uint32_t *row, int cnt, uint32_t e, uint32_t nb)
+__device__ void row_place(const Ctx &c, uint32_t *row, int cnt, uint32_t e, uint32_t nb, uint32_t nbm)
 {
-    const uint32_t b = (e & KEY_MASK) % nb;
+    auto bucket = [&](uint32_t k) { return k - div_magic(k, nb, nbm) * nb; };
+    const uint32_t b = bucket(e & KEY_MASK);
     int pos = 0;
     for (int base = 0; base < cnt; base += 64) {
         const int p = base + c.lane;
-        const bool m = p < cnt && ((row[p] & KEY_MASK) % nb) == b;
+        const bool m = p < cnt && bucket(row[p] & KEY_MASK) == b;
         const unsigned long long mask = __ballot(m);
         if (mask) { pos = base + __ffsll((long long)mask) - 1; break; }
     }
@@ -114,12 +150,12 @@ __device__ void row_place(const Ctx &c, uint32_t *row, int cnt, uint32_t e, uint
         const int lo = hi - 64 > pos ? hi - 64 : pos;
         const int p = lo + c.lane;
         const uint32_t v = p < hi ? row[p] : 0u;
-        __syncthreads();
+        wsync();
         if (p < hi) row[p + 1] = v;
-        __syncthreads();
+        wsync();
     }
     if (c.lane == 0) row[pos] = e;
-    __syncthreads();
+    wsync();
 }
 
 // insertion of a NEW key (unordered_map::operator[] on a missing key): rehash first when the policy asks for it
@@ -129,19 +165,21 @@ __device__ void row_insert(Ctx &c, int i, uint32_t e)
     int cnt = c.rowCnt[i];
     int nbi = c.rowNb[i];
     uint32_t nb = nbi < 0 ? 1u : (uint32_t)c.nb_seq[nbi];
+    uint32_t nbm = nbi < 0 ? 0u : c.nb_magic[nbi];
     if (cnt + 1 > c.cap) { c.err = 1; return; }
     if ((uint32_t)(cnt + 1) > nb || nbi < 0) {
         nbi++;
         if (nbi >= c.n_nb) { c.err = 1; return; }
         nb = (uint32_t)c.nb_seq[nbi];
+        nbm = c.nb_magic[nbi];
         for (int p = c.lane; p < cnt; p += 64) c.tmp[p] = row[p];
-        __syncthreads();
-        for (int t = 0; t < cnt; t++) row_place(c, row, t, c.tmp[t], nb);
+        wsync();
+        for (int t = 0; t < cnt; t++) row_place(c, row, t, c.tmp[t], nb, nbm);
         if (c.lane == 0) c.rowNb[i] = (int16_t)nbi;
     }
-    row_place(c, row, cnt, e, nb);
+    row_place(c, row, cnt, e, nb, nbm);
     if (c.lane == 0) c.rowCnt[i] = (uint16_t)(cnt + 1);
-    __syncthreads();
+    wsync();
 }
 
 __device__ void row_erase(Ctx &c, int i, uint32_t key)
@@ -152,12 +190,12 @@ __device__ void row_erase(Ctx &c, int i, uint32_t key)
     for (int lo = pos + 1; lo < cnt; lo += 64) {             // shift (pos, cnt) one to the left, first chunk first
         const int p = lo + c.lane;
         const uint32_t v = p < cnt ? row[p] : 0u;
-        __syncthreads();
+        wsync();
         if (p < cnt) row[p - 1] = v;
-        __syncthreads();
+        wsync();
     }
     if (c.lane == 0) c.rowCnt[i] = (uint16_t)(cnt - 1);
-    __syncthreads();
+    wsync();
 }
 
 // deleteMin's rescan (isearch.cpp:216-240): among the entries with the smallest F, the largest g; among those the
@@ -178,7 +216,7 @@ __device__ void row_rescan(Ctx &c, int i)
     const double fmin = wave_min_d(bf);
     const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
     if (c.lane == 0) { c.rowMin[i] = row[sel & 0xffffu]; c.rowF[i] = fmin; }
-    __syncthreads();
+    wsync();
 }
 
 // DynamicEDTOctomap::getDistance(point3d)
@@ -246,7 +284,8 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     const int N = a.N;
     Ctx c;
     c.H = a.H; c.W = a.W; c.A = a.A; c.HW = a.H * a.W; c.C = a.H * a.W * a.A; c.cap = a.row_cap; c.lane = lane;
-    c.nb_seq = a.nb_seq; c.n_nb = a.n_nb; c.err = 0;
+    c.nb_seq = a.nb_seq; c.nb_magic = a.nb_magic; c.n_nb = a.n_nb; c.err = 0;
+    c.mW = (uint32_t)(0x100000000ull / (uint32_t)c.W); c.mHW = (uint32_t)(0x100000000ull / (uint32_t)c.HW);
     {
         size_t off = 0;
         c.st = gsm; off += ((size_t)c.C + 15) & ~(size_t)15;
@@ -324,7 +363,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     for (int attempt = 0; attempt < 2 && !found && !c.err; attempt++) {
         for (int p = lane; p < c.C; p += 64) c.st[p] = occ_static[p];
         for (int i = lane; i < c.H; i += 64) { c.rowCnt[i] = 0; c.rowNb[i] = -1; }
-        __syncthreads();
+        wsync();
         if (attempt == 0) {
             for (int qj = lane; qj < N; qj += 64) {          // updateGridMap, AGENT branch :163-189
                 if (qj == qi) continue;
@@ -350,7 +389,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                             if (dist < r_a + r_o) c.st[key_of(i, j, k)] = ST_OCC;
                         }
             }
-            __syncthreads();
+            wsync();
         } else {
             flags |= 2;
         }
@@ -375,9 +414,9 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                         }
                     }
             s[0] = bc[0]; s[1] = bc[1]; s[2] = bc[2];
-            __syncthreads();
+            wsync();
             if (lane == 0 && (c.st[key_of(s[0], s[1], s[2])] & ST_OCC)) c.st[key_of(s[0], s[1], s[2])] = 0;
-            __syncthreads();
+            wsync();
         }
         // ---- ISearch::startSearch
         const uint32_t skey = key_of(s[0], s[1], s[2]);
@@ -387,7 +426,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             c.rowMin[s[0]] = skey;
             c.rowF[s[0]] = f_of(c, skey);
         }
-        __syncthreads();
+        wsync();
         int nopen = 1;
         while (nopen > 0 && !c.err) {
             expansions++;
@@ -408,37 +447,51 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             const int cg = (int)(ce >> KEY_BITS);
             int cj, cz, ci2;
             decode(c, ckey, ci2, cj, cz);
-            __syncthreads();
+            wsync();
             if (lane == 0) c.st[ckey] = (uint8_t)((c.st[ckey] & ~ST_OPEN) | ST_CLOSED);
             row_erase(c, ci, ckey);
             row_rescan(c, ci);
             nopen--;
             if (ci == c.gi && cj == c.gj) { found = true; end_key = ckey; break; }   // the altitude is not part of the goal test
             if (cg + 1 > G_MAX) { c.err = 1; break; }
-            // findSuccessors (:100-141): the six axis moves in the order of its nested loops
-#pragma unroll 1
-            for (int d = 0; d < 6; d++) {
+            // findSuccessors (:100-141): the six axis moves in the order of its nested loops.  Lanes 0..5 look at one
+            // neighbour each (bounds, occupancy, closed); only the survivors are then handled one after the other.
+            int nkey_l = -1;
+            uint32_t sv_l = ST_OCC;
+            if (lane < 6) {
+                const int d = lane;
                 const int di = d == 0 ? -1 : (d == 5 ? 1 : 0), dj = d == 1 ? -1 : (d == 4 ? 1 : 0), dz = d == 2 ? -1 : (d == 3 ? 1 : 0);
                 const int ni = ci + di, nj = cj + dj, nz = cz + dz;
-                if (ni < 0 || ni >= c.H || nj < 0 || nj >= c.W || nz < 0 || nz >= c.A) continue;
-                const uint32_t nkey = key_of(ni, nj, nz);
-                const uint8_t sv = c.st[nkey];
-                if (sv & (ST_OCC | ST_CLOSED)) continue;
-                const uint32_t ne = nkey | ((uint32_t)(cg + 1) << KEY_BITS);
+                if (ni >= 0 && ni < c.H && nj >= 0 && nj < c.W && nz >= 0 && nz < c.A) {
+                    nkey_l = (int)key_of(ni, nj, nz);
+                    sv_l = c.st[nkey_l];
+                }
+            }
+            unsigned long long todo = __ballot(nkey_l >= 0 && !(sv_l & (ST_OCC | ST_CLOSED)));
+            const int ng = cg + 1;
+            while (todo) {
+                const int d = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const uint32_t nkey = (uint32_t)__builtin_amdgcn_readlane(nkey_l, d);
+                const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)sv_l, d);
+                const int di = d == 0 ? -1 : (d == 5 ? 1 : 0), dj = d == 1 ? -1 : (d == 4 ? 1 : 0), dz = d == 2 ? -1 : (d == 3 ? 1 : 0);
+                const int ni = ci + di, nj = cj + dj, nz = cz + dz;
+                const uint32_t ne = nkey | ((uint32_t)ng << KEY_BITS);
                 uint32_t *row = c.rows + (size_t)ni * c.cap;
                 bool inserted = false;
-                if (sv & ST_OPEN) {                            // addOpen (:243-283): keep the better of the two
-                    const int p = row_find(c, row, c.rowCnt[ni], nkey);
+                uint32_t stored = ne;                          // the row's entry for this key after addOpen
+                if (sv & ST_OPEN) {                            // addOpen (:243-283): keep the better of the two; same cell,
+                    const int p = row_find(c, row, c.rowCnt[ni], nkey);   // same H, so "F smaller" is "g smaller"
                     const uint32_t old = row[p];
-                    if (f_of(c, ne) < f_of(c, old)) {
-                        __syncthreads();
+                    stored = old;
+                    if (ng < (int)(old >> KEY_BITS)) {
                         if (lane == 0) {
                             row[p] = ne;
                             c.st[nkey] = (uint8_t)(ST_OPEN | (d << 3));
-                            if ((c.rowMin[ni] & KEY_MASK) == nkey) { c.rowMin[ni] = ne; c.rowF[ni] = f_of(c, ne); }
                         }
+                        stored = ne;
                         inserted = true;
-                        __syncthreads();
+                        wsync();
                     }
                 } else {
                     row_insert(c, ni, ne);
@@ -446,18 +499,26 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                     if (lane == 0) c.st[nkey] = (uint8_t)(ST_OPEN | (d << 3));
                     inserted = true;
                     nopen++;
-                    __syncthreads();
+                    wsync();
                 }
+                // row minimum bookkeeping of addOpen (:262-282)
+                const int ei = c.gi - ni, ej = c.gj - nj, ez = c.gz - nz;
+                const double fs = 10.0 * (double)(stored >> KEY_BITS) + 10.0 * sqrt((double)(ei * ei + ej * ej + ez * ez));
                 if (c.rowCnt[ni] == 1) {
-                    if (lane == 0) { c.rowMin[ni] = ne; c.rowF[ni] = f_of(c, ne); }
-                } else if (inserted) {
-                    const double fn = f_of(c, ne), fm = c.rowF[ni];
-                    const int gm = (int)(c.rowMin[ni] >> KEY_BITS);
-                    if (fn < fm || (fn == fm && cg + 1 >= gm)) {
-                        if (lane == 0) { c.rowMin[ni] = ne; c.rowF[ni] = fn; }
+                    if (lane == 0) { c.rowMin[ni] = stored; c.rowF[ni] = fs; }
+                } else {
+                    const uint32_t me = c.rowMin[ni];
+                    const bool min_is_this = (me & KEY_MASK) == nkey;
+                    // the registered minimum is read AFTER the assignment: if it is this very node it already has the new g
+                    const double fm = min_is_this ? fs : c.rowF[ni];
+                    const int gm = min_is_this ? (int)(stored >> KEY_BITS) : (int)(me >> KEY_BITS);
+                    if (inserted && (fs < fm || (fs == fm && ng >= gm))) {
+                        if (lane == 0) { c.rowMin[ni] = stored; c.rowF[ni] = fs; }
+                    } else if (min_is_this && lane == 0) {
+                        c.rowMin[ni] = stored; c.rowF[ni] = fs;
                     }
                 }
-                __syncthreads();
+                wsync();
             }
         }
     }
@@ -481,7 +542,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             }
             c.tmp[0] = (uint32_t)n;
         }
-        __syncthreads();
+        wsync();
         n_path = (int)c.tmp[0];
         if (n_path < 0) { c.err = 1; n_path = 0; }
     }

@@ -94,6 +94,7 @@ struct GoalArgs {
     // libstdc++ unordered_map bucket-count sequence (13, 29, 59, ...), read from the real container on the host
     int n_nb;
     int nb_seq[16];
+    uint32_t nb_magic[16];                      // floor(2^32 / nb_seq[k])
     int row_cap;                                // LDS capacity of one OPEN row (entries)
     float *goal_out;                            // [N][3] current_goal_position
     int *err;                                   // [N] 0 ok, 1 capacity (row / path / g overflow), 2 ray stack overflow

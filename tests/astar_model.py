@@ -2,10 +2,9 @@
 import math, sys
 import numpy as np
 
-def bucket_growth():
-    # libstdc++ _Prime_rehash_policy with max_load 1.0, growth 2: first insert -> 13, then next prime >= 2*nb
-    return None
-
+# libstdc++ _Prime_rehash_policy (max load 1.0, growth factor 2): a fresh container has one bucket, the first insertion
+# takes it to 13, afterwards the count becomes the next entry of the library's prime table >= twice the current count
+# whenever an insertion would exceed one element per bucket.  (The product reads this sequence from the container.)
 PRIMES = [13, 29, 59, 127, 257, 541, 1109, 2357, 5087, 10273, 20753, 42043]
 
 class Row:
@@ -111,7 +110,7 @@ def astar(occ, start, goal):
         path.append(coords(k)); k = parent[k]
     return np.array(path[::-1]), nexp
 
-if __name__ == "__main__":
+if __name__ == "__main__":  # ad-hoc run; the pytest entry is tests/test_goal_planning.py
     sys.path.insert(0, "/root/repo")
     from oracle import oracle as O
     rng = np.random.default_rng(1)

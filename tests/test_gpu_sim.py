@@ -66,3 +66,39 @@ def test_simulator_trajectory_equals_python_host_layer(ticks, tmp_path):
             assert np.allclose(p, traj[q, :, 0], atol=2e-6), (tick, q)
         state = next_state_host(traj)
     pl.close()
+
+
+def test_forest_mission_in_the_default_goal_mode(tmp_path):
+    """Octomap world + mode/goal = prior_based (every shipped launch file): .bt -> EDT -> SFC boxes, grid A* goals, QP --
+    the 8-agent mission must finish collision-free, and the first ticks equal the Python host layer."""
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import next_state_host
+    from maputil import forest_leaves, write_bt
+    leaves, res = forest_leaves()
+    bt = tmp_path / "forest.bt"
+    write_bt(str(bt), leaves, res)
+    world = (-5, -5, 0, 5, 5, 2.5)
+    dist, kmin, r = L.edt_from_bt(str(bt), np.asarray(world[:3], np.float32), np.asarray(world[3:], np.float32))
+    ms = L.random_swarm(8, world=world, seed=21, edt=dist, edt_key_min=kmin, edt_res=r)
+    mp = tmp_path / "forest8.json"
+    _write_mission(str(mp), ms)
+    rr = subprocess.run([SIM, "--mission", str(mp), "--world", str(bt), "--csv", str(tmp_path), "--quiet", "--max-iter", "200"],
+                        capture_output=True, text=True, timeout=600)
+    assert rr.returncode == 0, rr.stdout + rr.stderr
+    ratio = float(rr.stdout.split("safety ratio between agent:")[1].split()[0])
+    assert ratio >= 1.0 - 1e-3
+    rows = list(csv.reader(open(tmp_path / "result_LSC_8agents.csv")))[1:]
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based", use_octomap=True))
+    pl.load_octomap(str(bt))
+    state = np.zeros((8, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((8, 3, 30), np.float32)
+    for tick in range(8):
+        g = pl.plan(state, ms.goal, traj)
+        assert (g["status"] == 0).all()
+        traj = g["traj"]
+        row = rows[2 * tick]
+        for q in range(8):
+            p = [float(row[15 * q + 2 + k]) for k in range(3)]
+            assert np.allclose(p, traj[q, :, 0], atol=2e-6), (tick, q)
+        state = next_state_host(traj)
+    pl.close()
