@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--no-latency-leg", action="store_true")
     ap.add_argument("--no-prune", action="store_true")
     ap.add_argument("--static-goal", action="store_true", help="mode/goal=static instead of the reference default prior_based")
+    ap.add_argument("--unfused", action="store_true",
+                    help="single GPU only: use the multi-GPU tick sequence (plan shard, exchange, propagate) instead of the fused launch")
     ap.add_argument("--sweep-agents", type=int, default=1024,
                     help="extra leg: dense LSC sweep at this swarm size (HBM-meaningful working set); 0 = skip")
     args = ap.parse_args()
@@ -146,7 +148,7 @@ def main():
         # several GPUs: plan the shard, all-gather the new trajectories, then every rank propagates all states
         nonlocal seq
         seq += 1
-        if G == 1:
+        if G == 1 and not args.unfused:
             pl.tick_device_fused(states[0], goal, prev, nxt, states[1], cost, status, iters, seq, stream)
             states.reverse()
         else:

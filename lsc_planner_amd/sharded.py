@@ -20,6 +20,8 @@ def all_gather_rows(dist, full, first, count, counts=None):
     """In-place exchange: `full` is [N, ...]; this rank has written rows [first, first+count).
     Equal shards use all_gather_into_tensor (one fused collective); ragged shards fall back to all_gather."""
     import torch
+    if dist is None or not dist.is_initialized():
+        return
     world = dist.get_world_size()
     if world == 1:
         return
