@@ -684,15 +684,6 @@ static void chol_solve(const double *L, int n, double *b)
     }
 }
 
-/* Experimental warm start (used to evaluate the kernel's start-point policy on the CPU): x0 = point to project
- * onto the equality subspace, s = max(slack, sqrt(mu0)), z = mu0 / s.  Disabled when mu0 <= 0. */
-static __thread const double *g_ws_x0 = NULL;
-static __thread double g_ws_mu0 = 0.0;
-static __thread const double *g_ws_z0 = NULL;   /* experimental: dual warm start, [R] in G order (or NULL) */
-static __thread double *g_zout = NULL;          /* experimental: duals out */
-void orc_set_dual_io(const double *z0, double *zout) { g_ws_z0 = z0; g_zout = zout; }
-void orc_set_warm_start(const double *x0, double mu0) { g_ws_x0 = x0; g_ws_mu0 = mu0; }
-
 int orc_qp_solve(const double *P, const double *c, double cst, const double *lo, const double *hi,
                  const orc_row *rows, int nrows, double *x, double *cost, int *iters, double *kkt)
 {
@@ -877,23 +868,6 @@ int orc_qp_solve(const double *P, const double *c, double cst, const double *lo,
     double hmax = 1.0;
     for (int r = 0; r < R; r++) { double a = fabs(G[r].rhs); if (a > hmax) hmax = a; }
 
-    if (g_ws_x0 && g_ws_mu0 > 0.0) {
-        /* y0 = Z'(x0 - xp): orthogonal projection on the equality subspace */
-        for (int a = 0; a < ny; a++) {
-            double t = 0;
-            for (int i = 0; i < NV; i++) t += Z[i * ny + a] * (g_ws_x0[i] - xp[i]);
-            y[a] = t;
-        }
-        X_FROM_Y(y, xx, 1);
-        const double smin = sqrt(g_ws_mu0);
-        for (int r = 0; r < R; r++) {
-            double sl = G[r].rhs - ROWDOT(r, xx);
-            s[r] = sl > smin ? sl : smin;
-            z[r] = g_ws_mu0 / s[r];
-            if (g_ws_z0 && g_ws_z0[r] > z[r]) z[r] = g_ws_z0[r];
-        }
-        goto iterate;
-    }
     /* ---- initial point: least-squares start (H + A'A) y = -g + A'h ---- */
     for (int r = 0; r < R; r++) u[r] = 1.0;
     BUILD_K(u);
@@ -917,7 +891,6 @@ int orc_qp_solve(const double *P, const double *c, double cst, const double *lo,
         if (minz <= 0) for (int r = 0; r < R; r++) z[r] += 1.0 - minz;
     }
 
-iterate:
     for (it = 0; it < 80; it++) {
         X_FROM_Y(y, xx, 1);
         /* residuals */
@@ -1015,7 +988,6 @@ iterate:
     }
 
 done:
-    if (g_zout) memcpy(g_zout, z, sizeof(double) * (size_t)R);
     X_FROM_Y(y, xx, 1);
     memcpy(x, xx, sizeof(double) * NV);
     {
