@@ -30,7 +30,10 @@ namespace {
 constexpr uint32_t KEY_BITS = 17;
 constexpr uint32_t KEY_MASK = (1u << KEY_BITS) - 1u;     // C <= 131071 cells; g (steps) in the upper 15 bits
 constexpr int G_MAX = (1 << (32 - KEY_BITS)) - 1;
-constexpr int ST_OCC = 1, ST_OPEN = 2, ST_CLOSED = 4;    // + parent direction << 3
+// per-cell byte: bits 0-1 state (0 free, 1 occupied, 2 open, 3 closed), bits 2-4 direction of the move that reached
+// the cell (7: none), bits 5-7 g (in steps) modulo 8
+constexpr int ST_FREE = 0, ST_OCC = 1, ST_OPEN = 2, ST_CLOSED = 3;
+__device__ __forceinline__ uint8_t st_open(int dir, int g) { return (uint8_t)(ST_OPEN | (dir << 2) | ((g & 7) << 5)); }
 constexpr int RAY_STACK = 24;
 
 
@@ -400,14 +403,14 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             const int hi = (k == 0 ? c.H : (k == 1 ? c.W : c.A)) - 1;
             s[k] = s[k] < 0 ? 0 : (s[k] > hi ? hi : s[k]);
         }
-        if (c.st[key_of(s[0], s[1], s[2])] & ST_OCC) {
+        if ((c.st[key_of(s[0], s[1], s[2])] & 3) == ST_OCC) {
             int best = 1000000000, bc[3] = {s[0], s[1], s[2]};
             for (int i = -2; i < 3; i++)
                 for (int j = -2; j < 3; j++)
                     for (int k = -1; k < 2; k++) {
                         const int x = s[0] + i, y = s[1] + j, z = s[2] + k;
                         const bool occd = x < 0 || x > c.H - 1 || y < 0 || y > c.W - 1 || z < 0 || z > c.A - 1 ||
-                                          (c.st[key_of(x, y, z)] & ST_OCC);
+                                          ((c.st[key_of(x, y, z)] & 3) == ST_OCC);
                         if (!occd) {
                             const int dist = abs(i) + abs(j) + abs(k);
                             if (dist < best) { best = dist; bc[0] = x; bc[1] = y; bc[2] = z; }
@@ -415,14 +418,14 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                     }
             s[0] = bc[0]; s[1] = bc[1]; s[2] = bc[2];
             wsync();
-            if (lane == 0 && (c.st[key_of(s[0], s[1], s[2])] & ST_OCC)) c.st[key_of(s[0], s[1], s[2])] = 0;
+            if (lane == 0 && (c.st[key_of(s[0], s[1], s[2])] & 3) == ST_OCC) c.st[key_of(s[0], s[1], s[2])] = ST_FREE;
             wsync();
         }
         // ---- ISearch::startSearch
         const uint32_t skey = key_of(s[0], s[1], s[2]);
         row_insert(c, s[0], skey);                            // g = 0
         if (lane == 0) {
-            c.st[skey] = ST_OPEN | (7 << 3);                  // parent code 7: none
+            c.st[skey] = st_open(7, 0);                       // parent code 7: none
             c.rowMin[s[0]] = skey;
             c.rowF[s[0]] = f_of(c, skey);
         }
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             int cj, cz, ci2;
             decode(c, ckey, ci2, cj, cz);
             wsync();
-            if (lane == 0) c.st[ckey] = (uint8_t)((c.st[ckey] & ~ST_OPEN) | ST_CLOSED);
+            if (lane == 0) c.st[ckey] = (uint8_t)(c.st[ckey] | ST_CLOSED);
             row_erase(c, ci, ckey);
             row_rescan(c, ci);
             nopen--;
@@ -467,8 +470,15 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                     sv_l = c.st[nkey_l];
                 }
             }
-            unsigned long long todo = __ballot(nkey_l >= 0 && !(sv_l & (ST_OCC | ST_CLOSED)));
+            // Unseen cells are inserted.  A cell that is already OPEN only matters if the new g is smaller (same cell, same
+            // H).  With a consistent heuristic the popped F never decreases, so an OPEN neighbour has
+            // g_old >= g_cur - 1 step, and it was reached from a cell adjacent to it, so g_old <= g_cur + 3 steps: the
+            // difference g_old - g_new lies in [-2, 2] and its sign can be read from g modulo 8 kept in the cell byte.
             const int ng = cg + 1;
+            const int state_l = (int)(sv_l & 3u);
+            const int gdiff = (int)(((sv_l >> 5) - (uint32_t)ng) & 7u);          // (g_old - g_new) mod 8: 1, 2 -> improvement
+            const bool want = nkey_l >= 0 && (state_l == ST_FREE || (state_l == ST_OPEN && (gdiff == 1 || gdiff == 2)));
+            unsigned long long todo = __ballot(want);
             while (todo) {
                 const int d = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
@@ -480,14 +490,14 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                 uint32_t *row = c.rows + (size_t)ni * c.cap;
                 bool inserted = false;
                 uint32_t stored = ne;                          // the row's entry for this key after addOpen
-                if (sv & ST_OPEN) {                            // addOpen (:243-283): keep the better of the two; same cell,
+                if ((sv & 3u) == ST_OPEN) {                    // addOpen (:243-283): keep the better of the two; same cell,
                     const int p = row_find(c, row, c.rowCnt[ni], nkey);   // same H, so "F smaller" is "g smaller"
                     const uint32_t old = row[p];
                     stored = old;
                     if (ng < (int)(old >> KEY_BITS)) {
                         if (lane == 0) {
                             row[p] = ne;
-                            c.st[nkey] = (uint8_t)(ST_OPEN | (d << 3));
+                            c.st[nkey] = st_open(d, ng);
                         }
                         stored = ne;
                         inserted = true;
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                 } else {
                     row_insert(c, ni, ne);
                     if (c.err) break;
-                    if (lane == 0) c.st[nkey] = (uint8_t)(ST_OPEN | (d << 3));
+                    if (lane == 0) c.st[nkey] = st_open(d, ng);
                     inserted = true;
                     nopen++;
                     wsync();
@@ -535,7 +545,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                 if (n >= path_cap) { n = -1; break; }
                 path[path_cap - 1 - n] = k;
                 n++;
-                const int pd = (c.st[k] >> 3) & 7;
+                const int pd = (c.st[k] >> 2) & 7;
                 if (pd == 7) break;
                 // the move that reached k was direction pd; step back
                 k = pd == 0 ? k + c.W : pd == 5 ? k - c.W : pd == 1 ? k + 1 : pd == 4 ? k - 1 : pd == 2 ? k + c.HW : k - c.HW;
