@@ -71,8 +71,9 @@ typedef struct {
     int    device;             /* HIP device ordinal                                   */
     int    max_rows_per_cp;    /* LDS row capacity per control point; 0 = min(N-1, 64) */
     int    max_iters;          /* interior-point iteration cap; 0 = 50                 */
-    int    prune;              /* 1 (default via lsc_default_config): drop LSC rows that are provably
-                                  redundant inside the reachable box; 0: keep all 27(N-1) rows  */
+    int    prune;              /* 1 (default via lsc_default_config): drop LSC rows that are provably redundant inside
+                                  the box each control point can reach under the velocity AND acceleration rows;
+                                  2: the same with the velocity rows only; 0: keep all 27(N-1) rows */
     int    goal_mode;          /* mode/goal: 0 static (the goal input IS current_goal_position), 1 prior_based: the goal
                                   input is the desired goal and TrajPlanner::goalPlanningWithPriority runs on the
                                   device: fused into the plan kernel on maps without a distance field (where the grid
@@ -82,7 +83,7 @@ typedef struct {
     double priority_dist_threshold; /* plan/priority_dist_threshold 0.4 */
     double goal_radius;        /* plan/goal_radius             2.0 */
     double warm_start_mu;      /* interior-point start: > 0 warm start from the shifted previous plan, every row
-                                  centred on this complementarity value (default 0.1), with the cold (Mehrotra)
+                                  centred on this complementarity value (default 0.05), with the cold (Mehrotra)
                                   start as fallback; 0 = always cold start */
     double grid_resolution;    /* grid/resolution 0.3: cell of the goal planner's search grid (goal_mode 1 + use_octomap) */
     double grid_margin;        /* grid/margin     0.2: a cell is occupied when EDT(centre) < radius + grid_margin        */

@@ -406,6 +406,7 @@ struct Smem {
     double red[6][NWAVE];
     double colbuf[2 * 64];      // Cholesky column broadcast buffer (double-buffered by column parity)
     double sc[8];               // broadcast scalars
+    double gap0;                // complementarity gap at the first iteration of the current start (divergence test)
     // axis rows: slot = type*90 + k*30 + t ; type 0 x<=hi, 1 -x<=-lo, 2/3 +-velocity, 4/5 +-acceleration
     double as_[AXROWS], az[AXROWS], at1[AXROWS], at2[AXROWS], ah[AXROWS];
     unsigned short amap[AXVALID + 2];   // valid slots, compact
@@ -421,6 +422,7 @@ struct Smem {
     double s0[3][3];            // c_{0,0..2} per axis
     double lo[3][M], hi[3][M];  // bounds per axis and segment (world box, intersected with the SFC)
     double goal[3];
+    double reachL[3][28], reachU[3][28];   // per axis: bounds of c_{m,i} - c_{0,2} after K = 5m+i-2 steps (phase B pruning)
     float pinit[NV];            // own initial trajectory (float32)
     int cnt[32];                // rows per control-point bucket
     int offs[32];               // exclusive prefix of cnt over the 27 buckets
@@ -790,6 +792,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                      dlz = a.vmax[3 * qi + 2] * md.hv_scale;   // largest step between consecutive control points
         const int n_units = n_obs * M;
         const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        // Reachable box of every control point relative to c_{0,2}.  Consecutive control points differ by at most
+        // V = vmax dt/n (velocity rows, traj_optimizer.cpp:472-492) and consecutive differences by at most
+        // A = amax dt^2/(n(n-1)) (acceleration rows :494-523; C1/C2 continuity carries both across segment ends), and the
+        // first difference d0 = c_{0,2} - c_{0,1} is fixed by the current state.  Hence after K steps, per axis,
+        //   sum_{j<=K} max(-V, d0 - jA)  <=  c - c_{0,2}  <=  sum_{j<=K} min(V, d0 + jA).
+        if (tid < 3) {
+            const int k = tid;
+            const double V = a.vmax[3 * qi + k] * md.hv_scale, A = a.amax[3 * qi + k] * md.ha_scale;
+            const double d0 = S.s0[k][2] - S.s0[k][1];
+            double lo = 0.0, hi = 0.0;
+            S.reachL[k][0] = 0.0; S.reachU[k][0] = 0.0;
+            for (int j = 1; j < 28; j++) {
+                lo += fmax(-V, d0 - (double)j * A) - 1e-9;
+                hi += fmin(V, d0 + (double)j * A) + 1e-9;
+                S.reachL[k][j] = lo; S.reachU[k][j] = hi;
+            }
+        }
+        __syncthreads();
         for (int base = 0; base < n_units; base += NT) {
             const int u = base + tid;
             const bool live = u < n_units;
@@ -819,8 +839,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     for (int i = 0; i < 6; i++) a.out_d[o * 6 + i] = d[i];
                 }
                 const double nx = (double)nrm.x, ny = (double)nrm.y, nz = (double)nrm.z;
-                const double reach1 = fabs(nx) * dlx + fabs(ny) * dly + fabs(nz) * dlz;
                 const double centre = nx * S.s0[0][2] + ny * S.s0[1][2] + nz * S.s0[2][2];
+                const double (*rx)[28] = nx >= 0.0 ? S.reachL : S.reachU, (*ry)[28] = ny >= 0.0 ? S.reachL : S.reachU,
+                             (*rz)[28] = nz >= 0.0 ? S.reachL : S.reachU;
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     double r = d[i];
@@ -830,8 +851,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     rhs[i] = r;
                     bool on = !(m == 0 && i < 3);
                     if (on && md.prune) {
-                        // every feasible c_{m,i} lies within (5m+i-2) velocity-limited steps of c_{0,2}
-                        double worst = centre - (double)(5 * m + i - 2) * reach1;
+                        // smallest n.c over the reachable box of c_{m,i} (K = 5m+i-2 steps from c_{0,2})
+                        const int K = 5 * m + i - 2;
+                        double worst = centre + nx * rx[0][K] + ny * ry[1][K] + nz * rz[2][K];
+                        if (md.prune == 2) worst = centre - (double)K * (fabs(nx) * dlx + fabs(ny) * dly + fabs(nz) * dlz);   // velocity rows only
                         if (worst >= r + 1e-6) on = false;
                     }
                     actv[i] = on;
@@ -1242,6 +1265,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (tid == 0) { S.sc[5] = gap; S.sc[6] = rpmax; }
                 stamp(PH_P1);
                 if (!(gap == gap) || !(rpmax == rpmax)) failed = true;
+                // Divergence: on an infeasible QP the multipliers run away and the gap grows without bound; a convergent
+                // run never exceeds its starting gap by orders of magnitude.  Stop this start instead of burning the
+                // iteration cap (the cold start still gets its turn, and decides).
+                if (iters == 0) { if (tid == 0) S.gap0 = gap; }
+                else if (gap > 1e8 * S.gap0) failed = true;
             }
         } else if (phase == ST_CORR) {
             // P3: corrector right-hand side  v = w rp - (ds dz - sigma mu)/s
