@@ -185,40 +185,42 @@ __device__ void row_insert(Ctx &c, int i, uint32_t e)
     wsync();
 }
 
-__device__ void row_erase(Ctx &c, int i, uint32_t key)
+// Pop bookkeeping of one row in a single sweep: erase `key` (the entries behind it move up by one) and redo
+// deleteMin's rescan (isearch.cpp:216-240) on what remains: among the entries with the smallest F, the largest g;
+// among those the LAST one in iteration order.
+__device__ void row_pop(Ctx &c, int i, uint32_t key)
 {
     uint32_t *row = c.rows + (size_t)i * c.cap;
     const int cnt = c.rowCnt[i];
-    const int pos = row_find(c, row, cnt, key);
-    for (int lo = pos + 1; lo < cnt; lo += 64) {             // shift (pos, cnt) one to the left, first chunk first
-        const int p = lo + c.lane;
-        const uint32_t v = p < cnt ? row[p] : 0u;
+    int pos = -1;
+    double bf = 1e300;
+    uint32_t bsel = 0, bent = 0;                              // g << 16 | new position, and the entry itself
+    for (int base = 0; base < cnt; base += 64) {
+        const int p = base + c.lane;
+        uint32_t e = p < cnt ? row[p] : 0u;
+        if (pos < 0) {
+            const unsigned long long m = __ballot(p < cnt && (e & KEY_MASK) == key);
+            if (m) pos = base + __ffsll((long long)m) - 1;
+        }
+        const bool moved = pos >= 0 && p >= pos;               // what sits at position p once `key` is gone
+        if (moved) e = p + 1 < cnt ? row[p + 1] : 0u;
+        wsync();                                               // every lane has read its successor before anybody overwrites it
+        if (moved && p < cnt - 1) row[p] = e;
+        if (p < cnt - 1) {
+            const double f = f_of(c, e);
+            const uint32_t sel = ((e >> KEY_BITS) << 16) | (uint32_t)p;
+            if (f < bf || (f == bf && sel >= bsel)) { bf = f; bsel = sel; bent = e; }
+        }
         wsync();
-        if (p < cnt) row[p - 1] = v;
-        wsync();
+    }
+    if (cnt > 1) {
+        const double fmin = wave_min_d(bf);
+        const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
+        const unsigned long long own = __ballot(bf == fmin && bsel == sel);
+        const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)bent, __ffsll((long long)own) - 1);
+        if (c.lane == 0) { c.rowMin[i] = ent; c.rowF[i] = fmin; }
     }
     if (c.lane == 0) c.rowCnt[i] = (uint16_t)(cnt - 1);
-    wsync();
-}
-
-// deleteMin's rescan (isearch.cpp:216-240): among the entries with the smallest F, the largest g; among those the
-// LAST one in iteration order
-__device__ void row_rescan(Ctx &c, int i)
-{
-    const uint32_t *row = c.rows + (size_t)i * c.cap;
-    const int cnt = c.rowCnt[i];
-    if (cnt == 0) return;
-    double bf = 1e300;
-    uint32_t bsel = 0;                                       // g << 16 | position
-    for (int p = c.lane; p < cnt; p += 64) {
-        const uint32_t e = row[p];
-        const double f = f_of(c, e);
-        const uint32_t sel = ((e >> KEY_BITS) << 16) | (uint32_t)p;
-        if (f < bf || (f == bf && sel >= bsel)) { bf = f; bsel = sel; }
-    }
-    const double fmin = wave_min_d(bf);
-    const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
-    if (c.lane == 0) { c.rowMin[i] = row[sel & 0xffffu]; c.rowF[i] = fmin; }
     wsync();
 }
 
@@ -452,8 +454,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             decode(c, ckey, ci2, cj, cz);
             wsync();
             if (lane == 0) c.st[ckey] = (uint8_t)(c.st[ckey] | ST_CLOSED);
-            row_erase(c, ci, ckey);
-            row_rescan(c, ci);
+            row_pop(c, ci, ckey);
             nopen--;
             if (ci == c.gi && cj == c.gj) { found = true; end_key = ckey; break; }   // the altitude is not part of the goal test
             if (cg + 1 > G_MAX) { c.err = 1; break; }
