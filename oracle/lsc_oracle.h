@@ -12,6 +12,13 @@
  *   - QP optimum    : CPLEX 20.1 is proprietary and absent -> PARITY UNPINNED for the
  *                     optimiser itself; the oracle certifies its optimum by KKT
  *                     residuals and is cross-checked against scipy in tests.
+ *   - EDT / SFC     : octomap and dynamicEDT3D are external and absent -> PARITY UNPINNED at
+ *                     the library level (file format and distance semantics restated from
+ *                     their documentation); the box growth follows corridor_constructor.hpp
+ *                     line by line; the reference's simple_forest.bt is the map fixture.
+ *   - goal planning : Astar-3D needs tinyxml2 (absent) -> PARITY UNPINNED; restated in C++ on
+ *                     the same std::unordered_map so that the reference's hash-order
+ *                     tie-breaking is inherited from libstdc++ (lsc_oracle_goal.cpp).
  *
  * Layouts (shared with the product C-ABI so that buffers compare element-wise):
  *   traj   : float  [N][3][M*(n+1)]   axis-major, x[k*30 + m*6 + i]   (M=5, n=5)
