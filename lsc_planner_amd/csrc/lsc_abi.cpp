@@ -206,6 +206,11 @@ struct lsc_ctx {
     int *d_status = nullptr, *d_iters = nullptr;
     float *d_onormal = nullptr;
     double *d_od = nullptr;
+    // host-pointer tick: inputs and outputs travel as ONE copy each, through pinned staging buffers.
+    //   d_state | d_goal | d_prev  are consecutive in one allocation (base d_state),
+    //   d_cost | d_next | d_status | d_iters  in another (base d_cost)
+    float *h_in = nullptr;
+    unsigned char *h_out = nullptr;
     hipStream_t stream = nullptr;
     // kernel timing: one HIP event pair per launch, recorded on the launch stream, read back on query
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[2];
@@ -275,9 +280,11 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
 static void free_agents(lsc_ctx *c)
 {
     void *ptrs[] = {c->d_radius, c->d_radius_obs, c->d_downwash, c->d_downwash_obs, c->d_vmax, c->d_amax, c->d_vnom,
-                    c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_goal, c->d_prev, c->d_next, c->d_cost, c->d_status,
-                    c->d_iters, c->d_onormal, c->d_od};
+                    c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_cost,
+                    c->d_onormal, c->d_od};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->h_in) { (void)hipHostFree(c->h_in); c->h_in = nullptr; }
+    if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
     void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
                   c->d_goal_path, c->d_goal_plen};
     for (void *p : gp) if (p) (void)hipFree(p);
@@ -357,14 +364,21 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMalloc(&c->d_dbg, sizeof(double) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_dbg, 0, sizeof(double) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_state, sizeof(float) * 9 * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_goal, sizeof(float) * 3 * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_prev, sizeof(float) * NV * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_next, sizeof(float) * NV * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_cost, sizeof(double) * (size_t)N));
-    HIPCHK(c, hipMemset(c->d_cost, 0, sizeof(double) * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_status, sizeof(int) * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_iters, sizeof(int) * (size_t)N));
+    {
+        const size_t n = (size_t)N;
+        float *in = nullptr;
+        HIPCHK(c, hipMalloc(&in, sizeof(float) * (9 + 3 + NV) * n));
+        c->d_state = in; c->d_goal = in + 9 * n; c->d_prev = in + 12 * n;
+        unsigned char *out = nullptr;
+        HIPCHK(c, hipMalloc(&out, (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * n));
+        HIPCHK(c, hipMemset(out, 0, (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * n));
+        c->d_cost = reinterpret_cast<double *>(out);
+        c->d_next = reinterpret_cast<float *>(out + sizeof(double) * n);
+        c->d_status = reinterpret_cast<int *>(out + (sizeof(double) + sizeof(float) * NV) * n);
+        c->d_iters = c->d_status + n;
+        HIPCHK(c, hipHostMalloc(&c->h_in, sizeof(float) * (9 + 3 + NV) * n));
+        HIPCHK(c, hipHostMalloc(&c->h_out, (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * n));
+    }
     return build_integrals(c);
 }
 
@@ -619,9 +633,10 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t N = c->N, cnt = c->count, first = c->first, nobs = N - 1;
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->d_state, state, sizeof(float) * 9 * N, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_goal, goal, sizeof(float) * 3 * N, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_prev, prev_traj, sizeof(float) * NV * N, hipMemcpyHostToDevice, st));
+    std::memcpy(c->h_in, state, sizeof(float) * 9 * N);
+    std::memcpy(c->h_in + 9 * N, goal, sizeof(float) * 3 * N);
+    std::memcpy(c->h_in + 12 * N, prev_traj, sizeof(float) * NV * N);
+    HIPCHK(c, hipMemcpyAsync(c->d_state, c->h_in, sizeof(float) * (9 + 3 + NV) * N, hipMemcpyHostToDevice, st));
     PlanArgs a;
     const float *d_goal_in = c->d_goal;
     int rc = run_goal(c, c->d_state, d_goal_in, c->d_prev, planner_seq, st);
@@ -639,14 +654,20 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
     if (rc) return rc;
     rc = run_plan(c, a, st);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out_traj, c->d_next + first * NV, sizeof(float) * NV * cnt, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(out_cost, c->d_cost + first, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(out_status, c->d_status + first, sizeof(int) * cnt, hipMemcpyDeviceToHost, st));
-    if (out_iters) HIPCHK(c, hipMemcpyAsync(out_iters, c->d_iters + first, sizeof(int) * cnt, hipMemcpyDeviceToHost, st));
+    const size_t out_bytes = (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * N;
+    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_cost, out_bytes, hipMemcpyDeviceToHost, st));
     if (out_lsc_normal) HIPCHK(c, hipMemcpyAsync(out_lsc_normal, c->d_onormal, sizeof(float) * 3 * M * nobs * cnt, hipMemcpyDeviceToHost, st));
     if (out_lsc_d) HIPCHK(c, hipMemcpyAsync(out_lsc_d, c->d_od, sizeof(double) * NC * M * nobs * cnt, hipMemcpyDeviceToHost, st));
     if (out_sfc) HIPCHK(c, hipMemcpyAsync(out_sfc, c->d_sfc + first * M * 6, sizeof(float) * M * 6 * cnt, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    {
+        const unsigned char *o = c->h_out;
+        std::memcpy(out_cost, o + sizeof(double) * first, sizeof(double) * cnt);
+        std::memcpy(out_traj, o + sizeof(double) * N + sizeof(float) * NV * first, sizeof(float) * NV * cnt);
+        const unsigned char *si = o + (sizeof(double) + sizeof(float) * NV) * N;
+        std::memcpy(out_status, si + sizeof(int) * first, sizeof(int) * cnt);
+        if (out_iters) std::memcpy(out_iters, si + sizeof(int) * (N + first), sizeof(int) * cnt);
+    }
     return LSC_OK;
 }
 
