@@ -1,0 +1,48 @@
+"""-m gpu: many short random missions (dense and sparse, uniform and heterogeneous agents, both goal modes), every tick
+of every agent against the oracle on the same inputs: equal statuses, cost and control points within the tolerances of
+test_gpu_parity.py.  Catches what single hand-picked missions do not (rare solver failures, warm-start corner cases)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COST_RTOL, COST_ATOL, TRAJ_ATOL = 1e-6, 1e-8, 2e-5
+
+
+def test_random_missions_tick_by_tick(oracle):
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import PlannerConfig, next_state_host
+    rng = np.random.default_rng(123)
+    agent_ticks = 0
+    for trial in range(24):
+        n = int(rng.integers(4, 40))
+        side = float(rng.uniform(2.5, 6.0))
+        ms = L.random_swarm(n, world=(-side, -side, 0, side, side, 2.5), seed=int(rng.integers(1, 1 << 30)), min_sep=0.5, shrink=0.4)
+        if trial % 3 == 0:
+            ms.radius[:] = rng.uniform(0.1, 0.25, n)
+            ms.downwash[:] = rng.uniform(1.0, 2.5, n)
+            ms.max_vel[:] = rng.uniform(0.6, 1.5, (n, 1))
+            ms.max_acc[:] = rng.uniform(1.0, 3.0, (n, 1))
+        mode = "prior_based" if trial % 2 else "static"
+        pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode=mode))
+        prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+        sw = oracle.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+        state = np.zeros((n, 9), np.float32)
+        state[:, :3] = ms.start
+        traj = np.zeros((n, 3, 30), np.float32)
+        stale = np.zeros_like(traj)               # TrajOptimizer::trajectory of every agent (kept on failure)
+        for tick in range(1, 49):
+            g = pl.plan(state, ms.goal, traj)
+            goals = pl.last_goals() if mode == "prior_based" else ms.goal
+            sw.stale[:] = stale
+            o = sw.tick(state, goals, traj, tick, want_lsc=False, nthreads=16)
+            assert np.array_equal(g["status"], o["status"]), (trial, n, tick)
+            ok = o["status"] == 0
+            assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok] + COST_ATOL).all(), (trial, tick)
+            assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL, (trial, tick)
+            stale = np.where(ok[:, None, None], g["traj"], stale).astype(np.float32)
+            traj = g["traj"]
+            state = next_state_host(traj)
+            agent_ticks += n
+        pl.close()
+    assert agent_ticks > 15000
