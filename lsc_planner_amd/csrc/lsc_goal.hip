@@ -220,7 +220,10 @@ __device__ void row_pop(Ctx &c, int i, uint32_t key)
         const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)bent, __ffsll((long long)own) - 1);
         if (c.lane == 0) { c.rowMin[i] = ent; c.rowF[i] = fmin; }
     }
-    if (c.lane == 0) c.rowCnt[i] = (uint16_t)(cnt - 1);
+    if (c.lane == 0) {
+        c.rowCnt[i] = (uint16_t)(cnt - 1);
+        if (cnt == 1) c.rowF[i] = 1e300;                       // empty row: never the minimum
+    }
     wsync();
 }
 
@@ -299,7 +302,12 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
         c.tmp = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.cap;
         c.rows = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.H * c.cap;
         c.rowCnt = reinterpret_cast<uint16_t *>(gsm + off); off += sizeof(uint16_t) * (size_t)c.H;
-        c.rowNb = reinterpret_cast<int16_t *>(gsm + off);
+        c.rowNb = reinterpret_cast<int16_t *>(gsm + off); off += sizeof(int16_t) * (size_t)c.H;
+        off = (off + 3) & ~(size_t)3;
+        int *nbs = reinterpret_cast<int *>(gsm + off); off += sizeof(int) * 16;
+        uint32_t *nbm = reinterpret_cast<uint32_t *>(gsm + off);
+        if (lane < 16) { nbs[lane] = a.nb_seq[lane]; nbm[lane] = a.nb_magic[lane]; }
+        c.nb_seq = nbs; c.nb_magic = nbm;
     }
     const float *pos = a.state + 9 * qi;
     const float *goal_i = a.goal + 3 * qi;
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     int flags = 0, expansions = 0;
     for (int attempt = 0; attempt < 2 && !found && !c.err; attempt++) {
         for (int p = lane; p < c.C; p += 64) c.st[p] = occ_static[p];
-        for (int i = lane; i < c.H; i += 64) { c.rowCnt[i] = 0; c.rowNb[i] = -1; }
+        for (int i = lane; i < c.H; i += 64) { c.rowCnt[i] = 0; c.rowNb[i] = -1; c.rowF[i] = 1e300; c.rowMin[i] = 0; }
         wsync();
         if (attempt == 0) {
             for (int qj = lane; qj < N; qj += 64) {          // updateGridMap, AGENT branch :163-189
@@ -437,23 +445,23 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             expansions++;
             // findMin (:181-209): smallest F over the row minima, then the largest g, then the LAST row
             double bf = 1e300;
-            uint32_t bsel = 0;
+            uint32_t bsel = 0, bent = 0;
             for (int i = lane; i < c.H; i += 64) {
-                if (c.rowCnt[i] == 0) continue;
-                const double f = c.rowF[i];
-                const uint32_t sel = ((c.rowMin[i] >> KEY_BITS) << 16) | (uint32_t)i;
-                if (f < bf || (f == bf && sel >= bsel)) { bf = f; bsel = sel; }
+                const double f = c.rowF[i];                    // 1e300 while the row is empty
+                const uint32_t me = c.rowMin[i];
+                const uint32_t sel = ((me >> KEY_BITS) << 16) | (uint32_t)i;
+                if (f < 1e300 && (f < bf || (f == bf && sel >= bsel))) { bf = f; bsel = sel; bent = me; }
             }
             const double fmin = wave_min_d(bf);
             const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
             const int ci = (int)(sel & 0xffffu);
-            const uint32_t ce = c.rowMin[ci];
+            const unsigned long long owner = __ballot(bf == fmin && bsel == sel);
+            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)bent, __ffsll((long long)owner) - 1);
             const uint32_t ckey = ce & KEY_MASK;
             const int cg = (int)(ce >> KEY_BITS);
             int cj, cz, ci2;
             decode(c, ckey, ci2, cj, cz);
-            wsync();
-            if (lane == 0) c.st[ckey] = (uint8_t)(c.st[ckey] | ST_CLOSED);
+            if (lane == 0) atomicOr(reinterpret_cast<unsigned int *>(c.st + (ckey & ~3u)), (unsigned int)ST_CLOSED << (8u * (ckey & 3u)));
             row_pop(c, ci, ckey);
             nopen--;
             if (ci == c.gi && cj == c.gj) { found = true; end_key = ckey; break; }   // the altitude is not part of the goal test
@@ -625,6 +633,7 @@ size_t goal_smem_bytes(int H, int W, int A, int cap)
     size_t b = ((size_t)H * W * A + 15) & ~(size_t)15;
     b += sizeof(double) * (size_t)H + sizeof(uint32_t) * (size_t)H + sizeof(uint32_t) * (size_t)cap;
     b += sizeof(uint32_t) * (size_t)H * cap + 2 * sizeof(uint16_t) * (size_t)H;
+    b += 4 + 2 * 16 * sizeof(int);                            // bucket-count / magic tables
     return (b + 15) & ~(size_t)15;
 }
 
