@@ -413,6 +413,7 @@ static int build_goal_grid(lsc_ctx *c, const std::vector<double> &radii)
     int cap = W * A;
     while (cap > 16 && goal_smem_bytes(H, W, A, cap) > 158 * 1024) cap--;
     if (goal_smem_bytes(H, W, A, cap) > 158 * 1024) { c->err = "goal planner: search grid does not fit LDS"; return LSC_EINVAL; }
+    if (const char *e = std::getenv("LSC_GOAL_ROW_CAP")) cap = std::max(4, std::min(cap, std::atoi(e)));   // tests: force the overflow path
     c->grid_row_cap = cap;
     // bucket counts of a growing std::unordered_map<uint_least32_t, T> (identity hash), from the container itself
     {

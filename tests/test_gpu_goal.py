@@ -80,3 +80,37 @@ def test_random_mazes_tie_breaking(L, oracle):
         traj = np.zeros((n, 3, 30), np.float32)
         _compare_goal_stage(L, oracle, ms, dm, dist, kmin, res, state, traj, 1, pl, grid_margin=0.05)
         pl.close()
+
+
+def test_open_row_overflow_is_reported_as_status_5(L, monkeypatch):
+    """An OPEN row that outgrows its LDS capacity must surface as LSC_STATUS_GOAL_CAPACITY (stale trajectory kept), never
+    as a silently different goal.  The capacity is forced down through the test hook LSC_GOAL_ROW_CAP."""
+    from maputil import forest_leaves, write_bt
+    import tempfile, os
+    leaves, res = forest_leaves()
+    bt = os.path.join(tempfile.mkdtemp(), "f.bt")
+    write_bt(bt, leaves, res)
+    world = (-5, -5, 0, 5, 5, 2.5)
+    dist, kmin, r = L.edt_from_bt(bt, np.asarray(world[:3], np.float32), np.asarray(world[3:], np.float32))
+    ms = L.random_swarm(16, world=world, seed=4, edt=dist, edt_key_min=kmin, edt_res=r)
+    state = np.zeros((16, 9), np.float32)
+    state[:, :3] = ms.start
+    traj = np.zeros((16, 3, 30), np.float32)
+    ref = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True, goal_mode="prior_based"))
+    ref.load_octomap(bt)
+    g_ref = ref.plan(state, ms.goal, traj)
+    goals_ref = ref.last_goals()
+    ref.close()
+    monkeypatch.setenv("LSC_GOAL_ROW_CAP", "30")
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True, goal_mode="prior_based"))
+    pl.load_octomap(bt)
+    g = pl.plan(state, ms.goal, traj)
+    goals = pl.last_goals()
+    pl.close()
+    over = g["status"] == 5
+    assert over.any() and (~over).any()
+    assert (g_ref["status"] == 0).all()
+    # agents whose search fitted are unaffected; the others keep their stale trajectory (zeros on the first tick)
+    assert np.array_equal(goals[~over], goals_ref[~over])
+    assert np.array_equal(g["traj"][~over], g_ref["traj"][~over])
+    assert (g["traj"][over] == 0).all()
