@@ -101,3 +101,24 @@ def test_tick_with_sfc_rows_on_forest(oracle, forest):
                 pts = t[q, :, m, :] if m > 0 else t[q, :, m, 3:]
                 assert (pts >= lo[:, None] - 1e-5).all() and (pts <= hi[:, None] + 1e-5).all()
         traj = r["traj"]; state = next_state_host(traj)
+
+
+def test_product_bt_reader_rejects_bad_files(tmp_path):
+    """lsc_edt_from_bt is host code: a missing, empty or truncated .bt file is an error code, not a crash or an empty map."""
+    import lsc_planner_amd as L
+    from maputil import forest_leaves, write_bt
+    wmin, wmax = np.asarray((-5, -5, 0), np.float32), np.asarray((5, 5, 2.5), np.float32)
+    with pytest.raises(Exception):
+        L.edt_from_bt(str(tmp_path / "nope.bt"), wmin, wmax)
+    (tmp_path / "empty.bt").write_bytes(b"")
+    with pytest.raises(Exception):
+        L.edt_from_bt(str(tmp_path / "empty.bt"), wmin, wmax)
+    leaves, res = forest_leaves()
+    good = tmp_path / "good.bt"
+    write_bt(str(good), leaves, res)
+    raw = good.read_bytes()
+    (tmp_path / "cut.bt").write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(Exception):
+        L.edt_from_bt(str(tmp_path / "cut.bt"), wmin, wmax)
+    dist, kmin, r = L.edt_from_bt(str(good), wmin, wmax)
+    assert dist.shape == (101, 101, 26) and r == res and (dist == 0).sum() > 0
