@@ -404,7 +404,10 @@ struct Smem {
     double Tz[NCP * 3];         // per control point: -sum z n
     double K[NY * KLD];         // reduced Hessian (lower band); rows of its Cholesky factor after factor()
     double red[6][NWAVE];
-    double colbuf[2 * 64];      // Cholesky column broadcast buffer (double-buffered by column parity)
+    double colbuf[2][2 * 64];   // column broadcast buffers of the two factorising waves (double-buffered by column parity)
+    double mid2[BAND * BAND];   // Schur contribution of the bottom-up sweep to the middle block (original indices)
+    double xch[BAND], xmid[BAND];   // solve: bottom contribution to the middle right-hand side; middle solution
+    double ok2;                 // pivots of the bottom-up sweep all positive
     double sc[8];               // broadcast scalars
     double gap0;                // complementarity gap at the first iteration of the current start (divergence test)
     // axis rows: slot = type*90 + k*30 + t ; type 0 x<=hi, 1 -x<=-lo, 2/3 +-velocity, 4/5 +-acceleration
@@ -487,7 +490,7 @@ __device__ __forceinline__ double rcp_nr(double d)
     y = fma(y, e, y);
     return y;
 }
-template <int J>
+template <int J, int JEND>
 __device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, double &dinv_own, int lane, bool &ok,
                                           double u_p1, const double (&pend_p1)[BAND], double u_p2, const double (&pend_p2)[BAND])
 {
@@ -531,45 +534,49 @@ __device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, dou
         }
     }
     row[J] = u;
-    if constexpr (J + 1 < NY) chol_step<J + 1>(row, colbuf, dinv_own, lane, ok, u, nxt, u_p1, pend_p1);
+    if constexpr (J + 1 < JEND) chol_step<J + 1, JEND>(row, colbuf, dinv_own, lane, ok, u, nxt, u_p1, pend_p1);
     else {
-        // flush: column J-1 may still hold deferred updates (none in practice: its far range is empty at the end)
-        (void)u_p1;
+        // end of this range of pivots: apply the far-column updates of the last two columns that are still deferred
+        if constexpr (J >= 1) {
+            constexpr int P = J - 1;
+            constexpr int PK1 = (P + BAND) < (NY - 1) ? (P + BAND) : (NY - 1);
+#pragma unroll
+            for (int q = 0; q < BAND; q++) {
+                const int k = P + 1 + CHOL_NEAR + q;
+                if (k <= PK1) row[k] = fma(-u_p1, pend_p1[q], row[k]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BAND; q++) {
+            const int k = J + 1 + CHOL_NEAR + q;
+            if (k <= K1) row[k] = fma(-u, nxt[q], row[k]);
+        }
     }
 }
 
-// Triangular solves with the unit-diagonal factor (K = M D M^T): the dependent chain of a substitution step is one
-// v_readlane pair and one fma, no multiply by an inverse pivot.
-//   forward : M u = b ;   v = D^-1 u ;   backward: M^T x = v
-// (rowS / the column chunks are zero on and above the diagonal, so a step is readlane + fma with no lane predicate)
-template <int J>
-__device__ __forceinline__ void fwd_step(const double (&rowS)[NY], double &b)
+// Twisted ("burn at both ends") factorisation: wave 0 eliminates columns 0..13 top-down, wave 1 columns 38..25
+// bottom-up (the same code on the index-reversed matrix), both Schur complements land on the 11x11 middle block
+// [14, 25) which wave 0 then factorises.  K = T D T^T with T unit lower triangular in its first 25 columns and unit
+// upper triangular in its last 14; the dependent chain is 14 + 11 pivots instead of 39.  The substitutions use the
+// same split: 14 steps from both ends in parallel, 11 + 10 in the middle, 13 steps back out in parallel.
+constexpr int TW_A = 14;                 // pivots taken from each end
+constexpr int TW_M1 = NY - TW_A;         // middle block = [TW_A, TW_M1)
+static_assert(TW_M1 - TW_A == BAND, "the middle block must absorb exactly one bandwidth");
+
+template <int J, int JEND>
+__device__ __forceinline__ void fwd_steps(const double (&rowS)[TW_M1], double &b)
 {
     const double bj = bcast_lane<J>(b);
     b = fma(-rowS[J], bj, b);
-    if constexpr (J + 1 < NY) fwd_step<J + 1>(rowS, b);
+    if constexpr (J + 1 < JEND) fwd_steps<J + 1, JEND>(rowS, b);
 }
-
-// Backward sweep: lane j needs column j of M = row j of M^T.  Keeping all 39 entries in registers would cost 78
-// VGPRs per lane for the whole kernel, so they are fetched from the published factor in LDS in three chunks of 13
-// (the loads of a chunk are independent of the dependency chain and are issued together).
-template <int I, int LO>
-__device__ __forceinline__ void bwd_chunk_steps(const double (&c)[13], double &b)
+// backward steps I = HI .. LO: lane i < I gets  b_i -= c[I - LO] * x_I  (c: column entries T[I][lane], zero where absent)
+template <int I, int LO, int CNT>
+__device__ __forceinline__ void bwd_steps(const double (&c)[CNT], double &b)
 {
     const double xi = bcast_lane<I>(b);
     b = fma(-c[I - LO], xi, b);
-    if constexpr (I > LO) bwd_chunk_steps<I - 1, LO>(c, b);
-}
-template <int LO>
-__device__ __forceinline__ void bwd_chunk(const double *K, double &b, int lane)
-{
-    double c[13];
-#pragma unroll
-    for (int q = 0; q < 13; q++) {
-        const int i = LO + q;
-        c[q] = (lane < NY && i > lane && i - lane <= BAND) ? K[i * KLD + lane] : 0.0;   // M[i][lane], strictly below the diagonal
-    }
-    bwd_chunk_steps<LO + 12, LO>(c, b);
+    if constexpr (I > LO) bwd_steps<I - 1, LO, CNT>(c, b);
 }
 
 // phase stamps (PROF variant only): cycles of lane 0 spent per phase, accumulated per agent
@@ -1103,36 +1110,120 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // The factor lives in LDS (S.K, unit-diagonal M = L D^-1, lower band) between phases; registers hold it only inside
     // factor() and solve(), so the row passes and reductions in between keep the whole register budget.
     auto factor = [&]() -> bool {
-        if (wave == 0) {
+        constexpr int RV = NY - 1;
+        double lrow[NY];          // lane = row, register = column (wave 1: of the index-reversed matrix)
+        bool ok = true;
+        const double pend0[BAND] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (wave < 2) {
             const bool act = lane < NY;
-            double lrow[NY];      // lane = row, register = column
+            if (wave == 0) {
 #pragma unroll
-            for (int j = 0; j < NY; j++) lrow[j] = (act && j <= lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
-            // (updates run on whole register rows; only the part left of the diagonal is meaningful afterwards)
-            bool ok = true;
+                for (int j = 0; j < NY; j++) lrow[j] = (act && j <= lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
+            } else {
+                // K'[r][c] = K[RV-c][RV-r]; the middle block (and what lies beyond it) starts at zero: it only collects
+                // the Schur updates of this sweep
+#pragma unroll
+                for (int j = 0; j < NY; j++)
+                    lrow[j] = (act && j <= lane && lane - j <= BAND && j < TW_A) ? S.K[(RV - j) * KLD + (RV - lane)] : 0.0;
+            }
             dinv_own = 0.0;
-            const double pend0[BAND] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            chol_step<0>(lrow, S.colbuf, dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
+            chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
+            if (wave == 1) {
+                if (lane >= TW_A && lane < TW_M1) {
 #pragma unroll
-            for (int j = 0; j < NY; j++)
-                if (act && j <= lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
-            if (lane == 0) S.sc[7] = ok ? 1.0 : 0.0;
+                    for (int c = TW_A; c < TW_M1; c++)
+                        if (c <= lane) S.mid2[(RV - c - TW_A) * BAND + (RV - lane - TW_A)] = lrow[c];
+                }
+                if (lane == 0) S.ok2 = ok ? 1.0 : 0.0;
+            }
         }
         __syncthreads();
-        return S.sc[7] != 0.0;
+        if (wave == 0) {
+            if (lane >= TW_A && lane < TW_M1) {
+#pragma unroll
+                for (int k = TW_A; k < TW_M1; k++)
+                    if (k <= lane) lrow[k] += S.mid2[(lane - TW_A) * BAND + (k - TW_A)];
+            }
+            if (lane >= TW_M1) {
+#pragma unroll
+                for (int k = TW_A; k < TW_M1; k++) lrow[k] = 0.0;      // rows below the middle block belong to the other sweep
+            }
+            chol_step<TW_A, TW_M1>(lrow, S.colbuf[0], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
+#pragma unroll
+            for (int j = 0; j < TW_M1; j++)
+                if (lane < TW_M1 && j < lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
+            if (lane == 0) S.sc[7] = ok ? 1.0 : 0.0;
+        } else if (wave == 1) {
+            // multipliers of the bottom-up sweep, reversed (r, c) -> original (RV-r, RV-c), kept at the mirrored band position
+#pragma unroll
+            for (int c = 0; c < TW_A; c++)
+                if (lane < TW_M1 && c < lane && lane - c <= BAND) S.K[(RV - c) * KLD + (RV - lane)] = lrow[c];
+        }
+        __syncthreads();
+        return S.sc[7] != 0.0 && S.ok2 != 0.0;
     };
     auto solve = [&]() {
-        if (wave == 0) {
-            double rowS[NY];      // strictly lower part of M, zeros elsewhere: substitution steps need no lane predicate
+        constexpr int RV = NY - 1;
+        double b = 0.0;
+        if (wave < 2) {
+            // forward, 14 steps from each end.  rowS: this lane's multipliers (zeros elsewhere, so no lane predicates)
+            double rowS[TW_M1];
+            if (wave == 0) {
 #pragma unroll
-            for (int j = 0; j < NY; j++) rowS[j] = (lane < NY && j < lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
-            double b = lane < NY ? S.rhs[lane] : 0.0;
-            fwd_step<0>(rowS, b);
-            b *= dinv_own;      // D^-1
-            bwd_chunk<26>(S.K, b, lane);
-            bwd_chunk<13>(S.K, b, lane);
-            bwd_chunk<0>(S.K, b, lane);
-            if (lane < NY) S.dy[lane] = b;
+                for (int j = 0; j < TW_M1; j++) rowS[j] = (lane < TW_M1 && j < lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
+            } else {
+#pragma unroll
+                for (int j = 0; j < TW_M1; j++)
+                    rowS[j] = (lane < TW_M1 && j < TW_A && j < lane && lane - j <= BAND) ? S.K[(RV - j) * KLD + (RV - lane)] : 0.0;
+            }
+            const double b_in = lane < NY ? S.rhs[wave == 0 ? lane : RV - lane] : 0.0;
+            b = b_in;
+            fwd_steps<0, TW_A>(rowS, b);
+            if (wave == 1) {
+                if (lane >= TW_A && lane < TW_M1) S.xch[RV - lane - TW_A] = b - b_in;   // what the bottom sweep takes off the middle rhs
+                b *= dinv_own;                                                          // D^-1 of its own 14 unknowns
+            }
+            __syncthreads();
+            if (wave == 0) {
+                if (lane >= TW_A && lane < TW_M1) b += S.xch[lane - TW_A];
+                fwd_steps<TW_A, TW_M1>(rowS, b);
+                b *= dinv_own;
+                // middle block, backward: lanes 14..23 need column entries T[I][lane], I = 15..24
+                double cm[BAND - 1];
+#pragma unroll
+                for (int q = 0; q < BAND - 1; q++) {
+                    const int I = TW_A + 1 + q;
+                    cm[q] = (lane >= TW_A && lane < I) ? S.K[I * KLD + lane] : 0.0;
+                }
+                bwd_steps<TW_M1 - 1, TW_A + 1, BAND - 1>(cm, b);
+                if (lane >= TW_A && lane < TW_M1) S.xmid[lane - TW_A] = b;
+            }
+            __syncthreads();
+            // back out: the middle solution enters the outer unknowns as eleven independent terms, then 13 dependent steps
+            {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < BAND; q++) {
+                    const int Im = TW_A + q;                     // middle index in this wave's own numbering
+                    const double coef = (lane < TW_A && Im - lane <= BAND)
+                                            ? (wave == 0 ? S.K[Im * KLD + lane] : S.K[(RV - lane) * KLD + (RV - Im)]) : 0.0;
+                    const double xm = S.xmid[wave == 0 ? q : BAND - 1 - q];
+                    acc = fma(coef, xm, acc);
+                }
+                if (lane < TW_A) b -= acc;
+                double co[TW_A - 1];
+#pragma unroll
+                for (int q = 0; q < TW_A - 1; q++) {
+                    const int I = 1 + q;
+                    co[q] = (lane < I && I - lane <= BAND) ? (wave == 0 ? S.K[I * KLD + lane] : S.K[(RV - lane) * KLD + (RV - I)]) : 0.0;
+                }
+                bwd_steps<TW_A - 1, 1, TW_A - 1>(co, b);
+            }
+            if (wave == 0) { if (lane < TW_M1) S.dy[lane] = b; }
+            else if (lane < TW_A) S.dy[RV - lane] = b;
+        } else {
+            __syncthreads();
+            __syncthreads();
         }
         __syncthreads();
         compute_x(S.dy, S.dx, false);
