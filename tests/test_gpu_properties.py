@@ -207,3 +207,29 @@ def test_fused_single_launch_tick_equals_host_buffer_ticks(L):
         assert np.array_equal(s0.cpu().numpy(), state_h), seq
         assert np.array_equal(cost.cpu().numpy(), g["cost"]), seq
     h.close(); d.close()
+
+
+def test_ticks_are_deterministic_across_contexts_and_runs(L):
+    """Same inputs -> bit-identical plans, costs and iteration counts, from a fresh context and on a repeated call (no
+    atomics or launch-order dependence anywhere on the path; the tie rules of the reductions are fixed)."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(48, 5.0)
+    runs = []
+    for rep in range(2):
+        pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))
+        state = np.zeros((48, 9), np.float32); state[:, :3] = ms.start
+        traj = np.zeros((48, 3, 30), np.float32)
+        out = []
+        for tick in range(30):
+            g = pl.plan(state, ms.goal, traj)
+            if tick == 10:
+                pl.planner_seq -= 1
+                g2 = pl.plan(state, ms.goal, traj)             # the same tick again on the same context
+                assert np.array_equal(g["traj"], g2["traj"]) and np.array_equal(g["cost"], g2["cost"])
+                assert np.array_equal(g["iters"], g2["iters"])
+            out.append((g["traj"].copy(), g["cost"].copy(), g["iters"].copy()))
+            traj = g["traj"]; state = next_state_host(traj)
+        pl.close()
+        runs.append(out)
+    for a, b in zip(*runs):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
