@@ -233,3 +233,33 @@ def test_ticks_are_deterministic_across_contexts_and_runs(L):
         runs.append(out)
     for a, b in zip(*runs):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_1024_agent_mission_against_the_oracle(L, oracle):
+    """BASELINE configs[4] at full size over a stretch of the mission (mode/goal prior_based): statuses equal, plans within
+    tolerance at checkpoints (the oracle runs the 1024 QPs of a tick on all host cores in ~0.2 s)."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.random_swarm(1024, seed=20260929)
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))
+    prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+    sw = oracle.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+    state = np.zeros((1024, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((1024, 3, 30), np.float32)
+    stale = np.zeros_like(traj)
+    for tick in range(1, 61):
+        g = pl.plan(state, ms.goal, traj)
+        if tick in (1, 2, 15, 30, 60):
+            sw.stale[:] = stale
+            o = sw.tick(state, pl.last_goals(), traj, tick, want_lsc=False, nthreads=32)
+            assert np.array_equal(g["status"], o["status"]), tick
+            ok = o["status"] == 0
+            # absolute floor: both solvers stop at a primal residual of 1e-9 * (world extent = 20 m), which moves a
+            # near-zero cost of an agent that has almost arrived by a few 1e-8
+            dc = np.abs(g["cost"] - o["cost"])[ok]
+            bad = dc > 1e-6 * np.abs(o["cost"])[ok] + 1e-7
+            assert not bad.any(), (tick, dc[bad], o["cost"][ok][bad], g["iters"][ok][bad])
+            assert np.abs(g["traj"] - o["traj"]).max() <= 2e-5, tick
+        stale = np.where((g["status"] == 0)[:, None, None], g["traj"], stale).astype(np.float32)
+        traj = g["traj"]
+        state = next_state_host(traj)
+    pl.close()
