@@ -1248,7 +1248,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // with the cold start as fallback; cold only otherwise.
     enum { ST_COLD = 0, ST_PRED = 1, ST_CORR = 2 };
     int phase = ST_PRED, attempt = md.ws_mu0 > 0.0 ? 0 : 1, spent = 0;
-    double alpha = 1.0, gap = 0.0, rpmax = 0.0, mu = 0.0, smu = 0.0;
+    double alpha = 1.0, gap = 0.0, rpmax = 0.0, mu = 0.0, smu = 0.0, tau = 0.99;
     bool gap_ok = false;
     const int max_iters = md.max_iters;
 
@@ -1473,6 +1473,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
                 sigma = sigma * sigma * sigma;
                 smu = sigma * mu;
+                tau = fmin(1.0 - 1e-5, fmax(0.99, aaff));
                 if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) {
                     double *tr = a.trace + iters * 8;
                     tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = aaff; tr[4] = sigma; tr[6] = S.sc[3]; tr[7] = mu;
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     rt1[r] = ds; rt2[r] = dz;
                 }
                 block_reduce(amin, 0.0, 0.0, 0.0, 0.0, 2, 0, 0, 0, 0);
-                alpha = fmin(1.0, 0.99 * S.sc[0]);
+                alpha = fmin(1.0, tau * S.sc[0]);
                 if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) a.trace[iters * 8 + 5] = alpha;
                 if (tid < NY) S.y[tid] += alpha * S.dy[tid];
                 __syncthreads();
