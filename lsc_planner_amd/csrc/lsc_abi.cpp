@@ -162,6 +162,8 @@ void build_model(const lsc_config &cfg, HostModel &H)
     if (n != 414) { std::fprintf(stderr, "lsc: axis row count %d != 414\n", n); std::abort(); }
     if (const char *e = std::getenv("LSC_DX_TOL")) m.dx_tol = std::atof(e);
     if (const char *e = std::getenv("LSC_WS_MU0")) m.ws_mu0 = std::atof(e);
+    m.sigma_pow = 3;
+    if (const char *e = std::getenv("LSC_SIGMA_POW")) m.sigma_pow = std::atoi(e);
 }
 
 }  // namespace

@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const double aaff = S.sc[0];
                 const double mu_aff = (gap + aaff * S.sc[1] + aaff * aaff * S.sc[2]) / nrow;
                 double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
-                sigma = sigma * sigma * sigma;
+                sigma = md.sigma_pow == 2 ? sigma * sigma : (md.sigma_pow == 4 ? (sigma * sigma) * (sigma * sigma) : sigma * sigma * sigma);
                 smu = sigma * mu;
                 tau = fmin(1.0 - 1e-5, fmax(0.99, aaff));
                 if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) {
