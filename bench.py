@@ -34,11 +34,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def pmc_traffic(key):
-    """HBM-side traffic per launch (bytes) from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary_v7.json,
+    """HBM-side traffic per launch (bytes) from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary_v8.json,
     made by profiles/summarize_rocpd.py): FETCH_SIZE + WRITE_SIZE, raw counter values in KB (see the file for the
     calibration caveat and for what the plan kernel's write traffic consists of).  None when absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_v7.json")))["kernels"][key]
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_v8.json")))["kernels"][key]
         return int((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
     except Exception:
         return None
