@@ -9,15 +9,19 @@ pytestmark = pytest.mark.gpu
 COST_RTOL, COST_ATOL, TRAJ_ATOL = 1e-6, 1e-8, 2e-5
 
 
-def test_random_missions_tick_by_tick(oracle):
+@pytest.mark.parametrize("dense", [False, True])
+def test_random_missions_tick_by_tick(oracle, dense):
+    """dense=True packs the agents so tightly that many QPs are infeasible: the failure verdicts (status 1, stale
+    trajectory kept) must be the oracle's too."""
     import lsc_planner_amd as L
     from lsc_planner_amd.planner import PlannerConfig, next_state_host
-    rng = np.random.default_rng(123)
-    agent_ticks = 0
+    rng = np.random.default_rng(123 + int(dense))
+    agent_ticks = failures = 0
     for trial in range(24):
-        n = int(rng.integers(4, 40))
-        side = float(rng.uniform(2.5, 6.0))
-        ms = L.random_swarm(n, world=(-side, -side, 0, side, side, 2.5), seed=int(rng.integers(1, 1 << 30)), min_sep=0.5, shrink=0.4)
+        n = int(rng.integers(8, 28)) if dense else int(rng.integers(4, 40))
+        side = float(rng.uniform(1.0, 1.8)) if dense else float(rng.uniform(2.5, 6.0))
+        ms = L.random_swarm(n, world=(-side, -side, 0, side, side, 2.5), seed=int(rng.integers(1, 1 << 30)),
+                            min_sep=0.33 if dense else 0.5, shrink=0.15 if dense else 0.4)
         if trial % 3 == 0:
             ms.radius[:] = rng.uniform(0.1, 0.25, n)
             ms.downwash[:] = rng.uniform(1.0, 2.5, n)
@@ -38,6 +42,7 @@ def test_random_missions_tick_by_tick(oracle):
             o = sw.tick(state, goals, traj, tick, want_lsc=False, nthreads=16)
             assert np.array_equal(g["status"], o["status"]), (trial, n, tick)
             ok = o["status"] == 0
+            failures += int((~ok).sum())
             assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok] + COST_ATOL).all(), (trial, tick)
             assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL, (trial, tick)
             stale = np.where(ok[:, None, None], g["traj"], stale).astype(np.float32)
@@ -46,6 +51,7 @@ def test_random_missions_tick_by_tick(oracle):
             agent_ticks += n
         pl.close()
     assert agent_ticks > 15000
+    assert (failures > 100) == dense
 
 
 def test_random_octomap_worlds_full_tick(oracle):
