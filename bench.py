@@ -13,7 +13,10 @@ Workload (config.workload): BASELINE.json configs[2], the 64-agent circle swap o
 prior_based: goalPlanningWithPriority runs on the device; on maps without a distance field the reference's grid A*
 has no observable effect on the planned goal).
 With --gpus G the swarm is 64*G agents on a circle of radius 8*G (same spacing), agent-sharded 64 per GPU with one
-all-gather of the new trajectories per tick: weak scaling.
+in-place RCCL all-gather of the new trajectories per tick (native: lsc_tick_device_sharded enqueues plan kernel,
+ncclAllGather and state propagation on one stream): weak scaling.  `python bench.py --gpus G` starts the G ranks itself
+(re-executes under torch.distributed.run when WORLD_SIZE is not set); torch.distributed is only the control plane
+(rendezvous token, barrier, max-over-ranks of the elapsed time).
 
 One JSON line on rank 0 with `roofline` (plan kernel), `roofline_sweep` (dense LSC sweep, HBM-bound) and
 `cpu_baseline` (the oracle = CPU restatement of the reference path, timed on this box's host cores).
@@ -33,15 +36,20 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (guide: half the 157.3 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+PMC_FILE = "profiles/r02_pmc_summary.json"
+
+
 def pmc_traffic(key):
-    """HBM-side traffic per launch (bytes) from the committed rocprofv3 PMC passes (profiles/r01_pmc_summary_v8.json,
-    made by profiles/summarize_rocpd.py): FETCH_SIZE + WRITE_SIZE, raw counter values in KB (see the file for the
-    calibration caveat and for what the plan kernel's write traffic consists of).  None when absent."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary_v8.json")))["kernels"][key]
-        return int((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024)
-    except Exception:
-        return None
+    """HBM-side traffic per launch (bytes).  NOT measured by this run: hardware counters need rocprofv3, so the
+    value is read from the committed PMC passes of this same command (PMC_FILE, made by profiles/summarize_rocpd.py;
+    FETCH_SIZE + WRITE_SIZE, raw counter values in KB); the bench line says so in `traffic_source`.  None when absent."""
+    for f in (PMC_FILE, "profiles/r01_pmc_summary_v8.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, f)))["kernels"][key]
+            return int((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024), f
+        except Exception:
+            continue
+    return None, None
 
 
 def algorithmic_flops(n_agents, iters_total):
@@ -100,40 +108,66 @@ def main():
                     help="extra leg: dense LSC sweep at this swarm size (HBM-meaningful working set); 0 = skip")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU (same command line the driver uses)
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner through C
+    # stdio when a communicator is created), so file descriptor 1 is pointed at stderr for the whole run and the JSON line
+    # goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     import lsc_planner_amd as L
-    from lsc_planner_amd.sharded import shard_bounds, all_gather_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    G = max(world, 1)
+    if args.gpus != G:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={G}: launch with --nproc-per-node {args.gpus} "
+                         "(or run `python bench.py --gpus N`, which starts the ranks itself)")
+    token = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    G = max(world, 1)
-    if args.gpus != G and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={G}; using {G}", file=sys.stderr)
+        box = [L.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)           # control plane only: the rendezvous token of the native communicator
+        token = box[0]
+    elif args.unfused:
+        token = L.comm_unique_id()                       # world-size-1 communicator: the same code path on one GPU
+    sharded = token is not None
 
     n_agents = args.agents_per_gpu * G
     R = 8.0 * n_agents / 64.0
     ms = L.circle_swap(n_agents, circle_radius=R, z=1.0, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
     goal_mode = "static" if args.static_goal else "prior_based"
-    pl = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode))
-    first, count = shard_bounds(n_agents, G, rank)
-    counts = [shard_bounds(n_agents, G, r)[1] for r in range(G)]
-    pl.set_shard(first, count)
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode,
+                                            comm=(G, rank, token) if sharded else None))
+    first, count, rows = pl.first, pl.count, pl.table_rows      # rank's block of the (padded) trajectory table
 
     f32 = dict(dtype=torch.float32, device=dev)
     state = torch.zeros((n_agents, 9), **f32)
     state[:, :3] = torch.from_numpy(ms.start).to(dev)
     goal = torch.from_numpy(ms.goal).to(dev).contiguous()
-    traj_a = torch.zeros((n_agents, 90), **f32)
-    traj_b = torch.zeros((n_agents, 90), **f32)
+    traj_a = torch.zeros((rows, 90), **f32)
+    traj_b = torch.zeros((rows, 90), **f32)
     cost = torch.zeros(n_agents, dtype=torch.float64, device=dev)
     status = torch.zeros(n_agents, dtype=torch.int32, device=dev)
     iters = torch.zeros(n_agents, dtype=torch.int32, device=dev)
@@ -148,13 +182,11 @@ def main():
         # several GPUs: plan the shard, all-gather the new trajectories, then every rank propagates all states
         nonlocal seq
         seq += 1
-        if G == 1 and not args.unfused:
+        if not sharded:
             pl.tick_device_fused(states[0], goal, prev, nxt, states[1], cost, status, iters, seq, stream)
             states.reverse()
         else:
-            pl.tick_device(states[0], goal, prev, nxt, cost, status, iters, seq, stream)
-            all_gather_rows(dist, nxt, first, count, counts)
-            pl.propagate_device(nxt, states[0], stream)
+            pl.tick_device_sharded(states[0], goal, prev, nxt, cost, status, iters, seq, stream)
 
     def sync():
         if G > 1:
@@ -177,9 +209,10 @@ def main():
     elapsed = time.perf_counter() - t0
     k_ms, k_n = pl.kernel_time_ms(0)
     k_all = pl.kernel_times_ms(0)
+    x_all = pl.kernel_times_ms(2) if sharded else np.zeros(0)
     iters_total = pl.iterations_total(reset=False)
     bad = int((status[first:first + count] != 0).sum().item())
-    rows = pl.row_counts()[first:first + count]
+    lrows = pl.row_counts()[first:first + count]
     pl.set_timing(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     it_t = torch.tensor([float(iters_total)], dtype=torch.float64, device=dev)
@@ -194,6 +227,7 @@ def main():
         value = n_agents * args.steps / elapsed
         flops = algorithmic_flops(n_agents, iters_total / G) / max(k_n, 1)   # per launch of this rank's kernel
         ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("lsc_plan_kernel@grid32768") if n_agents == 64 else (None, None)
         result = {
             "metric": "agent-replans/sec (whole node)", "value": round(value, 1), "unit": "agent-replans/s",
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -203,19 +237,32 @@ def main():
                               "note": "device time of the per-tick launch (HIP events, rank 0) over the timed steps"},
             "config": {"workload": f"{n_agents}-agent generated circle swap (R={R:g} m, z=1 m), empty map, LSC mode, "
                                    f"dt 0.2 s, M=5 n=5, mode/goal={goal_mode}, {args.agents_per_gpu} agents per GPU, "
-                                   "device-resident ticks (one fused launch per tick: goal planning + LSC + QP + state propagation"
-                                   + (", RCCL all-gather of trajectories per tick)" if G > 1 else ")"),
+                                   "device-resident ticks ("
+                                   + ("plan kernel -> in-place RCCL all-gather of the new trajectories -> state propagation, "
+                                      "one stream, per tick)" if sharded else
+                                      "one fused launch per tick: goal planning + LSC + QP + state propagation)"),
                        "agents": n_agents, "parallelism": f"agent-shard x{G}", "prune_redundant_rows": not args.no_prune},
             "qp": {"mean_ip_iterations": round(iters_total / (n_agents * args.steps), 2), "failed_agents_last_tick": bad,
-                   "active_lsc_rows_last_tick_mean": float(np.mean(rows)), "active_lsc_rows_last_tick_max": int(np.max(rows)),
+                   "active_lsc_rows_last_tick_mean": float(np.mean(lrows)), "active_lsc_rows_last_tick_max": int(np.max(lrows)),
                    "reference_rows_per_agent": 27 * (n_agents - 1)},
             "roofline": {"kernel": "lsc_plan_kernel", "bound": "valu_fp64", "achieved": round(ach, 5),
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_VALU_PEAK_TFLOPS, 7),
-                         "traffic": pmc_traffic("lsc_plan_kernel@grid32768") if n_agents == 64 else None,
+                         "traffic": traffic,
+                         "traffic_source": (f"not measured in this run: rocprofv3 --pmc passes of this command, {traffic_src}"
+                                            if traffic is not None else None),
                          "avg_launch_ms": round(k_ms, 5), "launches": k_n,
+                         "executed_rows_mean": float(np.mean(lrows)),
                          "note": "latency-bound: one 512-lane workgroup per agent; algorithmic flops = IP iterations x "
-                                 "((N-1) kflop + 0.3 Mflop) per SURVEY 8(d); neither HBM nor MFMA bounds this kernel"},
+                                 "((N-1) kflop + 0.3 Mflop) per SURVEY 8(d), which charges all 27(N-1) LSC rows although the "
+                                 "kernel executes only the non-redundant ones (executed_rows_mean, last tick); neither HBM nor "
+                                 "MFMA bounds this kernel"},
         }
+        if sharded:
+            result["rccl"] = {"world_size": G, "native": True, "collective": "ncclAllGather, in place, on the tick's stream",
+                              "bytes_per_rank_per_tick": pl.shard_rows * 360,
+                              "exchange_us_per_tick": {"mean": round(1e3 * float(x_all.mean()), 2) if len(x_all) else None,
+                                                       "p99": round(1e3 * float(np.percentile(x_all, 99)), 2) if len(x_all) else None},
+                              "note": "HIP events around the all-gather on rank 0 (includes waiting for the slowest rank's plan kernel)"}
 
     # ---- dense LSC sweep kernel (the HBM-class stage of SURVEY 8(d)): N(N-1)*180 B written per launch
     nobs = n_agents - 1
@@ -237,7 +284,7 @@ def main():
         result["roofline_sweep"] = {"kernel": "lsc_sweep_kernel", "bound": "hbm",
                                     "achieved": round(alg / (s_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                    "traffic": pmc_traffic("lsc_sweep_kernel@grid20224") if n_agents == 64 else None,
+                                    "traffic": pmc_traffic("lsc_sweep_kernel@grid20224")[0] if n_agents == 64 else None,
                                     "avg_launch_ms": round(s_ms, 5), "bytes_written_per_launch": wr,
                                     "algorithmic_bytes_per_launch": alg,
                                     "note": "N(N-1)*180 B + N*404 B per SURVEY 8(d); at this N the working set is "
@@ -271,7 +318,7 @@ def main():
         result["roofline_sweep_large"] = {"kernel": "lsc_sweep_kernel", "agents": n2, "bound": "hbm",
                                           "achieved": round(alg2 / (ms_l * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": round(alg2 / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                          "traffic": pmc_traffic("lsc_sweep_kernel@grid524288") if n2 == 1024 else None,
+                                          "traffic": pmc_traffic("lsc_sweep_kernel@grid524288")[0] if n2 == 1024 else None,
                                           "avg_launch_ms": round(ms_l, 4), "algorithmic_bytes_per_launch": alg2,
                                           "bytes_written_per_launch": wr2,
                                           "written_GBps": round(wr2 / (ms_l * 1e-3) / 1e9, 2),
@@ -297,6 +344,9 @@ def main():
         result["latency_host_abi_ms"] = {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),
                                          "ticks": len(lat), "agent_replans_per_s": round(n_agents / (np.median(lat) * 1e-3), 1),
                                          "note": "lsc_replan_tick: host buffers in/out, PCIe-inclusive, synchronous"}
+        # SURVEY 8(d) defines the per-tick solve time PCIe-inclusive: promote it next to the device-resident numbers
+        result["p99_tick_ms"] = {"host_abi_pcie_inclusive": result["latency_host_abi_ms"]["p99"],
+                                 "device_resident": result["tick_solve_ms"]["p99"]}
         pl2.close()
 
     if rank == 0 and G == 1 and not args.no_cpu_baseline:
@@ -305,7 +355,8 @@ def main():
         result["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(result))
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
     pl.close()
     if G > 1:
         dist.barrier()

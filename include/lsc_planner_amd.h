@@ -46,12 +46,14 @@ extern "C" {
 #define LSC_ENOMEM (-3)
 #define LSC_EHIP (-4)     /* HIP runtime error, see lsc_last_error()                   */
 #define LSC_ESTATE (-5)   /* call order (e.g. tick before set_agents)                  */
+#define LSC_ECOMM (-6)    /* RCCL error / librccl.so not loadable, see lsc_last_error() */
 
 /* per-agent status written by a tick (PlanningReport analogue, include/sp_const.hpp) */
 #define LSC_STATUS_OK 0          /* QP solved, trajectory replaced                                       */
 #define LSC_STATUS_INFEASIBLE 1  /* solver failed: optimiser's previous trajectory kept, like the reference
                                     (exception swallowed, src/traj_planner.cpp:1553-1584)                */
-#define LSC_STATUS_CAPACITY 3    /* more active LSC rows than the configured LDS row capacity            */
+/* (3 was "more LSC rows than the LDS row capacity" in round 1: such agents are now solved by a second pass with their
+ *  rows in HBM, so the code no longer reaches the caller)                                                  */
 #define LSC_STATUS_SFC_BLOCKED 4 /* seed box of the corridor touches an obstacle (the reference throws
                                     std::invalid_argument, corridor_constructor.hpp:35-38): stale trajectory kept */
 #define LSC_STATUS_GOAL_CAPACITY 5 /* the goal planner's search outgrew its LDS capacity (OPEN row / path / ray stack):
@@ -69,7 +71,9 @@ typedef struct {
     int    use_octomap;        /* world/use_octomap: adds the SFC rows                 */
     double world_resolution;   /* world/resolution (0.1)                               */
     int    device;             /* HIP device ordinal                                   */
-    int    max_rows_per_cp;    /* LDS row capacity per control point; 0 = min(N-1, 64) */
+    int    max_rows_per_cp;    /* LDS row capacity per control point of the first pass; 0 = min(N-1, 64) (lowered further if
+                                  the 160 KB LDS of a workgroup demands it).  Not a limit of the problem: an agent with more
+                                  rows is re-planned by the second pass with all its 27(N-1) rows in HBM */
     int    max_iters;          /* interior-point iteration cap; 0 = 50                 */
     int    prune;              /* 1 (default via lsc_default_config): drop LSC rows that are provably redundant inside
                                   the box each control point can reach under the velocity AND acceleration rows;
@@ -148,6 +152,38 @@ int lsc_tick_device_fused(lsc_ctx *ctx, const float *d_state, const float *d_goa
                           int planner_seq, float *d_traj_next, float *d_state_next, double *d_cost, int *d_status,
                           int *d_iters, void *hip_stream);
 
+/* ---- agent-sharded multi-GPU: one context (= one process, one GPU) per rank ---------------------
+ * The reference's exchange point is MultiSyncSimulator::update (src/multi_sync_simulator.cpp:297-303), where every
+ * agent receives every other agent's previous trajectory.  With the swarm partitioned over `world_size` ranks that
+ * hand-over is ONE RCCL all-gather per tick, in place on the trajectory table (xGMI on a node).  The table is padded to
+ * table_rows = shard_rows * world_size rows, shard_rows = ceil(N / world_size); rank r plans agents
+ * [r*shard_rows, min((r+1)*shard_rows, N)) -- the trailing ranks of a ragged split own fewer (possibly zero) agents.
+ *
+ *   lsc_comm_unique_id : rank 0 creates the rendezvous token (ncclGetUniqueId) and ships it to the other ranks by any
+ *                        means (a file, MPI, torch.distributed's store ...)
+ *   lsc_comm_init      : collective over all ranks, between lsc_create and lsc_set_agents (which then sets the shard
+ *                        and pads the context's tables); librccl.so is bound at run time (the copy already mapped into
+ *                        the process, else the system's)
+ *   lsc_comm_info      : world size, rank, shard_rows, table_rows                                                    */
+#define LSC_COMM_ID_BYTES 128
+int lsc_comm_unique_id(unsigned char id[LSC_COMM_ID_BYTES]);
+int lsc_comm_init(lsc_ctx *ctx, int world_size, int rank, const unsigned char id[LSC_COMM_ID_BYTES]);
+int lsc_comm_info(const lsc_ctx *ctx, int *world_size, int *rank, int *shard_rows, int *table_rows);
+
+/* One tick of a sharded swarm, device-resident: lsc_tick_device for the rank's agents, the in-place all-gather of
+ * d_traj_next (float [table_rows][90]: padded!), then the ideal next state of ALL N agents into d_state
+ * (lsc_propagate_device) -- i.e. d_state is read by the tick and overwritten for the next one.  d_cost / d_status /
+ * d_iters: the rank's entries only.  Everything is enqueued on hip_stream; no host synchronisation. */
+int lsc_tick_device_sharded(lsc_ctx *ctx, float *d_state, const float *d_goal, const float *d_traj_prev, int planner_seq,
+                            float *d_traj_next, double *d_cost, int *d_status, int *d_iters, void *hip_stream);
+
+/* Multi-GPU form of lsc_replan_tick (host buffers): every rank passes the same inputs for all N agents, plans its
+ * shard, and receives the outputs of ALL N agents (trajectories, costs, statuses, iterations and -- optional --
+ * current_goal_position are all-gathered in one RCCL group).  What a replicated MultiSyncSimulator per rank calls. */
+int lsc_replan_tick_all(lsc_ctx *ctx, const float *state, const float *goal, const float *prev_traj, int planner_seq,
+                        float *out_traj /*[N][3][30]*/, double *out_cost /*[N]*/, int *out_status /*[N]*/,
+                        int *out_iters /*[N] or NULL*/, float *out_goal /*[N][3] or NULL*/);
+
 /* MultiSyncSimulator::update()'s ideal-state step on device: state[qi] = traj[qi] evaluated at t = dt
  * (getFutureStateMsg -> getStateFromControlPoints, include/polynomial.hpp:63-97).  All N agents. */
 int lsc_propagate_device(lsc_ctx *ctx, const float *d_traj, float *d_state, void *hip_stream);
@@ -162,7 +198,8 @@ int lsc_sweep_device(lsc_ctx *ctx, const float *d_state, const float *d_traj_pre
 int lsc_gjk_batch(lsc_ctx *ctx, const double *pts, int count, double *v, double *dist);
 
 /* Introspection used by bench.py: name / average device time (ms, HIP events) of the kernels timed since
- * the last reset.  which: 0 = plan kernel, 1 = dense sweep kernel. */
+ * the last reset.  which: 0 = plan kernel (both passes), 1 = dense sweep kernel, 2 = the trajectory all-gather of the
+ * sharded ticks. */
 int lsc_kernel_time_ms(lsc_ctx *ctx, int which, double *avg_ms, long *launches);
 int lsc_set_timing(lsc_ctx *ctx, int enabled);
 /* Per-launch device times (ms) of the launches timed since lsc_set_timing(ctx, 1): up to `capacity` values in launch

@@ -11,7 +11,8 @@ _LIB = None
 
 M, DEG, NC, SEGV, NV = 5, 5, 6, 30, 90
 
-STATUS_OK, STATUS_INFEASIBLE, STATUS_CAPACITY, STATUS_SFC_BLOCKED = 0, 1, 3, 4
+STATUS_OK, STATUS_INFEASIBLE, STATUS_SFC_BLOCKED, STATUS_GOAL_CAPACITY = 0, 1, 4, 5
+COMM_ID_BYTES = 128
 
 
 class LscError(RuntimeError):
@@ -46,6 +47,7 @@ EXPORTS = [
     "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_sweep_device",
     "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_kernel_times_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals", "lsc_set_goal_trace", "lsc_get_goal_trace",
+    "lsc_comm_unique_id", "lsc_comm_init", "lsc_comm_info", "lsc_tick_device_sharded", "lsc_replan_tick_all",
 ]
 
 
@@ -86,6 +88,12 @@ def load_library():
     L.lsc_tick_device.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp]
     L.lsc_tick_device_fused.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, vp]
     L.lsc_propagate_device.argtypes = [vp, vp, vp, vp]
+    ubp = ctypes.POINTER(ctypes.c_ubyte)
+    L.lsc_comm_unique_id.argtypes = [ubp]
+    L.lsc_comm_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ubp]
+    L.lsc_comm_info.argtypes = [vp, ip, ip, ip, ip]
+    L.lsc_tick_device_sharded.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp]
+    L.lsc_replan_tick_all.argtypes = [vp, fp, fp, fp, ctypes.c_int, fp, dp, ip, ip, fp]
     L.lsc_sweep_device.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]
     L.lsc_gjk_batch.argtypes = [vp, dp, ctypes.c_int, dp, dp]
     L.lsc_kernel_time_ms.argtypes = [vp, ctypes.c_int, dp, ctypes.POINTER(ctypes.c_long)]

@@ -127,6 +127,9 @@ struct Param {   // defaults = launch/testall_empty.launch
     double grid_resolution = 0.3, grid_margin = 0.2;   // grid/resolution, grid/margin (launch/testall_forest.launch:88-89)
     std::string log_dir = ".";
     int device = 0;
+    // agent-sharded multi-GPU: one lsc_sim process per GPU (rank), every rank runs the same (deterministic) bookkeeping
+    int world = 1, rank = 0;
+    std::string comm_file;   // rank 0 writes the RCCL rendezvous token here, the others read it
     std::string getPlannerModeStr() const { return "LSC"; }
 };
 
@@ -244,7 +247,13 @@ class TrajPlanner {
             for (int i = 0; i <= n; i++)
                 traj_curr[m][i] = point3d(traj90[m * (n + 1) + i], traj90[30 + m * (n + 1) + i], traj90[60 + m * (n + 1) + i]);
         if (status == LSC_STATUS_OK) current_qp_cost = cost;
-        planning_report = PlanningReport::SUCCESS;   // QP failures are swallowed (src/traj_planner.cpp:1556-1584)
+        // QP failures are swallowed: trajOptimization() returns true whatever the solver did, so planLSC reports SUCCESS
+        // (src/traj_planner.cpp:1553-1584, :388-420).  A blocked corridor seed is different: expandBoxFromPoint throws
+        // std::invalid_argument out of plan() (include/corridor_constructor.hpp:35-38) -- the simulator re-throws it.
+        // Status 5 (goal search outgrew its LDS capacity) has no reference counterpart and must not look like a success.
+        planning_report = status == LSC_STATUS_SFC_BLOCKED    ? PlanningReport::CONSTRAINTGENERATIONFAILED
+                          : status == LSC_STATUS_GOAL_CAPACITY ? PlanningReport::INITTRAJGENERATIONFAILED
+                                                               : PlanningReport::SUCCESS;
         last_status = status;
         planning_time = seconds;
         state_updated = obstacles_updated = false;

@@ -1,11 +1,13 @@
 // multi_sync_simulator.cpp -- headless MultiSyncSimulator (src/multi_sync_simulator.cpp) over the C ABI.
 //   lsc_sim --mission m.json [--world map.bt] [--max-iter 300] [--csv DIR] [--device 0] [--quiet]
+//           [--ranks W --rank R --comm-file PATH]     one process per GPU; or RANK / WORLD_SIZE / LOCAL_RANK from the env
 // Loop: isFinished -> doStep -> update (ideal next state of every agent) -> plan (one lsc_replan_tick for the
 // swarm) -> savePlanningResult (safety ratio / collision accounting) -> optional result / summary CSV in the
 // reference's column layout, so that its replayer can read our runs.
 #include <chrono>
 #include <cstring>
 #include <iostream>
+#include <thread>
 
 #include "lsc_host.hpp"
 
@@ -26,6 +28,7 @@ class MultiSyncSimulator {
         cfg.grid_resolution = param.grid_resolution; cfg.grid_margin = param.grid_margin;
         ctx = lsc_create(&cfg);
         if (!ctx) throw std::runtime_error("[MultiSyncSimulator] lsc_create failed: no usable MI355X (there is no CPU path)");
+        if (param.world > 1 || !param.comm_file.empty()) initComm();
         const int N = mission.qn;
         std::vector<double> r(N), dw(N), vm(3 * N), am(3 * N), vn(N);
         for (int qi = 0; qi < N; qi++) {
@@ -41,6 +44,28 @@ class MultiSyncSimulator {
         file_name_param = param.getPlannerModeStr() + "_" + std::to_string(N) + "agents";
     }
     ~MultiSyncSimulator() { lsc_destroy(ctx); }
+
+    // Rendezvous of the native RCCL communicator: rank 0 makes the token and publishes it through a file (one node, one
+    // file system); lsc_comm_init is collective and must precede lsc_set_agents.
+    void initComm() {
+        if (param.comm_file.empty()) throw std::invalid_argument("[MultiSyncSimulator] --ranks needs --comm-file");
+        unsigned char id[LSC_COMM_ID_BYTES];
+        if (param.rank == 0) {
+            check(lsc_comm_unique_id(id));
+            const std::string tmp = param.comm_file + ".tmp";
+            { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(id), sizeof(id)); }
+            std::rename(tmp.c_str(), param.comm_file.c_str());
+        } else {
+            for (int tries = 0;; tries++) {
+                std::ifstream f(param.comm_file, std::ios::binary);
+                if (f && f.read(reinterpret_cast<char *>(id), sizeof(id))) break;
+                if (tries > 600) throw std::runtime_error("[MultiSyncSimulator] no rendezvous token in " + param.comm_file);
+                std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+        }
+        check(lsc_comm_init(ctx, param.world, param.rank, id));
+        sharded = true;
+    }
 
     // src/multi_sync_simulator.cpp:153-167
     void setOctomap(const std::string &file) {
@@ -61,7 +86,7 @@ class MultiSyncSimulator {
             else sim_current_time += param.multisim_time_step;
             update();
             if (!plan()) break;
-            if (!quiet && iter % 10 == 0) {
+            if (!quiet && param.rank == 0 && iter % 10 == 0) {
                 double worst = 0; int failed = 0;
                 for (int qi = 0; qi < mission.qn; qi++) {
                     worst = std::max(worst, (agents[qi]->getCurrentPosition() - mission.agents[qi].desired_goal_position).norm());
@@ -105,18 +130,35 @@ class MultiSyncSimulator {
             }
         }
         const auto t0 = std::chrono::steady_clock::now();
-        check(lsc_replan_tick(ctx, h_state.data(), h_goal.data(), h_prev.data(), agents[0]->getPlannerSeq() + 1, h_next.data(),
-                              h_cost.data(), h_status.data(), h_iters.data(), nullptr, nullptr, nullptr));
-        last_tick_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         std::vector<float> goals(3 * N);
-        check(lsc_last_goals(ctx, goals.data()));
+        if (sharded) {
+            // every rank plans its block of agents; one RCCL all-gather group brings everybody's results to every rank
+            check(lsc_replan_tick_all(ctx, h_state.data(), h_goal.data(), h_prev.data(), agents[0]->getPlannerSeq() + 1, h_next.data(),
+                                      h_cost.data(), h_status.data(), h_iters.data(), goals.data()));
+        } else {
+            check(lsc_replan_tick(ctx, h_state.data(), h_goal.data(), h_prev.data(), agents[0]->getPlannerSeq() + 1, h_next.data(),
+                                  h_cost.data(), h_status.data(), h_iters.data(), nullptr, nullptr, nullptr));
+            check(lsc_last_goals(ctx, goals.data()));
+        }
+        last_tick_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         for (int qi = 0; qi < N; qi++) {
             agents[qi]->agent.current_goal_position = point3d(goals[3 * qi], goals[3 * qi + 1], goals[3 * qi + 2]);
             agents[qi]->acceptPlan(h_next.data() + 90 * qi, h_cost[qi], h_status[qi], last_tick_ms * 1e-3 / N);
         }
         total_ticks++; total_tick_ms += last_tick_ms;
+        for (int qi = 0; qi < N; qi++) {
+            // what the reference's plan() does with these outcomes: the corridor's exception leaves the simulator
+            // (include/corridor_constructor.hpp:35-38); nothing else stops a run (:323-328 only tests QPFAILED, which
+            // planLSC never reports)
+            if (h_status[qi] == LSC_STATUS_SFC_BLOCKED)
+                throw std::invalid_argument("[CorridorConstructor] Invalid initial trajectory. Obstacle invades initial trajectory (agent " +
+                                            std::to_string(qi) + ")");
+            if (h_status[qi] == LSC_STATUS_GOAL_CAPACITY)
+                throw std::runtime_error("[MultiSyncSimulator] goal planner: search grid / OPEN list outgrew the LDS capacity (agent " +
+                                         std::to_string(qi) + "); no goal was guessed");
+        }
         savePlanningResult();
-        if (param.multisim_save_result) savePlanningResultAsCSV();
+        if (param.multisim_save_result && param.rank == 0) savePlanningResultAsCSV();
         return true;
     }
 
@@ -183,6 +225,7 @@ class MultiSyncSimulator {
     // :382-402 + :589-633 (25 columns; per-phase times that do not exist separately on the GPU are written as 0)
     void summarizeResult() {
         total_distance = getTotalDistance();
+        if (param.rank != 0) return;
         const double avg = N_average ? planning_time_sum / N_average : 0.0;
         std::printf("[MultiSyncSimulator] total flight time: %g\n[MultiSyncSimulator] total distance: %g\n"
                     "[MultiSyncSimulator] planning time per agent: %g\n[MultiSyncSimulator] safety ratio between agent: %g\n"
@@ -219,7 +262,7 @@ class MultiSyncSimulator {
     std::vector<double> h_cost;
     std::vector<int> h_status, h_iters;
     std::vector<std::vector<point3d>> points;
-    bool initial_update = true;
+    bool initial_update = true, sharded = false;
     double sim_start_time = 0, sim_current_time = 0, planning_time_sum = 0;
     long N_average = 0;
     std::string file_name_param;
@@ -243,9 +286,18 @@ int main(int argc, char **argv)
         else if (a == "--device") param.device = std::stoi(next());
         else if (a == "--quiet") quiet = true;
         else if (a == "--static-goal") param.goal_mode_prior_based = false;
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet]\n"); return 2; }
+        else if (a == "--ranks") param.world = std::stoi(next());
+        else if (a == "--rank") param.rank = std::stoi(next());
+        else if (a == "--comm-file") param.comm_file = next();
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH]\n"); return 2; }
     }
     if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
+    // torchrun / mpirun style environment: one process per GPU
+    if (param.world == 1 && std::getenv("WORLD_SIZE")) {
+        param.world = std::atoi(std::getenv("WORLD_SIZE"));
+        if (const char *r = std::getenv("RANK")) param.rank = std::atoi(r);
+        if (const char *lr = std::getenv("LOCAL_RANK")) param.device = std::atoi(lr);
+    }
     try {
         Mission mission;
         mission.initialize(mission_file, world_file);

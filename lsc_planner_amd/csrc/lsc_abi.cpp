@@ -2,6 +2,8 @@
 // per-context constants once (what TrajOptimizer's constructor does per agent in the reference,
 // src/traj_optimizer.cpp:4-25), owns HBM buffers and persistent per-agent state, launches kernels.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is bound at run time (see rccl_api())
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -181,6 +183,9 @@ struct lsc_ctx {
     double *d_vmax = nullptr, *d_amax = nullptr, *d_vnom = nullptr;
     float *d_stale = nullptr, *d_sfc = nullptr;
     float *d_goal_cur = nullptr;
+    unsigned char *d_spill = nullptr;    // HBM row workspaces of the second pass (agents beyond the LDS row capacity)
+    size_t spill_stride = 0;
+    int spill_slots = 0;
     float *fused_state_next = nullptr;   // set by lsc_tick_device_fused for one call
     int *d_sfc_init = nullptr, *d_sfc_err = nullptr, *d_img_of_agent = nullptr, *d_integral = nullptr;
     std::vector<float> h_edt;   // host copy of the distance field (integral images are rebuilt when agents change)
@@ -215,9 +220,62 @@ struct lsc_ctx {
     unsigned char *h_out = nullptr;
     hipStream_t stream = nullptr;
     // kernel timing: one HIP event pair per launch, recorded on the launch stream, read back on query
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[2];
-    size_t ev_used[2] = {0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[3];   // 0 plan kernel(s), 1 dense sweep, 2 trajectory exchange
+    size_t ev_used[3] = {0, 0, 0};
+    // agent-sharded multi-GPU: this context is rank `rank` of `world`; every rank owns a block of shard_rows agents of a
+    // table padded to table_rows = shard_rows * world rows, so that the exchange is ONE in-place equal-sized all-gather
+    int world = 1, rank = 0, shard_rows = 0, table_rows = 0;
+    ncclComm_t comm = nullptr;
 };
+
+// RCCL is bound with dlopen instead of a link-time dependency: inside a PyTorch process the wheel's own librccl (and
+// HIP runtime) is already mapped and must be the one that is used -- two RCCL copies in one process would each bring
+// their own view of the devices; stand-alone C++ users (lsc_sim) get /opt/rocm's.
+struct RcclApi {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+static const RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.h ? &api : nullptr;
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // the copy the process already has
+    for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return nullptr;
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GroupStart || !api.GroupEnd ||
+        !api.GetErrorString)
+        return nullptr;
+    api.h = h;
+    return &api;
+}
+
+#define NCCLCHK(ctx, api, call)                                                               \
+    do {                                                                                      \
+        ncclResult_t r_ = (call);                                                             \
+        if (r_ != ncclSuccess) {                                                              \
+            (ctx)->err = std::string(#call) + ": " + (api)->GetErrorString(r_);               \
+            return LSC_ECOMM;                                                                 \
+        }                                                                                     \
+    } while (0)
 
 static int timing_begin(lsc_ctx *c, int which, hipStream_t st, hipEvent_t *e1)
 {
@@ -266,6 +324,10 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
         return nullptr;
     }
     if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
+    if (init_device_kernels() != hipSuccess) {
+        std::fprintf(stderr, "lsc_create: device %d does not accept the gfx950 kernels' LDS request\n", cfg->device);
+        return nullptr;
+    }
     lsc_ctx *c = new lsc_ctx();
     c->cfg = *cfg;
     build_model(*cfg, c->hm);
@@ -283,8 +345,9 @@ static void free_agents(lsc_ctx *c)
 {
     void *ptrs[] = {c->d_radius, c->d_radius_obs, c->d_downwash, c->d_downwash_obs, c->d_vmax, c->d_amax, c->d_vnom,
                     c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_cost,
-                    c->d_onormal, c->d_od};
+                    c->d_onormal, c->d_od, c->d_spill};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    c->d_spill = nullptr; c->spill_slots = 0; c->spill_stride = 0;
     if (c->h_in) { (void)hipHostFree(c->h_in); c->h_in = nullptr; }
     if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
     void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
@@ -302,12 +365,13 @@ static void free_agents(lsc_ctx *c)
 void lsc_destroy(lsc_ctx *c)
 {
     if (!c) return;
+    if (c->comm) { if (const RcclApi *api = rccl_api()) (void)api->CommDestroy(c->comm); c->comm = nullptr; }
     free_agents(c);
     if (c->d_trace) (void)hipFree(c->d_trace);
     if (c->d_model) (void)hipFree(c->d_model);
     if (c->d_terms) (void)hipFree(c->d_terms);
     if (c->d_entries) (void)hipFree(c->d_entries);
-    for (int w = 0; w < 2; w++)
+    for (int w = 0; w < 3; w++)
         for (auto &p : c->ev_pool[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -321,7 +385,13 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     if (!c || N < 1 || !radius || !downwash || !max_vel || !max_acc || !nominal_vel) return LSC_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     free_agents(c);
-    c->N = N; c->first = 0; c->count = N;
+    c->N = N;
+    // rank's block of the (padded) table; world = 1 without lsc_comm_init: the whole swarm
+    c->shard_rows = (N + c->world - 1) / c->world;
+    c->table_rows = c->shard_rows * c->world;
+    c->first = std::min(c->rank * c->shard_rows, N);
+    c->count = std::min(c->shard_rows, N - c->first);
+    const size_t Np = (size_t)c->table_rows;
     int cap = c->cfg.max_rows_per_cp > 0 ? c->cfg.max_rows_per_cp : 64;
     if (cap > N - 1) cap = N - 1;
     if (cap < 1) cap = 1;
@@ -348,8 +418,8 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMemset(c->d_stale, 0, sizeof(float) * NV * (size_t)N));   // TrajOptimizer::trajectory starts at (0,0,0)
     HIPCHK(c, hipMalloc(&c->d_sfc, sizeof(float) * M * 6 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_sfc, 0, sizeof(float) * M * 6 * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_goal_cur, sizeof(float) * 3 * (size_t)N));
-    HIPCHK(c, hipMemset(c->d_goal_cur, 0, sizeof(float) * 3 * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_goal_cur, sizeof(float) * 3 * Np));
+    HIPCHK(c, hipMemset(c->d_goal_cur, 0, sizeof(float) * 3 * Np));
     HIPCHK(c, hipMalloc(&c->d_sfc_init, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_sfc_err, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMemset(c->d_sfc_err, 0, sizeof(int) * (size_t)N));
@@ -358,6 +428,14 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         HIPCHK(c, hipMemcpy(c->d_sfc_init, ones.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice));
     }
     c->h_radius.assign(radius, radius + N);
+    if (cap < N - 1) {
+        // An agent can carry more rows than the LDS capacity holds: those agents are re-planned by a second pass with
+        // their rows in HBM (the reference never drops a row, src/traj_optimizer.cpp:437-466).  One workspace per
+        // persistent workgroup; 256 = one per CU.
+        c->spill_stride = plan_spill_bytes(N);
+        c->spill_slots = std::min(N, 256);
+        HIPCHK(c, hipMalloc(&c->d_spill, c->spill_stride * (size_t)c->spill_slots));
+    }
     HIPCHK(c, hipMalloc(&c->d_nrows, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (size_t)N));
@@ -371,15 +449,16 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         float *in = nullptr;
         HIPCHK(c, hipMalloc(&in, sizeof(float) * (9 + 3 + NV) * n));
         c->d_state = in; c->d_goal = in + 9 * n; c->d_prev = in + 12 * n;
+        // outputs: padded to table_rows so that the multi-GPU form gathers them in place
         unsigned char *out = nullptr;
-        HIPCHK(c, hipMalloc(&out, (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * n));
-        HIPCHK(c, hipMemset(out, 0, (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * n));
+        HIPCHK(c, hipMalloc(&out, (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * Np));
+        HIPCHK(c, hipMemset(out, 0, (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * Np));
         c->d_cost = reinterpret_cast<double *>(out);
-        c->d_next = reinterpret_cast<float *>(out + sizeof(double) * n);
-        c->d_status = reinterpret_cast<int *>(out + (sizeof(double) + sizeof(float) * NV) * n);
-        c->d_iters = c->d_status + n;
+        c->d_next = reinterpret_cast<float *>(out + sizeof(double) * Np);
+        c->d_status = reinterpret_cast<int *>(out + (sizeof(double) + sizeof(float) * NV) * Np);
+        c->d_iters = c->d_status + Np;
         HIPCHK(c, hipHostMalloc(&c->h_in, sizeof(float) * (9 + 3 + NV) * n));
-        HIPCHK(c, hipHostMalloc(&c->h_out, (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * n));
+        HIPCHK(c, hipHostMalloc(&c->h_out, (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * Np));
     }
     return build_integrals(c);
 }
@@ -588,6 +667,7 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.goal_out = c->d_goal_cur; a.state_next = nullptr; a.finv = (float)std::pow(c->cfg.dt, -1);
     a.dbg = c->d_dbg; a.prof = c->profiling ? c->d_prof : nullptr;
     a.trace = c->trace_agent >= 0 ? c->d_trace : nullptr; a.trace_agent = c->trace_agent;
+    a.spill_ws = c->d_spill; a.spill_stride = c->spill_stride;
     return LSC_OK;
 }
 
@@ -597,6 +677,7 @@ static int run_plan(lsc_ctx *c, const PlanArgs &a, hipStream_t st)
     hipEvent_t e1 = nullptr;
     if (c->timing && timing_begin(c, 0, st, &e1) != LSC_OK) return LSC_EHIP;
     HIPCHK(c, launch_plan(a, smem, st));
+    if (c->d_spill) HIPCHK(c, launch_plan_spill(a, c->spill_slots, plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, 0), st));
     if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
     return LSC_OK;
 }
@@ -657,7 +738,8 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
     if (rc) return rc;
     rc = run_plan(c, a, st);
     if (rc) return rc;
-    const size_t out_bytes = (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * N;
+    const size_t Np = (size_t)c->table_rows;
+    const size_t out_bytes = (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * Np;
     HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_cost, out_bytes, hipMemcpyDeviceToHost, st));
     if (out_lsc_normal) HIPCHK(c, hipMemcpyAsync(out_lsc_normal, c->d_onormal, sizeof(float) * 3 * M * nobs * cnt, hipMemcpyDeviceToHost, st));
     if (out_lsc_d) HIPCHK(c, hipMemcpyAsync(out_lsc_d, c->d_od, sizeof(double) * NC * M * nobs * cnt, hipMemcpyDeviceToHost, st));
@@ -666,11 +748,126 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
     {
         const unsigned char *o = c->h_out;
         std::memcpy(out_cost, o + sizeof(double) * first, sizeof(double) * cnt);
-        std::memcpy(out_traj, o + sizeof(double) * N + sizeof(float) * NV * first, sizeof(float) * NV * cnt);
-        const unsigned char *si = o + (sizeof(double) + sizeof(float) * NV) * N;
+        std::memcpy(out_traj, o + sizeof(double) * Np + sizeof(float) * NV * first, sizeof(float) * NV * cnt);
+        const unsigned char *si = o + (sizeof(double) + sizeof(float) * NV) * Np;
         std::memcpy(out_status, si + sizeof(int) * first, sizeof(int) * cnt);
-        if (out_iters) std::memcpy(out_iters, si + sizeof(int) * (N + first), sizeof(int) * cnt);
+        if (out_iters) std::memcpy(out_iters, si + sizeof(int) * (Np + first), sizeof(int) * cnt);
     }
+    return LSC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Agent-sharded multi-GPU.  The reference hands every agent every other agent's previous trajectory in
+// MultiSyncSimulator::update (src/multi_sync_simulator.cpp:297-303); with the swarm partitioned over ranks that
+// hand-over is the one exchange of a tick: an in-place RCCL all-gather of the freshly planned rows.
+// ---------------------------------------------------------------------------------------------------
+int lsc_comm_unique_id(unsigned char id[LSC_COMM_ID_BYTES])
+{
+    static_assert(LSC_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    const RcclApi *api = rccl_api();
+    if (!api || !id) return LSC_ECOMM;
+    ncclUniqueId u;
+    if (api->GetUniqueId(&u) != ncclSuccess) return LSC_ECOMM;
+    std::memcpy(id, u.internal, LSC_COMM_ID_BYTES);
+    return LSC_OK;
+}
+
+int lsc_comm_init(lsc_ctx *c, int world_size, int rank, const unsigned char id[LSC_COMM_ID_BYTES])
+{
+    if (!c || world_size < 1 || rank < 0 || rank >= world_size || !id) return LSC_EINVAL;
+    if (c->N != 0) { c->err = "lsc_comm_init must precede lsc_set_agents (the tables are padded to the world size)"; return LSC_ESTATE; }
+    if (c->comm) { c->err = "lsc_comm_init: communicator already initialised"; return LSC_ESTATE; }
+    const RcclApi *api = rccl_api();
+    if (!api) { c->err = "librccl.so could not be loaded"; return LSC_ECOMM; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, LSC_COMM_ID_BYTES);
+    NCCLCHK(c, api, api->CommInitRank(&c->comm, world_size, u, rank));
+    c->world = world_size; c->rank = rank;
+    return LSC_OK;
+}
+
+int lsc_comm_info(const lsc_ctx *c, int *world_size, int *rank, int *shard_rows, int *table_rows)
+{
+    if (!c) return LSC_EINVAL;
+    if (world_size) *world_size = c->world;
+    if (rank) *rank = c->rank;
+    if (shard_rows) *shard_rows = c->shard_rows;
+    if (table_rows) *table_rows = c->table_rows;
+    return LSC_OK;
+}
+
+// in-place all-gather of `rows_elems` elements per agent row of a table padded to table_rows rows
+static int exchange_rows(lsc_ctx *c, const RcclApi *api, void *table, size_t row_bytes, hipStream_t st)
+{
+    const size_t cnt = (size_t)c->shard_rows * row_bytes;
+    NCCLCHK(c, api, api->AllGather(static_cast<unsigned char *>(table) + (size_t)c->rank * cnt, table, cnt, ncclUint8, c->comm, st));
+    return LSC_OK;
+}
+
+int lsc_tick_device_sharded(lsc_ctx *c, float *d_state, const float *d_goal, const float *d_traj_prev, int planner_seq,
+                            float *d_traj_next, double *d_cost, int *d_status, int *d_iters, void *hip_stream)
+{
+    if (!c || !d_state) return LSC_EINVAL;
+    if (!c->comm) { c->err = "lsc_tick_device_sharded: lsc_comm_init was not called"; return LSC_ESTATE; }
+    const RcclApi *api = rccl_api();
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc = lsc_tick_device(c, d_state, d_goal, d_traj_prev, planner_seq, d_traj_next, d_cost, d_status, d_iters, hip_stream);
+    if (rc) return rc;
+    hipEvent_t e1 = nullptr;
+    if (c->timing && timing_begin(c, 2, st, &e1) != LSC_OK) return LSC_EHIP;
+    rc = exchange_rows(c, api, d_traj_next, sizeof(float) * NV, st);
+    if (rc) return rc;
+    if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
+    // MultiSyncSimulator::update of the next tick: every rank needs every agent's ideal state
+    HIPCHK(c, launch_propagate(d_traj_next, d_state, c->N, c->cfg.dt, st));
+    return LSC_OK;
+}
+
+int lsc_replan_tick_all(lsc_ctx *c, const float *state, const float *goal, const float *prev_traj, int planner_seq,
+                        float *out_traj, double *out_cost, int *out_status, int *out_iters, float *out_goal)
+{
+    if (!c || !state || !goal || !prev_traj || !out_traj || !out_cost || !out_status) return LSC_EINVAL;
+    if (c->N == 0) return LSC_ESTATE;
+    if (!c->comm) { c->err = "lsc_replan_tick_all: lsc_comm_init was not called"; return LSC_ESTATE; }
+    const RcclApi *api = rccl_api();
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const size_t N = c->N, Np = (size_t)c->table_rows;
+    hipStream_t st = c->stream;
+    std::memcpy(c->h_in, state, sizeof(float) * 9 * N);
+    std::memcpy(c->h_in + 9 * N, goal, sizeof(float) * 3 * N);
+    std::memcpy(c->h_in + 12 * N, prev_traj, sizeof(float) * NV * N);
+    HIPCHK(c, hipMemcpyAsync(c->d_state, c->h_in, sizeof(float) * (9 + 3 + NV) * N, hipMemcpyHostToDevice, st));
+    PlanArgs a;
+    const float *d_goal_in = c->d_goal;
+    int rc = run_goal(c, c->d_state, d_goal_in, c->d_prev, planner_seq, st);
+    if (rc) return rc;
+    rc = fill_plan_args(c, a, c->d_state, d_goal_in, c->d_prev, planner_seq, c->d_next, c->d_cost, c->d_status, c->d_iters);
+    if (rc) return rc;
+    rc = run_sfc(c, c->d_state, d_goal_in, c->d_prev, st);
+    if (rc) return rc;
+    rc = run_plan(c, a, st);
+    if (rc) return rc;
+    hipEvent_t e1 = nullptr;
+    if (c->timing && timing_begin(c, 2, st, &e1) != LSC_OK) return LSC_EHIP;
+    NCCLCHK(c, api, api->GroupStart());
+    if ((rc = exchange_rows(c, api, c->d_next, sizeof(float) * NV, st))) return rc;
+    if ((rc = exchange_rows(c, api, c->d_cost, sizeof(double), st))) return rc;
+    if ((rc = exchange_rows(c, api, c->d_status, sizeof(int), st))) return rc;
+    if ((rc = exchange_rows(c, api, c->d_iters, sizeof(int), st))) return rc;
+    if ((rc = exchange_rows(c, api, c->d_goal_cur, sizeof(float) * 3, st))) return rc;
+    NCCLCHK(c, api, api->GroupEnd());
+    if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
+    const size_t out_bytes = (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * Np;
+    HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_cost, out_bytes, hipMemcpyDeviceToHost, st));
+    if (out_goal) HIPCHK(c, hipMemcpyAsync(out_goal, c->d_goal_cur, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const unsigned char *o = c->h_out;
+    std::memcpy(out_cost, o, sizeof(double) * N);
+    std::memcpy(out_traj, o + sizeof(double) * Np, sizeof(float) * NV * N);
+    const unsigned char *si = o + (sizeof(double) + sizeof(float) * NV) * Np;
+    std::memcpy(out_status, si, sizeof(int) * N);
+    if (out_iters) std::memcpy(out_iters, si + sizeof(int) * Np, sizeof(int) * N);
     return LSC_OK;
 }
 
@@ -721,13 +918,13 @@ int lsc_set_timing(lsc_ctx *c, int enabled)
 {
     if (!c) return LSC_EINVAL;
     c->timing = enabled != 0;
-    c->ev_used[0] = c->ev_used[1] = 0;
+    c->ev_used[0] = c->ev_used[1] = c->ev_used[2] = 0;
     return LSC_OK;
 }
 
 int lsc_kernel_time_ms(lsc_ctx *c, int which, double *avg_ms, long *launches)
 {
-    if (!c || which < 0 || which > 1 || !avg_ms) return LSC_EINVAL;
+    if (!c || which < 0 || which > 2 || !avg_ms) return LSC_EINVAL;
     double tot = 0;
     for (size_t i = 0; i < c->ev_used[which]; i++) {
         auto &p = c->ev_pool[which][i];
@@ -743,7 +940,7 @@ int lsc_kernel_time_ms(lsc_ctx *c, int which, double *avg_ms, long *launches)
 
 int lsc_kernel_times_ms(lsc_ctx *c, int which, double *out_ms, long capacity, long *launches)
 {
-    if (!c || which < 0 || which > 1 || (capacity > 0 && !out_ms)) return LSC_EINVAL;
+    if (!c || which < 0 || which > 2 || (capacity > 0 && !out_ms)) return LSC_EINVAL;
     const long n = (long)c->ev_used[which];
     for (long i = 0; i < n && i < capacity; i++) {
         auto &p = c->ev_pool[which][(size_t)i];

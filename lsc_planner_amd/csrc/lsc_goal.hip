@@ -637,18 +637,16 @@ size_t goal_smem_bytes(int H, int W, int A, int cap)
     return (b + 15) & ~(size_t)15;
 }
 
+hipError_t init_device_goal_kernel()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_goal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 hipError_t launch_goal(const GoalArgs &a, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;
     const size_t smem = goal_smem_bytes(a.H, a.W, a.A, a.row_cap);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_goal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
     hipLaunchKernelGGL(lsc_goal_kernel, dim3(a.count), dim3(64), smem, st, a);
     return hipGetLastError();
 }

@@ -44,6 +44,8 @@ struct PlanArgs {
     long long *prof;           // optional [N][12] phase cycle counters (selects the instrumented kernel)
     double *trace;             // optional [64][8] per-iteration trace of agent trace_agent (diagnostics)
     int trace_agent;
+    unsigned char *spill_ws;   // second pass only: HBM row workspaces, one of spill_stride bytes per workgroup
+    size_t spill_stride;
 };
 constexpr int PROF_PHASES = 12;
 
@@ -109,7 +111,11 @@ size_t goal_smem_bytes(int H, int W, int A, int cap);
 hipError_t launch_goal(const GoalArgs &a, hipStream_t st);
 
 size_t plan_smem_bytes(int n_terms, int n_entries, int cap);
+size_t plan_spill_bytes(int N);
+hipError_t init_device_kernels();
+hipError_t init_device_goal_kernel();
 hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st);
+hipError_t launch_plan_spill(const PlanArgs &a, int slots, size_t smem, hipStream_t st);
 hipError_t launch_sweep(const SweepArgs &a, hipStream_t st);
 hipError_t launch_propagate(const float *traj, float *state, int N, double dt, hipStream_t st);
 hipError_t launch_gjk(const double *pts, int count, double *v, double *dist, hipStream_t st);

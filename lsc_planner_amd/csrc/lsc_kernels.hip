@@ -423,6 +423,7 @@ struct Smem {
     unsigned char avalid[AXROWS];
     // agent constants
     double s0[3][3];            // c_{0,0..2} per axis
+    double x0c[NV];             // the same constants addressed by variable index (k*30 + t, t < 3)
     double lo[3][M], hi[3][M];  // bounds per axis and segment (world box, intersected with the SFC)
     double goal[3];
     double reachL[3][28], reachU[3][28];   // per axis: bounds of c_{m,i} - c_{0,2} after K = 5m+i-2 steps (phase B pruning)
@@ -582,9 +583,18 @@ __device__ __forceinline__ void bwd_steps(const double (&c)[CNT], double &b)
 // phase stamps (PROF variant only): cycles of lane 0 spent per phase, accumulated per agent
 enum { PH_SETUP = 0, PH_LSC, PH_INIT, PH_P1, PH_REDUCE, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_P2, PH_P3, PH_P45, PH_OUT, PH_COUNT };
 
-template <bool PROF>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_kernel(PlanArgs a)
+
+// One agent's replan on one 512-lane workgroup.
+//   SPILL = false : the LSC rows live in LDS (at most a.cap rows per control point); an agent with more rows than that
+//                   is flagged LSC_STATUS_CAPACITY_K and left to the second pass
+//   SPILL = true  : the row arrays live in this workgroup's HBM workspace `ws`, sized for all 27 (N-1) rows the
+//                   reference adds (src/traj_optimizer.cpp:437-466) -- same code, same arithmetic, no capacity limit
+template <bool PROF, bool SPILL>
+__device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *ws)
 {
+    // cmap entry = row slot | control point << CMAP_SHIFT (HBM variant: 24 bits of slot, 27 (N-1) slots fit for any N)
+    constexpr int CMAP_SHIFT = SPILL ? 24 : 16;
+    constexpr uint32_t CMAP_MASK = (1u << CMAP_SHIFT) - 1u;
     long long t_last = 0;
     long long t_acc[PH_COUNT];
     if constexpr (PROF) {
@@ -599,12 +609,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             t_last = now;
         }
     };
-    extern __shared__ __align__(16) unsigned char smem_raw[];
     Smem &S = *reinterpret_cast<Smem *>(smem_raw);
     const Model &md = *a.model;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qi = a.first + blockIdx.x;
-    const int N = a.N, n_obs = N - 1, CAP = a.cap;
+    const int qi = a.first + al;
+    const int N = a.N, n_obs = N - 1, CAP = SPILL ? (n_obs > 1 ? n_obs : 1) : a.cap;
     const int CS = (CAP & 1) ? CAP : CAP + 1;   // odd bucket stride: spreads the buckets over LDS banks
     const int R = NB * CS;
     const int n_terms = md.n_terms, n_entries = md.n_entries;
@@ -613,13 +622,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     uint32_t *terms = S.dyn;                                        // [n_terms]
     uint32_t *ent = terms + ((n_terms + 1) & ~1);                   // [n_entries+1][2] : (gi<<16|gj), first term
     double *kconst = reinterpret_cast<double *>(ent + 2 * n_entries + 2);
-    double *__restrict__ rrhs = kconst + n_entries;
+    double *rowbase;
+    if constexpr (SPILL) rowbase = reinterpret_cast<double *>(ws);
+    else rowbase = kconst + n_entries;
+    double *__restrict__ rrhs = rowbase;
     double *__restrict__ rs = rrhs + R;
     double *__restrict__ rz = rs + R;
     double *__restrict__ rt1 = rz + R;
     double *__restrict__ rt2 = rt1 + R;
     float *__restrict__ rn = reinterpret_cast<float *>(rt2 + R);     // [3][R]
-    uint32_t *__restrict__ cmap = reinterpret_cast<uint32_t *>(rn + 3 * R);  // compact row map: slot | cp << 16
+    uint32_t *__restrict__ cmap = reinterpret_cast<uint32_t *>(rn + 3 * R);  // compact row map: slot | cp << CMAP_SHIFT
     unsigned char *rcp = reinterpret_cast<unsigned char *>(cmap + R);        // control point of a slot, 255 = empty
 
     // ------------------------------------------------------------------ phase A: agent constants
@@ -718,6 +730,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         double c1 = c0 + (double)s[3 + k] * md.hv_scale;
         double c2 = (double)s[6 + k] * md.ha_scale + 2.0 * c1 - c0;
         S.s0[k][0] = c0; S.s0[k][1] = c1; S.s0[k][2] = c2;
+        S.x0c[k * SEGV] = c0; S.x0c[k * SEGV + 1] = c1; S.x0c[k * SEGV + 2] = c2;
         S.goal[k] = (double)S.goalf[k];
         if (a.goal_out) a.goal_out[3 * qi + k] = S.goalf[k];
         for (int m = 0; m < M; m++) {
@@ -840,7 +853,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 double d[6];
                 lsc_segment(pa, po, downwash, r_o + r_a, nrm, d);
                 if (a.out_normal) {
-                    size_t o = ((size_t)blockIdx.x * n_obs + oi) * M + m;
+                    size_t o = ((size_t)al * n_obs + oi) * M + m;
                     a.out_normal[o * 3] = nrm.x; a.out_normal[o * 3 + 1] = nrm.y; a.out_normal[o * 3 + 2] = nrm.z;
 #pragma unroll
                     for (int i = 0; i < 6; i++) a.out_d[o * 6 + i] = d[i];
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int cp = rcp[r];
         if (cp == 255) continue;
         const int b = cp - 3;
-        cmap[S.offs[b] + (r - b * CS)] = (uint32_t)r | ((uint32_t)cp << 16);
+        cmap[S.offs[b] + (r - b * CS)] = (uint32_t)r | ((uint32_t)cp << CMAP_SHIFT);
     }
     stamp(PH_LSC);
 
@@ -948,7 +961,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     auto compute_x = [&](const double *yv, double *xv, bool with_const) {
         if (tid < NV) {
             double v;
-            if (xt < 3) v = with_const ? S.s0[xk][xt] : 0.0;
+            if (xt < 3) v = with_const ? S.x0c[tid] : 0.0;
             else {
                 const uint32_t gp = S.xgp[tid];
                 const double *c = S.xtc[xt];
@@ -1263,7 +1276,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         for (int c = tid; c < nact; c += NT) {
             const uint32_t e = cmap[c];
-            const int r = e & 0xffff, cp = e >> 16;
+            const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
             rt2[r] = lsc_ax(S.x, r, cp) + rrhs[r];
         }
         __syncthreads();
@@ -1288,7 +1301,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         for (int c = tid; c < nact; c += NT) {
             const uint32_t e = cmap[c];
-            const int r = e & 0xffff, cp = e >> 16;
+            const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
             const double sv = fmax(-rrhs[r] - lsc_ax(S.x, r, cp), smin);
             rs[r] = sv; rz[r] = mu0 / sv; rt1[r] = 0.0; rt2[r] = 0.0;
         }
@@ -1334,7 +1347,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
-                    const int r = e & 0xffff, cp = e >> 16;
+                    const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
                     double sv = rs[r] + alpha * rt1[r], zv = rz[r] + alpha * rt2[r];
                     double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
                     double is = 1.0 / sv;
@@ -1372,7 +1385,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             for (int c = tid; c < nact; c += NT) {
                 const uint32_t e = cmap[c];
-                const int r = e & 0xffff, cp = e >> 16;
+                const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
                 double sv = rs[r], zv = rz[r], is = rt1[r];
                 double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
                 rt2[r] = zv * is * rp - (rt2[r] - smu) * is;
@@ -1421,7 +1434,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
-                    const int r = e & 0xffff, cp = e >> 16;
+                    const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
                     double sv = -rrhs[r] - lsc_ax(S.x, r, cp);
                     rs[r] = sv; rz[r] = -sv;
                     mins = fmin(mins, sv); minz = fmin(minz, -sv);
@@ -1431,7 +1444,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const double shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
                 // the shift enters the loop as a "step" of length 1 (t1 = ds, t2 = dz) applied by the first fused pass
                 for (int c = tid; c < AXVALID; c += NT) { const int sl = S.amap[c]; S.at1[sl] = shs; S.at2[sl] = shz; }
-                for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & 0xffff; rt1[r] = shs; rt2[r] = shz; }
+                for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt1[r] = shs; rt2[r] = shz; }
                 __syncthreads();
                 alpha = 1.0;
                 phase = ST_PRED;
@@ -1452,7 +1465,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
-                    const int r = e & 0xffff, cp = e >> 16;
+                    const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
                     double sv = rs[r], zv = rz[r], w = zv * rt1[r];
                     double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
                     double adx = lsc_ax(S.dx, r, cp);
@@ -1495,7 +1508,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
-                    const int r = e & 0xffff, cp = e >> 16;
+                    const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
                     double sv = rs[r], zv = rz[r], w = zv * rt1[r];
                     double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
                     double adx = lsc_ax(S.dx, r, cp);
@@ -1579,6 +1592,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+template <bool PROF>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_kernel(PlanArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    plan_agent<PROF, false>(a, blockIdx.x, smem_raw, nullptr);
+}
+
+// Second pass: agents whose rows did not fit the LDS capacity of the first pass are solved again with their rows in
+// HBM.  Persistent workgroups (one workspace each) walk the shard; everybody else's result is left untouched.
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_spill_kernel(PlanArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned char *ws = a.spill_ws + (size_t)blockIdx.x * a.spill_stride;
+    for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
+        if (a.status[a.first + al] != LSC_STATUS_CAPACITY_K) continue;   // uniform over the workgroup
+        __syncthreads();
+        plan_agent<false, true>(a, al, smem_raw, ws);
+        __syncthreads();
+    }
+}
+
 }  // namespace lsc
 
 // ---------------------------------------------------------------------------------------------------
@@ -1598,21 +1632,41 @@ size_t plan_smem_bytes(int n_terms, int n_entries, int cap)
     return (b + 15) & ~(size_t)15;
 }
 
+// bytes of one workgroup's HBM row workspace (second pass): all 27 (N-1) row slots
+size_t plan_spill_bytes(int N)
+{
+    const int cap = N - 1 > 1 ? N - 1 : 1;
+    const int cs = (cap & 1) ? cap : cap + 1;
+    const size_t R = (size_t)NB * cs;
+    return (R * (5 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t) + 1) + 255) & ~(size_t)255;
+}
+
+// The large-LDS opt-in is a per-device function attribute: lsc_create calls this once per context after hipSetDevice
+// (several contexts on several GPUs of one process each get it on their own device).
+hipError_t init_device_kernels()
+{
+    const void *fns[] = {reinterpret_cast<const void *>(&lsc_plan_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_kernel<true>),
+                         reinterpret_cast<const void *>(&lsc_plan_spill_kernel), reinterpret_cast<const void *>(&lsc_sfc_kernel)};
+    for (const void *f : fns) {
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return init_device_goal_kernel();
+}
+
 hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;          // empty shard (more ranks than agents): nothing to plan
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_plan_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_plan_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
     if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, a);
     else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_plan_spill(const PlanArgs &a, int slots, size_t smem, hipStream_t st)
+{
+    if (a.count == 0 || slots < 1 || !a.spill_ws) return hipSuccess;
+    const int grid = a.count < slots ? a.count : slots;
+    hipLaunchKernelGGL(lsc_plan_spill_kernel, dim3(grid), dim3(NT), smem, st, a);
     return hipGetLastError();
 }
 
@@ -1621,13 +1675,6 @@ hipError_t launch_sfc(const SfcArgs &a, hipStream_t st)
     if (a.count == 0) return hipSuccess;
     const size_t smem = sizeof(double) * 6 * (size_t)a.table_len;
     if (a.table_len < 8 || smem > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_sfc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
     hipLaunchKernelGGL(lsc_sfc_kernel, dim3(a.count), dim3(64), smem, st, a);
     return hipGetLastError();
 }

@@ -32,6 +32,7 @@ class PlannerConfig:
     goal_radius: float = 2.0
     grid_resolution: float = 0.3    # grid/resolution (goal planner's search grid; goal_mode prior_based + use_octomap)
     grid_margin: float = 0.2        # grid/margin
+    comm: tuple = None              # (world_size, rank, id bytes from comm_unique_id()): agent-sharded multi-GPU over RCCL
 
 
 def _fp(a):
@@ -75,12 +76,20 @@ class SwarmPlanner:
         if not self.ctx:
             raise LscError("lsc_create failed: no usable gfx950 device (there is no CPU fallback)")
         self.N = mission.qn
-        self.first, self.count = 0, self.N
+        if self.cfg.comm is not None:
+            world, rank, token = self.cfg.comm
+            buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(token))
+            self._check(self.L.lsc_comm_init(self.ctx, int(world), int(rank), buf))
         self._check(self.L.lsc_set_agents(self.ctx, self.N, _dp(np.ascontiguousarray(mission.radius, np.float64)),
                                           _dp(np.ascontiguousarray(mission.downwash, np.float64)),
                                           _dp(np.ascontiguousarray(mission.max_vel, np.float64)),
                                           _dp(np.ascontiguousarray(mission.max_acc, np.float64)),
                                           _dp(np.ascontiguousarray(mission.nominal_velocity, np.float64))))
+        w, r, sr, tr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self._check(self.L.lsc_comm_info(self.ctx, ctypes.byref(w), ctypes.byref(r), ctypes.byref(sr), ctypes.byref(tr)))
+        self.world, self.rank, self.shard_rows, self.table_rows = w.value, r.value, sr.value, tr.value
+        self.first = min(self.rank * self.shard_rows, self.N)
+        self.count = min(self.shard_rows, self.N - self.first)
         # TrajPlanner state (src/traj_planner.cpp:41-48)
         self.planner_seq = 0
         self.traj_curr = np.zeros((self.N, 3, SEGV), np.float32)
@@ -151,6 +160,27 @@ class SwarmPlanner:
             res["normal"], res["d"] = nrm, dd
         return res
 
+    def plan_all(self, state, current_goal, obs_prev_trajs):
+        """Multi-GPU form of plan(): every rank passes all N agents' inputs, plans its shard and receives ALL N outputs
+        (one RCCL all-gather group inside lsc_replan_tick_all)."""
+        N = self.N
+        state = np.ascontiguousarray(state, np.float32).reshape(N, 9)
+        goal = np.ascontiguousarray(current_goal, np.float32).reshape(N, 3)
+        prev = np.ascontiguousarray(obs_prev_trajs, np.float32).reshape(N, 3, SEGV)
+        self.planner_seq += 1
+        out = np.zeros((N, 3, SEGV), np.float32)
+        cost = self.qp_cost.copy()
+        status = np.zeros(N, np.int32)
+        iters = np.zeros(N, np.int32)
+        goals = np.zeros((N, 3), np.float32)
+        self._check(self.L.lsc_replan_tick_all(self.ctx, _fp(state), _fp(goal), _fp(prev), self.planner_seq, _fp(out), _dp(cost),
+                                               _ip(status), _ip(iters), _fp(goals)))
+        self.traj_curr[:] = out
+        self.qp_cost[:] = cost
+        self.planning_report[:] = status
+        self.iters[:] = iters
+        return {"traj": out, "cost": cost, "status": status, "iters": iters, "goal": goals}
+
     # ---- getters with the reference's names ------------------------------------------------------------
     def get_traj(self):
         return self.traj_curr
@@ -213,6 +243,12 @@ class SwarmPlanner:
                                                  traj_next.data_ptr(), state_next.data_ptr(), cost.data_ptr(), status.data_ptr(),
                                                  iters.data_ptr(), stream))
 
+    def tick_device_sharded(self, state, goal, traj_prev, traj_next, cost, status, iters, planner_seq, stream=0):
+        """Sharded tick, everything enqueued on `stream`: plan the rank's agents, in-place RCCL all-gather of traj_next
+        ([table_rows][90], padded), next ideal state of all N agents into `state`."""
+        self._check(self.L.lsc_tick_device_sharded(self.ctx, state.data_ptr(), goal.data_ptr(), traj_prev.data_ptr(), planner_seq,
+                                                   traj_next.data_ptr(), cost.data_ptr(), status.data_ptr(), iters.data_ptr(), stream))
+
     def propagate_device(self, traj, state, stream=0):
         self._check(self.L.lsc_propagate_device(self.ctx, traj.data_ptr(), state.data_ptr(), stream))
 
@@ -263,6 +299,16 @@ class SwarmPlanner:
         self._check(self.L.lsc_kernel_times_ms(self.ctx, which, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n.value,
                                                ctypes.byref(n)))
         return out[:n.value]
+
+
+def comm_unique_id():
+    """Rendezvous token of the RCCL communicator (ncclGetUniqueId): rank 0 makes it, every rank passes it to PlannerConfig.comm."""
+    L = _lib.load_library()
+    buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+    rc = L.lsc_comm_unique_id(buf)
+    if rc != 0:
+        raise LscError(f"lsc_comm_unique_id failed: {rc} (librccl.so not loadable?)")
+    return bytes(buf)
 
 
 def edt_from_bt(bt_path, world_min, world_max, maxdist=1.0):

@@ -1,60 +1,57 @@
-"""Agent-sharded stepping: one process per GPU, the trajectory table replicated, one all-gather per tick.
+"""Agent-sharded stepping, host-language mirror of the native path (lsc_comm_init / lsc_tick_device_sharded).
 
 Within a tick every agent's problem depends only on LAST tick's trajectories of all agents
-(src/multi_sync_simulator.cpp:249-304 freezes the inputs before anybody plans), so contiguous blocks of agents
-are planned independently per rank and the only exchange is an all-gather of the new trajectories
-(N * 360 B per tick) -- torch.distributed over RCCL/xGMI on GPUs, gloo in the CPU tests.
+(src/multi_sync_simulator.cpp:249-304 freezes the inputs before anybody plans; :297-303 is where every agent receives
+the others' trajectories), so blocks of agents are planned independently per rank and the only exchange is one
+all-gather of the new trajectory rows.  On GPUs the product does that exchange natively (RCCL, in place, enqueued on
+the tick's stream: csrc/lsc_abi.cpp); this module is the same partitioning driven through torch.distributed, used by
+the world-size-2 gloo tests on CPU and usable as a torch-only alternative.
+
+Partitioning (identical to lsc_comm_info): shard_rows = ceil(N / world); rank r owns agents
+[r*shard_rows, min((r+1)*shard_rows, N)); the table is padded ONCE, at allocation, to shard_rows*world rows so that
+the exchange is a single equal-sized collective with no per-tick packing.
 """
-import numpy as np
+
+
+def shard_rows(n_agents, world_size):
+    return -(-n_agents // world_size)
+
+
+def table_rows(n_agents, world_size):
+    return shard_rows(n_agents, world_size) * world_size
 
 
 def shard_bounds(n_agents, world_size, rank):
-    """Contiguous blocks, the first (n % world) ranks get one extra agent."""
-    base, extra = divmod(n_agents, world_size)
-    first = rank * base + min(rank, extra)
-    count = base + (1 if rank < extra else 0)
-    return first, count
+    """(first, count) of rank's block; trailing ranks of a ragged split own fewer (possibly zero) agents."""
+    s = shard_rows(n_agents, world_size)
+    first = min(rank * s, n_agents)
+    return first, min(s, n_agents - first)
 
 
-def all_gather_rows(dist, full, first, count, counts=None):
-    """In-place exchange: `full` is [N, ...]; this rank has written rows [first, first+count).
-    Equal shards use all_gather_into_tensor (one fused collective); ragged shards fall back to all_gather."""
-    import torch
-    if dist is None or not dist.is_initialized():
+def all_gather_rows(dist, table, rank, rows):
+    """In-place exchange: `table` is [rows*world, ...] (padded); this rank has written its block [rank*rows, (rank+1)*rows).
+    One collective, no staging beyond what the backend needs (NCCL/RCCL gathers in place; gloo wants a detached input)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    world = dist.get_world_size()
-    if world == 1:
-        return
-    mine = full[first:first + count].clone()      # own rows, detached from the receive buffer
-    if counts is None or len(set(counts)) == 1:
-        dist.all_gather_into_tensor(full.view(-1), mine.view(-1))
-        return
-    # ragged shards: pad every shard to the largest one so that a single equal-sized collective still does the job
-    maxc = max(counts)
-    row = int(np.prod(full.shape[1:]))
-    send = torch.zeros((maxc, row), dtype=full.dtype, device=full.device)
-    send[:count] = mine.view(count, row)
-    recv = torch.empty((world, maxc, row), dtype=full.dtype, device=full.device)
-    dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
-    off = 0
-    for r, c in enumerate(counts):
-        full[off:off + c] = recv[r, :c].view((c,) + tuple(full.shape[1:]))
-        off += c
+    mine = table[rank * rows:(rank + 1) * rows]
+    if dist.get_backend() != "nccl":
+        mine = mine.clone()
+    dist.all_gather_into_tensor(table.view(-1), mine.reshape(-1))
 
 
 class ShardedSwarm:
-    """Generic sharded tick loop.  `tick_fn(state, goal, traj_prev, planner_seq, first, count) -> traj rows of the
-    shard` is the HIP path on GPUs and the oracle in the gloo CPU tests; everything else is identical."""
+    """Generic sharded tick loop.  `tick_fn(state, goal, traj_prev, traj_next, planner_seq, first, count)` writes the
+    shard's rows of traj_next: the HIP path on GPUs, the oracle in the gloo CPU tests; everything else is identical.
+    Trajectory tables are [table_rows][90]; state / goal are [N][...]."""
 
     def __init__(self, dist, n_agents, tick_fn, propagate_fn, device="cpu"):
-        import torch
-        self.torch = torch
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.N = n_agents
+        self.rows = shard_rows(n_agents, self.world)
+        self.table_rows = self.rows * self.world
         self.first, self.count = shard_bounds(n_agents, self.world, self.rank)
-        self.counts = [shard_bounds(n_agents, self.world, r)[1] for r in range(self.world)]
         self.tick_fn, self.propagate_fn = tick_fn, propagate_fn
         self.device = device
         self.planner_seq = 0
@@ -62,8 +59,7 @@ class ShardedSwarm:
     def step(self, state, goal, traj_prev, traj_next):
         """One synchronous tick: plan own shard into traj_next, exchange, propagate all states."""
         self.planner_seq += 1
-        self.tick_fn(state, goal, traj_prev, traj_next, self.planner_seq, self.first, self.count)
-        if self.world > 1:
-            all_gather_rows(self.dist, traj_next, self.first, self.count, self.counts)
-        self.propagate_fn(traj_next, state)
+        self.tick_fn(state, goal, traj_prev[:self.N], traj_next, self.planner_seq, self.first, self.count)
+        all_gather_rows(self.dist, traj_next, self.rank, self.rows)
+        self.propagate_fn(traj_next[:self.N], state)
         return traj_next

@@ -135,15 +135,6 @@ def test_infeasible_qp_keeps_stale_trajectory_like_the_reference(L, oracle):
     pl.close()
 
 
-def test_row_capacity_overflow_is_reported_not_hidden(L):
-    ms = L.circle_swap(12, 0.9)          # dense ring: every neighbour is active
-    pl = L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=2, prune=False))
-    state = np.zeros((12, 9), np.float32); state[:, :3] = ms.start
-    g = pl.plan(state, ms.goal, np.zeros((12, 3, 30), np.float32))
-    assert (g["status"] == 3).all()
-    pl.close()
-
-
 def test_first_tick_with_moving_agents_uses_float32_constant_velocity_model(L, oracle):
     """planner_seq < 2: prediction = pos + vel * m_intp * dt in float32 (src/traj_planner.cpp:699-712) -- needs
     unfused float32 arithmetic on the device to stay bit-exact."""

@@ -1,0 +1,172 @@
+"""-m gpu: what round 2 added to the path, through the C ABI.
+
+  * second pass (rows in HBM) for agents whose LSC rows outgrow the LDS capacity: the reference never drops a row
+    (src/traj_optimizer.cpp:437-466), so "overflow" must be solved, not reported;
+  * the native agent-sharded tick (lsc_comm_init / lsc_tick_device_sharded / lsc_replan_tick_all): the exchange the
+    reference performs in MultiSyncSimulator::update (src/multi_sync_simulator.cpp:297-303) as one in-place RCCL
+    all-gather.  One GPU here, so the communicator has world size 1 -- the collective code path (librccl bound at run
+    time, ncclCommInitRank, ncclAllGather on the tick's stream) still executes on hardware.
+Same tolerances as test_gpu_parity.py.
+"""
+import numpy as np
+import pytest
+
+from conftest import oracle_swarm
+
+pytestmark = pytest.mark.gpu
+
+COST_RTOL = 1e-6
+COST_ATOL = 1e-8
+TRAJ_ATOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lsc_planner_amd as L
+    L.load_library()
+    return L
+
+
+def _start(ms):
+    N = ms.qn
+    state = np.zeros((N, 9), np.float32)
+    state[:, :3] = ms.start
+    return state, np.zeros((N, 3, 30), np.float32)
+
+
+def test_row_capacity_overflow_is_solved_by_the_second_pass(L, oracle):
+    """A dense ring with the LDS capacity forced down to 2 rows per control point and pruning off: every agent
+    overflows the first pass; the second pass (rows in HBM) must return what an unconstrained context and the oracle
+    return -- status 3 no longer exists."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(12, 0.9)
+    small = L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=2, prune=False))
+    roomy = L.SwarmPlanner(ms, L.PlannerConfig(prune=False))
+    sw = oracle_swarm(oracle, ms)
+    state, traj = _start(ms)
+    for tick in range(1, 9):
+        g, r = small.plan(state, ms.goal, traj, want_constraints=True), roomy.plan(state, ms.goal, traj)
+        sw.stale[:] = traj
+        o = sw.tick(state, ms.goal, traj, tick, want_lsc=True)
+        assert (g["status"] != 3).all(), tick
+        assert np.array_equal(g["status"], o["status"]) and np.array_equal(g["status"], r["status"]), tick
+        assert np.array_equal(g["normal"], o["normal"]) and np.array_equal(g["d"], o["d"]), tick
+        assert (small.row_counts() == 27 * 11).all(), tick          # all 27 (N-1) rows were kept
+        ok = o["status"] == 0
+        assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok] + COST_ATOL).all(), tick
+        assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL, tick
+        assert np.abs(g["traj"] - r["traj"]).max() <= TRAJ_ATOL, tick
+        traj = g["traj"]
+        state = next_state_host(traj)
+    small.close(); roomy.close()
+
+
+@pytest.mark.parametrize("n", [96, 256])
+def test_unpruned_swarms_beyond_the_lds_capacity(L, n):
+    """prune = 0 with N - 1 > 64 rows per control point: every agent takes the second pass and must agree with the pruned
+    solve (dropping redundant rows does not move the optimum)."""
+    from lsc_planner_amd.planner import next_state_host
+    R = 8.0 * n / 64
+    ms = L.circle_swap(n, R, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
+    a, b = L.SwarmPlanner(ms, L.PlannerConfig(prune=True)), L.SwarmPlanner(ms, L.PlannerConfig(prune=False))
+    state, traj = _start(ms)
+    for tick in range(1, 5):
+        ga, gb = a.plan(state, ms.goal, traj), b.plan(state, ms.goal, traj)
+        assert (ga["status"] == 0).all() and (gb["status"] == 0).all(), tick
+        assert (b.row_counts() == 27 * (n - 1)).all()
+        assert (np.abs(ga["cost"] - gb["cost"]) <= COST_RTOL * np.abs(gb["cost"]) + COST_ATOL).all(), tick
+        assert np.abs(ga["traj"] - gb["traj"]).max() <= TRAJ_ATOL, tick
+        traj = ga["traj"]
+        state = next_state_host(traj)
+    a.close(); b.close()
+
+
+def test_mixed_passes_in_one_tick(L, oracle):
+    """Capacity 6 with pruning on: some agents of a tight ring fit the LDS pass, others spill -- both kinds in one
+    launch pair, all against the oracle."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(16, 1.3)
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=6, prune=True))
+    sw = oracle_swarm(oracle, ms)
+    state, traj = _start(ms)
+    seen_small = seen_big = False
+    for tick in range(1, 13):
+        g = pl.plan(state, ms.goal, traj)
+        sw.stale[:] = traj
+        o = sw.tick(state, ms.goal, traj, tick)
+        assert np.array_equal(g["status"], o["status"]), tick
+        ok = o["status"] == 0
+        assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok] + COST_ATOL).all(), tick
+        assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL, tick
+        rows = pl.row_counts()
+        seen_small |= bool((rows <= 6).any())
+        seen_big |= bool((rows > 27 * 6).any())       # more rows than 27 buckets x 6 can hold: certainly spilled
+        traj = g["traj"]
+        state = next_state_host(traj)
+    assert seen_big
+    pl.close()
+
+
+def test_native_rccl_sharded_tick_equals_the_fused_tick(L):
+    """World-size-1 RCCL communicator: lsc_tick_device_sharded (plan -> ncclAllGather in place -> propagate) must be
+    bit-identical to the fused single-launch tick, in the default goal mode, on a padded table."""
+    import torch
+    ms = L.circle_swap(64, 8.0)
+    N = 64
+    dev = torch.device("cuda", 0)
+    f = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))
+    s = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based", comm=(1, 0, L.comm_unique_id())))
+    assert (s.world, s.rank, s.shard_rows, s.table_rows, s.first, s.count) == (1, 0, N, N, 0, N)
+    st0 = np.zeros((N, 9), np.float32); st0[:, :3] = ms.start
+    f0 = torch.from_numpy(st0.copy()).to(dev); f1 = torch.zeros_like(f0)
+    s0 = torch.from_numpy(st0.copy()).to(dev)
+    goal = torch.from_numpy(ms.goal).to(dev)
+    fa, fb = torch.zeros((N, 90), device=dev), torch.zeros((N, 90), device=dev)
+    sa, sb = torch.zeros((N, 90), device=dev), torch.zeros((N, 90), device=dev)
+    mk = lambda dt: torch.zeros(N, dtype=dt, device=dev)
+    fc, fs, fi = mk(torch.float64), mk(torch.int32), mk(torch.int32)
+    sc, ss, si = mk(torch.float64), mk(torch.int32), mk(torch.int32)
+    stream = torch.cuda.current_stream().cuda_stream
+    s.set_timing(True)
+    for seq in range(1, 31):
+        f.tick_device_fused(f0, goal, fa, fb, f1, fc, fs, fi, seq, stream)
+        fa, fb = fb, fa
+        f0, f1 = f1, f0
+        s.tick_device_sharded(s0, goal, sa, sb, sc, ss, si, seq, stream)
+        sa, sb = sb, sa
+        torch.cuda.synchronize()
+        assert torch.equal(fa, sa), seq
+        assert torch.equal(f0, s0), seq
+        assert torch.equal(fc, sc) and torch.equal(fs, ss), seq
+    x = s.kernel_times_ms(2)
+    assert len(x) == 30 and (x >= 0).all()
+    f.close(); s.close()
+
+
+def test_replan_tick_all_returns_every_agents_outputs(L):
+    """lsc_replan_tick_all (host buffers, what a replicated simulator per rank calls) == lsc_replan_tick, incl. the planned goals."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(10, 2.0)
+    a = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))
+    b = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based", comm=(1, 0, L.comm_unique_id())))
+    state, traj = _start(ms)
+    for _ in range(6):
+        ga, gb = a.plan(state, ms.goal, traj), b.plan_all(state, ms.goal, traj)
+        for k in ("traj", "cost", "status", "iters"):
+            assert np.array_equal(ga[k], gb[k]), k
+        assert np.array_equal(a.last_goals(), gb["goal"])
+        traj = ga["traj"]
+        state = next_state_host(traj)
+    a.close(); b.close()
+
+
+def test_comm_call_order_is_checked(L):
+    """lsc_comm_init after lsc_set_agents would leave unpadded tables: refused with LSC_ESTATE, not undefined behaviour."""
+    import ctypes
+    from lsc_planner_amd import _lib
+    ms = L.circle_swap(4, 1.0)
+    pl = L.SwarmPlanner(ms)
+    buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES).from_buffer_copy(L.comm_unique_id())
+    assert pl.L.lsc_comm_init(pl.ctx, 1, 0, buf) == -5
+    assert pl.L.lsc_comm_init(pl.ctx, 2, 2, buf) == -1
+    pl.close()

@@ -102,3 +102,46 @@ def test_forest_mission_in_the_default_goal_mode(tmp_path):
             assert np.allclose(p, traj[q, :, 0], atol=2e-6), (tick, q)
         state = next_state_host(traj)
     pl.close()
+
+
+def test_simulator_over_the_native_communicator_writes_the_same_run(ticks, tmp_path):
+    """lsc_sim --ranks 1 --comm-file: the multi-GPU form (rendezvous file, lsc_comm_init, lsc_replan_tick_all with its
+    RCCL all-gather group) must produce the same result CSV as the plain run.  One GPU here, hence world size 1."""
+    ms = golden_mission(ticks, "multi_simple4")
+    mp = tmp_path / "m.json"
+    _write_mission(str(mp), ms)
+    a, b = tmp_path / "plain", tmp_path / "comm"
+    a.mkdir(); b.mkdir()
+    r1 = subprocess.run([SIM, "--mission", str(mp), "--csv", str(a), "--quiet", "--max-iter", "40"], capture_output=True, text=True, timeout=300)
+    r2 = subprocess.run([SIM, "--mission", str(mp), "--csv", str(b), "--quiet", "--max-iter", "40", "--ranks", "1", "--rank", "0",
+                         "--comm-file", str(tmp_path / "token")], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
+    ra = list(csv.reader(open(a / "result_LSC_4agents.csv")))
+    rb = list(csv.reader(open(b / "result_LSC_4agents.csv")))
+    assert len(ra) == len(rb) > 40
+    skip = {15 * q + 11 for q in range(4)}                          # planning_time column (wall clock)
+    for x, y in zip(ra, rb):
+        assert [v for i, v in enumerate(x) if i not in skip] == [v for i, v in enumerate(y) if i not in skip]
+
+
+def test_blocked_corridor_seed_stops_the_run_like_the_reference(tmp_path):
+    """An agent that starts inside an obstacle's margin: the reference's expandBoxFromPoint throws std::invalid_argument
+    out of plan() (include/corridor_constructor.hpp:35-38) and the simulator dies; lsc_sim must fail as loudly instead
+    of flying a stale trajectory under planning_report = SUCCESS."""
+    import lsc_planner_amd as L
+    from maputil import forest_leaves, write_bt
+    leaves, res = forest_leaves()
+    bt = tmp_path / "forest.bt"
+    write_bt(str(bt), leaves, res)
+    world = (-5, -5, 0, 5, 5, 2.5)
+    dist, kmin, r = L.edt_from_bt(str(bt), np.asarray(world[:3], np.float32), np.asarray(world[3:], np.float32))
+    ms = L.random_swarm(4, world=world, seed=5, edt=dist, edt_key_min=kmin, edt_res=r)
+    # move agent 2 onto the centre of an occupied voxel
+    occ = np.argwhere(dist == 0)
+    c = occ[len(occ) // 2]
+    ms.start[2] = ((c + kmin - 32768) + 0.5) * r
+    mp = tmp_path / "blocked.json"
+    _write_mission(str(mp), ms)
+    rr = subprocess.run([SIM, "--mission", str(mp), "--world", str(bt), "--quiet", "--max-iter", "5"], capture_output=True, text=True, timeout=300)
+    assert rr.returncode == 3, rr.stdout + rr.stderr
+    assert "CorridorConstructor" in rr.stderr and "agent 2" in rr.stderr

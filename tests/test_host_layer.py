@@ -95,15 +95,18 @@ def test_mission_loader_and_generators(tmp_path):
 
 
 def test_shard_bounds_cover_all_agents():
-    from lsc_planner_amd.sharded import shard_bounds
-    for n in (1, 4, 20, 64, 65, 1024):
-        for w in (1, 2, 3, 8):
-            if w > n:
-                continue
+    from lsc_planner_amd.sharded import shard_bounds, shard_rows, table_rows
+    for n in (1, 4, 5, 20, 64, 65, 1024):
+        for w in (1, 2, 3, 4, 8):
             spans = [shard_bounds(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and sum(c for _, c in spans) == n
             for (f0, c0), (f1, _) in zip(spans, spans[1:]):
-                assert f0 + c0 == f1
+                assert f0 + c0 == f1 or (c0 == 0 and f0 == n)
+            # every block starts at a multiple of the padded block size: that is what makes the exchange one in-place
+            # equal-sized all-gather
+            rows = shard_rows(n, w)
+            assert table_rows(n, w) == rows * w >= n
+            assert all(f == min(r * rows, n) and c <= rows for r, (f, c) in enumerate(spans))
 
 
 _WORKER = r'''
@@ -112,12 +115,12 @@ import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from oracle import oracle as O
 import lsc_planner_amd as L
-from lsc_planner_amd.sharded import ShardedSwarm
+from lsc_planner_amd.sharded import ShardedSwarm, table_rows
 from lsc_planner_amd.planner import next_state_host
 rank, world = int(sys.argv[2]), int(sys.argv[3])
 os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[4]
 dist.init_process_group("gloo", rank=rank, world_size=world)
-ms = L.circle_swap(5, circle_radius=1.5, world=(-5, -5, 0, 5, 5, 2.5))       # 5 agents over 2 ranks: ragged shards
+ms = L.circle_swap(5, circle_radius=1.5, world=(-5, -5, 0, 5, 5, 2.5))       # 5 agents: ragged shards (world 4: one rank owns nobody)
 prm = O.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
 sw = O.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
 def tick_fn(state, goal, prev, nxt, seq, first, count):
@@ -128,18 +131,20 @@ def prop_fn(traj, state):
 sh = ShardedSwarm(dist, ms.qn, tick_fn, prop_fn)
 state = torch.zeros((ms.qn, 9)); state[:, :3] = torch.from_numpy(ms.start)
 goal = torch.from_numpy(ms.goal)
-a, b = torch.zeros((ms.qn, 90)), torch.zeros((ms.qn, 90))
+rows = table_rows(ms.qn, world)                                               # padded once, at allocation
+a, b = torch.zeros((rows, 90)), torch.zeros((rows, 90))
 for _ in range(4):
     b.zero_()
     sh.step(state, goal, a, b)
     a, b = b, a
-np.save(sys.argv[5] + f"/rank{rank}.npy", a.numpy())
+np.save(sys.argv[5] + f"/rank{rank}.npy", a[:ms.qn].numpy())
 dist.destroy_process_group()
 '''
 
 
-def test_sharded_stepping_world2_gloo_equals_single_process(oracle, tmp_path):
-    """world_size-2 gloo run of the sharded loop (ragged 3+2 shards) == the unsharded oracle run."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_stepping_gloo_equals_single_process(oracle, tmp_path, world):
+    """gloo runs of the sharded loop (5 agents: 3+2 over two ranks, 2+2+1+0 over four) == the unsharded oracle run."""
     import socket
     import lsc_planner_amd as L
     from lsc_planner_amd.planner import next_state_host
@@ -147,7 +152,7 @@ def test_sharded_stepping_world2_gloo_equals_single_process(oracle, tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     w = tmp_path / "worker.py"
     w.write_text(_WORKER)
-    procs = [subprocess.Popen([sys.executable, str(w), ROOT, str(r), "2", str(port), str(tmp_path)]) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(w), ROOT, str(r), str(world), str(port), str(tmp_path)]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=240) == 0
     ms = L.circle_swap(5, circle_radius=1.5, world=(-5, -5, 0, 5, 5, 2.5))
@@ -157,6 +162,5 @@ def test_sharded_stepping_world2_gloo_equals_single_process(oracle, tmp_path):
     for tick in range(1, 5):
         traj = sw.tick(state, ms.goal, traj, tick)["traj"]
         state = next_state_host(traj)
-    r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
-    assert np.array_equal(r0, r1)
-    assert np.array_equal(r0.reshape(5, 3, 30), traj)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rank{r}.npy").reshape(5, 3, 30), traj), r

@@ -1,0 +1,134 @@
+"""Pins of the oracle's QP optimum and of its infeasible verdict against an independent solver (HiGHS, tests/highs_qp.py).
+
+CPLEX -- what the reference calls (src/traj_optimizer.cpp:76-153) -- is absent, and no reference fixture holds an optimum.
+What can be pinned without it:
+  1. the reference's OWN fixture log/QPmodel.lp, read by HiGHS's own LP-file reader: same dimensions as our parse of it,
+     and infeasible (the file is written when CPLEX fails, src/traj_optimizer.cpp:100-102);
+  2. the optimum of a strictly convex QP is unique and infeasibility is a property of the rows, so for >1000 QPs the
+     oracle assembles on golden ticks and on seeded soak missions (sparse and dense: hundreds of infeasible ones),
+     HiGHS's active-set QP solver must return the oracle's cost to <= 1e-7 relative, and for every status-1 verdict a
+     phase-1 LP must have a strictly positive minimal violation (status 0: zero).
+The kernel is compared with the oracle on the same kind of QPs in tests/test_gpu_soak.py, so the chain
+kernel == oracle == HiGHS closes on cost and on the feasibility verdict.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import highs_qp as H
+from conftest import GOLDEN, golden_mission
+
+pytestmark = pytest.mark.skipif(not H.available(), reason="scipy's bundled HiGHS is not importable")
+
+REF_LP = "/root/reference/log/QPmodel.lp"
+COST_RTOL = 1e-7
+
+
+def _agent_qp(O, prm, ms, a, state, goal, obs_trajs, normal, d):
+    """QP of agent a in the reference's row order, from one oracle tick's inputs and its LSC dump."""
+    others = [j for j in range(ms.qn) if j != a]
+    return O.qp_assemble(prm, state[a], goal[a], float(ms.nominal_velocity[a]), ms.max_vel[a], ms.max_acc[a], obs_trajs[others],
+                         normal[a], d[a])
+
+
+def _check_against_highs(qp, status, cost):
+    """One QP: oracle verdict (status, cost) against HiGHS.  Returns 'opt' / 'inf'."""
+    A, lo, hi = H.rows_of(qp)
+    if status == 0:
+        ms_, x, obj = H.solve_qp(qp.P, qp.c, qp.cst, A, lo, hi, qp.lo, qp.hi)
+        assert ms_ == "Optimal", ms_
+        assert abs(obj - cost) <= COST_RTOL * abs(cost) + 1e-9, (obj, cost)
+        return "opt"
+    ms_, t = H.min_violation(A, lo, hi, qp.lo, qp.hi)
+    assert ms_ == "Optimal" and t > 1e-7, (ms_, t)          # the rows cannot all hold: certificate of infeasibility
+    ms_, _, _ = H.solve_qp(qp.P, qp.c, qp.cst, A, lo, hi, qp.lo, qp.hi)
+    assert ms_ == "Infeasible", ms_
+    return "inf"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_LP), reason="needs /root/reference (build container only)")
+def test_highs_reads_the_reference_fixture_itself_and_finds_it_infeasible():
+    """No parser of ours in between: HiGHS reads log/QPmodel.lp verbatim."""
+    lp = json.load(open(os.path.join(GOLDEN, "qpmodel_lp.json")))
+    status, rows, cols, hnz = H.read_lp_file(REF_LP)
+    assert (rows, cols) == (len(lp["rows"]), 90) == (546, 90)
+    assert hnz == len({(min(i, j), max(i, j)) for i, j, _ in lp["quad"]})      # same quadratic objective entries as our parse
+    assert status == "Infeasible"
+    pin = json.load(open(os.path.join(GOLDEN, "qp_pins.json")))
+    assert pin["reference_lp"]["highs_status"] == status and pin["reference_lp"]["rows"] == rows
+
+
+def test_parsed_fixture_is_infeasible_for_highs_and_for_the_oracle(oracle):
+    """The same instance through our parse (tests/golden/qpmodel_lp.json, travels to the GPU box): HiGHS's verdict, the
+    oracle's verdict and the recorded verdict of HiGHS on the reference file agree."""
+    from test_oracle_qp import _scene_qp
+    lp = json.load(open(os.path.join(GOLDEN, "qpmodel_lp.json")))
+    qp, _ = _scene_qp(oracle, lp)
+    st, x, cost, it, kkt = qp.solve()
+    assert st == 1
+    assert _check_against_highs(qp, st, cost) == "inf"
+    A, lo, hi = H.rows_of(qp)
+    _, t = H.min_violation(A, lo, hi, qp.lo, qp.hi)
+    assert abs(t - 0.0385092) < 1e-6                         # the LP-minimal uniform violation
+    pin = json.load(open(os.path.join(GOLDEN, "qp_pins.json")))
+    assert pin["reference_lp"]["highs_status"] == "Infeasible"
+
+
+def test_every_agent_of_the_golden_ticks_vs_highs(oracle, ticks):
+    """All agents of all committed snapshots (56 QPs), not a sample."""
+    n = 0
+    for name, keep in (("multi_simple4", (1, 2, 3, 20)), ("multi_circle20", (1, 15))):
+        ms = golden_mission(ticks, name)
+        prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+        for tick in keep:
+            g = lambda k: ticks[f"{name}/tick{tick}/{k}"]
+            state, prev = g("state"), g("prev")
+            obs = np.array([oracle.shift_traj(p) for p in prev]) if tick >= 2 else \
+                np.array([oracle.const_vel_traj(state[j, :3], state[j, 3:6]) for j in range(ms.qn)])
+            for a in range(ms.qn):
+                qp = _agent_qp(oracle, prm, ms, a, state, ms.goal, obs, g("normal"), g("d"))
+                st, x, cost, it, kkt = qp.solve()
+                assert st == 0 and abs(cost - g("cost")[a]) <= 1e-9 * abs(cost)
+                _check_against_highs(qp, st, cost)
+                n += 1
+    assert n == 56
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_soak_qps_optimum_and_infeasibility_vs_highs(oracle, dense):
+    """Seeded random missions like tests/test_gpu_soak.py (dense = packed so tightly that many QPs are infeasible):
+    every QP of every tick through HiGHS.  > 1000 QPs in total, > 100 certified-infeasible ones in the dense run."""
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import next_state_host
+    rng = np.random.default_rng(777 + int(dense))
+    n_opt = n_inf = 0
+    for trial in range(6):
+        n = int(rng.integers(8, 20)) if dense else int(rng.integers(4, 24))
+        side = float(rng.uniform(1.0, 1.6)) if dense else float(rng.uniform(2.5, 5.0))
+        ms = L.random_swarm(n, world=(-side, -side, 0, side, side, 2.5), seed=int(rng.integers(1, 1 << 30)),
+                            min_sep=0.33 if dense else 0.5, shrink=0.15 if dense else 0.4)
+        if trial % 3 == 0:
+            ms.radius[:] = rng.uniform(0.1, 0.25, n)
+            ms.downwash[:] = rng.uniform(1.0, 2.5, n)
+            ms.max_vel[:] = rng.uniform(0.6, 1.5, (n, 1))
+            ms.max_acc[:] = rng.uniform(1.0, 3.0, (n, 1))
+        prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+        sw = oracle.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+        state = np.zeros((n, 9), np.float32)
+        state[:, :3] = ms.start
+        traj = np.zeros((n, 3, 30), np.float32)
+        for tick in range(1, 9):
+            o = sw.tick(state, ms.goal, traj, tick, want_lsc=True, nthreads=8)
+            obs = np.array([oracle.shift_traj(p) for p in traj]) if tick >= 2 else \
+                np.array([oracle.const_vel_traj(state[j, :3], state[j, 3:6]) for j in range(n)])
+            for a in range(n):
+                qp = _agent_qp(oracle, prm, ms, a, state, ms.goal, obs, o["normal"], o["d"])
+                kind = _check_against_highs(qp, int(o["status"][a]), float(o["cost"][a]))
+                n_opt += kind == "opt"
+                n_inf += kind == "inf"
+            traj = o["traj"]
+            state = next_state_host(traj)
+    assert n_opt + n_inf >= 500
+    assert (n_inf > 100) == dense, (n_opt, n_inf)
