@@ -6,8 +6,9 @@ What can be pinned without it:
      and infeasible (the file is written when CPLEX fails, src/traj_optimizer.cpp:100-102);
   2. the optimum of a strictly convex QP is unique and infeasibility is a property of the rows, so for >1000 QPs the
      oracle assembles on golden ticks and on seeded soak missions (sparse and dense: hundreds of infeasible ones),
-     HiGHS's active-set QP solver must return the oracle's cost to <= 1e-7 relative, and for every status-1 verdict a
-     phase-1 LP must have a strictly positive minimal violation (status 0: zero).
+     HiGHS's active-set QP solver must return the oracle's cost to <= 1e-7 relative (never a better feasible point;
+     where HiGHS itself stops short -- <1 % of instances -- the oracle's point is checked to be feasible and better), and
+     for every status-1 verdict a phase-1 LP must have a strictly positive minimal violation.
 The kernel is compared with the oracle on the same kind of QPs in tests/test_gpu_soak.py, so the chain
 kernel == oracle == HiGHS closes on cost and on the feasibility verdict.
 """
@@ -24,6 +25,7 @@ pytestmark = pytest.mark.skipif(not H.available(), reason="scipy's bundled HiGHS
 
 REF_LP = "/root/reference/log/QPmodel.lp"
 COST_RTOL = 1e-7
+COST_ATOL = 1e-8          # costs go to zero when an agent hovers at its goal (same floor as tests/test_gpu_parity.py)
 
 
 def _agent_qp(O, prm, ms, a, state, goal, obs_trajs, normal, d):
@@ -37,14 +39,28 @@ def _check_against_highs(qp, status, cost):
     """One QP: oracle verdict (status, cost) against HiGHS.  Returns 'opt' / 'inf'."""
     A, lo, hi = H.rows_of(qp)
     if status == 0:
-        ms_, x, obj = H.solve_qp(qp.P, qp.c, qp.cst, A, lo, hi, qp.lo, qp.hi)
+        ms_, x, obj, viol = H.solve_oracle_qp(qp)
+        if ms_ in ("Solve error", "Time limit reached"):
+            return "gave_up"                                 # HiGHS's active-set code abandons a few degenerate instances
         assert ms_ == "Optimal", ms_
-        assert abs(obj - cost) <= COST_RTOL * abs(cost) + 1e-9, (obj, cost)
-        return "opt"
+        assert viol <= 1e-7, viol                            # the point HiGHS calls optimal satisfies the ORIGINAL rows
+        tol = COST_RTOL * abs(cost) + COST_ATOL
+        # the direction that could expose the oracle: an independent solver must never find a better feasible point
+        assert obj >= cost - tol, (obj, cost)
+        if obj <= cost + tol:
+            return "opt"
+        # HiGHS's "optimum" is WORSE than the oracle's (its active-set code stops ~1e-6 short on a few instances).  That
+        # says nothing against the oracle provided the oracle's own point really is feasible: re-solve in double and check
+        # it against the original rows.
+        st, xo, co, _, _ = qp.solve()
+        assert st == 0 and co == cost
+        vo = max(np.max(lo - A @ xo), np.max(A @ xo - hi), np.max(qp.lo - xo), np.max(xo - qp.hi))
+        assert vo <= 1e-9 and obj - cost <= 1e-5 * abs(cost), (vo, obj, cost)
+        return "highs_short"
     ms_, t = H.min_violation(A, lo, hi, qp.lo, qp.hi)
     assert ms_ == "Optimal" and t > 1e-7, (ms_, t)          # the rows cannot all hold: certificate of infeasibility
-    ms_, _, _ = H.solve_qp(qp.P, qp.c, qp.cst, A, lo, hi, qp.lo, qp.hi)
-    assert ms_ == "Infeasible", ms_
+    ms_, _, _, _ = H.solve_oracle_qp(qp)
+    assert ms_ in ("Infeasible", "Solve error", "Time limit reached"), ms_
     return "inf"
 
 
@@ -99,14 +115,14 @@ def test_every_agent_of_the_golden_ticks_vs_highs(oracle, ticks):
 @pytest.mark.parametrize("dense", [False, True])
 def test_soak_qps_optimum_and_infeasibility_vs_highs(oracle, dense):
     """Seeded random missions like tests/test_gpu_soak.py (dense = packed so tightly that many QPs are infeasible):
-    every QP of every tick through HiGHS.  > 1000 QPs in total, > 100 certified-infeasible ones in the dense run."""
+    the QPs of every tick through HiGHS.  > 1000 QPs in total, > 100 certified-infeasible ones in the dense run."""
     import lsc_planner_amd as L
     from lsc_planner_amd.planner import next_state_host
     rng = np.random.default_rng(777 + int(dense))
-    n_opt = n_inf = 0
-    for trial in range(6):
-        n = int(rng.integers(8, 20)) if dense else int(rng.integers(4, 24))
-        side = float(rng.uniform(1.0, 1.6)) if dense else float(rng.uniform(2.5, 5.0))
+    n_opt = n_inf = n_gave_up = 0
+    for trial in range(8 if dense else 6):
+        n = int(rng.integers(10, 22)) if dense else int(rng.integers(4, 24))
+        side = float(rng.uniform(0.9, 1.3)) if dense else float(rng.uniform(2.5, 5.0))
         ms = L.random_swarm(n, world=(-side, -side, 0, side, side, 2.5), seed=int(rng.integers(1, 1 << 30)),
                             min_sep=0.33 if dense else 0.5, shrink=0.15 if dense else 0.4)
         if trial % 3 == 0:
@@ -119,16 +135,21 @@ def test_soak_qps_optimum_and_infeasibility_vs_highs(oracle, dense):
         state = np.zeros((n, 9), np.float32)
         state[:, :3] = ms.start
         traj = np.zeros((n, 3, 30), np.float32)
-        for tick in range(1, 9):
+        for tick in range(1, 21 if dense else 9):
             o = sw.tick(state, ms.goal, traj, tick, want_lsc=True, nthreads=8)
             obs = np.array([oracle.shift_traj(p) for p in traj]) if tick >= 2 else \
                 np.array([oracle.const_vel_traj(state[j, :3], state[j, 3:6]) for j in range(n)])
             for a in range(n):
+                if dense and o["status"][a] == 0 and (a + tick) % 4:
+                    continue        # dense run: EVERY infeasible verdict is certified, the feasible ones are sampled (1 in 4)
                 qp = _agent_qp(oracle, prm, ms, a, state, ms.goal, obs, o["normal"], o["d"])
                 kind = _check_against_highs(qp, int(o["status"][a]), float(o["cost"][a]))
                 n_opt += kind == "opt"
                 n_inf += kind == "inf"
+                n_gave_up += kind in ("gave_up", "highs_short")
             traj = o["traj"]
             state = next_state_host(traj)
     assert n_opt + n_inf >= 500
     assert (n_inf > 100) == dense, (n_opt, n_inf)
+    print(f"dense={dense}: {n_opt} optimal, {n_inf} infeasible, {n_gave_up} without a HiGHS verdict")
+    assert n_gave_up <= 0.01 * (n_opt + n_inf), n_gave_up      # no verdict from HiGHS is not a disagreement, but must stay rare
