@@ -91,6 +91,9 @@ typedef struct {
                                   start as fallback; 0 = always cold start */
     double grid_resolution;    /* grid/resolution 0.3: cell of the goal planner's search grid (goal_mode 1 + use_octomap) */
     double grid_margin;        /* grid/margin     0.2: a cell is occupied when EDT(centre) < radius + grid_margin        */
+    double horizon;            /* traj/horizon 1.0: the kernels plan M = horizon/dt = 5 segments; anything else is refused
+                                  by lsc_create instead of silently planning a different horizon                          */
+    int    goal_row_cap;       /* 0 = as large as LDS allows; > 0 lowers the goal search's OPEN-row capacity (tests)       */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);

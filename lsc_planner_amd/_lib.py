@@ -39,6 +39,8 @@ class LscConfig(ctypes.Structure):
         ("warm_start_mu", ctypes.c_double),
         ("grid_resolution", ctypes.c_double),
         ("grid_margin", ctypes.c_double),
+        ("horizon", ctypes.c_double),
+        ("goal_row_cap", ctypes.c_int),
     ]
 
 

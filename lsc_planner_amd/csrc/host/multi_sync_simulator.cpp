@@ -20,6 +20,7 @@ class MultiSyncSimulator {
         lsc_config cfg;
         lsc_default_config(&cfg);
         cfg.dt = param.dt; cfg.control_weight = param.control_input_weight; cfg.terminal_weight = param.terminal_weight;
+        cfg.horizon = param.horizon;
         for (int k = 0; k < 3; k++) { cfg.world_min[k] = mission.world_min(k); cfg.world_max[k] = mission.world_max(k); }
         cfg.use_octomap = param.world_use_octomap; cfg.world_resolution = param.world_resolution; cfg.device = param.device;
         // mode/goal: prior_based like every shipped launch file (on octomap worlds that includes the grid search)

@@ -162,10 +162,8 @@ void build_model(const lsc_config &cfg, HostModel &H)
         if (valid) m.amap[n++] = (unsigned short)sl;
     }
     if (n != 414) { std::fprintf(stderr, "lsc: axis row count %d != 414\n", n); std::abort(); }
-    if (const char *e = std::getenv("LSC_DX_TOL")) m.dx_tol = std::atof(e);
-    if (const char *e = std::getenv("LSC_WS_MU0")) m.ws_mu0 = std::atof(e);
     m.sigma_pow = 3;
-    if (const char *e = std::getenv("LSC_SIGMA_POW")) m.sigma_pow = std::atoi(e);
+    // (no environment overrides: everything that changes the solve is an lsc_config field)
 }
 
 }  // namespace
@@ -313,11 +311,18 @@ void lsc_default_config(lsc_config *cfg)
     cfg->max_rows_per_cp = 0; cfg->max_iters = 50; cfg->prune = 1; cfg->warm_start_mu = 0.05;
     cfg->goal_mode = 0; cfg->goal_threshold = 0.1; cfg->priority_dist_threshold = 0.4; cfg->goal_radius = 2.0;
     cfg->grid_resolution = 0.3; cfg->grid_margin = 0.2;   // launch/testall_forest.launch:88-89
+    cfg->horizon = 1.0; cfg->goal_row_cap = 0;
 }
 
 lsc_ctx *lsc_create(const lsc_config *cfg)
 {
     if (!cfg || !(cfg->dt > 0)) return nullptr;
+    // M = horizon / dt (src/param.cpp, TrajPlanner ctor): the kernels are built for the M = 5 of every shipped launch file
+    if ((int)((cfg->horizon + 1e-9) / cfg->dt) != M) {
+        std::fprintf(stderr, "lsc_create: horizon %g / dt %g = %d segments, this build plans M = %d\n", cfg->horizon, cfg->dt,
+                     (int)((cfg->horizon + 1e-9) / cfg->dt), M);
+        return nullptr;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev) {
         std::fprintf(stderr, "lsc_create: no usable HIP device (there is no CPU fallback)\n");
@@ -494,7 +499,7 @@ static int build_goal_grid(lsc_ctx *c, const std::vector<double> &radii)
     int cap = W * A;
     while (cap > 16 && goal_smem_bytes(H, W, A, cap) > 158 * 1024) cap--;
     if (goal_smem_bytes(H, W, A, cap) > 158 * 1024) { c->err = "goal planner: search grid does not fit LDS"; return LSC_EINVAL; }
-    if (const char *e = std::getenv("LSC_GOAL_ROW_CAP")) cap = std::max(4, std::min(cap, std::atoi(e)));   // tests: force the overflow path
+    if (c->cfg.goal_row_cap > 0) cap = std::max(4, std::min(cap, c->cfg.goal_row_cap));   // explicit smaller capacity (tests force the overflow path)
     c->grid_row_cap = cap;
     // bucket counts of a growing std::unordered_map<uint_least32_t, T> (identity hash), from the container itself
     {
@@ -584,6 +589,12 @@ static int build_integrals(lsc_ctx *c)
 int lsc_set_distmap(lsc_ctx *c, const float *edt, int nx, int ny, int nz, const int key_min[3], double res)
 {
     if (!c || !edt || nx < 1 || ny < 1 || nz < 1 || !key_min || !(res > 0)) return LSC_EINVAL;
+    // The corridor kernel visits the reference's lattice samples (spacing world/resolution) as contiguous cell ranges of
+    // the distance field: that is only the same set when both resolutions agree (they do in every shipped launch file)
+    if (std::fabs(res - c->cfg.world_resolution) > 1e-9 * res) {
+        c->err = "lsc_set_distmap: map resolution differs from world_resolution";
+        return LSC_EINVAL;
+    }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     c->h_edt.assign(edt, edt + (size_t)nx * ny * nz);
     c->edt_dims[0] = nx; c->edt_dims[1] = ny; c->edt_dims[2] = nz;

@@ -1410,8 +1410,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 stamp(PH_FACTOR);
                 if (!fok) {
                     if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) { double *tr = a.trace + iters * 8; tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = -1; tr[5] = -1; tr[7] = mu; }
-                    // K lost definiteness to round-off: accept only if already within 1e-7 relative gap
-                    if (phase == ST_PRED && rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
+                    // K lost definiteness to round-off: accept only a point that is already optimal to slightly relaxed
+                    // tolerances -- primal residual, gap AND the projected stationarity residual (S.sc[0], reduced just
+                    // above for the cheap exit); otherwise this start has failed
+                    if (phase == ST_PRED && rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj)) &&
+                        S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
                     failed = true;
                 }
             }
@@ -1604,6 +1607,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_spill_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    // The common case is "nobody overflowed": leave before anything else happens (the planning code below keeps part of
+    // its loop invariants in scratch; a workgroup without work must not pay for setting them up).
+    {
+        bool work = false;
+        for (int al = blockIdx.x; al < a.count; al += gridDim.x) work |= a.status[a.first + al] == LSC_STATUS_CAPACITY_K;
+        if (!work) return;
+    }
     unsigned char *ws = a.spill_ws + (size_t)blockIdx.x * a.spill_stride;
     for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
         if (a.status[a.first + al] != LSC_STATUS_CAPACITY_K) continue;   // uniform over the workgroup

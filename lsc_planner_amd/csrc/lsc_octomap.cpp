@@ -119,14 +119,15 @@ int lsc_edt_from_bt(const char *path, const float world_min[3], const float worl
     const int md = (int)(maxdist / res + 1);
     const double trunc2 = (double)md * md;           // DynamicEDT3D(maxDist_squared)
     std::vector<double> g((size_t)nx * ny * nz, BIG);
-    for (const Leaf &l : occ)
-        for (int dx = 0; dx < l.size; dx++)
-            for (int dy = 0; dy < l.size; dy++)
-                for (int dz = 0; dz < l.size; dz++) {
-                    const int x = l.x + dx - kmin[0], y = l.y + dy - kmin[1], z = l.z + dz - kmin[2];
-                    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
-                    g[((size_t)x * ny + y) * nz + z] = 0.0;
-                }
+    for (const Leaf &l : occ) {
+        // a pruned leaf covers size^3 cells (up to 32768^3): intersect it with the grid before walking it
+        const long x0 = std::max<long>(l.x - kmin[0], 0), x1 = std::min<long>((long)l.x + l.size - kmin[0], nx);
+        const long y0 = std::max<long>(l.y - kmin[1], 0), y1 = std::min<long>((long)l.y + l.size - kmin[1], ny);
+        const long z0 = std::max<long>(l.z - kmin[2], 0), z1 = std::min<long>((long)l.z + l.size - kmin[2], nz);
+        for (long x = x0; x < x1; x++)
+            for (long y = y0; y < y1; y++)
+                for (long z = z0; z < z1; z++) g[((size_t)x * ny + y) * nz + z] = 0.0;
+    }
     const int nmax = std::max(nx, std::max(ny, nz));
     std::vector<double> f(nmax), o(nmax), zz(nmax + 2);
     std::vector<int> v(nmax + 1);

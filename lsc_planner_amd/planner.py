@@ -32,6 +32,8 @@ class PlannerConfig:
     goal_radius: float = 2.0
     grid_resolution: float = 0.3    # grid/resolution (goal planner's search grid; goal_mode prior_based + use_octomap)
     grid_margin: float = 0.2        # grid/margin
+    horizon: float = 1.0            # traj/horizon (M = horizon / dt must be 5)
+    goal_row_cap: int = 0           # > 0: smaller OPEN-row capacity of the goal search (tests of the overflow path)
     comm: tuple = None              # (world_size, rank, id bytes from comm_unique_id()): agent-sharded multi-GPU over RCCL
 
 
@@ -71,6 +73,7 @@ class SwarmPlanner:
         c.goal_threshold, c.priority_dist_threshold, c.goal_radius = (self.cfg.goal_threshold, self.cfg.priority_dist_threshold,
                                                                        self.cfg.goal_radius)
         c.grid_resolution, c.grid_margin = self.cfg.grid_resolution, self.cfg.grid_margin
+        c.horizon, c.goal_row_cap = self.cfg.horizon, self.cfg.goal_row_cap
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:

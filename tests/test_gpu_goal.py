@@ -82,9 +82,9 @@ def test_random_mazes_tie_breaking(L, oracle):
         pl.close()
 
 
-def test_open_row_overflow_is_reported_as_status_5(L, monkeypatch):
+def test_open_row_overflow_is_reported_as_status_5(L):
     """An OPEN row that outgrows its LDS capacity must surface as LSC_STATUS_GOAL_CAPACITY (stale trajectory kept), never
-    as a silently different goal.  The capacity is forced down through the test hook LSC_GOAL_ROW_CAP."""
+    as a silently different goal.  The capacity is forced down through lsc_config.goal_row_cap."""
     from maputil import forest_leaves, write_bt
     import tempfile, os
     leaves, res = forest_leaves()
@@ -101,8 +101,7 @@ def test_open_row_overflow_is_reported_as_status_5(L, monkeypatch):
     g_ref = ref.plan(state, ms.goal, traj)
     goals_ref = ref.last_goals()
     ref.close()
-    monkeypatch.setenv("LSC_GOAL_ROW_CAP", "30")
-    pl = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True, goal_mode="prior_based"))
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True, goal_mode="prior_based", goal_row_cap=30))
     pl.load_octomap(bt)
     g = pl.plan(state, ms.goal, traj)
     goals = pl.last_goals()

@@ -170,3 +170,66 @@ def test_comm_call_order_is_checked(L):
     assert pl.L.lsc_comm_init(pl.ctx, 1, 0, buf) == -5
     assert pl.L.lsc_comm_init(pl.ctx, 2, 2, buf) == -1
     pl.close()
+
+
+def test_config3_256_agents_in_simple_forest_as_written(L, oracle):
+    """BASELINE configs[3] exactly as SURVEY 8(d)#4 states it: 256 agents in world/simple_forest.bt, world
+    [-5,-5,0,5,5,2.5], starts/goals from numpy default_rng(20260928) (box shrunk by 0.5 m, EDT >= 0.45 m, pairwise
+    downwash-scaled distance >= 0.6 m, goals = permutation of a second such set -- L.random_swarm is that sampler; the
+    256 agents DO fit the 10 x 10 m world, no tiling needed), reference-default goal mode (grid A* + line-of-sight goal),
+    EDT + SFC path.  24 chained ticks; at checkpoints goals and corridor boxes bit-exact and statuses / costs / plans
+    within tolerance against the oracle; every tick the swarm planned through two shard contexts (as two ranks hold
+    them) equals the unsharded tick bit for bit."""
+    from maputil import forest_leaves
+    from lsc_planner_amd.planner import next_state_host
+    leaves, res = forest_leaves()
+    world = (-5, -5, 0, 5, 5, 2.5)
+    dm = oracle.DistMap(leaves, res, world[:3], world[3:])
+    N = 256
+    ms = L.random_swarm(N, world=world, seed=20260928, edt=dm.dist, edt_key_min=dm.key_min, edt_res=res)
+    q = ms.start.astype(np.float64).copy(); q[:, 2] /= 2
+    D = np.linalg.norm(q[:, None] - q[None], axis=2) + np.eye(N) * 9
+    assert D.min() >= 0.6 - 1e-6 and np.abs(ms.start[:, :2]).max() <= 4.5          # the sampler's contract
+    cfg = dict(use_octomap=True, goal_mode="prior_based")
+    full, s0, s1 = (L.SwarmPlanner(ms, L.PlannerConfig(**cfg)) for _ in range(3))
+    for p in (full, s0, s1):
+        p.set_distmap(dm.dist, dm.key_min, res)
+    s0.set_shard(0, 128); s1.set_shard(128, 128)
+    prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, use_sfc=True, obs_f32=True)
+    sw = oracle.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+    sw.set_distmap(dm)
+    state, traj = _start(ms)
+    stale = np.zeros_like(traj)
+    sfc_prev = np.zeros((N, 5, 6), np.float32)
+    checked = 0
+    for tick in range(1, 25):
+        g = full.plan(state, ms.goal, traj)
+        g0, g1 = s0.plan(state, ms.goal, traj), s1.plan(state, ms.goal, traj)
+        for k in ("traj", "cost", "status", "sfc"):
+            assert np.array_equal(np.concatenate([g0[k], g1[k]]), g[k]), (tick, k)
+        assert np.array_equal(np.concatenate([s0.last_goals()[:128], s1.last_goals()[128:]]), full.last_goals()), tick
+        assert (g["status"] != 5).all() and (g["status"] != 4).all(), tick
+        if tick in (1, 2, 12, 24):
+            goals_ref = oracle.goal_prior_based_map(prm, dm, state, ms.goal, traj, tick, ms.radius, ms.downwash)
+            assert np.array_equal(full.last_goals(), goals_ref), tick
+            # the oracle's persistent per-agent state (optimiser's last trajectory, corridor history) = what the previous tick left
+            sw.stale[:] = stale
+            sw.sfc[:] = sfc_prev
+            sw.sfc_init[:] = 1 if tick == 1 else 0
+            o = sw.tick(state, goals_ref, traj, tick, nthreads=16)
+            assert np.array_equal(g["sfc"], o["sfc"]), tick
+            assert np.array_equal(g["status"], o["status"]), (tick, np.flatnonzero(g["status"] != o["status"]))
+            ok = o["status"] == 0
+            assert ok.sum() >= N - 16, (tick, int(ok.sum()))
+            assert (np.abs(g["cost"] - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok] + COST_ATOL).all(), tick
+            assert np.abs(g["traj"][ok] - o["traj"][ok]).max() <= TRAJ_ATOL, tick
+            checked += 1
+        ok = g["status"] == 0
+        stale = np.where(ok[:, None, None], g["traj"], stale).astype(np.float32)
+        sfc_prev = g["sfc"].copy()
+        traj = g["traj"]
+        state = next_state_host(traj)
+    assert checked == 4
+    # the swarm is making progress towards its goals
+    assert np.linalg.norm(state[:, :3] - ms.goal, axis=1).mean() < np.linalg.norm(ms.start - ms.goal, axis=1).mean() - 1.0
+    full.close(); s0.close(); s1.close()
