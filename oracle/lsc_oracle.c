@@ -651,8 +651,6 @@ int orc_qp_assemble(const orc_params *prm, const float state[9], const float goa
  * interior-point method.  Stands where CPLEX's dual simplex stood (src/traj_optimizer.cpp:76).
  * ---------------------------------------------------------------------------------------- */
 
-#define NV ORC_NV
-
 static int chol_factor(double *A, int n)
 {
     for (int j = 0; j < n; j++) {
@@ -686,6 +684,14 @@ static void chol_solve(const double *L, int n, double *b)
 
 int orc_qp_solve(const double *P, const double *c, double cst, const double *lo, const double *hi,
                  const orc_row *rows, int nrows, double *x, double *cost, int *iters, double *kkt)
+{
+    return orc_qp_solve_n(ORC_NV, P, c, cst, lo, hi, rows, nrows, x, cost, iters, kkt);
+}
+
+/* The same solver for NV variables (the 90 control-point coordinates plus the slack variables of the alternate modes,
+ * src/traj_optimizer.cpp:306-326): nothing in it depends on what the variables mean. */
+int orc_qp_solve_n(const int NV, const double *P, const double *c, double cst, const double *lo, const double *hi,
+                   const orc_row *rows, int nrows, double *x, double *cost, int *iters, double *kkt)
 {
     /* ---- split rows ---- */
     int neq = 0, nin = 0;
@@ -812,7 +818,8 @@ int orc_qp_solve(const double *P, const double *c, double cst, const double *lo,
     double *rp = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
     double *u = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
     double *K = (double *)calloc((size_t)ny * ny, sizeof(double));
-    double Kx[NV * NV], xx[NV], dx[NV], tx[NV];
+    double *Kx = (double *)calloc((size_t)NV * NV, sizeof(double));
+    double xx[NV], dx[NV], tx[NV];
     double *rd = (double *)calloc(ny, sizeof(double));
     double *dy = (double *)calloc(ny, sizeof(double));
     double *KxZ = (double *)calloc((size_t)NV * ny, sizeof(double));
@@ -828,7 +835,7 @@ int orc_qp_solve(const double *P, const double *c, double cst, const double *lo,
     /* build K = Hy + Z' (sum w_r g_r g_r') Z */
     #define BUILD_K(wvec)                                                             \
     do {                                                                              \
-        memset(Kx, 0, sizeof(Kx));                                                    \
+        memset(Kx, 0, sizeof(double) * (size_t)NV * NV);                              \
         for (int r_ = 0; r_ < R; r_++) {                                              \
             double w_ = (wvec)[r_];                                                   \
             for (int a_ = 0; a_ < G[r_].nnz; a_++)                                    \
@@ -1024,7 +1031,7 @@ done:
         kkt[0] = st; kkt[1] = pf; kkt[2] = df; kkt[3] = cp;
     }
     free(G); free(W); free(beq); free(HV); free(Z); free(xp); free(PZ); free(Hy); free(gy);
-    free(y); free(s); free(z); free(ds); free(dz); free(rp); free(u); free(K); free(rd); free(dy); free(KxZ);
+    free(y); free(s); free(z); free(ds); free(dz); free(rp); free(u); free(K); free(rd); free(dy); free(KxZ); free(Kx);
     return status;
 }
 

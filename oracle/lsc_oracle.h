@@ -98,6 +98,30 @@ int  orc_qp_assemble(const orc_params *prm, const float state[9], const float go
 int  orc_qp_solve(const double *P, const double *c, double cst, const double *lo, const double *hi,
                   const orc_row *rows, int nrows, double *x, double *cost, int *iters, double *kkt);
 
+int  orc_qp_solve_n(int nv, const double *P, const double *c, double cst, const double *lo, const double *hi,
+                    const orc_row *rows, int nrows, double *x, double *cost, int *iters, double *kkt);
+
+/* ---- alternate planner modes (lsc_oracle_modes.c) ---- */
+typedef struct {
+    int    planner_mode;          /* 0 LSC, 1 BVC (mode/planner, src/param.cpp:33-48)                              */
+    int    slack_mode;            /* 0 none, 1 dynamical_limit, 2 collision_constraint (SlackMode, sp_const.hpp)   */
+    double slack_weight;          /* opt/slack_collision_weight (100000 in every launch file)                      */
+    int    n_constraint_segments; /* opt/N_constraint_segments, -1 -> M                                            */
+    double reset_threshold;       /* multisim/reset_threshold (0.15); <= 0 switches the disturbance checks off     */
+} orc_modes;
+int  orc_slack_count(const orc_modes *md, int n_obs, const unsigned char *slack_flags);
+void orc_bvc_pair(const float *init_traj, const float *obs_traj, double r_a, double r_o, double dw_a, double dw_o,
+                  float normal[ORC_M][3], double d[ORC_M][ORC_NC]);
+int  orc_qp_assemble_ex(const orc_params *prm, const orc_modes *md, const float state[9], const float goal[3], double v_nom,
+                        const double vmax[3], const double amax[3], int n_obs, const float *obs_traj, const float *normal,
+                        const double *d, const float *sfc, const unsigned char *slack_flags, int *nv_out, double *P, double *c,
+                        double *cst, double *lo, double *hi, orc_row *rows);
+void orc_disturbance_update(const orc_params *prm, const orc_modes *md, int N, const float *state, const float *prev_traj,
+                            int planner_seq, unsigned char *slack_set, int *sfc_init, unsigned char *own_reset);
+void orc_goal_prior_based_ex(int N, int qi, const float *state, const float *desired_goal, const float *prev_traj, int planner_seq,
+                             double dt, double goal_threshold, double priority_dist_threshold, double goal_radius,
+                             const unsigned char *slack_row, int own_reset, float out_goal[3]);
+
 /* ---- goal planning, prior_based, empty map (src/traj_planner.cpp:540-608; see the .c file) ---- */
 void orc_goal_prior_based(int N, int qi, const float *state, const float *desired_goal, const float *prev_traj,
                           int planner_seq, double dt, double goal_threshold, double priority_dist_threshold,
@@ -134,6 +158,12 @@ int  orc_expand_box(const orc_params *prm, const orc_edt *edt, double world_res,
                     const float point[3], const float goal[3], double radius, double box[6]);
 int  orc_update_sfc(const orc_params *prm, const orc_edt *edt, double world_res, const float pos[3], const float goal[3],
                     const float *prev_traj, double radius, float *sfc /*[M][6]*/, int *init_flag);
+
+int  orc_tick_ex(const orc_params *prm, const orc_modes *md, int N, const float *state, const float *goal, const float *prev_traj,
+                 int planner_seq, const double *radius, const double *downwash, const double *vmax, const double *amax,
+                 const double *vnom, float *stale_traj, unsigned char *slack_set, const orc_edt *edt, double world_res,
+                 float *sfc_io, int *sfc_init, float *out_traj, double *out_cost, int *out_status, int *out_iters,
+                 float *out_normal, double *out_d, int nthreads);
 
 /* ---- goal planning with a distance field: grid A* + line-of-sight goal (lsc_oracle_goal.cpp) ---- */
 long orc_astar_last_expansions(void);

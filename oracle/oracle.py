@@ -40,6 +40,26 @@ class OrcRow(ctypes.Structure):
     ]
 
 
+class OrcModes(ctypes.Structure):
+    _fields_ = [
+        ("planner_mode", ctypes.c_int),
+        ("slack_mode", ctypes.c_int),
+        ("slack_weight", ctypes.c_double),
+        ("n_constraint_segments", ctypes.c_int),
+        ("reset_threshold", ctypes.c_double),
+    ]
+
+
+def make_modes(planner="lsc", slack="none", slack_weight=100000.0, n_constraint_segments=-1, reset_threshold=0.0):
+    """Alternate-mode switches (mode/planner, SlackMode, opt/slack_collision_weight, opt/N_constraint_segments,
+    multisim/reset_threshold; reset_threshold <= 0 switches the disturbance checks off)."""
+    m = OrcModes()
+    m.planner_mode = {"lsc": 0, "bvc": 1}[planner]
+    m.slack_mode = {"none": 0, "dynamical_limit": 1, "collision_constraint": 2}[slack]
+    m.slack_weight, m.n_constraint_segments, m.reset_threshold = slack_weight, n_constraint_segments, reset_threshold
+    return m
+
+
 class OrcEdt(ctypes.Structure):
     _fields_ = [
         ("dist", _fp),
@@ -51,7 +71,7 @@ class OrcEdt(ctypes.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "liblsc_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("lsc_oracle.c", "lsc_oracle_sfc.c", "lsc_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lsc_oracle.c", "lsc_oracle_sfc.c", "lsc_oracle_modes.c", "lsc_oracle_goal.cpp", "lsc_oracle.h")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "liblsc_oracle.so"], stdout=subprocess.DEVNULL)
@@ -105,6 +125,25 @@ def lib():
                                                ctypes.c_double, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,
                                                ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp, _fp, _ip, ctypes.c_int,
                                                _ip, _ip]
+        _ubp = ctypes.POINTER(ctypes.c_ubyte)
+        pm, pp = ctypes.POINTER(OrcModes), ctypes.POINTER(OrcParams)
+        L.orc_qp_solve_n.restype = ctypes.c_int
+        L.orc_qp_solve_n.argtypes = [ctypes.c_int, _dp, _dp, ctypes.c_double, _dp, _dp, ctypes.POINTER(OrcRow), ctypes.c_int, _dp, _dp, _ip, _dp]
+        L.orc_slack_count.restype = ctypes.c_int
+        L.orc_slack_count.argtypes = [pm, ctypes.c_int, _ubp]
+        L.orc_qp_assemble_ex.restype = ctypes.c_int
+        L.orc_qp_assemble_ex.argtypes = [pp, pm, _fp, _fp, ctypes.c_double, _dp, _dp, ctypes.c_int, _fp, _fp, _dp, _fp, _ubp, _ip,
+                                         _dp, _dp, _dp, _dp, _dp, ctypes.POINTER(OrcRow)]
+        L.orc_bvc_pair.restype = None
+        L.orc_bvc_pair.argtypes = [_fp, _fp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _fp, _dp]
+        L.orc_disturbance_update.restype = None
+        L.orc_disturbance_update.argtypes = [pp, pm, ctypes.c_int, _fp, _fp, ctypes.c_int, _ubp, _ip, _ubp]
+        L.orc_goal_prior_based_ex.restype = None
+        L.orc_goal_prior_based_ex.argtypes = [ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                              ctypes.c_double, ctypes.c_double, _ubp, ctypes.c_int, _fp]
+        L.orc_tick_ex.restype = ctypes.c_int
+        L.orc_tick_ex.argtypes = [pp, pm, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _fp, _ubp,
+                                  ctypes.POINTER(OrcEdt), ctypes.c_double, _fp, _ip, _fp, _dp, _ip, _ip, _fp, _dp, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -196,9 +235,14 @@ class QP:
         R = self._rows[r]
         return [R.idx[j] for j in range(R.nnz)], [R.val[j] for j in range(R.nnz)], R.rhs, R.sense
 
+    @property
+    def nv(self):
+        return len(self.c)
+
     def dense(self):
         """(Aeq, beq, G, h) with inequalities as G x <= h (bounds appended: +x<=hi then -x<=-lo per variable)."""
         eq, be, G, h = [], [], [], []
+        NV = self.nv
         for r in range(self.nrows):
             idx, val, rhs, sense = self.row(r)
             a = np.zeros(NV)
@@ -217,12 +261,12 @@ class QP:
         return np.array(eq), np.array(be), np.array(G), np.array(h)
 
     def solve(self):
-        x = np.zeros(NV)
+        x = np.zeros(self.nv)
         cost = ctypes.c_double()
         it = ctypes.c_int()
         kkt = np.zeros(4)
-        st = lib().orc_qp_solve(_d(self.P), _d(self.c), self.cst, _d(self.lo), _d(self.hi), self._rows, self.nrows,
-                                _d(x), ctypes.byref(cost), ctypes.byref(it), _d(kkt))
+        st = lib().orc_qp_solve_n(self.nv, _d(self.P), _d(self.c), self.cst, _d(self.lo), _d(self.hi), self._rows, self.nrows,
+                                  _d(x), ctypes.byref(cost), ctypes.byref(it), _d(kkt))
         return st, x, cost.value, it.value, kkt
 
 
@@ -242,6 +286,40 @@ def qp_assemble(prm, state, goal, v_nom, vmax, amax, obs_traj, normal, d, sfc=No
     nr = lib().orc_qp_assemble(ctypes.byref(prm), _f(state), _f(goal), v_nom, _d(vmax), _d(amax), n_obs,
                                _f(obs_traj), _f(normal), _d(d), sfc_p, _d(P), _d(c), ctypes.byref(cst), _d(lo), _d(hi), rows)
     return QP(P, c, cst.value, lo, hi, rows, nr)
+
+
+def qp_assemble_ex(prm, modes, state, goal, v_nom, vmax, amax, obs_traj, normal, d, slack_flags=None, sfc=None):
+    """populatebyrow with the alternate-mode switches: variables = 90 control-point coordinates + the slack variables."""
+    state = np.ascontiguousarray(state, np.float32)
+    goal = np.ascontiguousarray(goal, np.float32)
+    vmax = np.ascontiguousarray(vmax, np.float64)
+    amax = np.ascontiguousarray(amax, np.float64)
+    obs_traj = np.ascontiguousarray(obs_traj, np.float32)
+    normal = np.ascontiguousarray(normal, np.float32)
+    d = np.ascontiguousarray(d, np.float64)
+    n_obs = obs_traj.shape[0] if obs_traj.size else 0
+    fl = np.ascontiguousarray(slack_flags if slack_flags is not None else np.zeros(max(n_obs, 1)), np.uint8)
+    ubp = ctypes.POINTER(ctypes.c_ubyte)
+    nv = NV + lib().orc_slack_count(ctypes.byref(modes), n_obs, fl.ctypes.data_as(ubp))
+    rows = (OrcRow * (51 + 27 * n_obs + 252 + 162))()
+    P = np.zeros((nv, nv)); c = np.zeros(nv); lo = np.zeros(nv); hi = np.zeros(nv)
+    cst = ctypes.c_double()
+    nvo = ctypes.c_int()
+    sfc_p = _f(np.ascontiguousarray(sfc, np.float32)) if sfc is not None else None
+    nr = lib().orc_qp_assemble_ex(ctypes.byref(prm), ctypes.byref(modes), _f(state), _f(goal), v_nom, _d(vmax), _d(amax), n_obs,
+                                  _f(obs_traj), _f(normal), _d(d), sfc_p, fl.ctypes.data_as(ubp), ctypes.byref(nvo), _d(P), _d(c),
+                                  ctypes.byref(cst), _d(lo), _d(hi), rows)
+    assert nvo.value == nv
+    return QP(P, c, cst.value, lo, hi, rows, nr)
+
+
+def bvc_pair(init_traj, obs_traj, r_a, r_o, dw_a, dw_o):
+    it = np.ascontiguousarray(init_traj, dtype=np.float32)
+    ot = np.ascontiguousarray(obs_traj, dtype=np.float32)
+    nrm = np.zeros((M, 3), np.float32)
+    d = np.zeros((M, NC))
+    lib().orc_bvc_pair(_f(it), _f(ot), r_a, r_o, dw_a, dw_o, _f(nrm), _d(d))
+    return nrm, d
 
 
 class Swarm:
@@ -283,6 +361,63 @@ class Swarm:
                        _d(self.downwash), _d(self.vmax), _d(self.amax), _d(self.vnom), _f(self.stale),
                        _f(self.sfc) if self.prm.use_sfc else None, _f(out), _d(self.cost), _i(status), _i(iters),
                        _f(nrm) if want_lsc else None, _d(dd) if want_lsc else None, nthreads)
+        res = {"traj": out, "cost": self.cost.copy(), "status": status, "iters": iters, "sfc": self.sfc.copy()}
+        if want_lsc:
+            res["normal"], res["d"] = nrm, dd
+        return res
+
+
+class SwarmEx(Swarm):
+    """Swarm with the alternate-mode switches: BVC planner mode, slack modes, disturbance reset with its persistent slack
+    set (slack_set[qi][qj] = 1 once agent qi put agent qj into obs_slack_indices; never cleared, like the reference)."""
+
+    def __init__(self, prm, modes, radius, downwash, vmax, amax, vnom):
+        super().__init__(prm, radius, downwash, vmax, amax, vnom)
+        self.modes = modes
+        self.slack_set = np.zeros((self.N, self.N), np.uint8)
+
+    def disturbance_update(self, state, prev_traj, planner_seq):
+        """The two checks the reference runs BEFORE goal planning; returns own_reset [N]."""
+        ubp = ctypes.POINTER(ctypes.c_ubyte)
+        state = np.ascontiguousarray(state, np.float32).reshape(self.N, 9)
+        prev = np.ascontiguousarray(prev_traj, np.float32).reshape(self.N, NV)
+        own = np.zeros(self.N, np.uint8)
+        lib().orc_disturbance_update(ctypes.byref(self.prm), ctypes.byref(self.modes), self.N, _f(state), _f(prev), planner_seq,
+                                     self.slack_set.ctypes.data_as(ubp), _i(self.sfc_init) if self.prm.use_sfc else None,
+                                     own.ctypes.data_as(ubp))
+        return own
+
+    def goal_prior_based(self, state, desired_goal, prev_traj, planner_seq, own_reset=None, dt=0.2, goal_threshold=0.1,
+                         priority_dist_threshold=0.4, goal_radius=2.0):
+        ubp = ctypes.POINTER(ctypes.c_ubyte)
+        N = self.N
+        state = np.ascontiguousarray(state, np.float32).reshape(N, 9)
+        dg = np.ascontiguousarray(desired_goal, np.float32).reshape(N, 3)
+        pt = np.ascontiguousarray(prev_traj, np.float32).reshape(N, NV)
+        out = np.zeros((N, 3), np.float32)
+        for qi in range(N):
+            lib().orc_goal_prior_based_ex(N, qi, _f(state), _f(dg), _f(pt), planner_seq, dt, goal_threshold, priority_dist_threshold,
+                                          goal_radius, self.slack_set[qi].ctypes.data_as(ubp),
+                                          int(own_reset[qi]) if own_reset is not None else 0, _f(out[qi]))
+        return out
+
+    def tick(self, state, goal, prev_traj, planner_seq, want_lsc=False, nthreads=1):
+        ubp = ctypes.POINTER(ctypes.c_ubyte)
+        N = self.N
+        state = np.ascontiguousarray(state, np.float32).reshape(N, 9)
+        goal = np.ascontiguousarray(goal, np.float32).reshape(N, 3)
+        prev = np.ascontiguousarray(prev_traj, np.float32).reshape(N, 3, SEGV)
+        out = np.zeros((N, 3, SEGV), np.float32)
+        status = np.zeros(N, np.int32)
+        iters = np.zeros(N, np.int32)
+        nrm = np.zeros((N, max(N - 1, 1), M, 3), np.float32) if want_lsc else None
+        dd = np.zeros((N, max(N - 1, 1), M, NC)) if want_lsc else None
+        use_map = bool(self.prm.use_sfc)
+        lib().orc_tick_ex(ctypes.byref(self.prm), ctypes.byref(self.modes), N, _f(state), _f(goal), _f(prev), planner_seq,
+                          _d(self.radius), _d(self.downwash), _d(self.vmax), _d(self.amax), _d(self.vnom), _f(self.stale),
+                          self.slack_set.ctypes.data_as(ubp), ctypes.byref(self.distmap.edt) if use_map else None, self.world_res,
+                          _f(self.sfc) if use_map else None, _i(self.sfc_init) if use_map else None, _f(out), _d(self.cost),
+                          _i(status), _i(iters), _f(nrm) if want_lsc else None, _d(dd) if want_lsc else None, nthreads)
         res = {"traj": out, "cost": self.cost.copy(), "status": status, "iters": iters, "sfc": self.sfc.copy()}
         if want_lsc:
             res["normal"], res["d"] = nrm, dd

@@ -70,7 +70,7 @@ def _pass_lp(h, c, A, row_lo, row_hi, col_lo, col_hi, offset=0.0, P=None):
 
 def rows_of(qp):
     """(A, lo, hi) of an oracle.QP: every constraint row as lo <= a.x <= hi (sense 0 '=', 1 '>=', 2 '<=')."""
-    n = 90
+    n = len(qp.c)
     A = np.zeros((qp.nrows, n))
     lo = np.full(qp.nrows, -np.inf)
     hi = np.full(qp.nrows, np.inf)
@@ -97,19 +97,32 @@ def solve_qp(P, c, cst, A, row_lo, row_hi, col_lo, col_hi):
 
 
 def solve_oracle_qp(qp):
-    """HiGHS on an oracle.QP.  The 51 equality rows are eliminated first with an orthonormal null-space basis from an
-    SVD (x = x0 + Z y; neither the oracle's Householder basis nor the kernel's analytic elimination): HiGHS 1.8's
-    active-set QP solver satisfies equalities with +-500 / +-1000 coefficients only to ~1e-5 relative and then reports
-    a slightly super-optimal "Optimal" (seen on 2 of 600 instances); on the reduced, inequality-only problem it agrees
-    with the oracle to <= 1e-8 relative.  Returns (status, x in the original 90 variables, objective, worst violation of
-    the ORIGINAL rows and bounds by x) so that the caller can check the point it is comparing against."""
+    """HiGHS on an oracle.QP, through a small portfolio of EXACT reformulations of the same problem, because HiGHS 1.8's
+    active-set QP code is not robust on every instance: (1) the 45/51 equality rows eliminated with an orthonormal
+    null-space basis from an SVD (x = x0 + Z y; neither the oracle's Householder basis nor the kernel's analytic
+    elimination) -- on the full problem it satisfies equalities with +-500/+-1000 coefficients only to ~1e-5 relative and then
+    reports a slightly super-optimal "Optimal"; (2) the full problem as is; (3) the full problem with the slack variables
+    (cost weight 1e5) rescaled by 1e-2; (4) formulation (1) with a 1e-9 proximal term (moves the optimum by < 1e-9
+    relative, breaks degenerate ties).  The first formulation that ends "Optimal" with a point satisfying the ORIGINAL rows
+    and bounds to 1e-7 is returned as (status, x in the original variables, objective, that violation); "Infeasible" from
+    the first formulation is returned as such; otherwise the last status."""
+    n = len(qp.c)
     A, lo, hi = rows_of(qp)
+
+    def viol_of(x):
+        if not np.isfinite(x).all():
+            return np.inf
+        return float(max(np.max(lo - A @ x), np.max(A @ x - hi), np.max(qp.lo - x), np.max(x - qp.hi)))
+
+    def obj_of(x):
+        return float(0.5 * x @ qp.P @ x + qp.c @ x + qp.cst)
+
     eq = lo == hi
     Ae, be = A[eq], lo[eq]
     pinv, Z = _null_space(Ae)
     x0 = pinv @ be
     fin = np.isfinite(qp.lo) | np.isfinite(qp.hi)
-    Ai = np.vstack([A[~eq], np.eye(90)[fin]])
+    Ai = np.vstack([A[~eq], np.eye(n)[fin]])
     li, ui = np.r_[lo[~eq], qp.lo[fin]], np.r_[hi[~eq], qp.hi[fin]]
     off = Ai @ x0
     P = Z.T @ qp.P @ Z
@@ -118,16 +131,28 @@ def solve_oracle_qp(qp):
     cst = 0.5 * x0 @ qp.P @ x0 + qp.c @ x0 + qp.cst
     ny = Z.shape[1]
     free = (np.full(ny, -np.inf), np.full(ny, np.inf))
-    status, y, obj = solve_qp(P, c, cst, Ai @ Z, li - off, ui - off, *free)
-    if status in ("Solve error", "Time limit reached"):
-        # the active-set code gives up on some degenerate vertices ("not possible to find non-active constraint to leave
-        # basis"); a 1e-9 proximal term moves the optimum by less than 1e-9 relative and breaks the tie
-        status, y, obj = solve_qp(P + 1e-9 * np.eye(ny), c, cst, Ai @ Z, li - off, ui - off, *free)
-        if status == "Optimal":
-            obj -= 0.5e-9 * float(y @ y)
-    x = x0 + Z @ y if len(y) == ny else np.full(90, np.nan)
-    viol = max(np.max(lo - A @ x), np.max(A @ x - hi), np.max(qp.lo - x), np.max(x - qp.hi)) if np.isfinite(x).all() else np.inf
-    return status, x, obj, float(viol)
+
+    def reduced(prox):
+        st, y, _ = solve_qp(P + prox * np.eye(ny), c, cst, Ai @ Z, li - off, ui - off, *free)
+        return st, (x0 + Z @ y if len(y) == ny else np.full(n, np.nan))
+
+    def full(scale):
+        S = np.ones(n)
+        S[90:] = scale
+        st, xs, _ = solve_qp(qp.P * S[:, None] * S[None, :], qp.c * S, qp.cst, A * S[None, :], lo, hi, qp.lo / S, qp.hi / S)
+        return st, (xs * S if len(xs) == n else np.full(n, np.nan))
+
+    last = None
+    for k, attempt in enumerate((lambda: reduced(0.0), lambda: full(1.0), lambda: full(1e-2), lambda: reduced(1e-9))):
+        if k == 2 and n == 90:
+            continue
+        st, x = attempt()
+        if k == 0 and st == "Infeasible":
+            return st, x, np.nan, np.inf
+        if st == "Optimal" and viol_of(x) <= 1e-7:
+            return st, x, obj_of(x), viol_of(x)
+        last = (st if st != "Optimal" else "Solve error", x, np.nan, viol_of(x))
+    return last
 
 
 _NS_CACHE = {}

@@ -153,3 +153,48 @@ def test_soak_qps_optimum_and_infeasibility_vs_highs(oracle, dense):
     assert (n_inf > 100) == dense, (n_opt, n_inf)
     print(f"dense={dense}: {n_opt} optimal, {n_inf} infeasible, {n_gave_up} without a HiGHS verdict")
     assert n_gave_up <= 0.01 * (n_opt + n_inf), n_gave_up      # no verdict from HiGHS is not a disagreement, but must stay rare
+
+
+@pytest.mark.parametrize("mode", ["bvc", "collision_constraint", "dynamical_limit", "reset"])
+def test_alternate_mode_qps_vs_highs(oracle, mode):
+    """the QPs of the alternate modes (BVC rows without the stop-at-horizon equalities; slack variables on the
+    collision rows / on the dynamic limits; the slack rows a disturbance leaves behind) as the oracle assembles and solves
+    them, against HiGHS with the slack variables as ordinary variables."""
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import next_state_host
+    O = oracle
+    md = {"bvc": O.make_modes(planner="bvc"), "collision_constraint": O.make_modes(slack="collision_constraint"),
+          "dynamical_limit": O.make_modes(slack="dynamical_limit"), "reset": O.make_modes(reset_threshold=0.15)}[mode]
+    ms = L.circle_swap(8, 1.2, world=(-5, -5, 0, 5, 5, 2.5))
+    N = ms.qn
+    prm = O.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+    sw = O.SwarmEx(prm, md, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+    state = np.zeros((N, 9), np.float32)
+    state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    checked = slack_vars = 0
+    for tick in range(1, 13):
+        if mode == "reset" and tick in (5, 9):
+            state[tick % N, :3] += np.float32([0.25, -0.2, 0.05])          # a gust moves one agent off its plan
+        own = sw.disturbance_update(state, traj, tick)
+        o = sw.tick(state, ms.goal, traj, tick, want_lsc=True, nthreads=4)
+        for a in range(N):
+            others = [j for j in range(N) if j != a]
+            obs = []
+            for j in others:
+                if mode == "bvc" or sw.slack_set[a, j] and np.linalg.norm(
+                        (O.shift_traj(traj[j]) if tick >= 2 else O.const_vel_traj(state[j, :3], state[j, 3:6]))[:, 0] - state[j, :3]) > 0.15:
+                    obs.append(np.repeat(state[j, :3, None], 30, axis=1))
+                else:
+                    obs.append(O.shift_traj(traj[j]) if tick >= 2 else O.const_vel_traj(state[j, :3], state[j, 3:6]))
+            qp = O.qp_assemble_ex(prm, md, state[a], ms.goal[a], float(ms.nominal_velocity[a]), ms.max_vel[a], ms.max_acc[a],
+                                  np.array(obs, np.float32), o["normal"][a], o["d"][a], slack_flags=sw.slack_set[a, others])
+            st, x, cost, it, kkt = qp.solve()
+            assert st == o["status"][a] and (st != 0 or abs(cost - o["cost"][a]) <= 1e-9 * abs(cost) + 1e-12), (tick, a)
+            kind = _check_against_highs(qp, st, cost)
+            checked += kind in ("opt", "inf")
+            slack_vars = max(slack_vars, qp.nv - 90)
+        traj = o["traj"]
+        state = next_state_host(traj)
+    assert checked >= 90
+    assert slack_vars == {"bvc": 0, "collision_constraint": 35, "dynamical_limit": 10, "reset": 35}[mode]
