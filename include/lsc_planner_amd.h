@@ -94,6 +94,22 @@ typedef struct {
     double horizon;            /* traj/horizon 1.0: the kernels plan M = horizon/dt = 5 segments; anything else is refused
                                   by lsc_create instead of silently planning a different horizon                          */
     int    goal_row_cap;       /* 0 = as large as LDS allows; > 0 lowers the goal search's OPEN-row capacity (tests)       */
+    /* ---- alternate planner modes.  Any of them changes the shape of the QP; such agents are solved by a
+     * general dense kernel (csrc/lsc_general.hip) instead of the banded fast path -- same results, several times slower. */
+    int    planner_mode;       /* mode/planner: 0 lsc (default), 1 bvc -- Buffered Voronoi Cells: TrajPlanner::generateBVC
+                                  (src/traj_planner.cpp:1409-1440), prediction / initial trajectory = current position, no
+                                  stop-at-horizon rows; empty maps only (generateSFC throws in BVC mode)                    */
+    int    slack_mode;         /* SlackMode: 0 none (default), 1 dynamical_limit, 2 collision_constraint
+                                  (src/traj_optimizer.cpp:306-326, 375-390, 455-457, 476-510)                               */
+    double slack_collision_weight; /* opt/slack_collision_weight, 100000 in every launch file                               */
+    int    n_constraint_segments;  /* opt/N_constraint_segments; -1 = all M segments carry collision / corridor rows        */
+    double reset_threshold;    /* multisim/reset_threshold (0.15 in the launch files).  > 0 switches the reference's disturbance
+                                  checks on (obstaclePredictionCheck / initialTrajPlanningCheck, src/traj_planner.cpp:866-878,
+                                  1047-1061): an agent found farther than this from where its plan puts it has its prediction
+                                  reset to its position, and -- for the rest of the mission, the reference never clears
+                                  obs_slack_indices -- every row against it carries a slack variable.  0 (default) = off:
+                                  identical results as long as the caller's states follow the plans, and no extra launch on
+                                  the device-resident ticks                                                                 */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);

@@ -41,6 +41,11 @@ class LscConfig(ctypes.Structure):
         ("grid_margin", ctypes.c_double),
         ("horizon", ctypes.c_double),
         ("goal_row_cap", ctypes.c_int),
+        ("planner_mode", ctypes.c_int),
+        ("slack_mode", ctypes.c_int),
+        ("slack_collision_weight", ctypes.c_double),
+        ("n_constraint_segments", ctypes.c_int),
+        ("reset_threshold", ctypes.c_double),
     ]
 
 

@@ -130,7 +130,13 @@ struct Param {   // defaults = launch/testall_empty.launch
     // agent-sharded multi-GPU: one lsc_sim process per GPU (rank), every rank runs the same (deterministic) bookkeeping
     int world = 1, rank = 0;
     std::string comm_file;   // rank 0 writes the RCCL rendezvous token here, the others read it
-    std::string getPlannerModeStr() const { return "LSC"; }
+    // mode/planner, SlackMode, opt/slack_collision_weight, opt/N_constraint_segments (src/param.cpp:33-48, 72-76)
+    int planner_mode = 0;              // 0 lsc, 1 bvc
+    int slack_mode = 0;                // 0 none, 1 dynamical_limit, 2 collision_constraint
+    double slack_collision_weight = 100000.0;
+    int N_constraint_segments = -1;
+    std::string getPlannerModeStr() const { return planner_mode == 1 ? "BVC" : "LSC"; }
+    std::string getSlackModeStr() const { return slack_mode == 1 ? "dynamical_limit" : (slack_mode == 2 ? "collision_constraint" : "none"); }
 };
 
 class Mission {

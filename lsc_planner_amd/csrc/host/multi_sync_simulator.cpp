@@ -21,6 +21,9 @@ class MultiSyncSimulator {
         lsc_default_config(&cfg);
         cfg.dt = param.dt; cfg.control_weight = param.control_input_weight; cfg.terminal_weight = param.terminal_weight;
         cfg.horizon = param.horizon;
+        cfg.planner_mode = param.planner_mode; cfg.slack_mode = param.slack_mode;
+        cfg.slack_collision_weight = param.slack_collision_weight; cfg.n_constraint_segments = param.N_constraint_segments;
+        cfg.reset_threshold = param.multisim_reset_threshold;   // the disturbance checks of every shipped launch file (0.15)
         for (int k = 0; k < 3; k++) { cfg.world_min[k] = mission.world_min(k); cfg.world_max[k] = mission.world_max(k); }
         cfg.use_octomap = param.world_use_octomap; cfg.world_resolution = param.world_resolution; cfg.device = param.device;
         // mode/goal: prior_based like every shipped launch file (on octomap worlds that includes the grid search)
@@ -245,7 +248,9 @@ class MultiSyncSimulator {
                    "initial_traj_mode,slack_mode,goal_mode,world_dimension,dt,horizon,N_constraint_segments\n";
         out << sim_start_time << "," << total_flight_time << "," << total_distance << "," << is_collided << "," << safety_ratio_agent << "," << avg
             << "," << avg << "," << avg << ",0,0,0,0,0," << avg << "," << mission.mission_file_name << "," << mission.world_file_name
-            << ",LSC,previous_solution,previous_solution,none,static,3," << param.dt << "," << param.horizon << ",-1\n";
+            << "," << param.getPlannerModeStr() << (param.planner_mode == 1 ? ",current_position,current_position," : ",previous_solution,previous_solution,")
+            << param.getSlackModeStr() << "," << (param.goal_mode_prior_based ? "prior_based" : "static") << ",3," << param.dt << ","
+            << param.horizon << "," << param.N_constraint_segments << "\n";
     }
 
     bool is_collided = false;
@@ -287,10 +292,14 @@ int main(int argc, char **argv)
         else if (a == "--device") param.device = std::stoi(next());
         else if (a == "--quiet") quiet = true;
         else if (a == "--static-goal") param.goal_mode_prior_based = false;
+        else if (a == "--planner") { const std::string v = next(); param.planner_mode = v == "bvc" ? 1 : 0; }
+        else if (a == "--slack") { const std::string v = next(); param.slack_mode = v == "dynamical_limit" ? 1 : (v == "collision_constraint" ? 2 : 0); }
+        else if (a == "--constraint-segments") param.N_constraint_segments = std::stoi(next());
+        else if (a == "--reset-threshold") param.multisim_reset_threshold = std::stod(next());
         else if (a == "--ranks") param.world = std::stoi(next());
         else if (a == "--rank") param.rank = std::stoi(next());
         else if (a == "--comm-file") param.comm_file = next();
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T]\n"); return 2; }
     }
     if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
     // torchrun / mpirun style environment: one process per GPU

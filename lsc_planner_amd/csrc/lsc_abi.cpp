@@ -166,6 +166,33 @@ void build_model(const lsc_config &cfg, HostModel &H)
     // (no environment overrides: everything that changes the solve is an lsc_config field)
 }
 
+// dense elimination tables of the alternate-mode kernel: axis-major y, with (LSC) or without (BVC) the stop rows
+void build_gmodel(const lsc_config &cfg, const Model &m, GModel &g)
+{
+    std::memset(&g, 0, sizeof(g));
+    const bool stop = cfg.planner_mode == 0;
+    g.nya = stop ? 13 : 15;
+    for (int mm = 0; mm < M; mm++)
+        for (int i = 0; i < NC; i++) {
+            const int t = mm * NC + i;
+            if (mm == M - 1 && i >= 3) { g.Z[t][stop ? 12 : 12 + (i - 3)] = 1.0; continue; }
+            if (i >= 3) { g.Z[t][3 * mm + (i - 3)] = 1.0; continue; }
+            if (mm == 0) continue;
+            const int u3 = 3 * (mm - 1), u4 = u3 + 1, u5 = u3 + 2;
+            if (i == 0) g.Z[t][u5] = 1.0;
+            if (i == 1) { g.Z[t][u5] = 2.0; g.Z[t][u4] = -1.0; }
+            if (i == 2) { g.Z[t][u5] = 4.0; g.Z[t][u4] = -4.0; g.Z[t][u3] = 1.0; }
+        }
+    for (int a = 0; a < g.nya; a++)
+        for (int b = 0; b < g.nya; b++) {
+            double s = 0;
+            for (int mm = 0; mm < M; mm++)
+                for (int i = 0; i < NC; i++)
+                    for (int j = 0; j < NC; j++) s += g.Z[mm * NC + i][a] * m.Qh[i * NC + j] * g.Z[mm * NC + j][b];
+            g.Hc[a * GNYA + b] = s;
+        }
+}
+
 }  // namespace
 
 struct lsc_ctx {
@@ -181,6 +208,12 @@ struct lsc_ctx {
     double *d_vmax = nullptr, *d_amax = nullptr, *d_vnom = nullptr;
     float *d_stale = nullptr, *d_sfc = nullptr;
     float *d_goal_cur = nullptr;
+    // alternate planner modes (lsc_general.hip)
+    GModel *d_gmodel = nullptr;
+    unsigned char *d_ever = nullptr, *d_gen_ws = nullptr;
+    size_t gen_stride = 0;
+    int gen_slots = 0;
+    std::vector<unsigned char> h_ever;   // host mirror for the host-buffer ticks (they decide on the host whether anybody is off plan)
     unsigned char *d_spill = nullptr;    // HBM row workspaces of the second pass (agents beyond the LDS row capacity)
     size_t spill_stride = 0;
     int spill_slots = 0;
@@ -312,6 +345,8 @@ void lsc_default_config(lsc_config *cfg)
     cfg->goal_mode = 0; cfg->goal_threshold = 0.1; cfg->priority_dist_threshold = 0.4; cfg->goal_radius = 2.0;
     cfg->grid_resolution = 0.3; cfg->grid_margin = 0.2;   // launch/testall_forest.launch:88-89
     cfg->horizon = 1.0; cfg->goal_row_cap = 0;
+    cfg->planner_mode = 0; cfg->slack_mode = 0; cfg->slack_collision_weight = 100000.0; cfg->n_constraint_segments = -1;
+    cfg->reset_threshold = 0.0;
 }
 
 lsc_ctx *lsc_create(const lsc_config *cfg)
@@ -333,6 +368,12 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
         std::fprintf(stderr, "lsc_create: device %d does not accept the gfx950 kernels' LDS request\n", cfg->device);
         return nullptr;
     }
+    if (cfg->planner_mode < 0 || cfg->planner_mode > 1 || cfg->slack_mode < 0 || cfg->slack_mode > 2 ||
+        (cfg->planner_mode == 1 && cfg->use_octomap)) {
+        // BVC + octomap: the reference's generateSFC throws for every planner mode but LSC (src/traj_planner.cpp:1442-1449)
+        std::fprintf(stderr, "lsc_create: unsupported planner_mode / slack_mode combination\n");
+        return nullptr;
+    }
     lsc_ctx *c = new lsc_ctx();
     c->cfg = *cfg;
     build_model(*cfg, c->hm);
@@ -340,6 +381,12 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
     ok = ok && hipMalloc(&c->d_terms, sizeof(uint32_t) * (c->hm.terms.size() + 2)) == hipSuccess;
     ok = ok && hipMalloc(&c->d_entries, sizeof(uint32_t) * c->hm.entries.size()) == hipSuccess;
     ok = ok && hipMalloc(&c->d_model, sizeof(Model)) == hipSuccess;
+    {
+        GModel g;
+        build_gmodel(*cfg, c->hm.m, g);
+        ok = ok && hipMalloc(&c->d_gmodel, sizeof(GModel)) == hipSuccess;
+        ok = ok && hipMemcpy(c->d_gmodel, &g, sizeof(GModel), hipMemcpyHostToDevice) == hipSuccess;
+    }
     ok = ok && hipMemcpy(c->d_terms, c->hm.terms.data(), sizeof(uint32_t) * c->hm.terms.size(), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(c->d_entries, c->hm.entries.data(), sizeof(uint32_t) * c->hm.entries.size(), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { lsc_destroy(c); return nullptr; }
@@ -350,9 +397,10 @@ static void free_agents(lsc_ctx *c)
 {
     void *ptrs[] = {c->d_radius, c->d_radius_obs, c->d_downwash, c->d_downwash_obs, c->d_vmax, c->d_amax, c->d_vnom,
                     c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_cost,
-                    c->d_onormal, c->d_od, c->d_spill};
+                    c->d_onormal, c->d_od, c->d_spill, c->d_ever, c->d_gen_ws};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->d_spill = nullptr; c->spill_slots = 0; c->spill_stride = 0;
+    c->d_ever = nullptr; c->d_gen_ws = nullptr; c->gen_slots = 0; c->gen_stride = 0;
     if (c->h_in) { (void)hipHostFree(c->h_in); c->h_in = nullptr; }
     if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
     void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
@@ -374,6 +422,7 @@ void lsc_destroy(lsc_ctx *c)
     free_agents(c);
     if (c->d_trace) (void)hipFree(c->d_trace);
     if (c->d_model) (void)hipFree(c->d_model);
+    if (c->d_gmodel) (void)hipFree(c->d_gmodel);
     if (c->d_terms) (void)hipFree(c->d_terms);
     if (c->d_entries) (void)hipFree(c->d_entries);
     for (int w = 0; w < 3; w++)
@@ -440,6 +489,19 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         c->spill_stride = plan_spill_bytes(N);
         c->spill_slots = std::min(N, 256);
         HIPCHK(c, hipMalloc(&c->d_spill, c->spill_stride * (size_t)c->spill_slots));
+    }
+    {
+        // alternate modes: persistent "was seen off its plan" flags, and -- when such a QP can occur at all -- the HBM
+        // workspaces of lsc_general_kernel (one per persistent workgroup)
+        HIPCHK(c, hipMalloc(&c->d_ever, (size_t)N));
+        HIPCHK(c, hipMemset(c->d_ever, 0, (size_t)N));
+        c->h_ever.assign(N, 0);
+        const bool general_all = c->cfg.planner_mode == 1 || c->cfg.slack_mode != 0;
+        if (general_all || c->cfg.reset_threshold > 0.0) {
+            c->gen_stride = general_ws_bytes(N);
+            c->gen_slots = std::min(N, 256);
+            HIPCHK(c, hipMalloc(&c->d_gen_ws, c->gen_stride * (size_t)c->gen_slots));
+        }
     }
     HIPCHK(c, hipMalloc(&c->d_nrows, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
@@ -635,7 +697,7 @@ static int run_goal(lsc_ctx *c, const float *d_state, const float *&d_goal, cons
     return LSC_OK;
 }
 
-static int run_sfc(lsc_ctx *c, const float *d_state, const float *d_goal, const float *d_prev, hipStream_t st)
+static int run_sfc(lsc_ctx *c, const float *d_state, const float *d_goal, const float *d_prev, int seq, hipStream_t st)
 {
     if (!c->cfg.use_octomap) return LSC_OK;
     if (!c->d_integral) { c->err = "use_octomap is set but lsc_set_distmap was not called"; return LSC_ESTATE; }
@@ -650,6 +712,7 @@ static int run_sfc(lsc_ctx *c, const float *d_state, const float *d_goal, const 
     double ext = 0.0;
     for (int k = 0; k < 3; k++) ext = std::max(ext, (double)c->cfg.world_max[k] - (double)c->cfg.world_min[k]);
     s.table_len = (int)std::ceil(ext / c->cfg.world_resolution) + 8;
+    s.planner_seq = seq; s.reset_thr = c->cfg.planner_mode == 0 ? c->cfg.reset_threshold : 0.0;
     if (sizeof(double) * 6 * (size_t)s.table_len > 160 * 1024) {
         c->err = "world extent / world_resolution too large for the SFC face tables (limit 3400 steps per axis)";
         return LSC_EINVAL;
@@ -679,16 +742,50 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.dbg = c->d_dbg; a.prof = c->profiling ? c->d_prof : nullptr;
     a.trace = c->trace_agent >= 0 ? c->d_trace : nullptr; a.trace_agent = c->trace_agent;
     a.spill_ws = c->d_spill; a.spill_stride = c->spill_stride;
+    a.gmodel = c->d_gmodel; a.planner_mode = c->cfg.planner_mode; a.slack_mode = c->cfg.slack_mode;
+    a.ncs = c->cfg.n_constraint_segments; a.general_all = (c->cfg.planner_mode == 1 || c->cfg.slack_mode != 0) ? 1 : 0;
+    a.slack_w = c->cfg.slack_collision_weight; a.reset_thr = c->cfg.planner_mode == 0 ? c->cfg.reset_threshold : 0.0;
+    a.ever = c->d_ever; a.gen_ws = c->d_gen_ws; a.gen_stride = c->gen_stride;
     return LSC_OK;
 }
 
-static int run_plan(lsc_ctx *c, const PlanArgs &a, hipStream_t st)
+// Whether lsc_general_kernel has to run in this tick.  The alternate-mode kernel follows the plan kernel when a
+// configured mode sends every agent there (BVC, slack modes).  With the disturbance checks on, a host-buffer tick knows
+// the answer exactly (same float32 test on the host copy of the inputs, general_hint 0 / 1); a device-resident tick does
+// not see the states (hint -1) and launches the kernel, whose workgroups leave at once when nobody was flagged.
+static bool want_general(const lsc_ctx *c, int general_hint)
+{
+    if (!c->d_gen_ws) return false;
+    if (c->cfg.planner_mode == 1 || c->cfg.slack_mode != 0) return true;
+    return general_hint != 0;
+}
+
+// obstaclePredictionCheck / initialTrajPlanningCheck on host copies (src/traj_planner.cpp:866-878, 1047-1061); keeps the
+// host mirror of the persistent flags in step with the device's
+static int host_disturbance_hint(lsc_ctx *c, const float *state, const float *prev_traj, int planner_seq)
+{
+    if (!(c->cfg.reset_threshold > 0.0) || c->cfg.planner_mode != 0) return 0;
+    int any = 0;
+    for (int q = 0; q < c->N; q++) {
+        if (planner_seq >= 2) {
+            const float *t = prev_traj + (size_t)q * NV + NC, *s = state + 9 * q;
+            const float dx = t[0] - s[0], dy = t[SEGV] - s[1], dz = t[2 * SEGV] - s[2];
+            const float n2 = dx * dx + dy * dy + dz * dz;
+            if (std::sqrt((double)n2) > c->cfg.reset_threshold) c->h_ever[q] = 1;
+        }
+        any |= c->h_ever[q];
+    }
+    return any;
+}
+
+static int run_plan(lsc_ctx *c, const PlanArgs &a, hipStream_t st, int general_hint = -1)
 {
     const size_t smem = plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, c->cap);
     hipEvent_t e1 = nullptr;
     if (c->timing && timing_begin(c, 0, st, &e1) != LSC_OK) return LSC_EHIP;
     HIPCHK(c, launch_plan(a, smem, st));
     if (c->d_spill) HIPCHK(c, launch_plan_spill(a, c->spill_slots, plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, 0), st));
+    if (want_general(c, general_hint)) HIPCHK(c, launch_general(a, c->gen_slots, st));
     if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
     return LSC_OK;
 }
@@ -704,7 +801,7 @@ int lsc_tick_device(lsc_ctx *c, const float *d_state, const float *d_goal, const
     rc = fill_plan_args(c, a, d_state, d_goal, d_traj_prev, planner_seq, d_traj_next, d_cost, d_status, d_iters);
     if (rc) return rc;
     a.state_next = c->fused_state_next;
-    rc = run_sfc(c, d_state, d_goal, d_traj_prev, (hipStream_t)hip_stream);
+    rc = run_sfc(c, d_state, d_goal, d_traj_prev, planner_seq, (hipStream_t)hip_stream);
     if (rc) return rc;
     return run_plan(c, a, (hipStream_t)hip_stream);
 }
@@ -745,9 +842,9 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
         }
         a.out_normal = c->d_onormal; a.out_d = c->d_od;
     }
-    rc = run_sfc(c, c->d_state, d_goal_in, c->d_prev, st);
+    rc = run_sfc(c, c->d_state, d_goal_in, c->d_prev, planner_seq, st);
     if (rc) return rc;
-    rc = run_plan(c, a, st);
+    rc = run_plan(c, a, st, host_disturbance_hint(c, state, prev_traj, planner_seq));
     if (rc) return rc;
     const size_t Np = (size_t)c->table_rows;
     const size_t out_bytes = (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * Np;
@@ -855,9 +952,9 @@ int lsc_replan_tick_all(lsc_ctx *c, const float *state, const float *goal, const
     if (rc) return rc;
     rc = fill_plan_args(c, a, c->d_state, d_goal_in, c->d_prev, planner_seq, c->d_next, c->d_cost, c->d_status, c->d_iters);
     if (rc) return rc;
-    rc = run_sfc(c, c->d_state, d_goal_in, c->d_prev, st);
+    rc = run_sfc(c, c->d_state, d_goal_in, c->d_prev, planner_seq, st);
     if (rc) return rc;
-    rc = run_plan(c, a, st);
+    rc = run_plan(c, a, st, host_disturbance_hint(c, state, prev_traj, planner_seq));
     if (rc) return rc;
     hipEvent_t e1 = nullptr;
     if (c->timing && timing_begin(c, 2, st, &e1) != LSC_OK) return LSC_EHIP;

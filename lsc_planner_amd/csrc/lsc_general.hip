@@ -1,0 +1,829 @@
+// lsc_general.hip -- the reference's ALTERNATE planner modes on gfx950, one 256-lane workgroup per agent:
+//
+//   BVC planner mode        TrajPlanner::generateBVC                                   src/traj_planner.cpp:1409-1440
+//                           prediction / initial trajectory = current position          :796-807, :1039-1045 (param.cpp:40-45)
+//                           no stop-at-horizon equalities (LSC only)                    src/traj_optimizer.cpp:527-536
+//                           opt/N_constraint_segments                                   src/traj_optimizer.cpp:410, 438
+//   slack variables         SlackMode::DYNAMICALLIMIT / COLLISIONCONSTRAINT             src/traj_optimizer.cpp:306-326, 375-390,
+//                                                                                       455-457, 476-510
+//   disturbance reset       obstaclePredictionCheck / initialTrajPlanningCheck and the slack rows they leave behind for the
+//                           rest of the mission (obs_slack_indices is never cleared)    src/traj_planner.cpp:866-878, 1047-1061
+//
+// These modes change the SHAPE of the QP (45 instead of 39 free coordinates without the stop rows; slack variables that
+// couple all control points of a segment), which the banded, register-resident solver of lsc_plan_kernel is built around.
+// They are off the reference's default path (every shipped launch file runs mode/planner = lsc, slack none, and the
+// disturbance checks only fire on a real disturbance), so this kernel trades speed for generality: dense reduced-space
+// Mehrotra interior point, all rows in an HBM workspace, no pruning, cold start -- the same algorithm as the fast path,
+// none of its structure.  Agents reach it through status LSC_STATUS_GENERAL_K set by lsc_plan_kernel's phase A.
+//
+// Unknowns: y (3 x nya free control-point coordinates, nya = 13 with / 15 without the stop rows), the 2M slack variables
+// of DYNAMICALLIMIT as explicit unknowns, and one slack variable per (slack obstacle, segment) that is eliminated from
+// every Newton system analytically (its Hessian block is diagonal): K = Kyy - sum_g m_g m_g^T / D_g.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "lsc_gjk.hpp"
+#include "lsc_model.hpp"
+#include "lsc_kernels.h"
+
+namespace lsc {
+
+namespace {
+
+constexpr int GT = 256;            // lanes per agent
+constexpr int GW = GT / 64;
+constexpr int PMAX = 3 * GNYA + 2 * M;      // 45 + 10
+constexpr int KL = PMAX + 1;       // leading dimension of the dense matrices in LDS
+constexpr int NBK = 27;            // control points that carry collision rows
+constexpr int SEG_E = 171;         // symmetric 18 x 18 block of one segment (6 control points x 3 axes)
+
+struct GS {
+    double x[96], dx[96];
+    double y[PMAX + 1], dy[PMAX + 1], rhs[PMAX + 1];
+    double K[PMAX * KL];
+    double gv[96], gz[96];         // x-space: cost gradient + sum vv_r a_r  /  + sum z_r a_r
+    double Wd[NV], W1[NV], W2[NV]; // x-space Hessian pieces of the bound / velocity / acceleration rows
+    double Ws[NCP * 6];            // per control point: sum w n n^T (xx xy xz yy yz zz)
+    double Tv[NCP * 3], Tz[NCP * 3];   // per control point: -sum vv n, -sum z n
+    double part[3][NBK * 3][2];    // partial sums of the control-point reductions
+    double Wu[2 * M][NV];          // DYNAMICALLIMIT: cross terms x-space <-> slack variable j
+    double Huu[2 * M], qu[2 * M], gu[2 * M];
+    double Cm[M][SEG_E];           // per segment: sum_g m_g m_g^T / D_g in x-space
+    double cq[NCP * 3];            // x-space: sum_g m_g q_g / D_g
+    double Z[SEGV][GNYA];
+    double Hc[GNYA * GNYA];
+    double Qh[NC * NC];
+    double s0[3][3], lo[3][M], hi[3][M], goal[3];
+    double ah[AXROWS];
+    double red[8][GW];
+    double sc[8];
+    float pinit[NV];
+    float goalf[3];
+    unsigned char avalid[AXROWS];
+    int tseg, ok;
+};
+
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wmax(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wmin(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// predicted control points of agent q for segment m in the general modes: current position (BVC, or after a
+// disturbance reset), else like the fast path
+__device__ __forceinline__ void g_segment(const PlanArgs &a, int q, int m, bool at_rest, float dtf, F3 out[6])
+{
+#pragma clang fp contract(off)
+    const float *s = a.state + 9 * q;
+    if (at_rest) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) out[i] = F3{s[0], s[1], s[2]};
+        return;
+    }
+    if (a.planner_seq < 2) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            float mi = (float)((double)m + (double)i / (double)DEG);
+            float ax = (s[3] * mi) * dtf, ay = (s[4] * mi) * dtf, az = (s[5] * mi) * dtf;
+            out[i] = F3{s[0] + ax, s[1] + ay, s[2] + az};
+        }
+    } else {
+        const float *t = a.traj_prev + (size_t)q * NV;
+        if (m < M - 1) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) { int c = (m + 1) * NC + i; out[i] = F3{t[c], t[SEGV + c], t[2 * SEGV + c]}; }
+        } else {
+            int c = (M - 1) * NC + DEG;
+            F3 e = F3{t[c], t[SEGV + c], t[2 * SEGV + c]};
+#pragma unroll
+            for (int i = 0; i < 6; i++) out[i] = e;
+        }
+    }
+}
+
+// obstaclePredictionCheck / initialTrajPlanningCheck for agent q: its plan says it should be at traj_prev[q](t = dt) now
+__device__ __forceinline__ bool disturbed_now(const PlanArgs &a, int q)
+{
+#pragma clang fp contract(off)
+    if (!(a.reset_thr > 0.0) || a.planner_seq < 2 || a.planner_mode != 0) return false;
+    const float *t = a.traj_prev + (size_t)q * NV + NC;          // shifted plan, segment 0, point 0
+    const float *s = a.state + 9 * q;
+    const float dx = t[0] - s[0], dy = t[SEGV] - s[1], dz = t[2 * SEGV] - s[2];
+    const float n2 = dx * dx + dy * dy + dz * dz;
+    return sqrt((double)n2) > a.reset_thr;
+}
+
+__device__ __forceinline__ double ax_x(const double *x, int type, int k, int t)
+{
+    const double *xk = x + k * SEGV;
+    switch (type) {
+    case 0: return xk[t];
+    case 1: return -xk[t];
+    case 2: return xk[t + 1] - xk[t];
+    case 3: return -(xk[t + 1] - xk[t]);
+    case 4: return xk[t + 2] - 2.0 * xk[t + 1] + xk[t];
+    default: return -(xk[t + 2] - 2.0 * xk[t + 1] + xk[t]);
+    }
+}
+
+}  // namespace
+
+__device__ void general_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb)
+{
+    GS &S = *reinterpret_cast<GS *>(smem_raw);
+    const GModel &gm = *a.gmodel;
+    const Model &md = *a.model;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = a.first + al;
+    const int N = a.N, n_obs = N - 1, nob = n_obs > 0 ? n_obs : 1;
+    const int nya = gm.nya, P0 = 3 * nya;
+    const int nu = a.slack_mode == 1 ? 2 * M : 0;
+    const int P = P0 + nu;
+    const int ncs = a.ncs < 0 ? M : (a.ncs > M ? M : a.ncs);
+    const bool bvc = a.planner_mode == 1;
+    const float dtf = (float)md.dt;
+    const double hv = md.hv_scale, ha = md.ha_scale;
+
+    // ---- workspace carve-up (HBM): per-row state of the interior point, collision rows of all obstacles
+    const int NCL = NBK * nob, NGR = M * nob;
+    const int US0 = AXROWS, CL0 = AXROWS + 2 * M, GS0 = CL0 + NCL, RT = GS0 + NGR;
+    double *rs = reinterpret_cast<double *>(wsb);
+    double *rz = rs + RT, *rt1 = rz + RT, *rt2 = rt1 + RT;
+    double *crhs = rt2 + RT;                 // [NCL]   d + n.q of a collision row
+    double *ev = crhs + NCL;                 // [NGR]   group slack variables
+    double *dev = ev + NGR, *Dg = dev + NGR, *qg = Dg + NGR;
+    float *nrm = reinterpret_cast<float *>(qg + NGR);          // [NGR][3]
+    unsigned char *slk = reinterpret_cast<unsigned char *>(nrm + 3 * NGR);   // [nob]
+
+    auto block_reduce = [&](double v0, double v1, double v2, double v3, int op0, int op1, int op2, int op3) {
+        auto wr = [&](double v, int op) { return op == 0 ? wsum(v) : (op == 1 ? wmax(v) : wmin(v)); };
+        const double r0 = wr(v0, op0), r1 = wr(v1, op1), r2 = wr(v2, op2), r3 = wr(v3, op3);
+        __syncthreads();
+        if (lane == 0) { S.red[0][wave] = r0; S.red[1][wave] = r1; S.red[2][wave] = r2; S.red[3][wave] = r3; }
+        __syncthreads();
+        if (tid < 4) {
+            const int op = tid == 0 ? op0 : (tid == 1 ? op1 : (tid == 2 ? op2 : op3));
+            double t = S.red[tid][0];
+            for (int w = 1; w < GW; w++) t = op == 0 ? t + S.red[tid][w] : (op == 1 ? fmax(t, S.red[tid][w]) : fmin(t, S.red[tid][w]));
+            S.sc[tid] = t;
+        }
+        __syncthreads();
+    };
+
+    // ------------------------------------------------------------------ setup
+    const bool own_now = disturbed_now(a, qi);
+    const bool ever_i = a.ever ? (a.ever[qi] != 0) : false;
+    const bool own_rest = bvc || own_now;
+    if (tid < NV) {
+#pragma clang fp contract(off)
+        const int k = tid / SEGV, c = tid % SEGV, m = c / NC, i = c % NC;
+        const float *s = a.state + 9 * qi;
+        float val;
+        if (own_rest) val = s[k];
+        else if (a.planner_seq < 2) {
+            float mi = (float)((double)m + (double)i / (double)DEG);
+            val = s[k] + (s[3 + k] * mi) * dtf;
+        } else {
+            const float *t = a.traj_prev + (size_t)qi * NV + k * SEGV;
+            val = (m < M - 1) ? t[(m + 1) * NC + i] : t[(M - 1) * NC + DEG];
+        }
+        S.pinit[tid] = val;
+    }
+    for (int i = tid; i < SEGV * GNYA; i += GT) S.Z[i / GNYA][i % GNYA] = gm.Z[i / GNYA][i % GNYA];
+    for (int i = tid; i < GNYA * GNYA; i += GT) S.Hc[i] = gm.Hc[i];
+    if (tid < NC * NC) S.Qh[tid] = md.Qh[tid];
+    if (tid < 3) {
+        const int k = tid;
+        const float *s = a.state + 9 * qi;
+        const double c0 = (double)s[k], c1 = c0 + (double)s[3 + k] * hv, c2 = (double)s[6 + k] * ha + 2.0 * c1 - c0;
+        S.s0[k][0] = c0; S.s0[k][1] = c1; S.s0[k][2] = c2;
+        S.goalf[k] = a.goal_out[3 * qi + k];                  // current_goal_position, planned by phase A of lsc_plan_kernel
+        S.goal[k] = (double)S.goalf[k];
+        for (int m = 0; m < M; m++) {
+            double lo = (double)md.world_min[k], hi = (double)md.world_max[k];
+            if (md.use_sfc && a.sfc && m < ncs) {
+                const float *b = a.sfc + ((size_t)qi * M + m) * 6;
+                lo = fmax(lo, (double)b[k]);
+                hi = fmin(hi, (double)b[3 + k]);
+            }
+            S.lo[k][m] = lo; S.hi[k][m] = hi;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma clang fp contract(off)
+        const float *s = a.state + 9 * qi;
+        const float *g = S.goalf;
+        float dxg = g[0] - s[0], dyg = g[1] - s[1], dzg = g[2] - s[2];
+        float n2 = dxg * dxg + dyg * dyg + dzg * dzg;
+        double flight = sqrt((double)n2) / a.vnom[qi];
+        int T = (int)((M * md.dt - flight + 1e-9) / md.dt);
+        S.tseg = T > 1 ? T : 1;
+    }
+    for (int sl = tid; sl < AXROWS; sl += GT) {
+        const int type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV, m = t / NC, i = t % NC;
+        bool valid;
+        double h;
+        if (type < 2) { valid = !(m == 0 && i < 3); h = type == 0 ? S.hi[k][m] : -S.lo[k][m]; }
+        else if (type < 4) { valid = i <= 4 && !(m == 0 && i < 2); h = a.vmax[3 * qi + k] * hv; }
+        else { valid = i <= 3 && !(m == 0 && i == 0); h = a.amax[3 * qi + k] * ha; }
+        S.avalid[sl] = valid ? 1 : 0;
+        S.ah[sl] = h;
+    }
+    // ---- collision rows of every obstacle (no pruning here): LSC via GJK, or the BVC half-space
+    {
+        const double r_a = a.radius[qi], dw_a = a.downwash[qi];
+        for (int oi = tid; oi < n_obs; oi += GT) {
+            const int qj = oi < qi ? oi : oi + 1;
+            const bool in_set = a.slack_mode == 2 ||
+                                (a.slack_mode == 0 && (ever_i || own_now || (a.ever && a.ever[qj]) || disturbed_now(a, qj)));
+            slk[oi] = in_set ? 1 : 0;
+        }
+        for (int u = tid; u < n_obs * M; u += GT) {
+            const int oi = u / M, m = u % M;
+            const int qj = oi < qi ? oi : oi + 1;
+            F3 pa[6], po[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { int c = m * NC + i; pa[i] = F3{S.pinit[c], S.pinit[SEGV + c], S.pinit[2 * SEGV + c]}; }
+            g_segment(a, qj, m, bvc || disturbed_now(a, qj), dtf, po);
+            const double r_o = a.radius_obs[qj];
+            const double downwash = (dw_a * r_a + a.downwash_obs[qj] * r_o) / (r_a + r_o);
+            F3 n;
+            double d[6];
+            if (bvc) {
+#pragma clang fp contract(off)
+                // generateBVC: normal from the two current positions, one margin for all rows of the obstacle
+                const float pz = (float)((double)S.pinit[2 * SEGV] / downwash), qz = (float)((double)po[0].z / downwash);
+                const F3 rel = F3{S.pinit[0] - po[0].x, S.pinit[SEGV] - po[0].y, pz - qz};
+                n = normalized_f32(rel);
+                const float dp = rel.x * n.x + rel.y * n.y + rel.z * n.z;
+                const double dd = 0.5 * ((r_o + r_a) + (double)dp);
+                n.z = (float)((double)n.z / downwash);
+#pragma unroll
+                for (int i = 0; i < 6; i++) d[i] = dd;
+            } else {
+                lsc_segment(pa, po, downwash, r_o + r_a, n, d);
+            }
+            if (a.out_normal) {
+                size_t o = ((size_t)al * n_obs + oi) * M + m;
+                a.out_normal[o * 3] = n.x; a.out_normal[o * 3 + 1] = n.y; a.out_normal[o * 3 + 2] = n.z;
+#pragma unroll
+                for (int i = 0; i < 6; i++) a.out_d[o * 6 + i] = d[i];
+            }
+            nrm[3 * u] = n.x; nrm[3 * u + 1] = n.y; nrm[3 * u + 2] = n.z;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const int cp = m * NC + i;
+                if (cp < 3) continue;
+                double r = d[i];
+                r += (double)n.x * (double)po[i].x;
+                r += (double)n.y * (double)po[i].y;
+                r += (double)n.z * (double)po[i].z;
+                crhs[oi * NBK + cp - 3] = r;
+            }
+        }
+    }
+    if (tid <= PMAX) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
+    for (int g = tid; g < NGR; g += GT) { ev[g] = 0.0; dev[g] = 0.0; }
+    __syncthreads();
+
+    const int tseg = S.tseg;
+    const int xk = tid < NV ? tid / SEGV : 0, xt = tid < NV ? tid % SEGV : 0;
+    auto compute_x = [&](const double *yv, double *xv, bool with_const) {
+        if (tid < NV) {
+            double v = (xt < 3 && with_const) ? S.s0[xk][xt] : 0.0;
+            if (xt >= 3)
+                for (int j = 0; j < nya; j++) v += S.Z[xt][j] * yv[xk * nya + j];
+            xv[tid] = v;
+        }
+    };
+    // row bookkeeping ---------------------------------------------------------------------------------
+    // kinds: axis slot sl in [0, AXROWS) (valid mask), slack sign rows US0 + j (DYNAMICALLIMIT), collision rows
+    // CL0 + oi*27 + (cp-3) (segment < ncs), group sign rows GS0 + oi*M + m (slack obstacles, segment < ncs)
+    auto coll_valid = [&](int c) { return ((c % NBK + 3) / NC) < ncs; };
+    auto grp_valid = [&](int g) { return slk[g / M] != 0 && (g % M) < ncs; };
+    // a_r . v for the three variable blocks (xv: control points, uv: explicit slack, gv: group slack)
+    auto val_axis = [&](int sl, const double *xv, const double *uv) {
+        const int type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
+        double v = ax_x(xv, type, k, t);
+        if (nu && type >= 2) v += type < 4 ? hv * uv[t / NC] : ha * uv[M + t / NC];
+        return v;
+    };
+    auto val_coll = [&](int c, const double *xv, const double *gv) {
+        const int oi = c / NBK, cp = c % NBK + 3, m = cp / NC;
+        const float *n = nrm + 3 * (oi * M + m);
+        double v = -((double)n[0] * xv[cp] + (double)n[1] * xv[SEGV + cp] + (double)n[2] * xv[2 * SEGV + cp]);
+        if (slk[oi]) v += gv[oi * M + m];
+        return v;
+    };
+    int nrow_i = 0;
+    for (int sl = tid; sl < AXROWS; sl += GT) nrow_i += S.avalid[sl];
+    if (tid < nu) nrow_i++;
+    for (int c = tid; c < NCL; c += GT) nrow_i += (c / NBK < n_obs && coll_valid(c)) ? 1 : 0;
+    for (int g = tid; g < NGR; g += GT) nrow_i += (g / M < n_obs && grp_valid(g)) ? 1 : 0;
+    block_reduce((double)nrow_i, 0, 0, 0, 0, 0, 0, 0);
+    const double nrow = S.sc[0];
+    double hmax = 1.0;
+    {
+        double hm = 1.0;
+        for (int sl = tid; sl < AXROWS; sl += GT) if (S.avalid[sl]) hm = fmax(hm, fabs(S.ah[sl]));
+        for (int c = tid; c < NCL; c += GT) if (c / NBK < n_obs && coll_valid(c)) hm = fmax(hm, fabs(crhs[c]));
+        block_reduce(hm, 0, 0, 0, 1, 0, 0, 0);
+        hmax = S.sc[0];
+    }
+    const double wg_base = 2.0 * a.slack_w / (double)M;       // Hessian of slack_w (M - m)/M eps^2 is 2 slack_w (M - m)/M
+    auto cost_grad = [&]() -> double {
+        const double *xs = S.x + xk * SEGV + (xt / NC) * NC;
+        double g = 0.0;
+        for (int j = 0; j < NC; j++) g += S.Qh[(xt % NC) * NC + j] * xs[j];
+        return g;
+    };
+
+    // x-space sums of a per-row coefficient (rt2 = vv, rz = z) and, with_w, of the weights rt1 = w: the only place where
+    // the rows meet the unknowns.  Fixed summation orders: results do not depend on scheduling.
+    auto reduce_rows = [&](bool with_w, bool unit_w) {
+        if (tid < NV) {
+            const int k = xk, t = xt, i = t % NC, b = tid;
+            const int t1i = t >= 1 ? t - 1 : 0, t2i = t >= 2 ? t - 2 : 0;
+            const int o0 = k * SEGV + t, o1 = k * SEGV + t1i, o2 = k * SEGV + t2i;
+            auto V = [&](const double *arr, int type, int o) { return S.avalid[type * NV + o] ? arr[type * NV + o] : 0.0; };
+            const double m1 = (t >= 1 && (t1i / NC == t / NC)) ? 1.0 : 0.0, m2 = (t >= 2 && (t2i / NC == t / NC)) ? 1.0 : 0.0;
+            auto gather = [&](const double *arr) {
+                return (V(arr, 0, o0) - V(arr, 1, o0)) + (V(arr, 3, o0) - V(arr, 2, o0)) + (V(arr, 4, o0) - V(arr, 5, o0)) +
+                       m1 * ((V(arr, 2, o1) - V(arr, 3, o1)) - 2.0 * (V(arr, 4, o1) - V(arr, 5, o1))) + m2 * (V(arr, 4, o2) - V(arr, 5, o2));
+            };
+            double cg = cost_grad();
+            if (i == DEG && t / NC >= M - tseg) cg += 2.0 * md.w_t * (S.x[b] - S.goal[k]);
+            S.gv[b] = cg + gather(rt2);
+            S.gz[b] = cg + gather(rz);
+            if (with_w) {
+                auto Wt = [&](int type, int o) { return S.avalid[type * NV + o] ? (unit_w ? 1.0 : rt1[type * NV + o]) : 0.0; };
+                const double wB = Wt(0, o0) + Wt(1, o0), wV0 = Wt(2, o0) + Wt(3, o0), wA0 = Wt(4, o0) + Wt(5, o0);
+                const double wV1 = m1 * (Wt(2, o1) + Wt(3, o1)), wA1 = m1 * (Wt(4, o1) + Wt(5, o1)), wA2 = m2 * (Wt(4, o2) + Wt(5, o2));
+                S.Wd[b] = wB + wV0 + wV1 + wA0 + 4.0 * wA1 + wA2;
+                S.W1[b] = -wV0 - 2.0 * wA0 - 2.0 * wA1;
+                S.W2[b] = wA0;
+            }
+        }
+        // collision rows per control point: unit (cpi, component) x 3 obstacle stripes, combined in a fixed order
+        if (tid < 3 * NBK * 3) {
+            const int part = tid / (NBK * 3), u = tid % (NBK * 3), cpi = u / 3, k = u % 3, m = (cpi + 3) / NC;
+            double sv = 0.0, sz = 0.0;
+            if (m < ncs)
+                for (int oi = part; oi < n_obs; oi += 3) {
+                    const double nk = (double)nrm[3 * (oi * M + m) + k];
+                    const int r = CL0 + oi * NBK + cpi;
+                    sv += rt2[r] * nk; sz += rz[r] * nk;
+                }
+            S.part[part][u][0] = sv; S.part[part][u][1] = sz;
+        }
+        if (with_w && tid < NBK * 6) {
+            const int cpi = tid / 6, c = tid % 6, m = (cpi + 3) / NC;
+            const int ia = c < 3 ? 0 : (c < 5 ? 1 : 2), ib = c < 3 ? c : (c < 5 ? c - 2 : 2);
+            double acc = 0.0;
+            if (m < ncs)
+                for (int oi = 0; oi < n_obs; oi++) {
+                    const float *n = nrm + 3 * (oi * M + m);
+                    const double w = unit_w ? 1.0 : rt1[CL0 + oi * NBK + cpi];
+                    acc += w * (double)n[ia] * (double)n[ib];
+                }
+            S.Ws[(cpi + 3) * 6 + c] = acc;
+        }
+        __syncthreads();
+        if (tid < NBK * 3) {
+            const int cp = tid / 3 + 3, k = tid % 3;
+            S.Tv[cp * 3 + k] = -((S.part[0][tid][0] + S.part[1][tid][0]) + S.part[2][tid][0]);
+            S.Tz[cp * 3 + k] = -((S.part[0][tid][1] + S.part[1][tid][1]) + S.part[2][tid][1]);
+        }
+        // explicit slack variables (DYNAMICALLIMIT): gradient entries and, with_w, their Hessian row
+        if (nu && tid < nu) {
+            const int j = tid, m = j % M, isacc = j >= M;
+            const double cu = isacc ? ha : hv;
+            double gvv = 0.0, gzz = 0.0, huu = 0.0;
+            for (int k = 0; k < 3; k++)
+                for (int i = 0; i < NC; i++)
+                    for (int sg = 0; sg < 2; sg++) {
+                        const int sl = ((isacc ? 4 : 2) + sg) * NV + k * SEGV + m * NC + i;
+                        if (!S.avalid[sl]) continue;
+                        gvv += rt2[sl] * cu; gzz += rz[sl] * cu;
+                        if (with_w) huu += (unit_w ? 1.0 : rt1[sl]) * cu * cu;
+                    }
+            const double hq = wg_base * (double)(M - m);
+            S.gu[j] = hq * S.y[P0 + j] + gzz + rz[US0 + j];                 // stationarity residual of u_j
+            S.qu[j] = -(hq * S.y[P0 + j] + gvv + rt2[US0 + j]);
+            if (with_w) S.Huu[j] = hq + huu + (unit_w ? 1.0 : rt1[US0 + j]);
+        }
+        if (nu && with_w) {
+            for (int e = tid; e < nu * NV; e += GT) {
+                const int j = e / NV, b = e % NV, k = b / SEGV, t = b % SEGV, m = j % M, isacc = j >= M;
+                double acc = 0.0;
+                if (t / NC == m) {
+                    const int ty = isacc ? 4 : 2, i = t % NC;
+                    auto Wt = [&](int type, int tt) {
+                        const int sl = type * NV + k * SEGV + tt;
+                        return (tt / NC == m && tt >= 0 && S.avalid[sl]) ? (unit_w ? 1.0 : rt1[sl]) : 0.0;
+                    };
+                    if (!isacc) {
+                        // rows +-(x[t+1] - x[t]) + hv u: coefficient on x[t] is -+1 (row starting at t), +-1 (row starting at t-1)
+                        acc = -(Wt(ty, t) - Wt(ty + 1, t)) + (i >= 1 ? (Wt(ty, t - 1) - Wt(ty + 1, t - 1)) : 0.0);
+                    } else {
+                        acc = (Wt(ty, t) - Wt(ty + 1, t)) - (i >= 1 ? 2.0 * (Wt(ty, t - 1) - Wt(ty + 1, t - 1)) : 0.0) +
+                              (i >= 2 ? (Wt(ty, t - 2) - Wt(ty + 1, t - 2)) : 0.0);
+                    }
+                    acc *= isacc ? ha : hv;
+                }
+                S.Wu[j][b] = acc;
+            }
+        }
+        // group slack variables: diagonal D_g, right-hand side q_g, stationarity residual (kept in dev for the test)
+        for (int g = tid; g < NGR; g += GT) {
+            if (!(g / M < n_obs) || !grp_valid(g)) continue;
+            const int oi = g / M, m = g % M;
+            double sw = 0.0, svv = 0.0, szz = 0.0;
+            for (int i = 0; i < NC; i++) {
+                const int cp = m * NC + i;
+                if (cp < 3) continue;
+                const int r = CL0 + oi * NBK + cp - 3;
+                sw += unit_w ? 1.0 : rt1[r]; svv += rt2[r]; szz += rz[r];
+            }
+            const double hq = wg_base * (double)(M - m);
+            if (with_w) Dg[g] = hq + sw + (unit_w ? 1.0 : rt1[GS0 + g]);
+            qg[g] = -(hq * ev[g] + svv + rt2[GS0 + g]);
+            dev[g] = hq * ev[g] + szz + rz[GS0 + g];
+        }
+        __syncthreads();
+        // elimination of the group slack variables: C_m = sum_g m_g m_g^T / D_g and c_q = sum_g m_g q_g / D_g in x-space,
+        // m_g = -w_r n_g at the control points of segment m
+        if (with_w)
+            for (int e = tid; e < M * SEG_E; e += GT) {
+                const int m = e / SEG_E;
+                int r = e % SEG_E, p = 0;
+                while (r >= 18 - p) { r -= 18 - p; p++; }
+                const int q = p + r;                                   // p <= q in 0..17 : (i, k) = (p / 3, p % 3)
+                const int i1 = p / 3, k1 = p % 3, i2 = q / 3, k2 = q % 3;
+                double acc = 0.0;
+                if (m < ncs && m * NC + i1 >= 3 && m * NC + i2 >= 3)
+                    for (int oi = 0; oi < n_obs; oi++) {
+                        if (!slk[oi]) continue;
+                        const float *n = nrm + 3 * (oi * M + m);
+                        const double w1 = unit_w ? 1.0 : rt1[CL0 + oi * NBK + m * NC + i1 - 3];
+                        const double w2 = unit_w ? 1.0 : rt1[CL0 + oi * NBK + m * NC + i2 - 3];
+                        acc += w1 * w2 * (double)n[k1] * (double)n[k2] / Dg[oi * M + m];
+                    }
+                S.Cm[m][e % SEG_E] = acc;
+            }
+        if (tid < NBK * 3) {
+            const int cp = tid / 3 + 3, k = tid % 3, m = cp / NC;
+            double acc = 0.0;
+            if (m < ncs)
+                for (int oi = 0; oi < n_obs; oi++) {
+                    if (!slk[oi]) continue;
+                    const int g = oi * M + m;
+                    const double w = unit_w ? 1.0 : rt1[CL0 + oi * NBK + cp - 3];
+                    acc += -w * (double)nrm[3 * g + k] * qg[g] / Dg[g];
+                }
+            S.cq[cp * 3 + k] = acc;
+        }
+        __syncthreads();
+    };
+    auto seg_c = [&](int m, int i1, int k1, int i2, int k2) {
+        int p = i1 * 3 + k1, q = i2 * 3 + k2;
+        if (p > q) { const int t = p; p = q; q = t; }
+        return S.Cm[m][p * 18 - p * (p - 1) / 2 + (q - p)];
+    };
+    // dense reduced system: K (lower triangle) and rhs = q_y - sum_g m_g q_g / D_g ; stationarity residual in dy
+    auto assemble = [&](bool with_k) {
+        if (with_k)
+            for (int e = tid; e < P * P; e += GT) {
+                const int r = e / P, c = e % P;
+                if (c > r) continue;
+                double v = 0.0;
+                if (r < P0 && c < P0) {
+                    const int k = r / nya, aa = r % nya, kk = c / nya, bb = c % nya;
+                    const int sc6 = k == kk ? (k == 0 ? 0 : (k == 1 ? 3 : 5)) : ((k < kk ? k : kk) == 0 ? (k + kk) : 4);   // xx xy xz yy yz zz
+                    if (k == kk) v = S.Hc[aa * GNYA + bb];
+                    for (int t = 3; t < SEGV; t++) {
+                        const double za = S.Z[t][aa];
+                        if (za == 0.0) continue;
+                        const int m = t / NC, i = t % NC;
+                        double row = S.Ws[t * 6 + sc6] * S.Z[t][bb];
+                        if (k == kk) {
+                            double dg = S.Wd[k * SEGV + t];
+                            if (i == DEG && m >= M - tseg) dg += 2.0 * md.w_t;
+                            row += dg * S.Z[t][bb];
+                            if (i + 1 < NC) row += S.W1[k * SEGV + t] * S.Z[t + 1][bb];
+                            if (i >= 1) row += S.W1[k * SEGV + t - 1] * S.Z[t - 1][bb];
+                            if (i + 2 < NC) row += S.W2[k * SEGV + t] * S.Z[t + 2][bb];
+                            if (i >= 2) row += S.W2[k * SEGV + t - 2] * S.Z[t - 2][bb];
+                        }
+                        if (m < ncs)
+                            for (int i2 = 0; i2 < NC; i2++) {
+                                const double zb = S.Z[m * NC + i2][bb];
+                                if (zb != 0.0 && m * NC + i2 >= 3) row -= seg_c(m, i, k, i2, kk) * zb;
+                            }
+                        v += za * row;
+                    }
+                } else if (r >= P0 && c < P0) {
+                    const int j = r - P0, kk = c / nya, bb = c % nya;
+                    for (int t = 3; t < SEGV; t++) v += S.Z[t][bb] * S.Wu[j][kk * SEGV + t];
+                } else if (r == c) {
+                    v = S.Huu[r - P0];
+                }
+                S.K[r * KL + c] = v;
+            }
+        if (tid < P0) {
+            const int k = tid / nya, aa = tid % nya;
+            double r = 0.0, rdv = 0.0;
+            for (int t = 3; t < SEGV; t++) {
+                const double za = S.Z[t][aa];
+                if (za == 0.0) continue;
+                r += za * (S.gv[k * SEGV + t] + S.Tv[t * 3 + k] + S.cq[t * 3 + k]);
+                rdv += za * (S.gz[k * SEGV + t] + S.Tz[t * 3 + k]);
+            }
+            S.rhs[tid] = -r;
+            S.dy[tid] = rdv;
+        } else if (tid < P) {
+            S.rhs[tid] = S.qu[tid - P0];
+            S.dy[tid] = S.gu[tid - P0];
+        }
+        __syncthreads();
+    };
+    // dense Cholesky K = L L^T in place (lower), then L L^T dy = rhs
+    auto factor = [&]() -> bool {
+        if (tid == 0) S.ok = 1;
+        __syncthreads();
+        for (int j = 0; j < P; j++) {
+            if (tid == 0) {
+                const double d = S.K[j * KL + j];
+                if (!(d > 0.0)) S.ok = 0;
+                S.K[j * KL + j] = sqrt(d > 0.0 ? d : 1.0);
+            }
+            __syncthreads();
+            if (tid > j && tid < P) S.K[tid * KL + j] /= S.K[j * KL + j];
+            __syncthreads();
+            const int nrem = P - j - 1;
+            for (int e = tid; e < nrem * nrem; e += GT) {
+                const int i = j + 1 + e / nrem, k = j + 1 + e % nrem;
+                if (k <= i) S.K[i * KL + k] -= S.K[i * KL + j] * S.K[k * KL + j];
+            }
+            __syncthreads();
+        }
+        return S.ok != 0;
+    };
+    auto solve = [&]() {
+        if (wave == 0) {
+            double b = lane < P ? S.rhs[lane] : 0.0;
+            for (int j = 0; j < P; j++) {
+                double bj = __shfl(b, j, 64) / S.K[j * KL + j];
+                if (lane == j) b = bj;
+                else if (lane > j && lane < P) b -= S.K[lane * KL + j] * bj;
+            }
+            for (int j = P - 1; j >= 0; j--) {
+                double bj = __shfl(b, j, 64) / S.K[j * KL + j];
+                if (lane == j) b = bj;
+                else if (lane < j) b -= S.K[j * KL + lane] * bj;
+            }
+            if (lane < P) S.dy[lane] = b;
+        }
+        __syncthreads();
+        compute_x(S.dy, S.dx, false);
+        __syncthreads();
+        // back-substitution of the eliminated group slack variables: de_g = (q_g - m_g . dx) / D_g
+        for (int g = tid; g < NGR; g += GT) {
+            if (!(g / M < n_obs) || !grp_valid(g)) { dev[g] = 0.0; continue; }
+            const int oi = g / M, m = g % M;
+            const float *n = nrm + 3 * g;
+            double mdx = 0.0;
+            for (int i = 0; i < NC; i++) {
+                const int cp = m * NC + i;
+                if (cp < 3) continue;
+                const double w = S.sc[7] != 0.0 ? 1.0 : rt1[CL0 + oi * NBK + cp - 3];
+                mdx += -w * ((double)n[0] * S.dx[cp] + (double)n[1] * S.dx[SEGV + cp] + (double)n[2] * S.dx[2 * SEGV + cp]);
+            }
+            dev[g] = (qg[g] - mdx) / Dg[g];
+        }
+        __syncthreads();
+    };
+    // generic sweep over all valid rows: f(row index r, value a_r.v at (xv, uv, gv), value at the step, rhs h)
+    auto for_rows = [&](auto &&f) {
+        for (int sl = tid; sl < AXROWS; sl += GT)
+            if (S.avalid[sl]) f(sl, val_axis(sl, S.x, S.y + P0), val_axis(sl, S.dx, S.dy + P0), S.ah[sl]);
+        if (tid < nu) f(US0 + tid, S.y[P0 + tid], S.dy[P0 + tid], 0.0);
+        for (int c = tid; c < NCL; c += GT)
+            if (c / NBK < n_obs && coll_valid(c)) f(CL0 + c, val_coll(c, S.x, ev), val_coll(c, S.dx, dev), -crhs[c]);
+        for (int g = tid; g < NGR; g += GT)
+            if (g / M < n_obs && grp_valid(g)) f(GS0 + g, ev[g], dev[g], 0.0);
+    };
+    auto objective = [&]() -> double {
+        double o = 0.0;
+        if (tid < NV) {
+            o = 0.5 * cost_grad() * S.x[tid];
+            if (xt % NC == DEG && xt / NC >= M - tseg) { const double e = S.x[tid] - S.goal[xk]; o += md.w_t * e * e; }
+        }
+        if (tid < nu) o += 0.5 * wg_base * (double)(M - tid % M) * S.y[P0 + tid] * S.y[P0 + tid];
+        for (int g = tid; g < NGR; g += GT)
+            if (g / M < n_obs && grp_valid(g)) o += 0.5 * wg_base * (double)(M - g % M) * ev[g] * ev[g];
+        return o;
+    };
+
+    // ------------------------------------------------------------------ cold start (least-squares point, then shift)
+    int status = LSC_STATUS_INFEASIBLE_K, iters = 0;
+    double obj = 0.0;
+    bool run = true;
+    if (a.goal_err && a.goal_err[qi] != 0) { status = LSC_STATUS_GOAL_K; run = false; }
+    else if (a.sfc_err && a.sfc_err[qi] != 0) { status = LSC_STATUS_SFC_K; run = false; }
+    if (run) {
+        compute_x(S.y, S.x, true);
+        __syncthreads();
+        for_rows([&](int r, double av, double, double h) { rt2[r] = av - h; rz[r] = 0.0; });
+        if (tid == 0) S.sc[7] = 1.0;                                  // unit weights in solve()'s back-substitution
+        __syncthreads();
+        reduce_rows(true, true);
+        assemble(true);
+        if (!factor()) run = false;
+    }
+    if (run) {
+        solve();
+        if (tid < P) S.y[tid] = S.dy[tid];
+        for (int g = tid; g < NGR; g += GT) ev[g] = dev[g];
+        __syncthreads();
+        compute_x(S.y, S.x, true);
+        __syncthreads();
+        double mins = 1e300, minz = 1e300;
+        for_rows([&](int r, double av, double, double h) {
+            const double sl = h - av;
+            rs[r] = sl; rz[r] = -sl;
+            mins = fmin(mins, sl); minz = fmin(minz, -sl);
+        });
+        block_reduce(mins, minz, 0, 0, 2, 2, 0, 0);
+        const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0, shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
+        for_rows([&](int r, double, double, double) { rs[r] += shs; rz[r] += shz; });
+        if (tid == 0) S.sc[7] = 0.0;
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ Mehrotra predictor-corrector
+    const int max_iters = 80;
+    while (run) {
+        if (iters >= max_iters) break;
+        // residuals, weights, predictor right-hand side
+        double gp = 0.0, rpm = 0.0;
+        for_rows([&](int r, double av, double, double h) {
+            const double sv = rs[r], zv = rz[r];
+            const double rp = av + sv - h, w = zv / sv;
+            rt1[r] = w; rt2[r] = w * rp;
+            gp += sv * zv; rpm = fmax(rpm, fabs(rp));
+        });
+        block_reduce(gp, rpm, objective(), 0, 0, 1, 0, 0);
+        const double gap = S.sc[0], rpmax = S.sc[1];
+        obj = S.sc[2];
+        const double mu = gap / nrow;
+        const bool gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
+        if (!(gap == gap) || !(rpmax == rpmax)) break;
+        reduce_rows(true, false);
+        assemble(true);
+        {
+            double rda = tid < P ? fabs(S.dy[tid]) : 0.0;
+            for (int g = tid; g < NGR; g += GT)
+                if (g / M < n_obs && grp_valid(g)) rda = fmax(rda, fabs(dev[g]));
+            block_reduce(rda, 0, 0, 0, 1, 0, 0, 0);
+            if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
+        }
+        if (!factor()) {
+            if (rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) status = LSC_STATUS_OK_K;
+            break;
+        }
+        solve();
+        // affine step length and centring statistics
+        double amin = 1.0, s1 = 0.0, s2 = 0.0;
+        for_rows([&](int r, double av, double adv, double h) {
+            const double sv = rs[r], zv = rz[r], w = rt1[r];
+            const double rp = av + sv - h;
+            const double ds = -rp - adv, dz = -zv - w * ds;
+            if (ds < 0.0) amin = fmin(amin, -sv / ds);
+            if (dz < 0.0) amin = fmin(amin, -zv / dz);
+            s1 += sv * dz + zv * ds; s2 += ds * dz;
+            rt2[r] = ds * dz;
+        });
+        const double dxa = tid < NV ? fabs(S.dx[tid]) : 0.0, xa = tid < NV ? fabs(S.x[tid]) : 0.0;
+        block_reduce(amin, s1, s2, dxa, 2, 0, 0, 1);
+        const double aaff = S.sc[0], ss1 = S.sc[1], ss2 = S.sc[2], dxn = S.sc[3];
+        block_reduce(xa, 0, 0, 0, 1, 0, 0, 0);
+        if (rpmax <= 1e-9 * hmax && gap_ok && dxn <= 1e-9 * fmax(1.0, S.sc[0])) { status = LSC_STATUS_OK_K; break; }
+        const double mu_aff = (gap + aaff * ss1 + aaff * aaff * ss2) / nrow;
+        double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
+        sigma = sigma * sigma * sigma;
+        const double smu = sigma * mu;
+        // corrector right-hand side, same factor
+        for_rows([&](int r, double av, double, double h) {
+            const double sv = rs[r];
+            const double rp = av + sv - h;
+            rt2[r] = rt1[r] * rp - (rt2[r] - smu) / sv;
+        });
+        __syncthreads();
+        reduce_rows(false, false);
+        assemble(false);
+        solve();
+        double amax = 1e300;
+        for_rows([&](int r, double av, double adv, double h) {
+            const double sv = rs[r], zv = rz[r], w = rt1[r];
+            const double rp = av + sv - h;
+            const double ds = -rp - adv, dz = -zv + rt2[r] + w * adv;
+            if (ds < 0.0) amax = fmin(amax, -sv / ds);
+            if (dz < 0.0) amax = fmin(amax, -zv / dz);
+            rt1[r] = ds; rt2[r] = dz;
+        });
+        block_reduce(amax, 0, 0, 0, 2, 0, 0, 0);
+        const double alpha = fmin(1.0, 0.99 * S.sc[0]);
+        for_rows([&](int r, double, double, double) { rs[r] += alpha * rt1[r]; rz[r] += alpha * rt2[r]; });
+        if (tid < P) S.y[tid] += alpha * S.dy[tid];
+        for (int g = tid; g < NGR; g += GT) ev[g] += alpha * dev[g];
+        __syncthreads();
+        compute_x(S.y, S.x, true);
+        __syncthreads();
+        iters++;
+    }
+
+    // ------------------------------------------------------------------ output (same conventions as lsc_plan_kernel)
+    float *out = a.traj_next + (size_t)qi * NV;
+    float *stale = a.stale + (size_t)qi * NV;
+    __syncthreads();
+    if (tid < NV) {
+        if (status == LSC_STATUS_OK_K) { const float v = (float)S.x[tid]; out[tid] = v; stale[tid] = v; }
+        else out[tid] = stale[tid];
+    }
+    if (a.state_next && tid < 3) {
+#pragma clang fp contract(off)
+        const int k = tid;
+        float c0, c1, c2;
+        if (status == LSC_STATUS_OK_K) { c0 = (float)S.x[k * SEGV + NC]; c1 = (float)S.x[k * SEGV + NC + 1]; c2 = (float)S.x[k * SEGV + NC + 2]; }
+        else { c0 = stale[k * SEGV + NC]; c1 = stale[k * SEGV + NC + 1]; c2 = stale[k * SEGV + NC + 2]; }
+        const float fn = (float)DEG, fn1 = (float)(DEG - 1), finv = a.finv;
+        const float v0 = ((c1 - c0) * fn) * finv, v1 = ((c2 - c1) * fn) * finv, a0 = ((v1 - v0) * fn1) * finv;
+        a.state_next[9 * qi + k] = c0; a.state_next[9 * qi + 3 + k] = v0; a.state_next[9 * qi + 6 + k] = a0;
+    }
+    if (tid == 0) {
+        if (status == LSC_STATUS_OK_K) a.cost[qi] = obj;
+        a.status[qi] = status;
+        a.iters[qi] = iters;
+        if (a.iters_acc) a.iters_acc[qi] += iters;
+        if (a.nrows) a.nrows[qi] = (int)nrow - 414 - nu;      // collision rows + group sign rows
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(GT) void lsc_general_kernel(PlanArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    {
+        bool work = false;
+        for (int al = blockIdx.x; al < a.count; al += gridDim.x) work |= a.status[a.first + al] == LSC_STATUS_GENERAL_K;
+        if (!work) return;
+    }
+    unsigned char *ws = a.gen_ws + (size_t)blockIdx.x * a.gen_stride;
+    for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
+        if (a.status[a.first + al] != LSC_STATUS_GENERAL_K) continue;
+        __syncthreads();
+        general_agent(a, al, smem_raw, ws);
+        __syncthreads();
+    }
+}
+
+size_t general_ws_bytes(int N)
+{
+    const size_t nob = N - 1 > 1 ? N - 1 : 1;
+    const size_t RT = AXROWS + 2 * M + NBK * nob + M * nob;
+    size_t b = sizeof(double) * (4 * RT + NBK * nob + 4 * M * nob) + sizeof(float) * 3 * M * nob + nob;
+    return (b + 255) & ~(size_t)255;
+}
+
+size_t general_smem_bytes() { return (sizeof(GS) + 15) & ~(size_t)15; }
+
+hipError_t init_device_general_kernel()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t launch_general(const PlanArgs &a, int slots, hipStream_t st)
+{
+    if (a.count == 0 || slots < 1 || !a.gen_ws) return hipSuccess;
+    const int grid = a.count < slots ? a.count : slots;
+    hipLaunchKernelGGL(lsc_general_kernel, dim3(grid), dim3(GT), general_smem_bytes(), st, a);
+    return hipGetLastError();
+}
+
+}  // namespace lsc

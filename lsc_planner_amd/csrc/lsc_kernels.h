@@ -11,6 +11,7 @@
 #define LSC_STATUS_CAPACITY_K 3
 #define LSC_STATUS_SFC_K 4
 #define LSC_STATUS_GOAL_K 5
+#define LSC_STATUS_GENERAL_K 6   /* internal: the agent's QP has an alternate-mode shape -> lsc_general_kernel solves it */
 
 namespace lsc {
 
@@ -46,6 +47,17 @@ struct PlanArgs {
     int trace_agent;
     unsigned char *spill_ws;   // second pass only: HBM row workspaces, one of spill_stride bytes per workgroup
     size_t spill_stride;
+    // alternate planner modes (lsc_general.hip)
+    const GModel *gmodel;
+    int planner_mode;          // 0 LSC, 1 BVC
+    int slack_mode;            // 0 none, 1 dynamical_limit, 2 collision_constraint
+    int ncs;                   // opt/N_constraint_segments (-1 -> M)
+    int general_all;           // every agent takes the general kernel (BVC or a slack mode is configured)
+    double slack_w;            // opt/slack_collision_weight
+    double reset_thr;          // multisim/reset_threshold; <= 0: no disturbance checks
+    unsigned char *ever;       // [N] persistent: agent was seen off its plan at some tick (its rows keep slack variables)
+    unsigned char *gen_ws;     // HBM workspaces of lsc_general_kernel, gen_stride bytes per workgroup
+    size_t gen_stride;
 };
 constexpr int PROF_PHASES = 12;
 
@@ -74,6 +86,8 @@ struct SfcArgs {
     int *init_flag;             // [N] flag_initialize_sfc
     int *err;                   // [N] 1 when the seed box already touches an obstacle
     int table_len;              // entries per face table in LDS: steps a face can move inside the world + slack
+    int planner_seq;
+    double reset_thr;           // initialTrajPlanningCheck: an agent found off its plan re-initialises its corridor
 };
 hipError_t launch_sfc(const SfcArgs &a, hipStream_t st);
 
@@ -110,6 +124,9 @@ struct GoalArgs {
 size_t goal_smem_bytes(int H, int W, int A, int cap);
 hipError_t launch_goal(const GoalArgs &a, hipStream_t st);
 
+size_t general_ws_bytes(int N);
+hipError_t init_device_general_kernel();
+hipError_t launch_general(const PlanArgs &a, int slots, hipStream_t st);
 size_t plan_smem_bytes(int n_terms, int n_entries, int cap);
 size_t plan_spill_bytes(int N);
 hipError_t init_device_kernels();

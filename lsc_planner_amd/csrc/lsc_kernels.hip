@@ -358,7 +358,17 @@ __global__ __launch_bounds__(64) void lsc_sfc_kernel(SfcArgs a)
     const float *goal = a.goal + 3 * qi;
     double box[6];
     int rc;
-    const bool init = a.init_flag[qi] != 0;
+    bool init = a.init_flag[qi] != 0;
+    if (a.reset_thr > 0.0 && a.planner_seq >= 2) {
+#pragma clang fp contract(off)
+        // initialTrajPlanningCheck (src/traj_planner.cpp:1047-1061): off the plan by more than reset_threshold ->
+        // flag_initialize_sfc: the corridor starts again from the current position
+        const float *t = a.traj_prev + (size_t)qi * NV + NC;
+        const float *s = a.state + 9 * qi;
+        const float dx = t[0] - s[0], dy = t[SEGV] - s[1], dz = t[2 * SEGV] - s[2];
+        const float n2 = dx * dx + dy * dy + dz * dz;
+        if (sqrt((double)n2) > a.reset_thr) init = true;
+    }
     float seed[3];
     if (init) {
         for (int k = 0; k < 3; k++) seed[k] = a.state[9 * qi + k];
@@ -370,19 +380,25 @@ __global__ __launch_bounds__(64) void lsc_sfc_kernel(SfcArgs a)
     const float gl[3] = {goal[0], goal[1], goal[2]};
     extern __shared__ __align__(16) unsigned char sfc_smem[];
     rc = sfc_expand(g, seed, gl, box, reinterpret_cast<double *>(sfc_smem), a.table_len);
-    // the shift of the previous boxes reads what it overwrites: one lane does the bookkeeping
-    if (lane == 0) {
-        if (rc == 0) {
-            if (init) {
-                for (int m = 0; m < M; m++)
-                    for (int j = 0; j < 6; j++) sfc[m * 6 + j] = (float)box[j];
-                a.init_flag[qi] = 0;
-            } else {
-                for (int m = 1; m < M; m++)
-                    for (int j = 0; j < 6; j++) sfc[(m - 1) * 6 + j] = sfc[m * 6 + j];
-                for (int j = 0; j < 6; j++) sfc[(M - 1) * 6 + j] = (float)box[j];
-            }
+    // The shift of the previous boxes reads what it overwrites.  Lane l holds float l of the NEW history: the old values
+    // are fetched with one per-lane (vector) load before anything is stored.  (A single lane walking the array reads it
+    // through wave-uniform addresses, which the compiler turns into scalar loads; those are not ordered against the
+    // vector stores that follow, and a store could overtake the load of the element it replaces.)
+    float keep = 0.0f;
+    if (!init && lane < (M - 1) * 6) keep = sfc[6 + lane];
+    if (rc == 0) {
+        const int j = lane % 6;
+        const float nb = (float)(j == 0 ? box[0] : j == 1 ? box[1] : j == 2 ? box[2] : j == 3 ? box[3] : j == 4 ? box[4] : box[5]);
+        if (init) {
+            if (lane < M * 6) sfc[lane] = nb;
+        } else if (lane < (M - 1) * 6) {
+            sfc[lane] = keep;
+        } else if (lane < M * 6) {
+            sfc[lane] = nb;
         }
+    }
+    if (lane == 0) {
+        if (rc == 0 && init) a.init_flag[qi] = 0;
         a.err[qi] = rc;
     }
 }
@@ -433,6 +449,7 @@ struct Smem {
     int wcnt[NWAVE][32];
     int tseg;                   // terminal segments
     int flag;                   // capacity overflow
+    int gen;                    // alternate-mode QP: lsc_general_kernel solves this agent
     int nact;                   // active LSC rows
     int itmp;                   // argmin scratch of the goal stage
     float goalf[3];             // current goal (float32, as agent.current_goal_position)
@@ -589,7 +606,9 @@ enum { PH_SETUP = 0, PH_LSC, PH_INIT, PH_P1, PH_REDUCE, PH_ASSEMBLE, PH_FACTOR, 
 //                   is flagged LSC_STATUS_CAPACITY_K and left to the second pass
 //   SPILL = true  : the row arrays live in this workgroup's HBM workspace `ws`, sized for all 27 (N-1) rows the
 //                   reference adds (src/traj_optimizer.cpp:437-466) -- same code, same arithmetic, no capacity limit
-template <bool PROF, bool SPILL>
+//   ALT = true    : the build with the alternate-mode hooks (disturbance checks, hand-over to lsc_general_kernel); kept
+//                   out of the default instantiation so that the fast path's register allocation is untouched by them
+template <bool PROF, bool SPILL, bool ALT = false>
 __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *ws)
 {
     // cmap entry = row slot | control point << CMAP_SHIFT (HBM variant: 24 bits of slot, 27 (N-1) slots fit for any N)
@@ -655,6 +674,34 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         }
         S.pinit[tid] = val;
     }
+    // ---- disturbance checks (obstaclePredictionCheck / initialTrajPlanningCheck, src/traj_planner.cpp:866-878, 1047-1061):
+    // an agent whose state is farther than reset_threshold from where its plan puts it is "disturbed"; every agent then
+    // keeps slack variables on its rows against that agent for the rest of the mission (obs_slack_indices only grows),
+    // which is a QP of another shape: the swarm switches to lsc_general_kernel (a.ever = the persistent per-agent flag).
+    auto off_plan = [&](int q) {
+#pragma clang fp contract(off)
+        const float *t = a.traj_prev + (size_t)q * NV + NC;
+        const float *s = a.state + 9 * q;
+        const float dx = t[0] - s[0], dy = t[SEGV] - s[1], dz = t[2 * SEGV] - s[2];
+        const float n2 = dx * dx + dy * dy + dz * dz;
+        return sqrt((double)n2) > a.reset_thr;
+    };
+    const bool checks = ALT && a.reset_thr > 0.0 && a.planner_seq >= 2 && a.planner_mode == 0 && a.ever != nullptr;
+    bool own_now = false, own_slack = false;
+    if (tid == 0) S.gen = ALT ? a.general_all : 0;
+    if (checks) {
+        own_now = off_plan(qi);
+        own_slack = own_now || a.ever[qi] != 0;
+        int any = own_slack ? 1 : 0;
+        for (int qj = tid; qj < N; qj += NT) {
+            const bool nw = off_plan(qj);
+            if (nw) a.ever[qj] = 1;
+            any |= (nw || a.ever[qj] != 0) ? 1 : 0;
+        }
+        __syncthreads();              // S.gen was initialised by lane 0 above
+        if (any) S.gen = 1;           // every writer stores the same value; read after the next barrier
+    }
+    const bool rest = ALT && (own_now || a.planner_mode == 1);   // own initial trajectory = current position (reset, or BVC)
     // ---- goal planning (TrajPlanner::goalPlanning, src/traj_planner.cpp:477-538)
     //   static      : current goal = the goal input
     //   prior_based : goalPlanningWithPriority (:540-608) on a map without a distance field.  There the grid A*
@@ -677,6 +724,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         int bq = 0x7fffffff;
         for (int qj = tid; qj < N; qj += NT) {
             if (qj == qi) continue;
+            if (checks && (own_slack || a.ever[qj] != 0 || off_plan(qj))) continue;   // slack obstacle: no retreat candidate (:548-551)
             const float *opos = a.state + 9 * qj, *ogoal = a.goal + 3 * qj;
             const double obs_dist_to_goal = distf(opos, ogoal);
             const double dist_to_obs = distf(opos, pos);
@@ -708,7 +756,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 const float keep = (float)(a.priority_dist_threshold + 0.1);
                 gx = pos[0] - dir.x * keep; gy = pos[1] - dir.y * keep; gz = pos[2] - dir.z * keep;
             } else {                                                              // findLOSFreeGoal, empty map
-                const float ex = S.pinit[cl], ey = S.pinit[SEGV + cl], ez = S.pinit[2 * SEGV + cl];   // initial_traj[M-1][n]
+                // initial_traj[M-1][n] (the current position when the initial trajectory was reset / in BVC mode)
+                const float ex = rest ? pos[0] : S.pinit[cl], ey = rest ? pos[1] : S.pinit[SEGV + cl], ez = rest ? pos[2] : S.pinit[2 * SEGV + cl];
                 F3 delta = F3{goal_i[0] - ex, goal_i[1] - ey, goal_i[2] - ez};
                 const float n2 = delta.x * delta.x + delta.y * delta.y + delta.z * delta.z;
                 if (sqrt((double)n2) > a.goal_radius) {
@@ -810,7 +859,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         const double r_a = a.radius[qi], dw_a = a.downwash[qi];
         const double dlx = a.vmax[3 * qi] * md.hv_scale, dly = a.vmax[3 * qi + 1] * md.hv_scale,
                      dlz = a.vmax[3 * qi + 2] * md.hv_scale;   // largest step between consecutive control points
-        const int n_units = n_obs * M;
+        const int n_units = (ALT && S.gen) ? 0 : n_obs * M;    // alternate-mode QP: rows are built by lsc_general_kernel
         const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         // Reachable box of every control point relative to c_{0,2}.  Consecutive control points differ by at most
         // V = vmax dt/n (velocity rows, traj_optimizer.cpp:472-492) and consecutive differences by at most
@@ -1315,6 +1364,9 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     } else if (a.sfc_err && a.sfc_err[qi] != 0) {
         status = LSC_STATUS_SFC_K;   // seed box of the corridor blocked (the reference throws out of plan())
         run = false;
+    } else if (ALT && S.gen) {
+        status = LSC_STATUS_GENERAL_K;   // solved by lsc_general_kernel, launched right after this one
+        run = false;
     } else if (overflow) {
         status = LSC_STATUS_CAPACITY_K;
         run = false;
@@ -1602,6 +1654,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     plan_agent<PROF, false>(a, blockIdx.x, smem_raw, nullptr);
 }
 
+// the same kernel with the alternate-mode hooks (contexts with reset_threshold > 0, BVC or a slack mode)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_alt_kernel(PlanArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    plan_agent<false, false, true>(a, blockIdx.x, smem_raw, nullptr);
+}
+
 // Second pass: agents whose rows did not fit the LDS capacity of the first pass are solved again with their rows in
 // HBM.  Persistent workgroups (one workspace each) walk the shard; everybody else's result is left untouched.
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_spill_kernel(PlanArgs a)
@@ -1618,7 +1677,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
         if (a.status[a.first + al] != LSC_STATUS_CAPACITY_K) continue;   // uniform over the workgroup
         __syncthreads();
-        plan_agent<false, true>(a, al, smem_raw, ws);
+        plan_agent<false, true, false>(a, al, smem_raw, ws);
         __syncthreads();
     }
 }
@@ -1656,18 +1715,23 @@ size_t plan_spill_bytes(int N)
 hipError_t init_device_kernels()
 {
     const void *fns[] = {reinterpret_cast<const void *>(&lsc_plan_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_kernel<true>),
+                         reinterpret_cast<const void *>(&lsc_plan_alt_kernel),
                          reinterpret_cast<const void *>(&lsc_plan_spill_kernel), reinterpret_cast<const void *>(&lsc_sfc_kernel)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
+    hipError_t e = init_device_general_kernel();
+    if (e != hipSuccess) return e;
     return init_device_goal_kernel();
 }
 
 hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;          // empty shard (more ranks than agents): nothing to plan
-    if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, a);
+    const bool alt = a.general_all || (a.reset_thr > 0.0 && a.ever);
+    if (alt) hipLaunchKernelGGL(lsc_plan_alt_kernel, dim3(a.count), dim3(NT), smem, st, a);
+    else if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, a);
     else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, a);
     return hipGetLastError();
 }

@@ -52,6 +52,15 @@ struct Model {
     unsigned short amap[416]; // compact list of the valid axis-row slots (414)
 };
 
+// Dense variant of the same elimination for the alternate planner modes (lsc_general.hip): axis-major y, with
+// (nya = 13) or without (nya = 15, BVC: c_{4,3..5} stay free) the stop-at-horizon rows.
+constexpr int GNYA = 15;
+struct GModel {
+    int    nya;
+    double Z[SEGV][GNYA];     // x_t = (state constants for t < 3) + sum_a Z[t][a] y[a]
+    double Hc[GNYA * GNYA];   // Z^T blockdiag(Qh) Z for one axis
+};
+
 // offsets inside the x-space weight array W that the assembly terms read from
 constexpr int W_D = 0;          // [3][30] diagonal        (bounds + velocity + acceleration stencils)
 constexpr int W_1 = 90;         // [3][30] (t, t+1) coupling

@@ -34,6 +34,11 @@ class PlannerConfig:
     grid_margin: float = 0.2        # grid/margin
     horizon: float = 1.0            # traj/horizon (M = horizon / dt must be 5)
     goal_row_cap: int = 0           # > 0: smaller OPEN-row capacity of the goal search (tests of the overflow path)
+    planner_mode: str = "lsc"       # mode/planner: "lsc" or "bvc"
+    slack_mode: str = "none"        # SlackMode: "none", "dynamical_limit", "collision_constraint"
+    slack_collision_weight: float = 100000.0
+    n_constraint_segments: int = -1
+    reset_threshold: float = 0.0    # multisim/reset_threshold; > 0 switches the disturbance checks on (launch files: 0.15)
     comm: tuple = None              # (world_size, rank, id bytes from comm_unique_id()): agent-sharded multi-GPU over RCCL
 
 
@@ -74,6 +79,10 @@ class SwarmPlanner:
                                                                        self.cfg.goal_radius)
         c.grid_resolution, c.grid_margin = self.cfg.grid_resolution, self.cfg.grid_margin
         c.horizon, c.goal_row_cap = self.cfg.horizon, self.cfg.goal_row_cap
+        c.planner_mode = {"lsc": 0, "bvc": 1}[self.cfg.planner_mode]
+        c.slack_mode = {"none": 0, "dynamical_limit": 1, "collision_constraint": 2}[self.cfg.slack_mode]
+        c.slack_collision_weight, c.n_constraint_segments = self.cfg.slack_collision_weight, self.cfg.n_constraint_segments
+        c.reset_threshold = self.cfg.reset_threshold
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:

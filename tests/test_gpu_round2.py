@@ -233,3 +233,34 @@ def test_config3_256_agents_in_simple_forest_as_written(L, oracle):
     # the swarm is making progress towards its goals
     assert np.linalg.norm(state[:, :3] - ms.goal, axis=1).mean() < np.linalg.norm(ms.start - ms.goal, axis=1).mean() - 1.0
     full.close(); s0.close(); s1.close()
+
+
+def test_corridor_history_shift_is_not_reordered(L, oracle):
+    """Regression: the shift of the corridor history used to be done by one lane through wave-uniform addresses; the
+    compiler issued those reads as scalar loads, which are not ordered against the vector stores that followed, and
+    now and then a store of the new box overtook the read of the element it replaced (one float of one box wrong,
+    depending on timing, i.e. on the context).  Four contexts on the same inputs must all equal the oracle."""
+    from maputil import forest_leaves
+    from lsc_planner_amd.planner import next_state_host
+    leaves, res = forest_leaves()
+    world = (-5, -5, 0, 5, 5, 2.5)
+    dm = oracle.DistMap(leaves, res, world[:3], world[3:])
+    ms = L.random_swarm(10, world=world, seed=31, edt=dm.dist, edt_key_min=dm.key_min)
+    pls = []
+    for _ in range(4):
+        p = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True))
+        p.set_distmap(dm.dist, dm.key_min, res)
+        pls.append(p)
+    prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True, use_sfc=True)
+    sw = oracle.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+    sw.set_distmap(dm)
+    state, traj = _start(ms)
+    for tick in range(1, 13):
+        gs = [p.plan(state, ms.goal, traj) for p in pls]
+        o = sw.tick(state, ms.goal, traj, tick, nthreads=4)
+        for g in gs:
+            assert np.array_equal(g["sfc"], o["sfc"]), tick
+        traj = gs[0]["traj"]
+        state = next_state_host(traj)
+    for p in pls:
+        p.close()

@@ -145,3 +145,17 @@ def test_blocked_corridor_seed_stops_the_run_like_the_reference(tmp_path):
     rr = subprocess.run([SIM, "--mission", str(mp), "--world", str(bt), "--quiet", "--max-iter", "5"], capture_output=True, text=True, timeout=300)
     assert rr.returncode == 3, rr.stdout + rr.stderr
     assert "CorridorConstructor" in rr.stderr and "agent 2" in rr.stderr
+
+
+def test_simulator_in_bvc_mode_finishes_the_mission(ticks, tmp_path):
+    """lsc_sim --planner bvc: the alternate planner mode end to end through the C++ host (mode/planner = bvc of
+    src/param.cpp:40-45), file name and summary columns as the reference writes them."""
+    ms = golden_mission(ticks, "multi_simple4")
+    mp = tmp_path / "m.json"
+    _write_mission(str(mp), ms)
+    r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(tmp_path), "--quiet", "--planner", "bvc"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ratio = float(r.stdout.split("safety ratio between agent:")[1].split()[0])
+    assert ratio >= 1.0 - 1e-3
+    summ = list(csv.reader(open(tmp_path / "summary_BVC_4agents.csv")))
+    assert summ[1][16] == "BVC" and summ[1][17] == "current_position"
