@@ -692,6 +692,7 @@ static int run_goal(lsc_ctx *c, const float *d_state, const float *&d_goal, cons
     g.goal_out = c->d_goal_planned; g.err = c->d_goal_err; g.flags = c->d_goal_flags; g.expansions = c->d_goal_exp;
     g.path_out = c->d_goal_path; g.path_cap = c->goal_path_cap; g.path_len = c->d_goal_plen;
     g.ray_stack = c->d_ray_stack;
+    g.reset_thr = c->cfg.planner_mode == 0 ? c->cfg.reset_threshold : 0.0; g.ever = c->d_ever;
     HIPCHK(c, launch_goal(g, st));
     d_goal = c->d_goal_planned;
     return LSC_OK;

@@ -314,6 +314,21 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     const double dist_to_goal = dist_f32(pos, goal_i);
     const int cl = (M - 1) * NC + DEG, cf = DEG;
 
+    // disturbance reset (traj_planner.cpp:866-878, 1047-1061): an agent off its plan by more than reset_threshold, now or at
+    // any earlier tick (a.ever), is in everybody's slack set -- "higher priority" by decree (:548-551): stamped into the
+    // grid, but no candidate for the retreat rule
+    auto off_plan = [&](int q) {
+        if (!(a.reset_thr > 0.0) || a.planner_seq < 2) return false;
+        const float *t = a.traj_prev + (size_t)q * NV + NC;
+        const float *s = a.state + 9 * q;
+        const float dx = t[0] - s[0], dy = t[SEGV] - s[1], dz = t[2 * SEGV] - s[2];
+        const float n2 = dx * dx + dy * dy + dz * dz;
+        return sqrt((double)n2) > a.reset_thr;
+    };
+    const bool checks = a.reset_thr > 0.0 && a.ever != nullptr;
+    const bool own_now = checks && off_plan(qi);
+    const bool own_slack = checks && (own_now || a.ever[qi] != 0);
+    auto in_slack = [&](int qj) { return checks && (own_slack || a.ever[qj] != 0 || off_plan(qj)); };
     // whether obstacle qj has priority over this agent (traj_planner.cpp:547-577); dist_to_obs returned for the retreat rule
     auto has_priority = [&](int qj, double &dist_to_obs) {
         const float *opos = a.state + 9 * qj, *ogoal = a.goal + 3 * qj;
@@ -335,6 +350,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
         for (int qj = lane; qj < N; qj += 64) {
             if (qj == qi) continue;
             double d;
+            if (in_slack(qj)) continue;
             if (has_priority(qj, d) && d < best) { best = d; bq = qj; }
         }
         const double dmin = wave_min_d(best);
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             for (int qj = lane; qj < N; qj += 64) {          // updateGridMap, AGENT branch :163-189
                 if (qj == qi) continue;
                 double d;
-                if (!has_priority(qj, d)) continue;
+                if (!in_slack(qj) && !has_priority(qj, d)) continue;
                 const double r_o = a.radius_obs[qj], dw_o = a.downwash_obs[qj];
                 const double px = (double)a.state[9 * qj], py = (double)a.state[9 * qj + 1], pz = (double)a.state[9 * qj + 2];
                 const int oi = (int)round((px - a.gmin[0] + 1e-9) / a.gres), oj = (int)round((py - a.gmin[1] + 1e-9) / a.gres),
@@ -572,7 +588,9 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
 
     // ---- findLOSFreeGoal(initial_traj[M-1][n], desired goal) (:350-407): one path point per lane
     float cur[3];
-    if (a.planner_seq < 2) {
+    if (own_now) {
+        cur[0] = pos[0]; cur[1] = pos[1]; cur[2] = pos[2];      // initial trajectory reset to the current position
+    } else if (a.planner_seq < 2) {
         // initial trajectory = constant-velocity model, its end point is pos + vel * (M-1 + n/n) * dt in float32
         for (int k = 0; k < 3; k++) {
             const float tt = (float)((double)(M - 1) + (double)DEG / (double)DEG);

@@ -120,6 +120,8 @@ struct GoalArgs {
     int path_cap;
     int *path_len;                              // optional [count]
     float *ray_stack;                           // [count][64][24][6] bisection stacks of castRay
+    double reset_thr;                           // disturbance checks (multisim/reset_threshold; <= 0 off)
+    const unsigned char *ever;                  // [N] persistent "was seen off its plan" flags
 };
 size_t goal_smem_bytes(int H, int W, int A, int cap);
 hipError_t launch_goal(const GoalArgs &a, hipStream_t st);

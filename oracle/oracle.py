@@ -141,6 +141,8 @@ def lib():
         L.orc_goal_prior_based_ex.restype = None
         L.orc_goal_prior_based_ex.argtypes = [ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                               ctypes.c_double, ctypes.c_double, _ubp, ctypes.c_int, _fp]
+        L.orc_goal_map_set_slack.restype = None
+        L.orc_goal_map_set_slack.argtypes = [_ubp, ctypes.c_int]
         L.orc_tick_ex.restype = ctypes.c_int
         L.orc_tick_ex.argtypes = [pp, pm, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _fp, _ubp,
                                   ctypes.POINTER(OrcEdt), ctypes.c_double, _fp, _ip, _fp, _dp, _ip, _ip, _fp, _dp, ctypes.c_int]
@@ -458,7 +460,8 @@ def astar(occ, start, goal, max_len=100000):
 
 
 def goal_prior_based_map(prm, dm, state, desired_goal, prev_traj, planner_seq, radius, downwash, world_res=0.1, grid_res=0.3,
-                         grid_margin=0.2, goal_threshold=0.1, priority_dist_threshold=0.4, goal_radius=2.0, want_paths=False):
+                         grid_margin=0.2, goal_threshold=0.1, priority_dist_threshold=0.4, goal_radius=2.0, want_paths=False,
+                         slack_set=None, own_reset=None):
     """current_goal_position of every agent, mode/goal = prior_based WITH a distance field (grid A* + LOS goal).
     Returns goals [N][3] float32 (and, with want_paths, the list of grid paths and the flag words)."""
     state = np.ascontiguousarray(state, np.float32)
@@ -470,8 +473,14 @@ def goal_prior_based_map(prm, dm, state, desired_goal, prev_traj, planner_seq, r
     out = np.zeros((N, 3), np.float32)
     paths, flags = [], np.zeros(N, np.int32)
     buf = np.zeros((8192, 3), np.int32)
+    ubp = ctypes.POINTER(ctypes.c_ubyte)
     for qi in range(N):
         n, fl = ctypes.c_int(), ctypes.c_int()
+        if slack_set is not None:
+            row = np.ascontiguousarray(slack_set[qi], np.uint8)
+            lib().orc_goal_map_set_slack(row.ctypes.data_as(ubp), int(own_reset[qi]) if own_reset is not None else 0)
+        else:
+            lib().orc_goal_map_set_slack(None, 0)
         lib().orc_goal_prior_based_map(ctypes.byref(prm), ctypes.byref(dm.edt), world_res, grid_res, grid_margin, N, qi, _f(state),
                                        _f(dg), _f(pt), planner_seq, goal_threshold, priority_dist_threshold, goal_radius, _d(r),
                                        _d(dw), _f(out[qi]), _i(buf), len(buf), ctypes.byref(n), ctypes.byref(fl))
