@@ -11,7 +11,8 @@ next tick.  Everything stays resident in HBM during the timed region (no host ro
 Workload (config.workload): BASELINE.json configs[2], the 64-agent circle swap on the empty map
 (matlab/mission_generator.m geometry, R = 8 m, z = 1 m, testall_empty.launch parameters incl. mode/goal =
 prior_based: goalPlanningWithPriority runs on the device; on maps without a distance field the reference's grid A*
-has no observable effect on the planned goal).
+has no observable effect on the planned goal, see DESIGN.md -- and multisim/reset_threshold = 0.15: the disturbance checks
+of the reference run every tick, lsc_plan_alt_kernel + the hand-over launch of lsc_general_kernel).
 With --gpus G the swarm is 64*G agents on a circle of radius 8*G (same spacing), agent-sharded 64 per GPU with one
 in-place RCCL all-gather of the new trajectories per tick (native: lsc_tick_device_sharded enqueues plan kernel,
 ncclAllGather and state propagation on one stream): weak scaling.  `python bench.py --gpus G` starts the G ranks itself
@@ -102,6 +103,11 @@ def main():
     ap.add_argument("--no-latency-leg", action="store_true")
     ap.add_argument("--no-prune", action="store_true")
     ap.add_argument("--static-goal", action="store_true", help="mode/goal=static instead of the reference default prior_based")
+    ap.add_argument("--reset-threshold", type=float, default=0.15,
+                    help="multisim/reset_threshold of testall_empty.launch: the reference's disturbance checks run every tick "
+                         "(they never fire on this mission; the tick pays the scan and the hand-over launch, ~2.4 %%); 0 = off")
+    ap.add_argument("--planner", default="lsc", choices=["lsc", "bvc"], help="mode/planner (bvc: the general dense kernel)")
+    ap.add_argument("--slack", default="none", choices=["none", "dynamical_limit", "collision_constraint"])
     ap.add_argument("--unfused", action="store_true",
                     help="single GPU only: use the multi-GPU tick sequence (plan shard, exchange, propagate) instead of the fused launch")
     ap.add_argument("--sweep-agents", type=int, default=1024,
@@ -159,6 +165,7 @@ def main():
     ms = L.circle_swap(n_agents, circle_radius=R, z=1.0, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
     goal_mode = "static" if args.static_goal else "prior_based"
     pl = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode,
+                                            reset_threshold=args.reset_threshold, planner_mode=args.planner, slack_mode=args.slack,
                                             comm=(G, rank, token) if sharded else None))
     first, count, rows = pl.first, pl.count, pl.table_rows      # rank's block of the (padded) trajectory table
 
@@ -227,7 +234,8 @@ def main():
         value = n_agents * args.steps / elapsed
         flops = algorithmic_flops(n_agents, iters_total / G) / max(k_n, 1)   # per launch of this rank's kernel
         ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("lsc_plan_kernel@grid32768") if n_agents == 64 else (None, None)
+        kname = "lsc_plan_kernel" if (args.reset_threshold <= 0 and args.planner == "lsc" and args.slack == "none") else "lsc_plan_alt_kernel"
+        traffic, traffic_src = pmc_traffic(kname + "@grid32768") if n_agents == 64 else (None, None)
         result = {
             "metric": "agent-replans/sec (whole node)", "value": round(value, 1), "unit": "agent-replans/s",
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -241,11 +249,12 @@ def main():
                                    + ("plan kernel -> in-place RCCL all-gather of the new trajectories -> state propagation, "
                                       "one stream, per tick)" if sharded else
                                       "one fused launch per tick: goal planning + LSC + QP + state propagation)"),
-                       "agents": n_agents, "parallelism": f"agent-shard x{G}", "prune_redundant_rows": not args.no_prune},
+                       "agents": n_agents, "parallelism": f"agent-shard x{G}", "prune_redundant_rows": not args.no_prune,
+                       "planner_mode": args.planner, "slack_mode": args.slack, "reset_threshold": args.reset_threshold},
             "qp": {"mean_ip_iterations": round(iters_total / (n_agents * args.steps), 2), "failed_agents_last_tick": bad,
                    "active_lsc_rows_last_tick_mean": float(np.mean(lrows)), "active_lsc_rows_last_tick_max": int(np.max(lrows)),
                    "reference_rows_per_agent": 27 * (n_agents - 1)},
-            "roofline": {"kernel": "lsc_plan_kernel", "bound": "valu_fp64", "achieved": round(ach, 5),
+            "roofline": {"kernel": kname, "bound": "valu_fp64", "achieved": round(ach, 5),
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_VALU_PEAK_TFLOPS, 7),
                          "traffic": traffic,
                          "traffic_source": (f"not measured in this run: rocprofv3 --pmc passes of this command, {traffic_src}"

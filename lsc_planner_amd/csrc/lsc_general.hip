@@ -52,6 +52,8 @@ struct GS {
     double Cm[M][SEG_E];           // per segment: sum_g m_g m_g^T / D_g in x-space
     double cq[NCP * 3];            // x-space: sum_g m_g q_g / D_g
     double Z[SEGV][GNYA];
+    double tc[GNYA][4];            // column a of Z as a short list: the (at most four) control points y_a moves ...
+    int tt[GNYA][4], tn[GNYA];     // ... their indices t and the list length
     double Hc[GNYA * GNYA];
     double Qh[NC * NC];
     double s0[3][3], lo[3][M], hi[3][M], goal[3];
@@ -61,7 +63,7 @@ struct GS {
     float pinit[NV];
     float goalf[3];
     unsigned char avalid[AXROWS];
-    int tseg, ok;
+    int tseg, ok, any_slack;
 };
 
 __device__ __forceinline__ double wsum(double v)
@@ -206,6 +208,13 @@ __device__ void general_agent(const PlanArgs &a, const int al, unsigned char *sm
     for (int i = tid; i < SEGV * GNYA; i += GT) S.Z[i / GNYA][i % GNYA] = gm.Z[i / GNYA][i % GNYA];
     for (int i = tid; i < GNYA * GNYA; i += GT) S.Hc[i] = gm.Hc[i];
     if (tid < NC * NC) S.Qh[tid] = md.Qh[tid];
+    if (tid >= 64 && tid < 64 + GNYA) {
+        const int aa = tid - 64;
+        int n = 0;
+        for (int t = 3; t < SEGV && aa < nya; t++)
+            if (gm.Z[t][aa] != 0.0 && n < 4) { S.tt[aa][n] = t; S.tc[aa][n] = gm.Z[t][aa]; n++; }
+        S.tn[aa] = n;
+    }
     if (tid < 3) {
         const int k = tid;
         const float *s = a.state + 9 * qi;
@@ -296,6 +305,12 @@ __device__ void general_agent(const PlanArgs &a, const int al, unsigned char *sm
                 crhs[oi * NBK + cp - 3] = r;
             }
         }
+    }
+    if (tid == 0) {
+        int any = 0;
+        for (int oi = 0; oi < n_obs; oi++) any |= (a.slack_mode == 2 || (a.slack_mode == 0 && (ever_i || own_now || (a.ever && a.ever[oi < qi ? oi : oi + 1]) ||
+                                                                                              disturbed_now(a, oi < qi ? oi : oi + 1)))) ? 1 : 0;
+        S.any_slack = any;
     }
     if (tid <= PMAX) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
     for (int g = tid; g < NGR; g += GT) { ev[g] = 0.0; dev[g] = 0.0; }
@@ -468,7 +483,7 @@ __device__ void general_agent(const PlanArgs &a, const int al, unsigned char *sm
         __syncthreads();
         // elimination of the group slack variables: C_m = sum_g m_g m_g^T / D_g and c_q = sum_g m_g q_g / D_g in x-space,
         // m_g = -w_r n_g at the control points of segment m
-        if (with_w)
+        if (with_w && S.any_slack)
             for (int e = tid; e < M * SEG_E; e += GT) {
                 const int m = e / SEG_E;
                 int r = e % SEG_E, p = 0;
@@ -489,7 +504,7 @@ __device__ void general_agent(const PlanArgs &a, const int al, unsigned char *sm
         if (tid < NBK * 3) {
             const int cp = tid / 3 + 3, k = tid % 3, m = cp / NC;
             double acc = 0.0;
-            if (m < ncs)
+            if (m < ncs && S.any_slack)
                 for (int oi = 0; oi < n_obs; oi++) {
                     if (!slk[oi]) continue;
                     const int g = oi * M + m;
@@ -516,9 +531,9 @@ __device__ void general_agent(const PlanArgs &a, const int al, unsigned char *sm
                     const int k = r / nya, aa = r % nya, kk = c / nya, bb = c % nya;
                     const int sc6 = k == kk ? (k == 0 ? 0 : (k == 1 ? 3 : 5)) : ((k < kk ? k : kk) == 0 ? (k + kk) : 4);   // xx xy xz yy yz zz
                     if (k == kk) v = S.Hc[aa * GNYA + bb];
-                    for (int t = 3; t < SEGV; t++) {
-                        const double za = S.Z[t][aa];
-                        if (za == 0.0) continue;
+                    for (int pz = 0; pz < S.tn[aa]; pz++) {
+                        const int t = S.tt[aa][pz];
+                        const double za = S.tc[aa][pz];
                         const int m = t / NC, i = t % NC;
                         double row = S.Ws[t * 6 + sc6] * S.Z[t][bb];
                         if (k == kk) {
@@ -530,7 +545,7 @@ __device__ void general_agent(const PlanArgs &a, const int al, unsigned char *sm
                             if (i + 2 < NC) row += S.W2[k * SEGV + t] * S.Z[t + 2][bb];
                             if (i >= 2) row += S.W2[k * SEGV + t - 2] * S.Z[t - 2][bb];
                         }
-                        if (m < ncs)
+                        if (m < ncs && S.any_slack)
                             for (int i2 = 0; i2 < NC; i2++) {
                                 const double zb = S.Z[m * NC + i2][bb];
                                 if (zb != 0.0 && m * NC + i2 >= 3) row -= seg_c(m, i, k, i2, kk) * zb;
@@ -539,7 +554,7 @@ __device__ void general_agent(const PlanArgs &a, const int al, unsigned char *sm
                     }
                 } else if (r >= P0 && c < P0) {
                     const int j = r - P0, kk = c / nya, bb = c % nya;
-                    for (int t = 3; t < SEGV; t++) v += S.Z[t][bb] * S.Wu[j][kk * SEGV + t];
+                    for (int pz = 0; pz < S.tn[bb]; pz++) v += S.tc[bb][pz] * S.Wu[j][kk * SEGV + S.tt[bb][pz]];
                 } else if (r == c) {
                     v = S.Huu[r - P0];
                 }
@@ -548,9 +563,9 @@ __device__ void general_agent(const PlanArgs &a, const int al, unsigned char *sm
         if (tid < P0) {
             const int k = tid / nya, aa = tid % nya;
             double r = 0.0, rdv = 0.0;
-            for (int t = 3; t < SEGV; t++) {
-                const double za = S.Z[t][aa];
-                if (za == 0.0) continue;
+            for (int pz = 0; pz < S.tn[aa]; pz++) {
+                const int t = S.tt[aa][pz];
+                const double za = S.tc[aa][pz];
                 r += za * (S.gv[k * SEGV + t] + S.Tv[t * 3 + k] + S.cq[t * 3 + k]);
                 rdv += za * (S.gz[k * SEGV + t] + S.Tz[t * 3 + k]);
             }
