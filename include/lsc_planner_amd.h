@@ -77,7 +77,9 @@ typedef struct {
     int    max_iters;          /* interior-point iteration cap; 0 = 50                 */
     int    prune;              /* 1 (default via lsc_default_config): drop LSC rows that are provably redundant inside
                                   the box each control point can reach under the velocity AND acceleration rows;
-                                  2: the same with the velocity rows only; 0: keep all 27(N-1) rows */
+                                  2: the same with the velocity rows only; 0: keep all 27(N-1) rows;
+                                  3: like 1 without the spatial pre-cull of far obstacles that large swarms use
+                                  (identical rows and plans by construction; the switch exists for the test of that claim) */
     int    goal_mode;          /* mode/goal: 0 static (the goal input IS current_goal_position), 1 prior_based: the goal
                                   input is the desired goal and TrajPlanner::goalPlanningWithPriority runs on the
                                   device: fused into the plan kernel on maps without a distance field (where the grid

@@ -447,6 +447,8 @@ struct Smem {
     int cnt[32];                // rows per control-point bucket
     int offs[32];               // exclusive prefix of cnt over the 27 buckets
     int wcnt[NWAVE][32];
+    double cullB[M];            // phase B pre-cull: per segment max_i(|c_{0,2} - p_{m,i}| + reach radius of c_{m,i})
+    int cullc[NWAVE + 1];       // survivors of the pre-cull per wave (compaction)
     int tseg;                   // terminal segments
     int flag;                   // capacity overflow
     int gen;                    // alternate-mode QP: lsc_general_kernel solves this agent
@@ -879,9 +881,81 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             }
         }
         __syncthreads();
-        for (int base = 0; base < n_units; base += NT) {
-            const int u = base + tid;
-            const bool live = u < n_units;
+        // ---- spatial pre-cull (large swarms): most obstacles are so far away that every row against them is redundant,
+        // and that can be seen without the GJK.  With w_j = p~_j - q~_j (scaled space), centroid w_c, R_w = max |w_j - w_c|:
+        // the closest point v of conv{w_j} to the origin has |v| >= |w_c| - R_w and n~.w >= |v| on the hull (n~ = v/|v|).  A row
+        // asks  n~.(c~ - p~_i) + (1/2) n~.(p~_i - q~_i) >= (1/2)(r_a + r_o); every reachable c lies within rho_K of c_{0,2}, so
+        //   (1/2)(|w_c| - R_w) - s (|c_{0,2} - p_i| + rho_K) >= (1/2)(r_a + r_o) + margin,   s = max(1, 1/downwash)
+        // implies the exact per-row test below (whose box is inside that sphere) for all rows of the unit: the unit is
+        // dropped before the GJK and the surviving units -- the same rows in the same order as without the cull, hence
+        // bit-identical plans -- are compacted so that whole waves do not idle behind a few near obstacles.
+        const int prune_mode = md.prune == 3 ? 1 : md.prune;      // 3: exact test only (parity tests of the cull itself)
+        uint16_t *ulist = reinterpret_cast<uint16_t *>(rs);       // rs .. rt2 are first written by phase C
+        const bool cull = md.prune == 1 && !a.out_normal && n_units > NT && n_units <= 0xffff && n_units <= 16 * R;
+        int n_list = n_units;
+        if (cull) {
+            if (tid < M) {
+                const int m = tid;
+                double b = 0.0;
+                for (int i = 0; i < NC; i++) {
+                    const int K = 5 * m + i - 2;
+                    if (K < 1) continue;
+                    double d2 = 0.0, r2 = 0.0;
+                    for (int k = 0; k < 3; k++) {
+                        const double dd = S.s0[k][2] - (double)S.pinit[k * SEGV + m * NC + i];
+                        const double e = fmax(fabs(S.reachL[k][K]), fabs(S.reachU[k][K]));
+                        d2 += dd * dd; r2 += e * e;
+                    }
+                    b = fmax(b, sqrt(d2) + sqrt(r2));
+                }
+                S.cullB[m] = b;
+            }
+            __syncthreads();
+            int total = 0;
+            for (int base = 0; base < n_units; base += NT) {
+                const int u = base + tid;
+                bool keep = false;
+                if (u < n_units) {
+                    const int oi = u / M, m = u % M, qj = oi < qi ? oi : oi + 1;
+                    F3 po[6];
+                    load_segment(a.state, a.traj_prev, qj, m, a.planner_seq, dtf, po);
+                    const double r_o = a.radius_obs[qj];
+                    const double downwash = (dw_a * r_a + a.downwash_obs[qj] * r_o) / (r_a + r_o);
+                    const double idw = 1.0 / downwash, sc = fmax(1.0, idw);
+                    double wx[6], wy[6], wz[6], cx = 0.0, cy = 0.0, cz = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        const int c = m * NC + i;
+                        wx[i] = (double)S.pinit[c] - (double)po[i].x;
+                        wy[i] = (double)S.pinit[SEGV + c] - (double)po[i].y;
+                        wz[i] = ((double)S.pinit[2 * SEGV + c] - (double)po[i].z) * idw;
+                        cx += wx[i]; cy += wy[i]; cz += wz[i];
+                    }
+                    cx *= (1.0 / 6.0); cy *= (1.0 / 6.0); cz *= (1.0 / 6.0);
+                    double rw2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        const double ex = wx[i] - cx, ey = wy[i] - cy, ez = wz[i] - cz;
+                        rw2 = fmax(rw2, ex * ex + ey * ey + ez * ez);
+                    }
+                    const double need = 2.0 * sc * S.cullB[m] + (r_o + r_a) + 2e-4 + sqrt(rw2);
+                    keep = !(cx * cx + cy * cy + cz * cz >= need * need);
+                }
+                const unsigned long long mask = __ballot(keep);
+                if (lane == 0) S.cullc[wave] = __popcll(mask);
+                __syncthreads();
+                int off = total;
+                for (int w = 0; w < wave; w++) off += S.cullc[w];
+                if (keep) ulist[off + __popcll(mask & lt_mask)] = (uint16_t)u;
+                for (int w = 0; w < NWAVE; w++) total += S.cullc[w];
+                __syncthreads();
+            }
+            n_list = total;
+        }
+        for (int base = 0; base < n_list; base += NT) {
+            const int pos_u = base + tid;
+            const bool live = pos_u < n_list;
+            const int u = live ? (cull ? (int)ulist[pos_u] : pos_u) : 0;
             const int oi = live ? u / M : 0, m = live ? u % M : 0;
             const int qj = oi < qi ? oi : oi + 1;
             F3 nrm = F3{0.f, 0.f, 0.f};
@@ -919,11 +993,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     r += nz * (double)po[i].z;
                     rhs[i] = r;
                     bool on = !(m == 0 && i < 3);
-                    if (on && md.prune) {
+                    if (on && prune_mode) {
                         // smallest n.c over the reachable box of c_{m,i} (K = 5m+i-2 steps from c_{0,2})
                         const int K = 5 * m + i - 2;
                         double worst = centre + nx * rx[0][K] + ny * ry[1][K] + nz * rz[2][K];
-                        if (md.prune == 2) worst = centre - (double)K * (fabs(nx) * dlx + fabs(ny) * dly + fabs(nz) * dlz);   // velocity rows only
+                        if (prune_mode == 2) worst = centre - (double)K * (fabs(nx) * dlx + fabs(ny) * dly + fabs(nz) * dlz);   // velocity rows only
                         if (worst >= r + 1e-6) on = false;
                     }
                     actv[i] = on;

@@ -72,7 +72,7 @@ class SwarmPlanner:
         c.device = self.cfg.device
         c.max_rows_per_cp = self.cfg.max_rows_per_cp
         c.max_iters = self.cfg.max_iters
-        c.prune = int(self.cfg.prune)
+        c.prune = int(self.cfg.prune)           # bool or the ABI's 0..3
         c.warm_start_mu = float(self.cfg.warm_start_mu)
         c.goal_mode = {"static": 0, "prior_based": 1}[self.cfg.goal_mode]
         c.goal_threshold, c.priority_dist_threshold, c.goal_radius = (self.cfg.goal_threshold, self.cfg.priority_dist_threshold,

@@ -264,3 +264,23 @@ def test_corridor_history_shift_is_not_reordered(L, oracle):
         state = next_state_host(traj)
     for p in pls:
         p.close()
+
+
+@pytest.mark.parametrize("n", [160, 1024])
+def test_spatial_pre_cull_changes_nothing_but_the_time(L, n):
+    """Large swarms drop far obstacles before the GJK (a sphere bound that implies the exact per-row redundancy test) and
+    compact the survivors: same rows in the same order, hence bit-identical plans, costs, iteration counts and row counts
+    (prune = 3 is prune = 1 without the pre-cull)."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.random_swarm(n, seed=20260929) if n >= 512 else L.random_swarm(n, world=(-8, -8, 0, 8, 8, 2.5), seed=4)
+    a, b = L.SwarmPlanner(ms, L.PlannerConfig(prune=1)), L.SwarmPlanner(ms, L.PlannerConfig(prune=3))
+    state, traj = _start(ms)
+    for tick in range(1, 7):
+        ga, gb = a.plan(state, ms.goal, traj), b.plan(state, ms.goal, traj)
+        for k in ("traj", "cost", "status", "iters"):
+            assert np.array_equal(ga[k], gb[k]), (tick, k)
+        assert np.array_equal(a.row_counts(), b.row_counts()), tick
+        traj = ga["traj"]
+        state = next_state_host(traj)
+    assert 0 < a.row_counts().mean() < 27 * (n - 1) / 10
+    a.close(); b.close()
