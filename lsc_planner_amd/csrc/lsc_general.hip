@@ -144,7 +144,9 @@ __device__ __forceinline__ double ax_x(const double *x, int type, int k, int t)
 
 }  // namespace
 
-__device__ void general_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb)
+// (noinline: the kernel below must be able to leave before this function's frame -- it keeps part of its state in
+// scratch -- is set up; the common launch is the one that finds nobody flagged)
+__device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb)
 {
     GS &S = *reinterpret_cast<GS *>(smem_raw);
     const GModel &gm = *a.gmodel;
@@ -801,14 +803,11 @@ __device__ void general_agent(const PlanArgs &a, const int al, unsigned char *sm
     __syncthreads();
 }
 
-__global__ __launch_bounds__(GT) void lsc_general_kernel(PlanArgs a)
+// The agents of one workgroup, out of line: the argument block is copied into private memory HERE, not in the kernel's
+// prologue (see below).
+__device__ __attribute__((noinline)) void general_entry(const PlanArgs *ka, unsigned char *smem_raw)
 {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    {
-        bool work = false;
-        for (int al = blockIdx.x; al < a.count; al += gridDim.x) work |= a.status[a.first + al] == LSC_STATUS_GENERAL_K;
-        if (!work) return;
-    }
+    const PlanArgs a = *ka;
     unsigned char *ws = a.gen_ws + (size_t)blockIdx.x * a.gen_stride;
     for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
         if (a.status[a.first + al] != LSC_STATUS_GENERAL_K) continue;
@@ -816,6 +815,24 @@ __global__ __launch_bounds__(GT) void lsc_general_kernel(PlanArgs a)
         general_agent(a, al, smem_raw, ws);
         __syncthreads();
     }
+}
+
+// Most launches of this kernel find nobody flagged (it follows the plan kernel whenever the disturbance checks are on):
+// that case must cost a launch and nothing else.  The argument block is therefore read in place, through the kernarg
+// segment pointer -- naming the by-value parameter would make the compiler copy all of it into scratch in the prologue,
+// before the exit test.
+__global__ __launch_bounds__(GT) void lsc_general_kernel(PlanArgs)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+#if defined(__HIP_DEVICE_COMPILE__)
+    const PlanArgs *ka = (const PlanArgs *)__builtin_amdgcn_kernarg_segment_ptr();   // constant -> generic address space
+#else
+    const PlanArgs *ka = nullptr;                                                    // (host pass of the single-source build)
+#endif
+    bool work = false;
+    for (int al = blockIdx.x; al < ka->count; al += gridDim.x) work |= ka->status[ka->first + al] == LSC_STATUS_GENERAL_K;
+    if (!work) return;
+    general_entry(ka, smem_raw);
 }
 
 size_t general_ws_bytes(int N)
