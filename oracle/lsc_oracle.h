@@ -9,9 +9,11 @@
  *                     (oracle/_ref, tests/golden/gjk_vectors.npz)
  *   - QP assembly   : pinned against the reference fixture log/QPmodel.lp
  *                     (tests/golden/qpmodel_lp.json)
- *   - QP optimum    : CPLEX 20.1 is proprietary and absent -> PARITY UNPINNED for the
- *                     optimiser itself; the oracle certifies its optimum by KKT
- *                     residuals and is cross-checked against scipy in tests.
+ *   - QP optimum    : CPLEX 20.1 is proprietary and absent and no reference fixture holds an
+ *                     optimum; pinned instead to an independent solver, HiGHS (tests/highs_qp.py,
+ *                     tests/test_oracle_pins.py): the reference's log/QPmodel.lp read verbatim
+ *                     (infeasible), all golden-tick QPs and >1300 soak QPs to <= 1e-7 relative
+ *                     cost, every infeasible verdict certified by a phase-1 LP.
  *   - EDT / SFC     : octomap and dynamicEDT3D are external and absent -> PARITY UNPINNED at
  *                     the library level (file format and distance semantics restated from
  *                     their documentation); the box growth follows corridor_constructor.hpp
