@@ -112,6 +112,8 @@ typedef struct {
                                   obs_slack_indices -- every row against it carries a slack variable.  0 (default) = off:
                                   identical results as long as the caller's states follow the plans, and no extra launch on
                                   the device-resident ticks                                                                 */
+    double gap_tolerance;      /* interior point: duality gap <= gap_tolerance (1 + |objective|) at the optimum; 0 = 1e-9
+                                  (CPLEX's barrier default, CPX_PARAM_BAREPCOMP, is 1e-8)                                   */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);
@@ -242,6 +244,13 @@ int lsc_get_goal_trace(lsc_ctx *ctx, int *path_cells, int *path_len, int *flags,
 
 /* Active (non-redundant) LSC rows each agent's QP carried in the last tick, [N] (diagnostics). */
 int lsc_last_row_counts(lsc_ctx *ctx, int *rows);
+/* LSC rows one agent may carry in LDS before the second pass (rows in HBM) takes it over: *lds_rows for the 512-lane latency
+ * build (shards of at most one agent per CU), *throughput_rows for the 256-lane build that larger shards use (two workgroups
+ * per CU, half the LDS each; 0 = not available, e.g. when max_rows_per_cp was set explicitly). */
+int lsc_row_capacity(const lsc_ctx *ctx, int *lds_rows, int *throughput_rows);
+/* Rows of each agent's fullest control-point bucket in the last tick, [N]: what the first pass's LDS capacity
+ * (max_rows_per_cp) has to hold for the agent not to take the second pass (diagnostics). */
+int lsc_last_bucket_max(lsc_ctx *ctx, int *rows);
 
 /* Sum over agents of interior-point iterations since the last reset (bench flop accounting). Synchronises. */
 int lsc_iterations_total(lsc_ctx *ctx, long long *total, int reset);

@@ -154,6 +154,7 @@ void build_model(const lsc_config &cfg, HostModel &H)
     m.prune = cfg.prune;
     m.max_iters = cfg.max_iters > 0 ? cfg.max_iters : 50;
     m.dx_tol = 2e-8;
+    m.gap_tol = cfg.gap_tolerance > 0.0 ? cfg.gap_tolerance : 1e-9;
     m.ws_mu0 = cfg.warm_start_mu >= 0.0 ? cfg.warm_start_mu : 0.05;
     int n = 0;
     for (int sl = 0; sl < AXROWS; sl++) {
@@ -198,7 +199,8 @@ void build_gmodel(const lsc_config &cfg, const Model &m, GModel &g)
 struct lsc_ctx {
     lsc_config cfg;
     HostModel hm;
-    int N = 0, first = 0, count = 0, cap = 0;
+    int N = 0, first = 0, count = 0, cap = 0, cap_tp = 0, n_cu = 256;
+    size_t smem_tp = 0;
     std::string err;
     bool timing = false;
     // device
@@ -231,7 +233,7 @@ struct lsc_ctx {
     int grid_dims[3] = {0, 0, 0}, grid_row_cap = 0;
     double grid_min[3] = {0, 0, 0};
     std::vector<int> nb_seq;
-    int *d_nrows = nullptr;
+    int *d_nrows = nullptr, *d_bmax = nullptr;
     long long *d_iters_acc = nullptr;
     long long *d_prof = nullptr;
     double *d_dbg = nullptr;
@@ -347,6 +349,7 @@ void lsc_default_config(lsc_config *cfg)
     cfg->horizon = 1.0; cfg->goal_row_cap = 0;
     cfg->planner_mode = 0; cfg->slack_mode = 0; cfg->slack_collision_weight = 100000.0; cfg->n_constraint_segments = -1;
     cfg->reset_threshold = 0.0;
+    cfg->gap_tolerance = 1e-9;
 }
 
 lsc_ctx *lsc_create(const lsc_config *cfg)
@@ -376,6 +379,10 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
     }
     lsc_ctx *c = new lsc_ctx();
     c->cfg = *cfg;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    }
     build_model(*cfg, c->hm);
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
     ok = ok && hipMalloc(&c->d_terms, sizeof(uint32_t) * (c->hm.terms.size() + 2)) == hipSuccess;
@@ -397,10 +404,10 @@ static void free_agents(lsc_ctx *c)
 {
     void *ptrs[] = {c->d_radius, c->d_radius_obs, c->d_downwash, c->d_downwash_obs, c->d_vmax, c->d_amax, c->d_vnom,
                     c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_cost,
-                    c->d_onormal, c->d_od, c->d_spill, c->d_ever, c->d_gen_ws};
+                    c->d_onormal, c->d_od, c->d_spill, c->d_ever, c->d_gen_ws, c->d_bmax};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->d_spill = nullptr; c->spill_slots = 0; c->spill_stride = 0;
-    c->d_ever = nullptr; c->d_gen_ws = nullptr; c->gen_slots = 0; c->gen_stride = 0;
+    c->d_bmax = nullptr; c->d_ever = nullptr; c->d_gen_ws = nullptr; c->gen_slots = 0; c->gen_stride = 0;
     if (c->h_in) { (void)hipHostFree(c->h_in); c->h_in = nullptr; }
     if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
     void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
@@ -446,13 +453,26 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     c->first = std::min(c->rank * c->shard_rows, N);
     c->count = std::min(c->shard_rows, N - c->first);
     const size_t Np = (size_t)c->table_rows;
-    int cap = c->cfg.max_rows_per_cp > 0 ? c->cfg.max_rows_per_cp : 64;
-    if (cap > N - 1) cap = N - 1;
-    if (cap < 1) cap = 1;
-    // keep the kernel's LDS request under the 160 KiB a workgroup may own
-    while (cap > 1 && plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, cap) > 160 * 1024) cap--;
+    // Row capacity of the LDS pass: 27 x max_rows_per_cp rows in total (rows are stored compactly, so a control point may
+    // hold more than its share), at most what the 160 KiB of a workgroup allow; never more than the 27 (N-1) that exist.
+    int per_cp = c->cfg.max_rows_per_cp > 0 ? c->cfg.max_rows_per_cp : 64;
+    if (per_cp > N - 1) per_cp = N - 1;
+    if (per_cp < 1) per_cp = 1;
+    int cap = 27 * per_cp;
+    while (cap > 27 && plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, cap) > 160 * 1024) cap -= 27;
     c->cap = cap;
     c->hm.m.cap = cap;
+    // Throughput build (256 lanes, two workgroups per CU): used when the shard has more agents than the GPU has CUs; its
+    // capacity is what fits half a CU's LDS.  (Pointless -- and slower per agent -- for a shard that fits the chip.)
+    c->cap_tp = 0; c->smem_tp = 0;
+    if (c->cfg.max_rows_per_cp == 0) {
+        int ct = 27;
+        while (plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, ct + 27, false) <= 80 * 1024 - 512) ct += 27;
+        if (ct < cap && plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, ct, false) <= 80 * 1024 - 512) {
+            c->cap_tp = ct;
+            c->smem_tp = plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, ct, false);
+        }
+    }
     HIPCHK(c, hipMemcpy(c->d_model, &c->hm.m, sizeof(Model), hipMemcpyHostToDevice));
     std::vector<double> r_obs(N), dw_obs(N);
     for (int i = 0; i < N; i++) { r_obs[i] = (double)(float)radius[i]; dw_obs[i] = (double)(float)downwash[i]; }
@@ -482,7 +502,7 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         HIPCHK(c, hipMemcpy(c->d_sfc_init, ones.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice));
     }
     c->h_radius.assign(radius, radius + N);
-    if (cap < N - 1) {
+    if (cap < 27 * (N - 1)) {
         // An agent can carry more rows than the LDS capacity holds: those agents are re-planned by a second pass with
         // their rows in HBM (the reference never drops a row, src/traj_optimizer.cpp:437-466).  One workspace per
         // persistent workgroup; 256 = one per CU.
@@ -504,6 +524,8 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         }
     }
     HIPCHK(c, hipMalloc(&c->d_nrows, sizeof(int) * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_bmax, sizeof(int) * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_bmax, 0, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * PROF_PHASES * (size_t)N));
@@ -728,10 +750,11 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     if (c->N == 0) return LSC_ESTATE;
     a.model = c->d_model; a.terms = c->d_terms; a.entries = c->d_entries;
     a.N = c->N; a.first = c->first; a.count = c->count; a.planner_seq = seq; a.cap = c->cap;
+    a.cap_tp = (c->count > c->n_cu) ? c->cap_tp : 0; a.smem_tp = c->smem_tp;
     a.state = d_state; a.goal = d_goal; a.traj_prev = d_prev;
     a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
     a.vmax = c->d_vmax; a.amax = c->d_amax; a.vnom = c->d_vnom;
-    a.traj_next = d_next; a.cost = d_cost; a.status = d_status; a.iters = d_iters; a.nrows = c->d_nrows; a.iters_acc = c->d_iters_acc;
+    a.traj_next = d_next; a.cost = d_cost; a.status = d_status; a.iters = d_iters; a.nrows = c->d_nrows; a.bucket_max = c->d_bmax; a.iters_acc = c->d_iters_acc;
     a.stale = c->d_stale; a.sfc = c->cfg.use_octomap ? c->d_sfc : nullptr;
     a.sfc_err = c->cfg.use_octomap ? c->d_sfc_err : nullptr;
     const bool planned = c->cfg.goal_mode == 1 && c->cfg.use_octomap;   // goals come from lsc_goal_kernel
@@ -1161,6 +1184,24 @@ int lsc_last_goals(lsc_ctx *c, float *goals)
     if (!c || !goals || c->N == 0) return LSC_EINVAL;
     HIPCHK(c, hipDeviceSynchronize());
     HIPCHK(c, hipMemcpy(goals, c->d_goal_cur, sizeof(float) * 3 * (size_t)c->N, hipMemcpyDeviceToHost));
+    return LSC_OK;
+}
+
+// LSC rows an agent may carry before it is handed to the pass with its rows in HBM: latency build (512 lanes, shards that fit
+// the chip) and throughput build (256 lanes, two workgroups per CU; 0 when that build is not available for this context)
+int lsc_row_capacity(const lsc_ctx *c, int *lds_rows, int *throughput_rows)
+{
+    if (!c || c->N == 0) return LSC_EINVAL;
+    if (lds_rows) *lds_rows = c->cap;
+    if (throughput_rows) *throughput_rows = c->cap_tp;
+    return LSC_OK;
+}
+
+// rows of the fullest control-point bucket of every agent in the last tick (what the LDS row capacity has to hold)
+int lsc_last_bucket_max(lsc_ctx *c, int *rows /*[N]*/)
+{
+    if (!c || !rows || c->N == 0) return LSC_EINVAL;
+    HIPCHK(c, hipMemcpy(rows, c->d_bmax, sizeof(int) * (size_t)c->N, hipMemcpyDeviceToHost));
     return LSC_OK;
 }
 

@@ -19,7 +19,10 @@ struct PlanArgs {
     const Model *model;
     const uint32_t *terms;     // packed Hessian assembly terms
     const uint32_t *entries;   // [n_entries+1][2] : (gi<<16|gj, first term)
-    int N, first, count, planner_seq, cap;
+    int N, first, count, planner_seq;
+    int cap;                   // LSC rows the LDS pass holds (total over the 27 control points; compact layout)
+    int cap_tp;                // > 0: use the 256-lane throughput build with this row capacity and smem_tp bytes of LDS
+    size_t smem_tp;
     const float *state;        // [N][9]
     const float *goal;         // [N][3] current goal (mode/goal static) or desired goal (prior_based)
     int goal_mode;             // 0 static, 1 prior_based: goalPlanningWithPriority runs in phase A of the plan kernel
@@ -34,6 +37,7 @@ struct PlanArgs {
     float *traj_next;          // [N][90]
     double *cost;              // [N]
     int *status, *iters, *nrows;
+    int *bucket_max;           // optional [N]: rows of the fullest control-point bucket (diagnostics)
     long long *iters_acc;      // [N] running sum of interior-point iterations (bench accounting), may be null
     float *stale;              // [N][90] optimiser's last good trajectory (persistent)
     const float *sfc;          // [N][M][6] or null
@@ -129,7 +133,7 @@ hipError_t launch_goal(const GoalArgs &a, hipStream_t st);
 size_t general_ws_bytes(int N);
 hipError_t init_device_general_kernel();
 hipError_t launch_general(const PlanArgs &a, int slots, hipStream_t st);
-size_t plan_smem_bytes(int n_terms, int n_entries, int cap);
+size_t plan_smem_bytes(int n_terms, int n_entries, int rows, bool tables_in_lds = true);
 size_t plan_spill_bytes(int N);
 hipError_t init_device_kernels();
 hipError_t init_device_goal_kernel();

@@ -409,7 +409,10 @@ __global__ __launch_bounds__(64) void lsc_sfc_kernel(SfcArgs a)
 constexpr int NB = 27;        // control points that carry LSC rows: all but (m=0, i<3)
 constexpr int AXVALID = 414;  // 162 bound + 138 velocity + 114 acceleration rows (src/traj_optimizer.cpp:274-303, 468-525)
 
-struct Smem {
+// SMALL = the throughput build's variant: what can be recomputed or read from L2 (right-hand sides of the axis rows, the
+// constant part of the Hessian entries, the assembly tables) is not kept, the LDS goes to row capacity instead
+template <bool SMALL>
+struct SmemT {
     // PDIP vectors
     double x[96], dx[96];       // control points (axis-major, 90 used) and their step
     double gx[96];              // x-space gradient: cost + sum a_r v_r
@@ -427,7 +430,8 @@ struct Smem {
     double sc[8];               // broadcast scalars
     double gap0;                // complementarity gap at the first iteration of the current start (divergence test)
     // axis rows: slot = type*90 + k*30 + t ; type 0 x<=hi, 1 -x<=-lo, 2/3 +-velocity, 4/5 +-acceleration
-    double as_[AXROWS], az[AXROWS], at1[AXROWS], at2[AXROWS], ah[AXROWS];
+    double as_[AXROWS], az[AXROWS], at1[AXROWS], at2[AXROWS], ah[SMALL ? 2 : AXROWS];
+    double vlim[3], alim[3];    // right-hand sides of the velocity / acceleration rows (SMALL: ah is computed from these)
     unsigned short amap[AXVALID + 2];   // valid slots, compact
     // solver constants addressed per lane (LDS tables instead of ~40 long-lived registers per lane, which the
     // register allocator would otherwise park in scratch for the whole kernel)
@@ -449,6 +453,8 @@ struct Smem {
     int wcnt[NWAVE][32];
     double cullB[M];            // phase B pre-cull: per segment max_i(|c_{0,2} - p_{m,i}| + reach radius of c_{m,i})
     int cullc[NWAVE + 1];       // survivors of the pre-cull per wave (compaction)
+    int ntmp;                   // rows appended in phase B (arrival order), listfull: the pre-cull list overflowed
+    int listfull;
     int tseg;                   // terminal segments
     int flag;                   // capacity overflow
     int gen;                    // alternate-mode QP: lsc_general_kernel solves this agent
@@ -457,6 +463,7 @@ struct Smem {
     float goalf[3];             // current goal (float32, as agent.current_goal_position)
     alignas(8) uint32_t dyn[2]; // dynamic part starts here: terms, entry table, kconst, LSC rows, row map
 };
+using Smem = SmemT<false>;
 
 __device__ __forceinline__ double ax_row(const double *x, int type, int k, int t)
 {
@@ -610,9 +617,13 @@ enum { PH_SETUP = 0, PH_LSC, PH_INIT, PH_P1, PH_REDUCE, PH_ASSEMBLE, PH_FACTOR, 
 //                   reference adds (src/traj_optimizer.cpp:437-466) -- same code, same arithmetic, no capacity limit
 //   ALT = true    : the build with the alternate-mode hooks (disturbance checks, hand-over to lsc_general_kernel); kept
 //                   out of the default instantiation so that the fast path's register allocation is untouched by them
-template <bool PROF, bool SPILL, bool ALT = false>
+//   NTT           : lanes of the workgroup -- 512 (8 waves, one workgroup per CU: the latency build) or 256 (4 waves, two
+//                   workgroups per CU when the LDS request allows it: the throughput build for swarms larger than the chip)
+template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512>
 __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *ws)
 {
+    constexpr int NT = NTT;             // shadow the namespace-level constants (those size the LDS arrays: maxima)
+    constexpr int NWAVE = NTT / 64;
     // cmap entry = row slot | control point << CMAP_SHIFT (HBM variant: 24 bits of slot, 27 (N-1) slots fit for any N)
     constexpr int CMAP_SHIFT = SPILL ? 24 : 16;
     constexpr uint32_t CMAP_MASK = (1u << CMAP_SHIFT) - 1u;
@@ -630,19 +641,33 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             t_last = now;
         }
     };
-    Smem &S = *reinterpret_cast<Smem *>(smem_raw);
+    constexpr bool TABLES_IN_LDS = NTT != 256;
+    SmemT<!TABLES_IN_LDS> &S = *reinterpret_cast<SmemT<!TABLES_IN_LDS> *>(smem_raw);
     const Model &md = *a.model;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = a.first + al;
-    const int N = a.N, n_obs = N - 1, CAP = SPILL ? (n_obs > 1 ? n_obs : 1) : a.cap;
-    const int CS = (CAP & 1) ? CAP : CAP + 1;   // odd bucket stride: spreads the buckets over LDS banks
-    const int R = NB * CS;
+    const int N = a.N, n_obs = N - 1;
+    // Row capacity of this pass.  Rows are stored COMPACTLY, sorted by control point (bucket b occupies
+    // [offs[b], offs[b] + cnt[b])), so the capacity is a total, not a per-bucket limit: LDS pass a.cap rows, HBM pass all
+    // 27 (N-1) rows the reference can add.
+    const int R = SPILL ? NB * (n_obs > 1 ? n_obs : 1) : a.cap;
     const int n_terms = md.n_terms, n_entries = md.n_entries;
 
-    // dynamic LDS carve-up
-    uint32_t *terms = S.dyn;                                        // [n_terms]
-    uint32_t *ent = terms + ((n_terms + 1) & ~1);                   // [n_entries+1][2] : (gi<<16|gj), first term
-    double *kconst = reinterpret_cast<double *>(ent + 2 * n_entries + 2);
+    // dynamic LDS carve-up.  The throughput build leaves the (agent-independent, 9 KB) assembly tables in HBM/L2 -- its two
+    // workgroups per CU hide that latency -- and spends the LDS on row capacity instead.
+    const uint32_t *terms, *ent;
+    double *kconst;
+    if constexpr (TABLES_IN_LDS) {
+        uint32_t *lt = S.dyn;                                       // [n_terms]
+        uint32_t *le = lt + ((n_terms + 1) & ~1);                   // [n_entries+1][2] : (gi<<16|gj), first term
+        for (int i = tid; i < n_terms; i += NT) lt[i] = a.terms[i];
+        for (int i = tid; i < 2 * n_entries + 2; i += NT) le[i] = a.entries[i];
+        terms = lt; ent = le;
+        kconst = reinterpret_cast<double *>(le + 2 * n_entries + 2);
+    } else {
+        terms = a.terms; ent = a.entries;
+        kconst = reinterpret_cast<double *>(S.dyn) - n_entries;     // not stored: recomputed in assemble(); rows start at S.dyn
+    }
     double *rowbase;
     if constexpr (SPILL) rowbase = reinterpret_cast<double *>(ws);
     else rowbase = kconst + n_entries;
@@ -652,15 +677,16 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     double *__restrict__ rt1 = rz + R;
     double *__restrict__ rt2 = rt1 + R;
     float *__restrict__ rn = reinterpret_cast<float *>(rt2 + R);     // [3][R]
-    uint32_t *__restrict__ cmap = reinterpret_cast<uint32_t *>(rn + 3 * R);  // compact row map: slot | cp << CMAP_SHIFT
-    unsigned char *rcp = reinterpret_cast<unsigned char *>(cmap + R);        // control point of a slot, 255 = empty
+    uint32_t *__restrict__ cmap = reinterpret_cast<uint32_t *>(rn + 3 * R);  // row map: slot | cp << CMAP_SHIFT
+    // phase B scratch, aliased onto arrays that are first written later: rows in arrival order (rs .. rt2, 32 B per row,
+    // written by phase C's start) and the pre-cull's unit list (rrhs .. cmap, written by the scatter that ends phase B)
+    struct TmpRow { double rhs; float nx, ny, nz; uint32_t cp_pos; };
+    static_assert(sizeof(TmpRow) <= 4 * sizeof(double), "a temporary row fits the (rs, rz, rt1, rt2) slot of a row");
+    TmpRow *tmp_rows = reinterpret_cast<TmpRow *>(rs);
 
     // ------------------------------------------------------------------ phase A: agent constants
-    for (int i = tid; i < n_terms; i += NT) terms[i] = a.terms[i];
-    for (int i = tid; i < 2 * n_entries + 2; i += NT) ent[i] = a.entries[i];
-    for (int i = tid; i < R; i += NT) rcp[i] = 255;
     if (tid < 32) S.cnt[tid] = 0;
-    if (tid == 0) S.flag = 0;
+    if (tid == 0) { S.flag = 0; S.ntmp = 0; }
     const float dtf = (float)md.dt;
     if (tid < NV) {
 #pragma clang fp contract(off)
@@ -837,8 +863,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     __syncthreads();
     const bool xterm = (tid < NV) && (xt % NC == DEG) && (xt / NC >= M - S.tseg);
     // constant part of every Hessian entry: cost Hessian (same axis) + terminal weight on c_{m,5}
-    for (int e = tid; e < n_entries; e += NT) {
-        const uint32_t id = ent[2 * e];
+    auto kconst_of = [&](uint32_t id) -> double {
         const int gi = id >> 16, gj = id & 0xffff;
         const int ki = gi < 36 ? (gi % 9) / 3 : gi - 36, kj = gj < 36 ? (gj % 9) / 3 : gj - 36;
         const int va = gi < 36 ? (gi / 9) * 3 + (gi % 3) : 12, vb = gj < 36 ? (gj / 9) * 3 + (gj % 3) : 12;
@@ -850,8 +875,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 if (mterm >= M - S.tseg) v += 2.0 * md.w_t;
             }
         }
-        kconst[e] = v;
-    }
+        return v;
+    };
+    if constexpr (TABLES_IN_LDS)
+        for (int e = tid; e < n_entries; e += NT) kconst[e] = kconst_of(ent[2 * e]);
     stamp(PH_SETUP);
 
     // ------------------------------------------------------------------ phase B: LSC rows
@@ -890,10 +917,12 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         // dropped before the GJK and the surviving units -- the same rows in the same order as without the cull, hence
         // bit-identical plans -- are compacted so that whole waves do not idle behind a few near obstacles.
         const int prune_mode = md.prune == 3 ? 1 : md.prune;      // 3: exact test only (parity tests of the cull itself)
-        uint16_t *ulist = reinterpret_cast<uint16_t *>(rs);       // rs .. rt2 are first written by phase C
-        const bool cull = md.prune == 1 && !a.out_normal && n_units > NT && n_units <= 0xffff && n_units <= 16 * R;
+        uint16_t *ulist = reinterpret_cast<uint16_t *>(rrhs);     // rrhs, rn, cmap (24 B per row) are first written by the scatter
+        const int list_cap = SPILL ? 0x7fffffff : 4 * R + 6 * R + 2 * R;
+        bool cull = md.prune == 1 && !a.out_normal && n_units > NT && n_units <= 0xffff;
         int n_list = n_units;
         if (cull) {
+            if (tid == 0) S.listfull = 0;
             if (tid < M) {
                 const int m = tid;
                 double b = 0.0;
@@ -946,11 +975,16 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 __syncthreads();
                 int off = total;
                 for (int w = 0; w < wave; w++) off += S.cullc[w];
-                if (keep) ulist[off + __popcll(mask & lt_mask)] = (uint16_t)u;
+                if (keep) {
+                    const int at = off + __popcll(mask & lt_mask);
+                    if (at < list_cap) ulist[at] = (uint16_t)u;
+                    else S.listfull = 1;
+                }
                 for (int w = 0; w < NWAVE; w++) total += S.cullc[w];
                 __syncthreads();
             }
-            n_list = total;
+            if (S.listfull) cull = false;          // more survivors than the list holds: every unit takes the GJK
+            else n_list = total;
         }
         for (int base = 0; base < n_list; base += NT) {
             const int pos_u = base + tid;
@@ -1022,16 +1056,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int i = 0; i < 6; i++) {
                     if (!actv[i]) continue;
                     const int cp = m * NC + i;
-                    int pos = S.cnt[cp] + rank[i];
+                    int pos = S.cnt[cp] + rank[i];          // position inside the bucket: obstacle order, deterministic
                     for (int w = 0; w < wave; w++) pos += S.wcnt[w][cp];
-                    if (pos < CAP) {
-                        const int r = (cp - 3) * CS + pos;
-                        rn[r] = nrm.x; rn[R + r] = nrm.y; rn[2 * R + r] = nrm.z;
-                        rrhs[r] = rhs[i];
-                        rcp[r] = (unsigned char)cp;
-                    } else {
-                        S.flag = 1;
-                    }
+                    const int k = atomicAdd(&S.ntmp, 1);    // arrival slot: order irrelevant, (cp, pos) decides the final place
+                    if (k < R) tmp_rows[k] = TmpRow{rhs[i], nrm.x, nrm.y, nrm.z, (uint32_t)cp | ((uint32_t)pos << 8)};
                 }
             }
             __syncthreads();
@@ -1043,20 +1071,28 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             __syncthreads();
         }
     }
-    if (tid < NCP && S.cnt[tid] > CAP) S.cnt[tid] = CAP;
-    __syncthreads();
     if (tid == 0) {
-        int o = 0;
-        for (int b = 0; b < NB; b++) { S.offs[b] = o; o += S.cnt[b + 3]; }
+        int o = 0, mx = 0;
+        for (int b = 0; b < NB; b++) { S.offs[b] = o; o += S.cnt[b + 3]; mx = S.cnt[b + 3] > mx ? S.cnt[b + 3] : mx; }
+        if (a.bucket_max) a.bucket_max[qi] = mx;     // diagnostics: the fullest control-point bucket
+        if (o > R) {                                 // more rows than this pass holds: left to the pass with the rows in HBM
+            S.flag = 1;
+            o = 0;
+            for (int b = 0; b < 32; b++) S.cnt[b] = 0;
+        }
         S.nact = o;
     }
     __syncthreads();
-    for (int r = tid; r < R; r += NT) {
-        const int cp = rcp[r];
-        if (cp == 255) continue;
-        const int b = cp - 3;
-        cmap[S.offs[b] + (r - b * CS)] = (uint32_t)r | ((uint32_t)cp << CMAP_SHIFT);
+    // scatter from arrival order to the compact, bucket-sorted layout
+    for (int k = tid; k < S.nact; k += NT) {
+        const TmpRow t = tmp_rows[k];
+        const int cp = (int)(t.cp_pos & 0xffu), pos = (int)(t.cp_pos >> 8);
+        const int r = S.offs[cp - 3] + pos;
+        rn[r] = t.nx; rn[R + r] = t.ny; rn[2 * R + r] = t.nz;
+        rrhs[r] = t.rhs;
+        cmap[r] = (uint32_t)r | ((uint32_t)cp << CMAP_SHIFT);
     }
+    __syncthreads();
     stamp(PH_LSC);
 
     // ------------------------------------------------------------------ phase C: interior point
@@ -1068,9 +1104,18 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         else if (type < 4) { valid = i <= 4 && !(m == 0 && i < 2); h = a.vmax[3 * qi + k] * md.hv_scale; }
         else { valid = i <= 3 && !(m == 0 && i == 0); h = a.amax[3 * qi + k] * md.ha_scale; }
         S.avalid[sl] = valid ? 1 : 0;
-        S.ah[sl] = h;
+        if constexpr (TABLES_IN_LDS) S.ah[sl] = h;
         S.as_[sl] = 1.0; S.az[sl] = 0.0; S.at1[sl] = 0.0; S.at2[sl] = 0.0;
     }
+    if (tid < 3) { S.vlim[tid] = a.vmax[3 * qi + tid] * md.hv_scale; S.alim[tid] = a.amax[3 * qi + tid] * md.ha_scale; }
+    // right-hand side of axis row sl
+    auto AH = [&](int sl) -> double {
+        if constexpr (TABLES_IN_LDS) return S.ah[sl];
+        else {
+            const int type = sl / NV, kt = sl % NV, k = kt / SEGV, m = (kt % SEGV) / NC;
+            return type == 0 ? S.hi[k][m] : (type == 1 ? -S.lo[k][m] : (type < 4 ? S.vlim[k] : S.alim[k]));
+        }
+    };
     if (tid < 40) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
     for (int i = tid; i < NY * KLD; i += NT) S.K[i] = 0.0;
     for (int i = tid; i < NCP * 3; i += NT) { S.Tv[i] = 0.0; S.Tz[i] = 0.0; }
@@ -1170,12 +1215,12 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         // LSC buckets: unit (bucket, c): c 0..5 -> sum w n n^T, 6..8 -> -sum v n and -sum z n  (row vector a_r = -n).
         // Two lanes per unit take the even / odd rows of the bucket and combine through a lane-pair shuffle.
         const int nunits = with_w ? NB * 9 : NB * 3;
-        {
-            const int u = tid >> 1, half = tid & 1;
+        for (int ub = 0; ub < 2 * nunits; ub += NT) {      // one trip with 512 lanes, two with 256
+            const int u = (ub + tid) >> 1, half = tid & 1;
             const bool live = u < nunits;
             const int bkt = live ? (with_w ? u / 9 : u / 3) : 0, c = live ? (with_w ? u % 9 : 6 + u % 3) : 6, cp = bkt + 3;
             const int cnt = live ? S.cnt[cp] : 0;
-            const int r0 = bkt * CS;
+            const int r0 = S.offs[bkt];
             double acc0 = 0.0, acc1 = 0.0, az0 = 0.0, az1 = 0.0;
             if (c < 6) {
                 const int ia = c < 3 ? 0 : (c < 5 ? 1 : 2), ib = c < 3 ? c : (c < 5 ? c - 2 : 2);
@@ -1218,7 +1263,9 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         if (with_k) {
             for (int e = tid; e < n_entries; e += NT) {
                 const uint32_t id = ent[2 * e], t0 = ent[2 * e + 1], t1 = ent[2 * e + 3];
-                double v = kconst[e];
+                double v;
+                if constexpr (TABLES_IN_LDS) v = kconst[e];
+                else v = kconst_of(id);
                 for (uint32_t q = t0; q < t1; q++) {
                     const uint32_t tm = terms[q];
                     v += (double)((int)(tm & 0xff) - 128) * S.W[(tm >> 8) & 0x3ff];
@@ -1395,7 +1442,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         __syncthreads();
         for (int c = tid; c < AXVALID; c += NT) {
             const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
-            S.at2[sl] = ax_row(S.x, type, kt / SEGV, kt % SEGV) - S.ah[sl];
+            S.at2[sl] = ax_row(S.x, type, kt / SEGV, kt % SEGV) - AH(sl);
         }
         for (int c = tid; c < nact; c += NT) {
             const uint32_t e = cmap[c];
@@ -1419,7 +1466,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             // velocity / acceleration rows are stored divided by n/dt and n(n-1)/dt^2: scale the floor with them so that
             // the start equals the one of the reference's row scaling
             const double floor_s = type < 2 ? smin : (type < 4 ? smin * md.hv_scale : smin * md.ha_scale);
-            const double sv = fmax(S.ah[sl] - ax_row(S.x, type, kt / SEGV, kt % SEGV), floor_s);
+            const double sv = fmax(AH(sl) - ax_row(S.x, type, kt / SEGV, kt % SEGV), floor_s);
             S.as_[sl] = sv; S.az[sl] = mu0 / sv; S.at1[sl] = 0.0; S.at2[sl] = 0.0;
         }
         for (int c = tid; c < nact; c += NT) {
@@ -1464,7 +1511,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int c = tid; c < AXVALID; c += NT) {
                     const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
                     double sv = S.as_[sl] + alpha * S.at1[sl], zv = S.az[sl] + alpha * S.at2[sl];
-                    double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - S.ah[sl];
+                    double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - AH(sl);
                     double is = 1.0 / sv;
                     S.as_[sl] = sv; S.az[sl] = zv;
                     S.at1[sl] = is;
@@ -1491,7 +1538,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 block_reduce(gp, rpm, objp, 0.0, 0.0, 0, 1, 0, 0, 0);
                 gap = S.sc[0]; rpmax = S.sc[1]; obj = S.sc[2];
                 mu = gap / nrow;
-                gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
+                gap_ok = gap <= md.gap_tol * (1.0 + fabs(obj));
                 if (tid == 0) { S.sc[5] = gap; S.sc[6] = rpmax; }
                 stamp(PH_P1);
                 if (!(gap == gap) || !(rpmax == rpmax)) failed = true;
@@ -1506,7 +1553,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             for (int c = tid; c < AXVALID; c += NT) {
                 const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
                 double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl];
-                double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - S.ah[sl];
+                double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - AH(sl);
                 S.at2[sl] = zv * is * rp - (S.at2[sl] - smu) * is;
             }
             for (int c = tid; c < nact; c += NT) {
@@ -1557,7 +1604,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 double mins = 1e300, minz = 1e300;
                 for (int c = tid; c < AXVALID; c += NT) {
                     const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
-                    double sv = S.ah[sl] - ax_row(S.x, type, kt / SEGV, kt % SEGV);
+                    double sv = AH(sl) - ax_row(S.x, type, kt / SEGV, kt % SEGV);
                     S.as_[sl] = sv; S.az[sl] = -sv;
                     mins = fmin(mins, sv); minz = fmin(minz, -sv);
                 }
@@ -1584,7 +1631,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int c = tid; c < AXVALID; c += NT) {
                     const int sl = S.amap[c], type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
                     double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
-                    double rp = ax_row(S.x, type, k, t) + sv - S.ah[sl];
+                    double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
                     double adx = ax_row(S.dx, type, k, t);
                     double ds = -rp - adx, dz = -zv - w * ds;
                     if (ds < 0.0) amin = fmin(amin, -sv / ds);
@@ -1628,7 +1675,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int c = tid; c < AXVALID; c += NT) {
                     const int sl = S.amap[c], type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
                     double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
-                    double rp = ax_row(S.x, type, k, t) + sv - S.ah[sl];
+                    double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
                     double adx = ax_row(S.dx, type, k, t);
                     double ds = -rp - adx, dz = -zv + S.at2[sl] + w * adx;
                     if (ds < 0.0) amin = fmin(amin, -sv / ds);
@@ -1735,6 +1782,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     plan_agent<false, false, true>(a, blockIdx.x, smem_raw, nullptr);
 }
 
+// Throughput build for swarms larger than the chip (more agents in the shard than CUs): 256 lanes = one wave per SIMD, and
+// an LDS request of at most half a CU's 160 KB, so that two agents share a CU and one hides the other's latencies (the
+// solver is a chain of dependent LDS / cross-lane operations: VALU active 13 % of wave-cycles in the latency build).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_tp_kernel(PlanArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    plan_agent<false, false, false, 256>(a, blockIdx.x, smem_raw, nullptr);
+}
+
 // Second pass: agents whose rows did not fit the LDS capacity of the first pass are solved again with their rows in
 // HBM.  Persistent workgroups (one workspace each) walk the shard; everybody else's result is left untouched.
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_spill_kernel(PlanArgs a)
@@ -1751,7 +1807,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
         if (a.status[a.first + al] != LSC_STATUS_CAPACITY_K) continue;   // uniform over the workgroup
         __syncthreads();
-        plan_agent<false, true, false>(a, al, smem_raw, ws);
+        plan_agent<false, true, false, NT>(a, al, smem_raw, ws);
         __syncthreads();
     }
 }
@@ -1763,25 +1819,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // ---------------------------------------------------------------------------------------------------
 namespace lsc {
 
-size_t plan_smem_bytes(int n_terms, int n_entries, int cap)
+// LDS request of the plan kernel for a capacity of `rows` LSC rows (rows are stored compactly: a total, not per bucket)
+size_t plan_smem_bytes(int n_terms, int n_entries, int rows, bool tables_in_lds)
 {
-    size_t b = sizeof(Smem);
-    b += sizeof(uint32_t) * (size_t)((n_terms + 1) & ~1);
-    b += sizeof(uint32_t) * (size_t)(2 * n_entries + 2);
-    b += sizeof(double) * (size_t)n_entries;
-    const int cs = (cap & 1) ? cap : cap + 1;
-    size_t R = (size_t)NB * cs;
-    b += R * (5 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t) + 1);
+    size_t b = tables_in_lds ? sizeof(SmemT<false>) : sizeof(SmemT<true>);
+    if (tables_in_lds) {
+        b += sizeof(uint32_t) * (size_t)((n_terms + 1) & ~1);
+        b += sizeof(uint32_t) * (size_t)(2 * n_entries + 2);
+        b += sizeof(double) * (size_t)n_entries;
+    }
+    b += (size_t)rows * (5 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t));
     return (b + 15) & ~(size_t)15;
 }
 
 // bytes of one workgroup's HBM row workspace (second pass): all 27 (N-1) row slots
 size_t plan_spill_bytes(int N)
 {
-    const int cap = N - 1 > 1 ? N - 1 : 1;
-    const int cs = (cap & 1) ? cap : cap + 1;
-    const size_t R = (size_t)NB * cs;
-    return (R * (5 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t) + 1) + 255) & ~(size_t)255;
+    const size_t R = (size_t)NB * (N - 1 > 1 ? N - 1 : 1);
+    return (R * (5 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t)) + 255) & ~(size_t)255;
 }
 
 // The large-LDS opt-in is a per-device function attribute: lsc_create calls this once per context after hipSetDevice
@@ -1789,7 +1844,7 @@ size_t plan_spill_bytes(int N)
 hipError_t init_device_kernels()
 {
     const void *fns[] = {reinterpret_cast<const void *>(&lsc_plan_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_kernel<true>),
-                         reinterpret_cast<const void *>(&lsc_plan_alt_kernel),
+                         reinterpret_cast<const void *>(&lsc_plan_alt_kernel), reinterpret_cast<const void *>(&lsc_plan_tp_kernel),
                          reinterpret_cast<const void *>(&lsc_plan_spill_kernel), reinterpret_cast<const void *>(&lsc_sfc_kernel)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1804,6 +1859,13 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;          // empty shard (more ranks than agents): nothing to plan
     const bool alt = a.general_all || (a.reset_thr > 0.0 && a.ever);
+    if (a.cap_tp > 0 && !alt && !a.prof && !a.out_normal && !a.trace) {
+        // throughput build: smaller capacity (an agent beyond it takes the second pass), two workgroups per CU
+        PlanArgs t = a;
+        t.cap = a.cap_tp;
+        hipLaunchKernelGGL(lsc_plan_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
+        return hipGetLastError();
+    }
     if (alt) hipLaunchKernelGGL(lsc_plan_alt_kernel, dim3(a.count), dim3(NT), smem, st, a);
     else if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, a);
     else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, a);

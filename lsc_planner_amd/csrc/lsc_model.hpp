@@ -47,6 +47,7 @@ struct Model {
     float  world_min[3], world_max[3];
     int    use_sfc, prune, max_iters, cap;
     double dx_tol;            // Newton-step convergence tolerance (relative to max(1, |x|_inf))
+    double gap_tol;           // duality-gap tolerance, relative to 1 + |objective|
     double ws_mu0;            // warm start: initial complementarity target (0 = cold start only)
     int sigma_pow;            // Mehrotra centering exponent: sigma = (mu_aff / mu)^sigma_pow  (2, 3 or 4)
     unsigned short amap[416]; // compact list of the valid axis-row slots (414)

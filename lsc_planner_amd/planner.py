@@ -39,6 +39,7 @@ class PlannerConfig:
     slack_collision_weight: float = 100000.0
     n_constraint_segments: int = -1
     reset_threshold: float = 0.0    # multisim/reset_threshold; > 0 switches the disturbance checks on (launch files: 0.15)
+    gap_tolerance: float = 1e-9     # interior point: relative duality gap at the optimum
     comm: tuple = None              # (world_size, rank, id bytes from comm_unique_id()): agent-sharded multi-GPU over RCCL
 
 
@@ -83,6 +84,7 @@ class SwarmPlanner:
         c.slack_mode = {"none": 0, "dynamical_limit": 1, "collision_constraint": 2}[self.cfg.slack_mode]
         c.slack_collision_weight, c.n_constraint_segments = self.cfg.slack_collision_weight, self.cfg.n_constraint_segments
         c.reset_threshold = self.cfg.reset_threshold
+        c.gap_tolerance = self.cfg.gap_tolerance
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:
@@ -235,6 +237,18 @@ class SwarmPlanner:
     def row_counts(self):
         rows = np.zeros(self.N, np.int32)
         self._check(self.L.lsc_last_row_counts(self.ctx, _ip(rows)))
+        return rows
+
+    def row_capacity(self):
+        """(rows of the LDS pass in the latency build, rows in the throughput build or 0)."""
+        a, b = ctypes.c_int(), ctypes.c_int()
+        self._check(self.L.lsc_row_capacity(self.ctx, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def bucket_max(self):
+        """Rows of every agent's fullest control-point bucket in the last tick (first-pass LDS capacity needed)."""
+        rows = np.zeros(self.N, np.int32)
+        self._check(self.L.lsc_last_bucket_max(self.ctx, _ip(rows)))
         return rows
 
     def gjk_batch(self, pts):
