@@ -41,6 +41,7 @@ class MultiSyncSimulator {
             for (int k = 0; k < 3; k++) { vm[3 * qi + k] = a.max_vel[k]; am[3 * qi + k] = a.max_acc[k]; }
         }
         check(lsc_set_agents(ctx, N, r.data(), dw.data(), vm.data(), am.data(), vn.data()));
+        check(lsc_set_timing(ctx, 1));   // per-kernel device times -> the per-phase columns of the summary
         if (param.world_use_octomap) setOctomap(mission.world_file_name);
         h_state.resize(9 * N); h_goal.resize(3 * N); h_prev.assign(90 * N, 0.f); h_next.resize(90 * N);
         h_cost.assign(N, 0.0); h_status.assign(N, 0); h_iters.assign(N, 0);
@@ -226,11 +227,21 @@ class MultiSyncSimulator {
         return d;
     }
 
-    // :382-402 + :589-633 (25 columns; per-phase times that do not exist separately on the GPU are written as 0)
+    // :382-402 + :589-633 (25 columns; goal / corridor / optimisation times are the device times of the respective launches
+    // per agent-plan, the LSC generation is part of the optimisation launch and prediction / initial trajectory are not
+    // separate steps on the GPU: written as 0)
     void summarizeResult() {
         total_distance = getTotalDistance();
         if (param.rank != 0) return;
         const double avg = N_average ? planning_time_sum / N_average : 0.0;
+        // PlanningTimeStatistics per agent-plan (src/multi_sync_simulator.cpp:589-633) from the launches that exist separately:
+        // goal kernel, corridor kernel, plan kernel (LSC generation + QP in one launch); seconds per agent-plan
+        auto per_plan = [&](int which) {
+            double ms = 0; long n = 0;
+            if (lsc_kernel_time_ms(ctx, which, &ms, &n) != LSC_OK || n == 0) return 0.0;
+            return ms * 1e-3 / mission.qn;
+        };
+        const double t_goal = per_plan(3), t_sfc = per_plan(4), t_plan = per_plan(0);
         std::printf("[MultiSyncSimulator] total flight time: %g\n[MultiSyncSimulator] total distance: %g\n"
                     "[MultiSyncSimulator] planning time per agent: %g\n[MultiSyncSimulator] safety ratio between agent: %g\n"
                     "[MultiSyncSimulator] collided: %d, ticks: %d, mean tick %.3f ms -> %.1f agent-replans/s (host-buffer ABI)\n",
@@ -247,7 +258,7 @@ class MultiSyncSimulator {
                    "sfc_generation_time,traj_optimization_time,mission_file_name,world_file_name,planner_mode,prediction_mode,"
                    "initial_traj_mode,slack_mode,goal_mode,world_dimension,dt,horizon,N_constraint_segments\n";
         out << sim_start_time << "," << total_flight_time << "," << total_distance << "," << is_collided << "," << safety_ratio_agent << "," << avg
-            << "," << avg << "," << avg << ",0,0,0,0,0," << avg << "," << mission.mission_file_name << "," << mission.world_file_name
+            << "," << avg << "," << avg << ",0,0," << t_goal << ",0," << t_sfc << "," << t_plan << "," << mission.mission_file_name << "," << mission.world_file_name
             << "," << param.getPlannerModeStr() << (param.planner_mode == 1 ? ",current_position,current_position," : ",previous_solution,previous_solution,")
             << param.getSlackModeStr() << "," << (param.goal_mode_prior_based ? "prior_based" : "static") << ",3," << param.dt << ","
             << param.horizon << "," << param.N_constraint_segments << "\n";

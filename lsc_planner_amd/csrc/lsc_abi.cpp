@@ -253,8 +253,8 @@ struct lsc_ctx {
     unsigned char *h_out = nullptr;
     hipStream_t stream = nullptr;
     // kernel timing: one HIP event pair per launch, recorded on the launch stream, read back on query
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[3];   // 0 plan kernel(s), 1 dense sweep, 2 trajectory exchange
-    size_t ev_used[3] = {0, 0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[5];   // 0 plan kernel(s), 1 dense sweep, 2 trajectory exchange, 3 goal kernel, 4 corridor kernel
+    size_t ev_used[5] = {0, 0, 0, 0, 0};
     // agent-sharded multi-GPU: this context is rank `rank` of `world`; every rank owns a block of shard_rows agents of a
     // table padded to table_rows = shard_rows * world rows, so that the exchange is ONE in-place equal-sized all-gather
     int world = 1, rank = 0, shard_rows = 0, table_rows = 0;
@@ -432,7 +432,7 @@ void lsc_destroy(lsc_ctx *c)
     if (c->d_gmodel) (void)hipFree(c->d_gmodel);
     if (c->d_terms) (void)hipFree(c->d_terms);
     if (c->d_entries) (void)hipFree(c->d_entries);
-    for (int w = 0; w < 3; w++)
+    for (int w = 0; w < 5; w++)
         for (auto &p : c->ev_pool[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -715,7 +715,10 @@ static int run_goal(lsc_ctx *c, const float *d_state, const float *&d_goal, cons
     g.path_out = c->d_goal_path; g.path_cap = c->goal_path_cap; g.path_len = c->d_goal_plen;
     g.ray_stack = c->d_ray_stack;
     g.reset_thr = c->cfg.planner_mode == 0 ? c->cfg.reset_threshold : 0.0; g.ever = c->d_ever;
+    hipEvent_t e1 = nullptr;
+    if (c->timing && timing_begin(c, 3, st, &e1) != LSC_OK) return LSC_EHIP;
     HIPCHK(c, launch_goal(g, st));
+    if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
     d_goal = c->d_goal_planned;
     return LSC_OK;
 }
@@ -740,7 +743,10 @@ static int run_sfc(lsc_ctx *c, const float *d_state, const float *d_goal, const 
         c->err = "world extent / world_resolution too large for the SFC face tables (limit 3400 steps per axis)";
         return LSC_EINVAL;
     }
+    hipEvent_t e1 = nullptr;
+    if (c->timing && timing_begin(c, 4, st, &e1) != LSC_OK) return LSC_EHIP;
     HIPCHK(c, launch_sfc(s, st));
+    if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
     return LSC_OK;
 }
 
@@ -1050,13 +1056,13 @@ int lsc_set_timing(lsc_ctx *c, int enabled)
 {
     if (!c) return LSC_EINVAL;
     c->timing = enabled != 0;
-    c->ev_used[0] = c->ev_used[1] = c->ev_used[2] = 0;
+    for (int w = 0; w < 5; w++) c->ev_used[w] = 0;
     return LSC_OK;
 }
 
 int lsc_kernel_time_ms(lsc_ctx *c, int which, double *avg_ms, long *launches)
 {
-    if (!c || which < 0 || which > 2 || !avg_ms) return LSC_EINVAL;
+    if (!c || which < 0 || which > 4 || !avg_ms) return LSC_EINVAL;
     double tot = 0;
     for (size_t i = 0; i < c->ev_used[which]; i++) {
         auto &p = c->ev_pool[which][i];
@@ -1072,7 +1078,7 @@ int lsc_kernel_time_ms(lsc_ctx *c, int which, double *avg_ms, long *launches)
 
 int lsc_kernel_times_ms(lsc_ctx *c, int which, double *out_ms, long capacity, long *launches)
 {
-    if (!c || which < 0 || which > 2 || (capacity > 0 && !out_ms)) return LSC_EINVAL;
+    if (!c || which < 0 || which > 4 || (capacity > 0 && !out_ms)) return LSC_EINVAL;
     const long n = (long)c->ev_used[which];
     for (long i = 0; i < n && i < capacity; i++) {
         auto &p = c->ev_pool[which][(size_t)i];

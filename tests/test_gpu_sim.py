@@ -87,6 +87,9 @@ def test_forest_mission_in_the_default_goal_mode(tmp_path):
     assert rr.returncode == 0, rr.stdout + rr.stderr
     ratio = float(rr.stdout.split("safety ratio between agent:")[1].split()[0])
     assert ratio >= 1.0 - 1e-3
+    summ = list(csv.reader(open(tmp_path / "summary_LSC_8agents.csv")))
+    goal_t, sfc_t, opt_t = float(summ[1][10]), float(summ[1][12]), float(summ[1][13])   # per-phase columns (seconds per agent-plan)
+    assert 0 < sfc_t < opt_t < 1e-3 and goal_t > 0
     rows = list(csv.reader(open(tmp_path / "result_LSC_8agents.csv")))[1:]
     pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based", use_octomap=True))
     pl.load_octomap(str(bt))
