@@ -450,6 +450,7 @@ struct SmemT {
     float pinit[NV];            // own initial trajectory (float32)
     int cnt[32];                // rows per control-point bucket
     int offs[32];               // exclusive prefix of cnt over the 27 buckets
+    uint32_t offcnt[32];        // offs | cnt << 16 per bucket (LDS pass: both below 65536), one load per reduction unit
     int wcnt[NWAVE][32];
     double cullB[M];            // phase B pre-cull: per segment max_i(|c_{0,2} - p_{m,i}| + reach radius of c_{m,i})
     int cullc[NWAVE + 1];       // survivors of the pre-cull per wave (compaction)
@@ -1050,6 +1051,20 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     if (lane == 0) S.wcnt[wave][mm * NC + i] = __popcll(mask);
                 }
             }
+            // arrival slots: one reservation per wave (the order is irrelevant, (cp, pos) decides the final place)
+            int kslot = 0;
+            {
+                int pre = 0, tot = 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const unsigned long long mk = __ballot(live && actv[i]);
+                    pre += __popcll(mk & lt_mask);
+                    tot += __popcll(mk);
+                }
+                int base = 0;
+                if (lane == 0 && tot) base = atomicAdd(&S.ntmp, tot);
+                kslot = __builtin_amdgcn_readfirstlane(base) + pre;
+            }
             __syncthreads();
             if (live) {
 #pragma unroll
@@ -1058,7 +1073,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     const int cp = m * NC + i;
                     int pos = S.cnt[cp] + rank[i];          // position inside the bucket: obstacle order, deterministic
                     for (int w = 0; w < wave; w++) pos += S.wcnt[w][cp];
-                    const int k = atomicAdd(&S.ntmp, 1);    // arrival slot: order irrelevant, (cp, pos) decides the final place
+                    const int k = kslot++;
                     if (k < R) tmp_rows[k] = TmpRow{rhs[i], nrm.x, nrm.y, nrm.z, (uint32_t)cp | ((uint32_t)pos << 8)};
                 }
             }
@@ -1080,6 +1095,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             o = 0;
             for (int b = 0; b < 32; b++) S.cnt[b] = 0;
         }
+        for (int b = 0; b < NB; b++) S.offcnt[b] = (uint32_t)S.offs[b] | ((uint32_t)S.cnt[b + 3] << 16);
         S.nact = o;
     }
     __syncthreads();
@@ -1219,8 +1235,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             const int u = (ub + tid) >> 1, half = tid & 1;
             const bool live = u < nunits;
             const int bkt = live ? (with_w ? u / 9 : u / 3) : 0, c = live ? (with_w ? u % 9 : 6 + u % 3) : 6, cp = bkt + 3;
-            const int cnt = live ? S.cnt[cp] : 0;
-            const int r0 = S.offs[bkt];
+            // bucket base and size in one LDS word (offs | cnt << 16), written once after phase B
+            int cnt, r0;
+            if constexpr (SPILL) { cnt = live ? S.cnt[cp] : 0; r0 = S.offs[bkt]; }      // 27 (N-1) rows: may exceed 16 bits
+            else { const uint32_t oc = live ? S.offcnt[bkt] : 0u; cnt = (int)(oc >> 16); r0 = (int)(oc & 0xffffu); }
             double acc0 = 0.0, acc1 = 0.0, az0 = 0.0, az1 = 0.0;
             if (c < 6) {
                 const int ia = c < 3 ? 0 : (c < 5 ? 1 : 2), ib = c < 3 ? c : (c < 5 ? c - 2 : 2);
