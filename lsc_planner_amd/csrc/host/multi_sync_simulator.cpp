@@ -259,8 +259,11 @@ class MultiSyncSimulator {
                    "initial_traj_mode,slack_mode,goal_mode,world_dimension,dt,horizon,N_constraint_segments\n";
         out << sim_start_time << "," << total_flight_time << "," << total_distance << "," << is_collided << "," << safety_ratio_agent << "," << avg
             << "," << avg << "," << avg << ",0,0," << t_goal << ",0," << t_sfc << "," << t_plan << "," << mission.mission_file_name << "," << mission.world_file_name
-            << "," << param.getPlannerModeStr() << (param.planner_mode == 1 ? ",current_position,current_position," : ",previous_solution,previous_solution,")
-            << param.getSlackModeStr() << "," << (param.goal_mode_prior_based ? "prior_based" : "static") << ",3," << param.dt << ","
+            // mode strings exactly as the reference's writer produces them, quirks included: "current_posiotion" is its
+            // spelling (src/param.cpp:158), and getGoalModeStr() indexes its table with the PLANNER mode (src/param.cpp:168-171),
+            // so the goal_mode column reads "static" for LSC and "orca" for BVC whatever mode/goal was
+            << "," << param.getPlannerModeStr() << (param.planner_mode == 1 ? ",current_position,current_posiotion," : ",previous_solution,previous_solution,")
+            << param.getSlackModeStr() << "," << (param.planner_mode == 1 ? "orca" : "static") << ",3," << param.dt << ","
             << param.horizon << "," << param.N_constraint_segments << "\n";
     }
 

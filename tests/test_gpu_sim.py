@@ -161,4 +161,27 @@ def test_simulator_in_bvc_mode_finishes_the_mission(ticks, tmp_path):
     ratio = float(r.stdout.split("safety ratio between agent:")[1].split()[0])
     assert ratio >= 1.0 - 1e-3
     summ = list(csv.reader(open(tmp_path / "summary_BVC_4agents.csv")))
-    assert summ[1][16] == "BVC" and summ[1][17] == "current_position"
+    assert summ[1][16] == "BVC" and summ[1][17] == "current_position" and summ[1][18] == "current_posiotion" and summ[1][20] == "orca"
+
+
+def test_the_one_published_mission_outcome_of_the_reference(tmp_path):
+    """log/summary_LSC_16agents.csv is the only outcome the reference publishes for this path: multi_square16.json in
+    simple_forest.bt, no collision, minimal safety ratio 1.004-1.010, flight time 21.8 / 22.8 s, flown distance 169.0 /
+    169.5 m (two runs with multisim/max_noise 0.02, unseeded -- a soft target).  The same mission file (reference schema)
+    and map through lsc_sim in the reference's default goal mode must land in that neighbourhood."""
+    from conftest import GOLDEN
+    from maputil import forest_leaves, write_bt
+    fix = json.load(open(os.path.join(GOLDEN, "multi_square16.json")))
+    leaves, res = forest_leaves()
+    bt = tmp_path / "simple_forest.bt"
+    write_bt(str(bt), leaves, res)
+    rr = subprocess.run([SIM, "--mission", os.path.join(GOLDEN, "multi_square16.json"), "--world", str(bt), "--csv", str(tmp_path), "--quiet"],
+                        capture_output=True, text=True, timeout=900)
+    assert rr.returncode == 0, rr.stdout + rr.stderr                      # finished, no collision
+    summ = list(csv.DictReader(open(tmp_path / "summary_LSC_16agents.csv")))[0]
+    pub = fix["published_outcome"]
+    t_pub = np.mean([p["total_flight_time"] for p in pub]); d_pub = np.mean([p["total_flight_distance"] for p in pub])
+    assert float(summ["is_collided"]) == 0 and float(summ["safety_ratio_agent"]) >= 1.0 - 1e-3
+    assert abs(float(summ["total_flight_time"]) - t_pub) <= 0.25 * t_pub, summ["total_flight_time"]
+    assert abs(float(summ["total_flight_distance"]) - d_pub) <= 0.10 * d_pub, summ["total_flight_distance"]
+    print("lsc_sim:", summ["total_flight_time"], "s,", summ["total_flight_distance"], "m; published:", t_pub, "s,", d_pub, "m")

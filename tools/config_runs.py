@@ -7,7 +7,7 @@ bench lines): device-resident tick loop, one JSON line per configuration.
   circle20    20-agent circle swap, empty map, mode/goal prior_based           (BASELINE configs[1] geometry)
   circle64    the bench headline workload                                      (configs[2])
   forest256   256 agents, the simple_forest occupancy tiled 2 x 2 (20 x 20 x 2.5 m), EDT + SFC path, mode/goal static
-              (configs[3] on one GPU, the goal mode of the reference's own logged forest runs)
+              (configs[3]-sized on one GPU; configs[3] exactly as SURVEY 8(d)#4 states it is a -m gpu test)
   forest256p  the same with mode/goal prior_based: priority rule + grid A* + line-of-sight goal on the device
   random1024  1024-agent random swarm, empty 40 x 40 x 5 m world               (configs[4] on one GPU)
 Needs a GPU; nothing here touches oracle/ or /root/reference.  The forest occupancy comes from the committed leaf
