@@ -1806,7 +1806,39 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_tp_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<false, false, false, 256>(a, blockIdx.x, smem_raw, nullptr);
+    plan_agent<false, false, false, 256>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
+}
+
+// ... and the throughput build with the alternate-mode hooks
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_alt_tp_kernel(PlanArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    plan_agent<false, false, true, 256>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
+}
+
+// Launch order of the throughput build: the shard takes several rounds of workgroups there, and the tick ends with the
+// last one, so the agents that were expensive in the previous tick (iterations x rows) go first and the cheap ones fill
+// the gaps (longest-processing-time-first list scheduling; the hardware dispatches workgroups in blockIdx order).
+// Any content of iters / nrows gives a permutation; results do not depend on it.
+__global__ __launch_bounds__(256) void lsc_order_kernel(const int *iters, const int *nrows, int first, int count, int *order)
+{
+    constexpr int TILE = 2048;
+    __shared__ long long tile[TILE];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    auto cost = [&](int p) { return (long long)iters[first + p] * (long long)(nrows[first + p] + 600); };
+    const long long cq = q < count ? cost(q) : 0;
+    int r = 0;
+    for (int p0 = 0; p0 < count; p0 += TILE) {
+        const int n = count - p0 < TILE ? count - p0 : TILE;
+        __syncthreads();
+        for (int p = threadIdx.x; p < n; p += blockDim.x) tile[p] = cost(p0 + p);
+        __syncthreads();
+        for (int p = 0; p < n; ++p) {          // uniform address: one LDS broadcast per step
+            const long long cp = tile[p];
+            r += (cp > cq) || (cp == cq && p0 + p < q);
+        }
+    }
+    if (q < count) order[r] = q;
 }
 
 // Second pass: agents whose rows did not fit the LDS capacity of the first pass are solved again with their rows in
@@ -1863,6 +1895,7 @@ hipError_t init_device_kernels()
 {
     const void *fns[] = {reinterpret_cast<const void *>(&lsc_plan_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_alt_kernel), reinterpret_cast<const void *>(&lsc_plan_tp_kernel),
+                         reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel),
                          reinterpret_cast<const void *>(&lsc_plan_spill_kernel), reinterpret_cast<const void *>(&lsc_sfc_kernel)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1877,11 +1910,13 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;          // empty shard (more ranks than agents): nothing to plan
     const bool alt = a.general_all || (a.reset_thr > 0.0 && a.ever);
-    if (a.cap_tp > 0 && !alt && !a.prof && !a.out_normal && !a.trace) {
+    if (a.cap_tp > 0 && !a.prof && !a.out_normal && !a.trace) {
         // throughput build: smaller capacity (an agent beyond it takes the second pass), two workgroups per CU
         PlanArgs t = a;
         t.cap = a.cap_tp;
-        hipLaunchKernelGGL(lsc_plan_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
+        if (t.order) hipLaunchKernelGGL(lsc_order_kernel, dim3((a.count + 255) / 256), dim3(256), 0, st, a.iters, a.nrows, a.first, a.count, a.order);
+        if (alt) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
+        else hipLaunchKernelGGL(lsc_plan_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
         return hipGetLastError();
     }
     if (alt) hipLaunchKernelGGL(lsc_plan_alt_kernel, dim3(a.count), dim3(NT), smem, st, a);

@@ -286,22 +286,27 @@ def test_spatial_pre_cull_changes_nothing_but_the_time(L, n):
     a.close(); b.close()
 
 
-def test_throughput_build_agrees_with_the_latency_build(L):
+@pytest.mark.parametrize("n,world,reset_threshold", [(320, (-12, -12, 0, 12, 12, 3.0), 0.0),
+                                                     (600, (-16, -16, 0, 16, 16, 3.0), 0.15)])
+def test_throughput_build_agrees_with_the_latency_build(L, n, world, reset_threshold):
     """A shard with more agents than the GPU has CUs runs the 256-lane throughput build (two workgroups per CU, smaller LDS
     row capacity, assembly tables read from L2); max_rows_per_cp = 64 pins the 512-lane latency build.  Same rows, same
-    statuses; costs and plans within the parity tolerances (block reductions combine 4 instead of 8 partial sums)."""
+    statuses; costs and plans within the parity tolerances (block reductions combine 4 instead of 8 partial sums).
+    The second case has more than two workgroups per CU, so the launch is ordered longest-agent-first by the previous
+    tick's iterations and rows (lsc_order_kernel), and runs the build with the disturbance checks compiled in."""
     from lsc_planner_amd.planner import next_state_host
-    n = 320
-    ms = L.random_swarm(n, world=(-12, -12, 0, 12, 12, 3.0), seed=9)
-    tp, lat = L.SwarmPlanner(ms, L.PlannerConfig()), L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=64))
+    ms = L.random_swarm(n, world=world, seed=9)
+    tp = L.SwarmPlanner(ms, L.PlannerConfig(reset_threshold=reset_threshold))
+    lat = L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=64, reset_threshold=reset_threshold))
     lds, thr = tp.row_capacity()
     assert 0 < thr < lds and lat.row_capacity()[1] == 0
     state, traj = _start(ms)
     for tick in range(1, 11):
         ga, gb = tp.plan(state, ms.goal, traj), lat.plan(state, ms.goal, traj)
-        assert np.array_equal(ga["status"], gb["status"]) and (ga["status"] == 0).all(), tick
+        assert np.array_equal(ga["status"], gb["status"]) and (ga["status"] == 0).mean() > 0.98, tick
         assert np.array_equal(tp.row_counts(), lat.row_counts()), tick
-        assert (np.abs(ga["cost"] - gb["cost"]) <= COST_RTOL * np.abs(gb["cost"]) + COST_ATOL).all(), tick
+        ok = ga["status"] == 0        # an infeasible agent keeps its stale plan in both builds; its cost is not defined
+        assert (np.abs(ga["cost"] - gb["cost"])[ok] <= (COST_RTOL * np.abs(gb["cost"]) + COST_ATOL)[ok]).all(), tick
         assert np.abs(ga["traj"] - gb["traj"]).max() <= TRAJ_ATOL, tick
         traj = gb["traj"]
         state = next_state_host(traj)
