@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--slack", default="none", choices=["none", "dynamical_limit", "collision_constraint"])
     ap.add_argument("--unfused", action="store_true",
                     help="single GPU only: use the multi-GPU tick sequence (plan shard, exchange, propagate) instead of the fused launch")
+    ap.add_argument("--torch-exchange", action="store_true",
+                    help="several GPUs (or --unfused): exchange through torch.distributed instead of the library's own communicator")
     ap.add_argument("--sweep-agents", type=int, default=1024,
                     help="extra leg: dense LSC sweep at this swarm size (HBM-meaningful working set); 0 = skip")
     args = ap.parse_args()
@@ -164,9 +166,34 @@ def main():
     R = 8.0 * n_agents / 64.0
     ms = L.circle_swap(n_agents, circle_radius=R, z=1.0, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
     goal_mode = "static" if args.static_goal else "prior_based"
-    pl = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode,
-                                            reset_threshold=args.reset_threshold, planner_mode=args.planner, slack_mode=args.slack,
-                                            comm=(G, rank, token) if sharded else None))
+    def make_planner(comm):
+        return L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode,
+                                                  reset_threshold=args.reset_threshold, planner_mode=args.planner,
+                                                  slack_mode=args.slack, comm=comm))
+
+    # Several GPUs: the exchange is the library's own RCCL all-gather (lsc_comm_init).  Should that communicator not come
+    # up on this node, the ranks agree on it and the run falls back to the torch.distributed all-gather of
+    # lsc_planner_amd/sharded.py around the same shard kernels (reported as "native": false) instead of dying without a line.
+    from lsc_planner_amd.sharded import shard_bounds, shard_rows as _shard_rows, table_rows as _table_rows, all_gather_rows
+    native, why, pl = sharded and not args.torch_exchange, "--torch-exchange" if args.torch_exchange else None, None
+    try:
+        pl = make_planner((G, rank, token) if native else None)
+    except L.LscError as e:
+        if world == 1:
+            raise
+        native, why = False, str(e)
+    if world > 1:
+        agree = torch.tensor([1 if native else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree.item()) == 0 and not args.torch_exchange:
+            native = False
+            why = why or "another rank could not create the native communicator"
+            if pl is not None:
+                pl.close()
+            pl = make_planner(None)
+    if sharded and not native:
+        pl.set_shard(*shard_bounds(n_agents, G, rank))
+        pl.shard_rows, pl.table_rows = _shard_rows(n_agents, G), _table_rows(n_agents, G)
     first, count, rows = pl.first, pl.count, pl.table_rows      # rank's block of the (padded) trajectory table
 
     f32 = dict(dtype=torch.float32, device=dev)
@@ -192,8 +219,12 @@ def main():
         if not sharded:
             pl.tick_device_fused(states[0], goal, prev, nxt, states[1], cost, status, iters, seq, stream)
             states.reverse()
-        else:
+        elif native:
             pl.tick_device_sharded(states[0], goal, prev, nxt, cost, status, iters, seq, stream)
+        else:
+            pl.tick_device(states[0], goal, prev, nxt, cost, status, iters, seq, stream)
+            all_gather_rows(dist, nxt, rank, pl.shard_rows)
+            pl.propagate_device(nxt, states[0], stream)
 
     def sync():
         if G > 1:
@@ -216,7 +247,7 @@ def main():
     elapsed = time.perf_counter() - t0
     k_ms, k_n = pl.kernel_time_ms(0)
     k_all = pl.kernel_times_ms(0)
-    x_all = pl.kernel_times_ms(2) if sharded else np.zeros(0)
+    x_all = pl.kernel_times_ms(2) if native else np.zeros(0)
     iters_total = pl.iterations_total(reset=False)
     bad = int((status[first:first + count] != 0).sum().item())
     lrows = pl.row_counts()[first:first + count]
@@ -267,7 +298,9 @@ def main():
                                  "MFMA bounds this kernel"},
         }
         if sharded:
-            result["rccl"] = {"world_size": G, "native": True, "collective": "ncclAllGather, in place, on the tick's stream",
+            result["rccl"] = {"world_size": G, "native": native,
+                              "collective": "ncclAllGather, in place, on the tick's stream" if native else
+                                            f"torch.distributed all_gather_into_tensor (fallback: {why})",
                               "bytes_per_rank_per_tick": pl.shard_rows * 360,
                               "exchange_us_per_tick": {"mean": round(1e3 * float(x_all.mean()), 2) if len(x_all) else None,
                                                        "p99": round(1e3 * float(np.percentile(x_all, 99)), 2) if len(x_all) else None},
