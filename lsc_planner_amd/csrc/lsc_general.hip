@@ -26,6 +26,7 @@
 #include "lsc_gjk.hpp"
 #include "lsc_model.hpp"
 #include "lsc_kernels.h"
+#include <type_traits>
 
 namespace lsc {
 
@@ -42,6 +43,7 @@ struct GS {
     double x[96], dx[96];
     double y[PMAX + 1], dy[PMAX + 1], rhs[PMAX + 1];
     double K[PMAX * KL];
+    double invd[PMAX + 1];         // reciprocal diagonal of the Cholesky factor
     double gv[96], gz[96];         // x-space: cost gradient + sum vv_r a_r  /  + sum z_r a_r
     double Wd[NV], W1[NV], W2[NV]; // x-space Hessian pieces of the bound / velocity / acceleration rows
     double Ws[NCP * 6];            // per control point: sum w n n^T (xx xy xz yy yz zz)
@@ -146,7 +148,8 @@ __device__ __forceinline__ double ax_x(const double *x, int type, int k, int t)
 
 // (noinline: the kernel below must be able to leave before this function's frame -- it keeps part of its state in
 // scratch -- is set up; the common launch is the one that finds nobody flagged)
-__device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb)
+__device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb,
+                                                         unsigned char *lds_ws, size_t lds_ws_bytes)
 {
     GS &S = *reinterpret_cast<GS *>(smem_raw);
     const GModel &gm = *a.gmodel;
@@ -165,13 +168,26 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     // ---- workspace carve-up (HBM): per-row state of the interior point, collision rows of all obstacles
     const int NCL = NBK * nob, NGR = M * nob;
     const int US0 = AXROWS, CL0 = AXROWS + 2 * M, GS0 = CL0 + NCL, RT = GS0 + NGR;
-    double *rs = reinterpret_cast<double *>(wsb);
-    double *rz = rs + RT, *rt1 = rz + RT, *rt2 = rt1 + RT;
-    double *crhs = rt2 + RT;                 // [NCL]   d + n.q of a collision row
-    double *ev = crhs + NCL;                 // [NGR]   group slack variables
-    double *dev = ev + NGR, *Dg = dev + NGR, *qg = Dg + NGR;
-    float *nrm = reinterpret_cast<float *>(qg + NGR);          // [NGR][3]
-    unsigned char *slk = reinterpret_cast<unsigned char *>(nrm + 3 * NGR);   // [nob]
+    // Each array goes to LDS while there is room (most latency-critical first: the ones the per-control-point reductions
+    // walk obstacle by obstacle), else to the workgroup's HBM workspace; the code below only sees flat pointers.
+    auto take = [&](size_t bytes) -> unsigned char * {
+        bytes = (bytes + 15) & ~(size_t)15;
+        unsigned char *p;
+        if (bytes <= lds_ws_bytes) { p = lds_ws; lds_ws += bytes; lds_ws_bytes -= bytes; }
+        else { p = wsb; wsb += bytes; }
+        return p;
+    };
+    float *nrm = reinterpret_cast<float *>(take(sizeof(float) * 3 * NGR));              // [NGR][3]
+    unsigned char *slk = take(nob);                                                     // [nob]
+    double *rt1 = reinterpret_cast<double *>(take(sizeof(double) * RT));
+    double *rt2 = reinterpret_cast<double *>(take(sizeof(double) * RT));
+    double *rz = reinterpret_cast<double *>(take(sizeof(double) * RT));
+    double *crhs = reinterpret_cast<double *>(take(sizeof(double) * NCL));              // [NCL]   d + n.q of a collision row
+    double *ev = reinterpret_cast<double *>(take(sizeof(double) * NGR));                // [NGR]   group slack variables
+    double *dev = reinterpret_cast<double *>(take(sizeof(double) * NGR));
+    double *Dg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
+    double *qg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
+    double *rs = reinterpret_cast<double *>(take(sizeof(double) * RT));
 
     auto block_reduce = [&](double v0, double v1, double v2, double v3, int op0, int op1, int op2, int op3) {
         auto wr = [&](double v, int op) { return op == 0 ? wsum(v) : (op == 1 ? wmax(v) : wmin(v)); };
@@ -579,42 +595,73 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         }
         __syncthreads();
     };
-    // dense Cholesky K = L L^T in place (lower), then L L^T dy = rhs
-    auto factor = [&]() -> bool {
-        if (tid == 0) S.ok = 1;
-        __syncthreads();
-        for (int j = 0; j < P; j++) {
-            if (tid == 0) {
-                const double d = S.K[j * KL + j];
-                if (!(d > 0.0)) S.ok = 0;
-                S.K[j * KL + j] = sqrt(d > 0.0 ? d : 1.0);
-            }
-            __syncthreads();
-            if (tid > j && tid < P) S.K[tid * KL + j] /= S.K[j * KL + j];
-            __syncthreads();
-            const int nrem = P - j - 1;
-            for (int e = tid; e < nrem * nrem; e += GT) {
-                const int i = j + 1 + e / nrem, k = j + 1 + e % nrem;
-                if (k <= i) S.K[i * KL + k] -= S.K[i * KL + j] * S.K[k * KL + j];
-            }
-            __syncthreads();
+    // dense Cholesky K = L L^T, then L L^T dy = rhs -- both on wave 0 alone, without barriers: lane = row.  The factor runs
+    // right-looking in registers (a[c] = K[lane][c]; column j is scaled by the pivot read through v_readlane, and every later
+    // column k takes l * L[k][j] with L[k][j] again a v_readlane: ~P^2/2 readlane + fma pairs, no LDS traffic), L goes back
+    // to LDS once; the substitutions chain readlane -> mul -> fma per unknown with the factor's entries streaming in from LDS
+    // ahead of the chain (they do not depend on it).
+    auto rl = [&](double v, int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    };
+    // (PU: compile-time bound of the unrolled loops, 45 without and 55 with the explicit slack variables; rows and columns
+    // P..PU-1 are the identity)
+    auto factor_w0 = [&](auto pu) {
+        constexpr int PU = decltype(pu)::value;
+        const int lr = lane < PU ? lane : PU - 1;
+        double av[PU];
+#pragma unroll
+        for (int c = 0; c < PU; c++) av[c] = (lane < P && c <= lane) ? S.K[lr * KL + c] : ((c == lane) ? 1.0 : 0.0);
+        bool ok = true;
+        double myinv = 1.0;
+#pragma unroll
+        for (int j = 0; j < PU; j++) {
+            const double d = rl(av[j], j);
+            if (!(d > 0.0)) ok = false;
+            const double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+            const double l = av[j] * inv;
+            av[j] = l;
+            if (lane == j) myinv = inv;
+#pragma unroll
+            for (int k = j + 1; k < PU; k++) av[k] = fma(-l, rl(l, k), av[k]);
         }
+        if (lane < P) {
+#pragma unroll
+            for (int c = 0; c < PU; c++) if (c <= lane) S.K[lr * KL + c] = av[c];
+            S.invd[lane] = myinv;
+        }
+        if (lane == 0) S.ok = ok ? 1 : 0;
+    };
+    auto factor = [&]() -> bool {
+        if (wave == 0) {
+            if (P <= 45) factor_w0(std::integral_constant<int, 45>{});
+            else factor_w0(std::integral_constant<int, PMAX>{});
+        }
+        __syncthreads();
         return S.ok != 0;
+    };
+    auto solve_w0 = [&](auto pu) {
+        constexpr int PU = decltype(pu)::value;
+        const int lr = lane < PU ? lane : PU - 1;
+        double b = lane < P ? S.rhs[lane] : 0.0;
+        const double myinv = lane < P ? S.invd[lane] : 1.0;
+#pragma unroll
+        for (int j = 0; j < PU; j++) {
+            const double l = S.K[lr * KL + j];
+            const double bj = rl(b, j) * rl(myinv, j);
+            b = lane == j ? bj : ((lane > j && lane < P) ? fma(-l, bj, b) : b);
+        }
+#pragma unroll
+        for (int j = PU - 1; j >= 0; j--) {
+            const double l = S.K[j * KL + lr];
+            const double bj = rl(b, j) * rl(myinv, j);
+            b = lane == j ? bj : ((lane < j && j < P) ? fma(-l, bj, b) : b);
+        }
+        if (lane < P) S.dy[lane] = b;
     };
     auto solve = [&]() {
         if (wave == 0) {
-            double b = lane < P ? S.rhs[lane] : 0.0;
-            for (int j = 0; j < P; j++) {
-                double bj = __shfl(b, j, 64) / S.K[j * KL + j];
-                if (lane == j) b = bj;
-                else if (lane > j && lane < P) b -= S.K[lane * KL + j] * bj;
-            }
-            for (int j = P - 1; j >= 0; j--) {
-                double bj = __shfl(b, j, 64) / S.K[j * KL + j];
-                if (lane == j) b = bj;
-                else if (lane < j) b -= S.K[j * KL + lane] * bj;
-            }
-            if (lane < P) S.dy[lane] = b;
+            if (P <= 45) solve_w0(std::integral_constant<int, 45>{});
+            else solve_w0(std::integral_constant<int, PMAX>{});
         }
         __syncthreads();
         compute_x(S.dy, S.dx, false);
@@ -657,123 +704,162 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         return o;
     };
 
-    // ------------------------------------------------------------------ cold start (least-squares point, then shift)
-    int status = LSC_STATUS_INFEASIBLE_K, iters = 0;
+    // ------------------------------------------------------------------ starts
+    // Warm (from the third tick on): y = free control points of the shifted previous plan, every row centred on mu0 -- the
+    // start of lsc_plan_kernel -- with the cold start (least-squares point, then shift) as fallback; cold only otherwise.
+    int status = LSC_STATUS_INFEASIBLE_K, iters = 0, spent = 0;
     double obj = 0.0;
-    bool run = true;
-    if (a.goal_err && a.goal_err[qi] != 0) { status = LSC_STATUS_GOAL_K; run = false; }
-    else if (a.sfc_err && a.sfc_err[qi] != 0) { status = LSC_STATUS_SFC_K; run = false; }
-    if (run) {
-        compute_x(S.y, S.x, true);
-        __syncthreads();
-        for_rows([&](int r, double av, double, double h) { rt2[r] = av - h; rz[r] = 0.0; });
-        if (tid == 0) S.sc[7] = 1.0;                                  // unit weights in solve()'s back-substitution
-        __syncthreads();
-        reduce_rows(true, true);
-        assemble(true);
-        if (!factor()) run = false;
-    }
-    if (run) {
-        solve();
-        if (tid < P) S.y[tid] = S.dy[tid];
-        for (int g = tid; g < NGR; g += GT) ev[g] = dev[g];
-        __syncthreads();
-        compute_x(S.y, S.x, true);
-        __syncthreads();
-        double mins = 1e300, minz = 1e300;
-        for_rows([&](int r, double av, double, double h) {
-            const double sl = h - av;
-            rs[r] = sl; rz[r] = -sl;
-            mins = fmin(mins, sl); minz = fmin(minz, -sl);
-        });
-        block_reduce(mins, minz, 0, 0, 2, 2, 0, 0);
-        const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0, shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
-        for_rows([&](int r, double, double, double) { rs[r] += shs; rz[r] += shz; });
-        if (tid == 0) S.sc[7] = 0.0;
-        __syncthreads();
-    }
+    bool can = true;
+    if (a.goal_err && a.goal_err[qi] != 0) { status = LSC_STATUS_GOAL_K; can = false; }
+    else if (a.sfc_err && a.sfc_err[qi] != 0) { status = LSC_STATUS_SFC_K; can = false; }
+    const bool try_warm = md.ws_mu0 > 0.0 && a.planner_seq >= 2;
+    for (int attempt = try_warm ? 0 : 1; can && attempt < 2; attempt++) {
+        bool run = true;
+        iters = 0;
+        if (attempt == 0) {
+            const double mu0 = md.ws_mu0, smin = sqrt(mu0);
+            if (tid < P0) {
+                const int k = tid / nya, aa = tid % nya;
+                const int t = aa < 12 ? (aa / 3) * NC + 3 + aa % 3 : (M - 1) * NC + 3 + (aa - 12);
+                const int m = t / NC, i = t % NC;
+                const float *tp = a.traj_prev + (size_t)qi * NV + k * SEGV;
+                S.y[tid] = (double)((m < M - 1) ? tp[(m + 1) * NC + i] : tp[(M - 1) * NC + DEG]);
+            } else if (tid < P) S.y[tid] = 0.0;
+            for (int g = tid; g < NGR; g += GT) ev[g] = 0.0;
+            __syncthreads();
+            compute_x(S.y, S.x, true);
+            if (tid == 0) S.sc[7] = 0.0;
+            __syncthreads();
+            for_rows([&](int r, double av, double, double h) {
+                const int type = r < AXROWS ? r / NV : 0;
+                const double floor_s = type < 2 ? smin : (type < 4 ? smin * hv : smin * ha);
+                const double sv = fmax(h - av, floor_s);
+                rs[r] = sv; rz[r] = mu0 / sv;
+            });
+            __syncthreads();
+        } else {
+            if (tid <= PMAX) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
+            for (int g = tid; g < NGR; g += GT) { ev[g] = 0.0; dev[g] = 0.0; }
+            __syncthreads();
+            if (run) {
+                compute_x(S.y, S.x, true);
+                __syncthreads();
+                for_rows([&](int r, double av, double, double h) { rt2[r] = av - h; rz[r] = 0.0; });
+                if (tid == 0) S.sc[7] = 1.0;                                  // unit weights in solve()'s back-substitution
+                __syncthreads();
+                reduce_rows(true, true);
+                assemble(true);
+                if (!factor()) run = false;
+            }
+            if (run) {
+                solve();
+                if (tid < P) S.y[tid] = S.dy[tid];
+                for (int g = tid; g < NGR; g += GT) ev[g] = dev[g];
+                __syncthreads();
+                compute_x(S.y, S.x, true);
+                __syncthreads();
+                double mins = 1e300, minz = 1e300;
+                for_rows([&](int r, double av, double, double h) {
+                    const double sl = h - av;
+                    rs[r] = sl; rz[r] = -sl;
+                    mins = fmin(mins, sl); minz = fmin(minz, -sl);
+                });
+                block_reduce(mins, minz, 0, 0, 2, 2, 0, 0);
+                const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0, shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
+                for_rows([&](int r, double, double, double) { rs[r] += shs; rz[r] += shz; });
+                if (tid == 0) S.sc[7] = 0.0;
+                __syncthreads();
+            }
 
-    // ------------------------------------------------------------------ Mehrotra predictor-corrector
-    const int max_iters = 80;
-    while (run) {
-        if (iters >= max_iters) break;
-        // residuals, weights, predictor right-hand side
-        double gp = 0.0, rpm = 0.0;
-        for_rows([&](int r, double av, double, double h) {
-            const double sv = rs[r], zv = rz[r];
-            const double rp = av + sv - h, w = zv / sv;
-            rt1[r] = w; rt2[r] = w * rp;
-            gp += sv * zv; rpm = fmax(rpm, fabs(rp));
-        });
-        block_reduce(gp, rpm, objective(), 0, 0, 1, 0, 0);
-        const double gap = S.sc[0], rpmax = S.sc[1];
-        obj = S.sc[2];
-        const double mu = gap / nrow;
-        const bool gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
-        if (!(gap == gap) || !(rpmax == rpmax)) break;
-        reduce_rows(true, false);
-        assemble(true);
-        {
-            double rda = tid < P ? fabs(S.dy[tid]) : 0.0;
-            for (int g = tid; g < NGR; g += GT)
-                if (g / M < n_obs && grp_valid(g)) rda = fmax(rda, fabs(dev[g]));
-            block_reduce(rda, 0, 0, 0, 1, 0, 0, 0);
-            if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
         }
-        if (!factor()) {
-            if (rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) status = LSC_STATUS_OK_K;
-            break;
+
+        // -------------------------------------------------------------- Mehrotra predictor-corrector
+        const int max_iters = attempt == 0 ? 30 : 80;
+        while (run) {
+            if (iters >= max_iters) break;
+            // residuals, weights, predictor right-hand side
+            double gp = 0.0, rpm = 0.0;
+            for_rows([&](int r, double av, double, double h) {
+                const double sv = rs[r], zv = rz[r];
+                const double rp = av + sv - h, w = zv / sv;
+                rt1[r] = w; rt2[r] = w * rp;
+                gp += sv * zv; rpm = fmax(rpm, fabs(rp));
+            });
+            block_reduce(gp, rpm, objective(), 0, 0, 1, 0, 0);
+            const double gap = S.sc[0], rpmax = S.sc[1];
+            obj = S.sc[2];
+            const double mu = gap / nrow;
+            const bool gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
+            if (!(gap == gap) || !(rpmax == rpmax)) break;
+            reduce_rows(true, false);
+            assemble(true);
+            {
+                double rda = tid < P ? fabs(S.dy[tid]) : 0.0;
+                for (int g = tid; g < NGR; g += GT)
+                    if (g / M < n_obs && grp_valid(g)) rda = fmax(rda, fabs(dev[g]));
+                block_reduce(rda, 0, 0, 0, 1, 0, 0, 0);
+                if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
+            }
+            if (!factor()) {
+                if (rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) status = LSC_STATUS_OK_K;
+                break;
+            }
+            solve();
+            // affine step length and centring statistics
+            double amin = 1.0, s1 = 0.0, s2 = 0.0;
+            for_rows([&](int r, double av, double adv, double h) {
+                const double sv = rs[r], zv = rz[r], w = rt1[r];
+                const double rp = av + sv - h;
+                const double ds = -rp - adv, dz = -zv - w * ds;
+                if (ds < 0.0) amin = fmin(amin, -sv / ds);
+                if (dz < 0.0) amin = fmin(amin, -zv / dz);
+                s1 += sv * dz + zv * ds; s2 += ds * dz;
+                rt2[r] = ds * dz;
+            });
+            const double dxa = tid < NV ? fabs(S.dx[tid]) : 0.0, xa = tid < NV ? fabs(S.x[tid]) : 0.0;
+            block_reduce(amin, s1, s2, dxa, 2, 0, 0, 1);
+            const double aaff = S.sc[0], ss1 = S.sc[1], ss2 = S.sc[2], dxn = S.sc[3];
+            block_reduce(xa, 0, 0, 0, 1, 0, 0, 0);
+            if (rpmax <= 1e-9 * hmax && gap_ok && dxn <= 1e-9 * fmax(1.0, S.sc[0])) { status = LSC_STATUS_OK_K; break; }
+            const double mu_aff = (gap + aaff * ss1 + aaff * aaff * ss2) / nrow;
+            double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
+            sigma = sigma * sigma * sigma;
+            const double smu = sigma * mu;
+            // corrector right-hand side, same factor
+            for_rows([&](int r, double av, double, double h) {
+                const double sv = rs[r];
+                const double rp = av + sv - h;
+                rt2[r] = rt1[r] * rp - (rt2[r] - smu) / sv;
+            });
+            __syncthreads();
+            reduce_rows(false, false);
+            assemble(false);
+            solve();
+            double amax = 1e300;
+            for_rows([&](int r, double av, double adv, double h) {
+                const double sv = rs[r], zv = rz[r], w = rt1[r];
+                const double rp = av + sv - h;
+                const double ds = -rp - adv, dz = -zv + rt2[r] + w * adv;
+                if (ds < 0.0) amax = fmin(amax, -sv / ds);
+                if (dz < 0.0) amax = fmin(amax, -zv / dz);
+                rt1[r] = ds; rt2[r] = dz;
+            });
+            block_reduce(amax, 0, 0, 0, 2, 0, 0, 0);
+            const double alpha = fmin(1.0, 0.99 * S.sc[0]);
+            for_rows([&](int r, double, double, double) { rs[r] += alpha * rt1[r]; rz[r] += alpha * rt2[r]; });
+            if (tid < P) S.y[tid] += alpha * S.dy[tid];
+            for (int g = tid; g < NGR; g += GT) ev[g] += alpha * dev[g];
+            __syncthreads();
+            compute_x(S.y, S.x, true);
+            __syncthreads();
+            iters++;
         }
-        solve();
-        // affine step length and centring statistics
-        double amin = 1.0, s1 = 0.0, s2 = 0.0;
-        for_rows([&](int r, double av, double adv, double h) {
-            const double sv = rs[r], zv = rz[r], w = rt1[r];
-            const double rp = av + sv - h;
-            const double ds = -rp - adv, dz = -zv - w * ds;
-            if (ds < 0.0) amin = fmin(amin, -sv / ds);
-            if (dz < 0.0) amin = fmin(amin, -zv / dz);
-            s1 += sv * dz + zv * ds; s2 += ds * dz;
-            rt2[r] = ds * dz;
-        });
-        const double dxa = tid < NV ? fabs(S.dx[tid]) : 0.0, xa = tid < NV ? fabs(S.x[tid]) : 0.0;
-        block_reduce(amin, s1, s2, dxa, 2, 0, 0, 1);
-        const double aaff = S.sc[0], ss1 = S.sc[1], ss2 = S.sc[2], dxn = S.sc[3];
-        block_reduce(xa, 0, 0, 0, 1, 0, 0, 0);
-        if (rpmax <= 1e-9 * hmax && gap_ok && dxn <= 1e-9 * fmax(1.0, S.sc[0])) { status = LSC_STATUS_OK_K; break; }
-        const double mu_aff = (gap + aaff * ss1 + aaff * aaff * ss2) / nrow;
-        double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
-        sigma = sigma * sigma * sigma;
-        const double smu = sigma * mu;
-        // corrector right-hand side, same factor
-        for_rows([&](int r, double av, double, double h) {
-            const double sv = rs[r];
-            const double rp = av + sv - h;
-            rt2[r] = rt1[r] * rp - (rt2[r] - smu) / sv;
-        });
-        __syncthreads();
-        reduce_rows(false, false);
-        assemble(false);
-        solve();
-        double amax = 1e300;
-        for_rows([&](int r, double av, double adv, double h) {
-            const double sv = rs[r], zv = rz[r], w = rt1[r];
-            const double rp = av + sv - h;
-            const double ds = -rp - adv, dz = -zv + rt2[r] + w * adv;
-            if (ds < 0.0) amax = fmin(amax, -sv / ds);
-            if (dz < 0.0) amax = fmin(amax, -zv / dz);
-            rt1[r] = ds; rt2[r] = dz;
-        });
-        block_reduce(amax, 0, 0, 0, 2, 0, 0, 0);
-        const double alpha = fmin(1.0, 0.99 * S.sc[0]);
-        for_rows([&](int r, double, double, double) { rs[r] += alpha * rt1[r]; rz[r] += alpha * rt2[r]; });
-        if (tid < P) S.y[tid] += alpha * S.dy[tid];
-        for (int g = tid; g < NGR; g += GT) ev[g] += alpha * dev[g];
-        __syncthreads();
-        compute_x(S.y, S.x, true);
-        __syncthreads();
-        iters++;
+
+        if (status == LSC_STATUS_OK_K) break;
+        spent += iters;
+        iters = 0;
     }
+    iters += spent;
 
     // ------------------------------------------------------------------ output (same conventions as lsc_plan_kernel)
     float *out = a.traj_next + (size_t)qi * NV;
@@ -803,6 +889,24 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     __syncthreads();
 }
 
+// Per-workgroup row workspace (per-row state of the interior point, collision rows of all obstacles).  As much of it as
+// fits behind the solver state lives in LDS (all but one array at N = 64), the rest in HBM: the row passes are chains of
+// dependent loads, an order of magnitude shorter out of LDS than out of L2.  The code is the same either way (flat
+// addressing).
+__host__ __device__ inline size_t ws_bytes_of(int N)
+{
+    const size_t nob = N - 1 > 1 ? N - 1 : 1;
+    const size_t RT = AXROWS + 2 * M + NBK * nob + M * nob;
+    size_t b = sizeof(double) * (4 * RT + NBK * nob + 4 * M * nob) + sizeof(float) * 3 * M * nob + nob + 16 * 11;
+    return (b + 255) & ~(size_t)255;
+}
+__host__ __device__ inline size_t gs_bytes() { return (sizeof(GS) + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t ws_lds_bytes(int N)
+{
+    const size_t room = 160 * 1024 - gs_bytes(), all = ws_bytes_of(N);
+    return all < room ? all : room;
+}
+
 // The agents of one workgroup, out of line: the argument block is copied into private memory HERE, not in the kernel's
 // prologue (see below).
 __device__ __attribute__((noinline)) void general_entry(const PlanArgs *ka, unsigned char *smem_raw)
@@ -812,7 +916,7 @@ __device__ __attribute__((noinline)) void general_entry(const PlanArgs *ka, unsi
     for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
         if (a.status[a.first + al] != LSC_STATUS_GENERAL_K) continue;
         __syncthreads();
-        general_agent(a, al, smem_raw, ws);
+        general_agent(a, al, smem_raw, ws, smem_raw + gs_bytes(), ws_lds_bytes(a.N));
         __syncthreads();
     }
 }
@@ -835,15 +939,9 @@ __global__ __launch_bounds__(GT) void lsc_general_kernel(PlanArgs)
     general_entry(ka, smem_raw);
 }
 
-size_t general_ws_bytes(int N)
-{
-    const size_t nob = N - 1 > 1 ? N - 1 : 1;
-    const size_t RT = AXROWS + 2 * M + NBK * nob + M * nob;
-    size_t b = sizeof(double) * (4 * RT + NBK * nob + 4 * M * nob) + sizeof(float) * 3 * M * nob + nob;
-    return (b + 255) & ~(size_t)255;
-}
+size_t general_ws_bytes(int N) { return ws_bytes_of(N); }
 
-size_t general_smem_bytes() { return (sizeof(GS) + 15) & ~(size_t)15; }
+size_t general_smem_bytes() { return gs_bytes(); }
 
 hipError_t init_device_general_kernel()
 {
@@ -854,7 +952,8 @@ hipError_t launch_general(const PlanArgs &a, int slots, hipStream_t st)
 {
     if (a.count == 0 || slots < 1 || !a.gen_ws) return hipSuccess;
     const int grid = a.count < slots ? a.count : slots;
-    hipLaunchKernelGGL(lsc_general_kernel, dim3(grid), dim3(GT), general_smem_bytes(), st, a);
+    const size_t smem = gs_bytes() + ws_lds_bytes(a.N);
+    hipLaunchKernelGGL(lsc_general_kernel, dim3(grid), dim3(GT), smem, st, a);
     return hipGetLastError();
 }
 
