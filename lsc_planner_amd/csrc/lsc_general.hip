@@ -43,7 +43,7 @@ struct GS {
     double x[96], dx[96];
     double y[PMAX + 1], dy[PMAX + 1], rhs[PMAX + 1];
     double K[PMAX * KL];
-    double invd[PMAX + 1];         // reciprocal diagonal of the Cholesky factor
+    double invd[PMAX + 1];         // 1 / D of K = L D L^T
     double gv[96], gz[96];         // x-space: cost gradient + sum vv_r a_r  /  + sum z_r a_r
     double Wd[NV], W1[NV], W2[NV]; // x-space Hessian pieces of the bound / velocity / acceleration rows
     double Ws[NCP * 6];            // per control point: sum w n n^T (xx xy xz yy yz zz)
@@ -541,9 +541,11 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     // dense reduced system: K (lower triangle) and rhs = q_y - sum_g m_g q_g / D_g ; stationarity residual in dy
     auto assemble = [&](bool with_k) {
         if (with_k)
-            for (int e = tid; e < P * P; e += GT) {
-                const int r = e / P, c = e % P;
-                if (c > r) continue;
+            for (int e = tid; e < P * (P + 1) / 2; e += GT) {       // lower triangle, row-major: e = r (r + 1) / 2 + c
+                int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                if (r * (r + 1) / 2 > e) r--;
+                else if ((r + 1) * (r + 2) / 2 <= e) r++;
+                const int c = e - r * (r + 1) / 2;
                 double v = 0.0;
                 if (r < P0 && c < P0) {
                     const int k = r / nya, aa = r % nya, kk = c / nya, bb = c % nya;
@@ -595,11 +597,11 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         }
         __syncthreads();
     };
-    // dense Cholesky K = L L^T, then L L^T dy = rhs -- both on wave 0 alone, without barriers: lane = row.  The factor runs
-    // right-looking in registers (a[c] = K[lane][c]; column j is scaled by the pivot read through v_readlane, and every later
-    // column k takes l * L[k][j] with L[k][j] again a v_readlane: ~P^2/2 readlane + fma pairs, no LDS traffic), L goes back
-    // to LDS once; the substitutions chain readlane -> mul -> fma per unknown with the factor's entries streaming in from LDS
-    // ahead of the chain (they do not depend on it).
+    // dense K = L D L^T (L unit lower), then L D L^T dy = rhs -- both on wave 0 alone, without barriers: lane = row.  The
+    // factor runs right-looking in registers (a[c] = K[lane][c]; column j is scaled by the pivot read through v_readlane, and
+    // every later column k takes l * l_k with l_k again a v_readlane: ~P^2/2 readlane + fma pairs, no LDS traffic), L and 1/D
+    // go back to LDS once; the substitutions chain readlane -> fma per unknown (no division on the chain) with the factor's
+    // entries streaming in from LDS ahead of the chain (they do not depend on it).
     auto rl = [&](double v, int l) {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
     };
@@ -619,14 +621,14 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
             if (!(d > 0.0)) ok = false;
             const double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
             const double l = av[j] * inv;
-            av[j] = l;
-            if (lane == j) myinv = inv;
+            av[j] = l * inv;                               // stored: unit-lower column of K = L D L^T ...
+            if (lane == j) myinv = inv * inv;              // ... and 1 / D: no division on the substitution chains
 #pragma unroll
             for (int k = j + 1; k < PU; k++) av[k] = fma(-l, rl(l, k), av[k]);
         }
         if (lane < P) {
 #pragma unroll
-            for (int c = 0; c < PU; c++) if (c <= lane) S.K[lr * KL + c] = av[c];
+            for (int c = 0; c < PU; c++) if (c < lane) S.K[lr * KL + c] = av[c];
             S.invd[lane] = myinv;
         }
         if (lane == 0) S.ok = ok ? 1 : 0;
@@ -647,14 +649,13 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
 #pragma unroll
         for (int j = 0; j < PU; j++) {
             const double l = S.K[lr * KL + j];
-            const double bj = rl(b, j) * rl(myinv, j);
-            b = lane == j ? bj : ((lane > j && lane < P) ? fma(-l, bj, b) : b);
+            b = (lane > j && lane < P) ? fma(-l, rl(b, j), b) : b;
         }
+        b *= myinv;
 #pragma unroll
         for (int j = PU - 1; j >= 0; j--) {
             const double l = S.K[j * KL + lr];
-            const double bj = rl(b, j) * rl(myinv, j);
-            b = lane == j ? bj : ((lane < j && j < P) ? fma(-l, bj, b) : b);
+            b = (lane < j && j < P) ? fma(-l, rl(b, j), b) : b;
         }
         if (lane < P) S.dy[lane] = b;
     };
