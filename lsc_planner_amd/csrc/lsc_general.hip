@@ -13,8 +13,8 @@
 // couple all control points of a segment), which the banded, register-resident solver of lsc_plan_kernel is built around.
 // They are off the reference's default path (every shipped launch file runs mode/planner = lsc, slack none, and the
 // disturbance checks only fire on a real disturbance), so this kernel trades speed for generality: dense reduced-space
-// Mehrotra interior point, all rows in an HBM workspace, no pruning, cold start -- the same algorithm as the fast path,
-// none of its structure.  Agents reach it through status LSC_STATUS_GENERAL_K set by lsc_plan_kernel's phase A.
+// Mehrotra interior point over all rows (no pruning; row arrays in LDS as far as it reaches, the rest in an HBM workspace),
+// warm start with the cold start as fallback -- the same algorithm as the fast path, little of its structure.  Agents reach it through status LSC_STATUS_GENERAL_K set by lsc_plan_kernel's phase A.
 //
 // Unknowns: y (3 x nya free control-point coordinates, nya = 13 with / 15 without the stop rows), the 2M slack variables
 // of DYNAMICALLIMIT as explicit unknowns, and one slack variable per (slack obstacle, segment) that is eliminated from
@@ -186,6 +186,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     double *ev = reinterpret_cast<double *>(take(sizeof(double) * NGR));                // [NGR]   group slack variables
     double *dev = reinterpret_cast<double *>(take(sizeof(double) * NGR));
     double *Dg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
+    double *iDg = reinterpret_cast<double *>(take(sizeof(double) * NGR));               // 1 / D_g
     double *qg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
     double *rs = reinterpret_cast<double *>(take(sizeof(double) * RT));
 
@@ -494,7 +495,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 sw += unit_w ? 1.0 : rt1[r]; svv += rt2[r]; szz += rz[r];
             }
             const double hq = wg_base * (double)(M - m);
-            if (with_w) Dg[g] = hq + sw + (unit_w ? 1.0 : rt1[GS0 + g]);
+            if (with_w) { const double dg = hq + sw + (unit_w ? 1.0 : rt1[GS0 + g]); Dg[g] = dg; iDg[g] = 1.0 / dg; }
             qg[g] = -(hq * ev[g] + svv + rt2[GS0 + g]);
             dev[g] = hq * ev[g] + szz + rz[GS0 + g];
         }
@@ -510,12 +511,13 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 const int i1 = p / 3, k1 = p % 3, i2 = q / 3, k2 = q % 3;
                 double acc = 0.0;
                 if (m < ncs && m * NC + i1 >= 3 && m * NC + i2 >= 3)
-                    for (int oi = 0; oi < n_obs; oi++) {
-                        if (!slk[oi]) continue;
+#pragma unroll 4
+                    for (int oi = 0; oi < n_obs; oi++) {                  // branch-free: the loads of several obstacles in flight
                         const float *n = nrm + 3 * (oi * M + m);
                         const double w1 = unit_w ? 1.0 : rt1[CL0 + oi * NBK + m * NC + i1 - 3];
                         const double w2 = unit_w ? 1.0 : rt1[CL0 + oi * NBK + m * NC + i2 - 3];
-                        acc += w1 * w2 * (double)n[k1] * (double)n[k2] / Dg[oi * M + m];
+                        const double t = w1 * w2 * (double)n[k1] * (double)n[k2] * iDg[oi * M + m];
+                        acc += slk[oi] ? t : 0.0;
                     }
                 S.Cm[m][e % SEG_E] = acc;
             }
@@ -523,11 +525,12 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
             const int cp = tid / 3 + 3, k = tid % 3, m = cp / NC;
             double acc = 0.0;
             if (m < ncs && S.any_slack)
+#pragma unroll 4
                 for (int oi = 0; oi < n_obs; oi++) {
-                    if (!slk[oi]) continue;
                     const int g = oi * M + m;
                     const double w = unit_w ? 1.0 : rt1[CL0 + oi * NBK + cp - 3];
-                    acc += -w * (double)nrm[3 * g + k] * qg[g] / Dg[g];
+                    const double t = -w * (double)nrm[3 * g + k] * qg[g] * iDg[g];
+                    acc += slk[oi] ? t : 0.0;
                 }
             S.cq[cp * 3 + k] = acc;
         }
@@ -898,7 +901,7 @@ __host__ __device__ inline size_t ws_bytes_of(int N)
 {
     const size_t nob = N - 1 > 1 ? N - 1 : 1;
     const size_t RT = AXROWS + 2 * M + NBK * nob + M * nob;
-    size_t b = sizeof(double) * (4 * RT + NBK * nob + 4 * M * nob) + sizeof(float) * 3 * M * nob + nob + 16 * 11;
+    size_t b = sizeof(double) * (4 * RT + NBK * nob + 5 * M * nob) + sizeof(float) * 3 * M * nob + nob + 16 * 12;
     return (b + 255) & ~(size_t)255;
 }
 __host__ __device__ inline size_t gs_bytes() { return (sizeof(GS) + 255) & ~(size_t)255; }
