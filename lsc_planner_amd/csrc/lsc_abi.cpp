@@ -234,6 +234,7 @@ struct lsc_ctx {
     double grid_min[3] = {0, 0, 0};
     std::vector<int> nb_seq;
     int *d_nrows = nullptr, *d_bmax = nullptr, *d_order = nullptr;
+    float *d_obs_bound = nullptr;
     long long *d_iters_acc = nullptr;
     long long *d_prof = nullptr;
     double *d_dbg = nullptr;
@@ -404,10 +405,10 @@ static void free_agents(lsc_ctx *c)
 {
     void *ptrs[] = {c->d_radius, c->d_radius_obs, c->d_downwash, c->d_downwash_obs, c->d_vmax, c->d_amax, c->d_vnom,
                     c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_cost,
-                    c->d_onormal, c->d_od, c->d_spill, c->d_ever, c->d_gen_ws, c->d_bmax, c->d_order};
+                    c->d_onormal, c->d_od, c->d_spill, c->d_ever, c->d_gen_ws, c->d_bmax, c->d_order, c->d_obs_bound};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     c->d_spill = nullptr; c->spill_slots = 0; c->spill_stride = 0;
-    c->d_bmax = nullptr; c->d_order = nullptr; c->d_ever = nullptr; c->d_gen_ws = nullptr; c->gen_slots = 0; c->gen_stride = 0;
+    c->d_bmax = nullptr; c->d_order = nullptr; c->d_obs_bound = nullptr; c->d_ever = nullptr; c->d_gen_ws = nullptr; c->gen_slots = 0; c->gen_stride = 0;
     if (c->h_in) { (void)hipHostFree(c->h_in); c->h_in = nullptr; }
     if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
     void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
@@ -527,6 +528,7 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMalloc(&c->d_bmax, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMemset(c->d_bmax, 0, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_order, sizeof(int) * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_obs_bound, sizeof(float) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * PROF_PHASES * (size_t)N));
@@ -759,6 +761,7 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.N = c->N; a.first = c->first; a.count = c->count; a.planner_seq = seq; a.cap = c->cap;
     a.cap_tp = (c->count > c->n_cu) ? c->cap_tp : 0; a.smem_tp = c->smem_tp;
     a.order = (c->count > 2 * c->n_cu) ? c->d_order : nullptr;   // more than one round of throughput workgroups
+    a.obs_bound = a.cap_tp > 0 ? c->d_obs_bound : nullptr;       // obstacle-level pre-cull of the throughput build
     a.state = d_state; a.goal = d_goal; a.traj_prev = d_prev;
     a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
     a.vmax = c->d_vmax; a.amax = c->d_amax; a.vnom = c->d_vnom;

@@ -22,6 +22,7 @@ struct PlanArgs {
     int N, first, count, planner_seq;
     int cap;                   // LSC rows the LDS pass holds (total over the 27 control points; compact layout)
     int *order;                // throughput build: launch order of the shard's agents (longest first), or null
+    float *obs_bound;          // throughput build: [N][4] bounding sphere of every agent's predicted control points, or null
     int cap_tp;                // > 0: use the 256-lane throughput build with this row capacity and smem_tp bytes of LDS
     size_t smem_tp;
     const float *state;        // [N][9]

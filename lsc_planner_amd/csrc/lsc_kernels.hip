@@ -453,6 +453,7 @@ struct SmemT {
     uint32_t offcnt[32];        // offs | cnt << 16 per bucket (LDS pass: both below 65536), one load per reduction unit
     int wcnt[NWAVE][32];
     double cullB[M];            // phase B pre-cull: per segment max_i(|c_{0,2} - p_{m,i}| + reach radius of c_{m,i})
+    double cullA[2];            // obstacle-level cull: rho_a = max |c_{0,2} - p| over the own points, max_m cullB[m]
     int cullc[NWAVE + 1];       // survivors of the pre-cull per wave (compaction)
     int ntmp;                   // rows appended in phase B (arrival order), listfull: the pre-cull list overflowed
     int listfull;
@@ -941,12 +942,61 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 S.cullB[m] = b;
             }
             __syncthreads();
+            // Obstacle level first (throughput build: lsc_prep_kernel left a bounding sphere (B_o, rho_o) of every agent's
+            // predicted control points): all w_j of all segments lie in the ball around D = c_{0,2} - B_o (scaled space) of
+            // radius s (rho_a + rho_o), so |w_c| >= |D| - s (rho_a + rho_o) and R_w <= 2 s (rho_a + rho_o); hence
+            //   |D| >= s (3 (rho_a + rho_o) + 2 max_m B_m) + (r_a + r_o) + margin
+            // implies the per-segment test below for all five segments.  Survivors keep their order, so the unit list --
+            // and with it every plan -- is the same as without this level.
+            uint16_t *olist = reinterpret_cast<uint16_t *>(rs);      // the (rs .. rt2) slots are first written by the GJK pass
+            const bool lvl0 = a.obs_bound != nullptr && n_obs <= (SPILL ? 0x7fffffff : 16 * R);
+            int n_o = n_obs;
+            if (lvl0) {
+                if (tid == 0) {
+                    double ra2 = 0.0, bm = 0.0;
+                    for (int c = 0; c < SEGV; c++) {
+                        double d2 = 0.0;
+                        for (int k = 0; k < 3; k++) { const double dd = S.s0[k][2] - (double)S.pinit[k * SEGV + c]; d2 += dd * dd; }
+                        ra2 = fmax(ra2, d2);
+                    }
+                    for (int m = 0; m < M; m++) bm = fmax(bm, S.cullB[m]);
+                    S.cullA[0] = sqrt(ra2); S.cullA[1] = bm;
+                }
+                __syncthreads();
+                int tot0 = 0;
+                for (int base = 0; base < n_obs; base += NT) {
+                    const int oi = base + tid;
+                    bool keep = false;
+                    if (oi < n_obs) {
+                        const int qj = oi < qi ? oi : oi + 1;
+                        const float4 bo = reinterpret_cast<const float4 *>(a.obs_bound)[qj];
+                        const double r_o = a.radius_obs[qj];
+                        const double downwash = (dw_a * r_a + a.downwash_obs[qj] * r_o) / (r_a + r_o);
+                        const double idw = 1.0 / downwash, sc = fmax(1.0, idw);
+                        const double dx = S.s0[0][2] - (double)bo.x, dy = S.s0[1][2] - (double)bo.y, dz = (S.s0[2][2] - (double)bo.z) * idw;
+                        const double need = sc * (3.0 * (S.cullA[0] + (double)bo.w) + 2.0 * S.cullA[1]) + (r_o + r_a) + 2e-4 + 1e-6;
+                        keep = !(dx * dx + dy * dy + dz * dz >= need * need);
+                    }
+                    const unsigned long long mask = __ballot(keep);
+                    if (lane == 0) S.cullc[wave] = __popcll(mask);
+                    __syncthreads();
+                    int off = tot0;
+                    for (int w = 0; w < wave; w++) off += S.cullc[w];
+                    if (keep) olist[off + __popcll(mask & lt_mask)] = (uint16_t)oi;
+                    for (int w = 0; w < NWAVE; w++) tot0 += S.cullc[w];
+                    __syncthreads();
+                }
+                n_o = tot0;
+            }
+            const int n_units1 = n_o * M;
             int total = 0;
-            for (int base = 0; base < n_units; base += NT) {
-                const int u = base + tid;
+            for (int base = 0; base < n_units1; base += NT) {
+                const int u1 = base + tid;
                 bool keep = false;
-                if (u < n_units) {
-                    const int oi = u / M, m = u % M, qj = oi < qi ? oi : oi + 1;
+                const int oi = u1 < n_units1 ? (lvl0 ? (int)olist[u1 / M] : u1 / M) : 0, m = u1 % M;
+                const int u = oi * M + m;
+                if (u1 < n_units1) {
+                    const int qj = oi < qi ? oi : oi + 1;
                     F3 po[6];
                     load_segment(a.state, a.traj_prev, qj, m, a.planner_seq, dtf, po);
                     const double r_o = a.radius_obs[qj];
@@ -1816,15 +1866,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     plan_agent<false, false, true, 256>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
 }
 
-// Launch order of the throughput build: the shard takes several rounds of workgroups there, and the tick ends with the
-// last one, so the agents that were expensive in the previous tick (iterations x rows) go first and the cheap ones fill
-// the gaps (longest-processing-time-first list scheduling; the hardware dispatches workgroups in blockIdx order).
-// Any content of iters / nrows gives a permutation; results do not depend on it.
-__global__ __launch_bounds__(256) void lsc_order_kernel(const int *iters, const int *nrows, int first, int count, int *order)
+// Preparation pass of the throughput build, one thread per agent of the whole swarm:
+//  * bounding sphere (centre, radius; float32, radius rounded up) of the agent's predicted control points of all segments --
+//    what every OTHER agent's obstacle-level pre-cull tests against (phase B of plan_agent);
+//  * launch order of the shard (only when it takes more than one round of workgroups): the tick ends with the last
+//    workgroup, so the agents that were expensive in the previous tick (iterations x rows) go first and the cheap ones
+//    fill the gaps (longest-processing-time-first list scheduling; the hardware dispatches workgroups in blockIdx order).
+//    Any content of iters / nrows gives a permutation; results do not depend on it.
+__global__ __launch_bounds__(256) void lsc_prep_kernel(PlanArgs a)
 {
     constexpr int TILE = 2048;
     __shared__ long long tile[TILE];
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.obs_bound && q < a.N) {
+        const float dtf = (float)a.model->dt;
+        double cx = 0.0, cy = 0.0, cz = 0.0;
+        for (int m = 0; m < M; m++) {
+            F3 po[6];
+            load_segment(a.state, a.traj_prev, q, m, a.planner_seq, dtf, po);
+#pragma unroll
+            for (int i = 0; i < 6; i++) { cx += (double)po[i].x; cy += (double)po[i].y; cz += (double)po[i].z; }
+        }
+        const float fx = (float)(cx / SEGV), fy = (float)(cy / SEGV), fz = (float)(cz / SEGV);
+        double r2 = 0.0;
+        for (int m = 0; m < M; m++) {
+            F3 po[6];
+            load_segment(a.state, a.traj_prev, q, m, a.planner_seq, dtf, po);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double ex = (double)po[i].x - (double)fx, ey = (double)po[i].y - (double)fy, ez = (double)po[i].z - (double)fz;
+                r2 = fmax(r2, ex * ex + ey * ey + ez * ez);
+            }
+        }
+        const float rad = (float)(sqrt(r2) * (1.0 + 1e-6) + 1e-6);      // never below the true radius after the float32 rounding
+        reinterpret_cast<float4 *>(a.obs_bound)[q] = make_float4(fx, fy, fz, rad);
+    }
+    if (!a.order) return;
+    const int *iters = a.iters, *nrows = a.nrows;
+    const int first = a.first, count = a.count;
     auto cost = [&](int p) { return (long long)iters[first + p] * (long long)(nrows[first + p] + 600); };
     const long long cq = q < count ? cost(q) : 0;
     int r = 0;
@@ -1838,7 +1917,7 @@ __global__ __launch_bounds__(256) void lsc_order_kernel(const int *iters, const 
             r += (cp > cq) || (cp == cq && p0 + p < q);
         }
     }
-    if (q < count) order[r] = q;
+    if (q < count) a.order[r] = q;
 }
 
 // Second pass: agents whose rows did not fit the LDS capacity of the first pass are solved again with their rows in
@@ -1906,22 +1985,26 @@ hipError_t init_device_kernels()
     return init_device_goal_kernel();
 }
 
+// whether this launch takes the throughput build (and with it lsc_prep_kernel's bounds / order)
+static bool uses_throughput_build(const PlanArgs &a) { return a.cap_tp > 0 && !a.prof && !a.out_normal && !a.trace; }
+
 hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;          // empty shard (more ranks than agents): nothing to plan
     const bool alt = a.general_all || (a.reset_thr > 0.0 && a.ever);
-    if (a.cap_tp > 0 && !a.prof && !a.out_normal && !a.trace) {
+    PlanArgs t = a;
+    if (uses_throughput_build(a)) {
         // throughput build: smaller capacity (an agent beyond it takes the second pass), two workgroups per CU
-        PlanArgs t = a;
         t.cap = a.cap_tp;
-        if (t.order) hipLaunchKernelGGL(lsc_order_kernel, dim3((a.count + 255) / 256), dim3(256), 0, st, a.iters, a.nrows, a.first, a.count, a.order);
+        if (t.order || t.obs_bound) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? a.N : a.count) + 255) / 256), dim3(256), 0, st, t);
         if (alt) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
         else hipLaunchKernelGGL(lsc_plan_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
         return hipGetLastError();
     }
-    if (alt) hipLaunchKernelGGL(lsc_plan_alt_kernel, dim3(a.count), dim3(NT), smem, st, a);
-    else if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, a);
-    else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, a);
+    t.order = nullptr; t.obs_bound = nullptr;     // filled by lsc_prep_kernel only
+    if (alt) hipLaunchKernelGGL(lsc_plan_alt_kernel, dim3(a.count), dim3(NT), smem, st, t);
+    else if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, t);
+    else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, t);
     return hipGetLastError();
 }
 
@@ -1929,7 +2012,9 @@ hipError_t launch_plan_spill(const PlanArgs &a, int slots, size_t smem, hipStrea
 {
     if (a.count == 0 || slots < 1 || !a.spill_ws) return hipSuccess;
     const int grid = a.count < slots ? a.count : slots;
-    hipLaunchKernelGGL(lsc_plan_spill_kernel, dim3(grid), dim3(NT), smem, st, a);
+    PlanArgs t = a;
+    if (!uses_throughput_build(a)) t.obs_bound = nullptr;      // (bounds of this tick exist only behind the throughput launch)
+    hipLaunchKernelGGL(lsc_plan_spill_kernel, dim3(grid), dim3(NT), smem, st, t);
     return hipGetLastError();
 }
 

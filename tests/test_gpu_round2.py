@@ -293,7 +293,7 @@ def test_throughput_build_agrees_with_the_latency_build(L, n, world, reset_thres
     row capacity, assembly tables read from L2); max_rows_per_cp = 64 pins the 512-lane latency build.  Same rows, same
     statuses; costs and plans within the parity tolerances (block reductions combine 4 instead of 8 partial sums).
     The second case has more than two workgroups per CU, so the launch is ordered longest-agent-first by the previous
-    tick's iterations and rows (lsc_order_kernel), and runs the build with the disturbance checks compiled in."""
+    tick's iterations and rows (lsc_prep_kernel), and runs the build with the disturbance checks compiled in."""
     from lsc_planner_amd.planner import next_state_host
     ms = L.random_swarm(n, world=world, seed=9)
     tp = L.SwarmPlanner(ms, L.PlannerConfig(reset_threshold=reset_threshold))
