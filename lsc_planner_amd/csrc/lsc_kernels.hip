@@ -1866,8 +1866,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     plan_agent<false, false, true, 256>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
 }
 
-// Preparation pass of the throughput build, one thread per agent of the whole swarm:
-//  * bounding sphere (centre, radius; float32, radius rounded up) of the agent's predicted control points of all segments --
+// Preparation pass of the throughput build:
+//  * bounding sphere (centre, radius; float32, radius rounded up) of the agent's predicted control points of all segments
+//    (32 lanes per agent) --
 //    what every OTHER agent's obstacle-level pre-cull tests against (phase B of plan_agent);
 //  * launch order of the shard (only when it takes more than one round of workgroups): the tick ends with the last
 //    workgroup, so the agents that were expensive in the previous tick (iterations x rows) go first and the cheap ones
@@ -1876,48 +1877,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 __global__ __launch_bounds__(256) void lsc_prep_kernel(PlanArgs a)
 {
     constexpr int TILE = 2048;
-    __shared__ long long tile[TILE];
+    __shared__ unsigned tile[TILE];
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a.obs_bound && q < a.N) {
-        const float dtf = (float)a.model->dt;
-        double cx = 0.0, cy = 0.0, cz = 0.0;
-        for (int m = 0; m < M; m++) {
-            F3 po[6];
-            load_segment(a.state, a.traj_prev, q, m, a.planner_seq, dtf, po);
+    if (a.obs_bound) {
+        // 32 lanes per agent, one predicted control point each (lanes 30, 31 repeat the last one)
+        const int qa = q >> 5, pi = (q & 31) < SEGV ? (q & 31) : SEGV - 1;
+        const bool live = qa < a.N;
+        F3 po[6];
+        load_segment(a.state, a.traj_prev, live ? qa : 0, pi / NC, a.planner_seq, (float)a.model->dt, po);
+        F3 me = po[0];
 #pragma unroll
-            for (int i = 0; i < 6; i++) { cx += (double)po[i].x; cy += (double)po[i].y; cz += (double)po[i].z; }
-        }
-        const float fx = (float)(cx / SEGV), fy = (float)(cy / SEGV), fz = (float)(cz / SEGV);
-        double r2 = 0.0;
-        for (int m = 0; m < M; m++) {
-            F3 po[6];
-            load_segment(a.state, a.traj_prev, q, m, a.planner_seq, dtf, po);
+        for (int i = 1; i < 6; i++) if (pi % NC == i) me = po[i];
+        double cx = (double)me.x, cy = (double)me.y, cz = (double)me.z;
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                const double ex = (double)po[i].x - (double)fx, ey = (double)po[i].y - (double)fy, ez = (double)po[i].z - (double)fz;
-                r2 = fmax(r2, ex * ex + ey * ey + ez * ez);
-            }
-        }
+        for (int o = 16; o > 0; o >>= 1) { cx += __shfl_xor(cx, o, 32); cy += __shfl_xor(cy, o, 32); cz += __shfl_xor(cz, o, 32); }
+        // any centre will do as long as the radius is taken around the float32 centre that is stored
+        const float fx = (float)(cx * (1.0 / 32.0)), fy = (float)(cy * (1.0 / 32.0)), fz = (float)(cz * (1.0 / 32.0));
+        const double ex = (double)me.x - (double)fx, ey = (double)me.y - (double)fy, ez = (double)me.z - (double)fz;
+        double r2 = ex * ex + ey * ey + ez * ez;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) r2 = fmax(r2, __shfl_xor(r2, o, 32));
         const float rad = (float)(sqrt(r2) * (1.0 + 1e-6) + 1e-6);      // never below the true radius after the float32 rounding
-        reinterpret_cast<float4 *>(a.obs_bound)[q] = make_float4(fx, fy, fz, rad);
+        if (live && (q & 31) == 0) reinterpret_cast<float4 *>(a.obs_bound)[qa] = make_float4(fx, fy, fz, rad);
     }
-    if (!a.order) return;
+    // rank of agent qo among the shard's agents by cost, descending (ties: lower index first); 16 lanes per agent, each
+    // counting every 16th competitor out of an LDS tile
+    const int count = a.count, first = a.first;
+    if (!a.order || (int)((blockIdx.x * blockDim.x) >> 4) >= count) return;   // (whole blocks leave: the loop below has barriers)
     const int *iters = a.iters, *nrows = a.nrows;
-    const int first = a.first, count = a.count;
-    auto cost = [&](int p) { return (long long)iters[first + p] * (long long)(nrows[first + p] + 600); };
-    const long long cq = q < count ? cost(q) : 0;
+    auto cost = [&](int p) { return (unsigned)iters[first + p] * (unsigned)(nrows[first + p] + 600); };
+    const int qo = q >> 4, part = q & 15;
+    const unsigned cq = qo < count ? cost(qo) : 0u;
     int r = 0;
     for (int p0 = 0; p0 < count; p0 += TILE) {
         const int n = count - p0 < TILE ? count - p0 : TILE;
         __syncthreads();
         for (int p = threadIdx.x; p < n; p += blockDim.x) tile[p] = cost(p0 + p);
         __syncthreads();
-        for (int p = 0; p < n; ++p) {          // uniform address: one LDS broadcast per step
-            const long long cp = tile[p];
-            r += (cp > cq) || (cp == cq && p0 + p < q);
+        for (int p = part; p < n; p += 16) {
+            const unsigned cp = tile[p];
+            r += (cp > cq) || (cp == cq && p0 + p < qo);
         }
     }
-    if (q < count) a.order[r] = q;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) r += __shfl_xor(r, o, 16);
+    if (qo < count && part == 0) a.order[r] = qo;
 }
 
 // Second pass: agents whose rows did not fit the LDS capacity of the first pass are solved again with their rows in
@@ -1996,7 +2000,7 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     if (uses_throughput_build(a)) {
         // throughput build: smaller capacity (an agent beyond it takes the second pass), two workgroups per CU
         t.cap = a.cap_tp;
-        if (t.order || t.obs_bound) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? a.N : a.count) + 255) / 256), dim3(256), 0, st, t);
+        if (t.order || t.obs_bound) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
         if (alt) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
         else hipLaunchKernelGGL(lsc_plan_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
         return hipGetLastError();

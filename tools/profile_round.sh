@@ -10,23 +10,27 @@ export TMPDIR=/tmp
 ROOT=$PWD
 BENCH="python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-latency-leg"
 FOREST="python $ROOT/tools/config_runs.py --only forest256p,forest256 --ticks 30 --warmup 5"
+LARGE="python $ROOT/tools/config_runs.py --only random1024 --ticks 30 --warmup 5"
 cd /tmp
 # 1. kernel trace + stats (no counters)
 rocprofv3 --kernel-trace --stats -d $OUT/stats_bench -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/stats_bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats_forest -o forest -- $FOREST > $OUT/forest_under_rocprof.jsonl 2> $OUT/stats_forest.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats_large -o large -- $LARGE > $OUT/large_under_rocprof.jsonl 2> $OUT/stats_large.err
 # 2. counters, each group in its own pass, kernel trace only
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_bench_$tag -o bench -- $BENCH --steps 30 > /dev/null 2> $OUT/pmc_bench_$tag.err
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_forest_$tag -o forest -- $FOREST --ticks 10 > /dev/null 2> $OUT/pmc_forest_$tag.err
+  rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_large_$tag -o large -- $LARGE --ticks 10 > /dev/null 2> $OUT/pmc_large_$tag.err
 done
 cd $ROOT
-for d in stats_bench stats_forest; do
+for d in stats_bench stats_forest stats_large; do
   db=$(find $OUT/$d -name "*.db" | head -1)
   [ -n "$db" ] && python profiles/summarize_rocpd.py stats $db > $OUT/$d.csv
 done
 python profiles/summarize_rocpd.py pmc $(find $OUT/pmc_bench_* -name "*.db") > $OUT/pmc_bench.json
 python profiles/summarize_rocpd.py pmc $(find $OUT/pmc_forest_* -name "*.db") > $OUT/pmc_forest.json
+python profiles/summarize_rocpd.py pmc $(find $OUT/pmc_large_* -name "*.db") > $OUT/pmc_large.json
 # the databases are large: keep only the summaries
 find $OUT -name "*.db" -delete
 ls -la $OUT
