@@ -114,6 +114,10 @@ typedef struct {
                                   the device-resident ticks                                                                 */
     double gap_tolerance;      /* interior point: duality gap <= gap_tolerance (1 + |objective|) at the optimum; 0 = 1e-9
                                   (CPLEX's barrier default, CPX_PARAM_BAREPCOMP, is 1e-8)                                   */
+    int    world_dimension;    /* world/dimension (src/param.cpp:12; 3).  2 = the goal planner's grid is the single layer
+                                  z = world_z_2d (src/grid_based_planner.cpp:82-85, 127-133, 199-215); the QP stays 3-D as in
+                                  the reference (src/traj_optimizer.cpp never looks at the dimension).  0 is read as 3       */
+    double world_z_2d;         /* world/z_2d (src/param.cpp:15; 1.0)                                                        */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);

@@ -47,6 +47,8 @@ class LscConfig(ctypes.Structure):
         ("n_constraint_segments", ctypes.c_int),
         ("reset_threshold", ctypes.c_double),
         ("gap_tolerance", ctypes.c_double),
+        ("world_dimension", ctypes.c_int),
+        ("world_z_2d", ctypes.c_double),
     ]
 
 

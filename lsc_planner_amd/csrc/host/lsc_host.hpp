@@ -124,6 +124,8 @@ struct Param {   // defaults = launch/testall_empty.launch
     bool goal_mode_prior_based = true;   // mode/goal (launch/*.launch: prior_based)
     bool world_use_octomap = false;
     double world_resolution = 0.1;
+    int world_dimension = 3;           // world/dimension (src/param.cpp:12)
+    double world_z_2d = 1.0;           // world/z_2d (src/param.cpp:15): height of every agent when world/dimension is 2
     double grid_resolution = 0.3, grid_margin = 0.2;   // grid/resolution, grid/margin (launch/testall_forest.launch:88-89)
     std::string log_dir = ".";
     int device = 0;
@@ -146,7 +148,8 @@ class Mission {
     point3d world_min, world_max;
     std::string mission_file_name, world_file_name;
 
-    bool initialize(const std::string &mission_file, const std::string &world_file = "") {
+    // world_dimension == 2: every start and goal is put at z = world_z_2d (src/mission.cpp:88-112)
+    bool initialize(const std::string &mission_file, const std::string &world_file = "", int world_dimension = 3, double world_z_2d = 1.0) {
         mission_file_name = mission_file; world_file_name = world_file;
         std::ifstream ifs(mission_file);
         if (!ifs) throw std::invalid_argument("There is no such mission file " + mission_file + "\n");
@@ -174,8 +177,8 @@ class Mission {
             agents[qi] = quad.at(a["type"].str);
             agents[qi].id = qi;
             agents[qi].cid = a.has("cid") ? (int)a["cid"].num : qi;
-            agents[qi].start_position = point3d(a["start"][0].num, a["start"][1].num, a["start"][2].num);
-            agents[qi].desired_goal_position = point3d(a["goal"][0].num, a["goal"][1].num, a["goal"][2].num);
+            agents[qi].start_position = point3d(a["start"][0].num, a["start"][1].num, world_dimension == 2 ? world_z_2d : a["start"][2].num);
+            agents[qi].desired_goal_position = point3d(a["goal"][0].num, a["goal"][1].num, world_dimension == 2 ? world_z_2d : a["goal"][2].num);
             if (a.has("downwash")) agents[qi].downwash = a["downwash"].num;
             if (a.has("nominal_velocity")) agents[qi].nominal_velocity = a["nominal_velocity"].num;
         }

@@ -24,6 +24,7 @@ class MultiSyncSimulator {
         cfg.planner_mode = param.planner_mode; cfg.slack_mode = param.slack_mode;
         cfg.slack_collision_weight = param.slack_collision_weight; cfg.n_constraint_segments = param.N_constraint_segments;
         cfg.reset_threshold = param.multisim_reset_threshold;   // the disturbance checks of every shipped launch file (0.15)
+        cfg.world_dimension = param.world_dimension; cfg.world_z_2d = param.world_z_2d;
         for (int k = 0; k < 3; k++) { cfg.world_min[k] = mission.world_min(k); cfg.world_max[k] = mission.world_max(k); }
         cfg.use_octomap = param.world_use_octomap; cfg.world_resolution = param.world_resolution; cfg.device = param.device;
         // mode/goal: prior_based like every shipped launch file (on octomap worlds that includes the grid search)
@@ -263,7 +264,7 @@ class MultiSyncSimulator {
             // spelling (src/param.cpp:158), and getGoalModeStr() indexes its table with the PLANNER mode (src/param.cpp:168-171),
             // so the goal_mode column reads "static" for LSC and "orca" for BVC whatever mode/goal was
             << "," << param.getPlannerModeStr() << (param.planner_mode == 1 ? ",current_position,current_posiotion," : ",previous_solution,previous_solution,")
-            << param.getSlackModeStr() << "," << (param.planner_mode == 1 ? "orca" : "static") << ",3," << param.dt << ","
+            << param.getSlackModeStr() << "," << (param.planner_mode == 1 ? "orca" : "static") << "," << param.world_dimension << "," << param.dt << ","
             << param.horizon << "," << param.N_constraint_segments << "\n";
     }
 
@@ -310,10 +311,12 @@ int main(int argc, char **argv)
         else if (a == "--slack") { const std::string v = next(); param.slack_mode = v == "dynamical_limit" ? 1 : (v == "collision_constraint" ? 2 : 0); }
         else if (a == "--constraint-segments") param.N_constraint_segments = std::stoi(next());
         else if (a == "--reset-threshold") param.multisim_reset_threshold = std::stod(next());
+        else if (a == "--dimension") param.world_dimension = std::stoi(next());
+        else if (a == "--z-2d") param.world_z_2d = std::stod(next());
         else if (a == "--ranks") param.world = std::stoi(next());
         else if (a == "--rank") param.rank = std::stoi(next());
         else if (a == "--comm-file") param.comm_file = next();
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z]\n"); return 2; }
     }
     if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
     // torchrun / mpirun style environment: one process per GPU
@@ -324,7 +327,7 @@ int main(int argc, char **argv)
     }
     try {
         Mission mission;
-        mission.initialize(mission_file, world_file);
+        mission.initialize(mission_file, world_file, param.world_dimension, param.world_z_2d);
         MultiSyncSimulator sim(param, mission);
         sim.run(quiet);
         return sim.is_collided ? 1 : 0;

@@ -351,6 +351,7 @@ void lsc_default_config(lsc_config *cfg)
     cfg->planner_mode = 0; cfg->slack_mode = 0; cfg->slack_collision_weight = 100000.0; cfg->n_constraint_segments = -1;
     cfg->reset_threshold = 0.0;
     cfg->gap_tolerance = 1e-9;
+    cfg->world_dimension = 3; cfg->world_z_2d = 1.0;
 }
 
 lsc_ctx *lsc_create(const lsc_config *cfg)
@@ -576,7 +577,12 @@ static int build_goal_grid(lsc_ctx *c, const std::vector<double> &radii)
     for (int a = 0; a < 3; a++) {
         c->grid_min[a] = -std::floor((-(double)c->cfg.world_min[a] + 1e-9) / res) * res;
         const double gmax = std::floor(((double)c->cfg.world_max[a] + 1e-9) / res) * res;
-        dim[a] = (int)std::round((gmax - c->grid_min[a]) / res) + 1;
+        if (a == 2 && c->cfg.world_dimension == 2) {          // planar world: one layer at z = world/z_2d (:82-85)
+            c->grid_min[a] = c->cfg.world_z_2d;
+            dim[a] = 1;
+        } else {
+            dim[a] = (int)std::round((gmax - c->grid_min[a]) / res) + 1;
+        }
         c->grid_dims[a] = dim[a];
     }
     const int H = dim[0], W = dim[1], A = dim[2];
@@ -702,7 +708,7 @@ static int run_goal(lsc_ctx *c, const float *d_state, const float *&d_goal, cons
     g.radius = c->d_radius; g.downwash = c->d_downwash; g.radius_obs = c->d_radius_obs; g.downwash_obs = c->d_downwash_obs;
     g.goal_threshold = c->cfg.goal_threshold; g.priority_dist_threshold = c->cfg.priority_dist_threshold;
     g.goal_radius = c->cfg.goal_radius;
-    g.H = c->grid_dims[0]; g.W = c->grid_dims[1]; g.A = c->grid_dims[2];
+    g.H = c->grid_dims[0]; g.W = c->grid_dims[1]; g.A = c->grid_dims[2]; g.dim2 = c->cfg.world_dimension == 2 ? 1 : 0;
     for (int k = 0; k < 3; k++) { g.gmin[k] = c->grid_min[k]; g.key_min[k] = c->edt_kmin[k]; }
     g.gres = c->cfg.grid_resolution;
     g.occ_static = c->d_occ_static; g.img_of_agent = c->d_img_of_agent;

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     auto key_of = [&](int i, int j, int z) { return (uint32_t)(c.HW * z + c.W * i + j); };
     int gcell[3];
     cell_of(goal_i, gcell);
-    c.gi = gcell[0]; c.gj = gcell[1]; c.gz = gcell[2];
+    c.gi = gcell[0]; c.gj = gcell[1]; c.gz = a.dim2 ? 0 : gcell[2];        // planar world: :199-202
     bool found = false;
     uint32_t end_key = 0;
     int flags = 0, expansions = 0;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                 const double r_o = a.radius_obs[qj], dw_o = a.downwash_obs[qj];
                 const double px = (double)a.state[9 * qj], py = (double)a.state[9 * qj + 1], pz = (double)a.state[9 * qj + 2];
                 const int oi = (int)round((px - a.gmin[0] + 1e-9) / a.gres), oj = (int)round((py - a.gmin[1] + 1e-9) / a.gres),
-                          ok = (int)round((pz - a.gmin[2] + 1e-9) / a.gres);
+                          ok = a.dim2 ? 0 : (int)round((pz - a.gmin[2] + 1e-9) / a.gres);    // `obs_k = 0` stays in a planar world
                 const int sxy = (int)ceil((r_a + r_o) / a.gres);
                 const int sz = (int)ceil((r_a * dw_a + r_o * dw_o) / a.gres);
                 const double dwt = (r_a * dw_a + r_o * dw_o) / (r_a + r_o);

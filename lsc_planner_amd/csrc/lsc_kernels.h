@@ -106,6 +106,7 @@ struct GoalArgs {
     double goal_threshold, priority_dist_threshold, goal_radius;
     // planning grid (GridBasedPlanner::updateGridInfo): dims, origin, resolution; cells addressed by key = H*W*z + W*i + j
     int H, W, A;
+    int dim2;                                   // world/dimension == 2: start, goal and stamped agents sit in layer 0
     double gmin[3], gres;
     const unsigned char *occ_static;            // [n_img][H*W*A] by key: EDT(cell centre) < radius + grid_margin
     const int *img_of_agent;                    // [N]

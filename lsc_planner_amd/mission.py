@@ -31,7 +31,8 @@ class Mission:
         return len(self.start)
 
 
-def load_mission(path):
+def load_mission(path, world_dimension=3, world_z_2d=1.0):
+    """Mission::initialize (src/mission.cpp:20-132).  world_dimension == 2 puts every start and goal at z = world_z_2d (:88-112)."""
     doc = json.load(open(path))
     world = doc["world"]
     if len(world) != 1:
@@ -50,6 +51,8 @@ def load_mission(path):
         q = quads[a["type"]]
         start[i] = np.asarray(a["start"], np.float64).astype(np.float32)
         goal[i] = np.asarray(a["goal"], np.float64).astype(np.float32)
+        if world_dimension == 2:
+            start[i, 2] = goal[i, 2] = np.float32(world_z_2d)
         radius[i] = q["radius"]
         downwash[i] = a.get("downwash", q["downwash"])
         vnom[i] = a.get("nominal_velocity", q["nominal_velocity"])

@@ -40,6 +40,8 @@ class PlannerConfig:
     n_constraint_segments: int = -1
     reset_threshold: float = 0.0    # multisim/reset_threshold; > 0 switches the disturbance checks on (launch files: 0.15)
     gap_tolerance: float = 1e-9     # interior point: relative duality gap at the optimum
+    world_dimension: int = 3        # world/dimension: 2 = planar goal grid at z = world_z_2d
+    world_z_2d: float = 1.0         # world/z_2d
     comm: tuple = None              # (world_size, rank, id bytes from comm_unique_id()): agent-sharded multi-GPU over RCCL
 
 
@@ -85,6 +87,7 @@ class SwarmPlanner:
         c.slack_collision_weight, c.n_constraint_segments = self.cfg.slack_collision_weight, self.cfg.n_constraint_segments
         c.reset_threshold = self.cfg.reset_threshold
         c.gap_tolerance = self.cfg.gap_tolerance
+        c.world_dimension, c.world_z_2d = int(self.cfg.world_dimension), float(self.cfg.world_z_2d)
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:

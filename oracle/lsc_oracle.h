@@ -52,6 +52,8 @@ typedef struct {
     double reset_threshold;  /* multisim/reset_threshold (0.15)            */
     int    use_sfc;          /* world/use_octomap                          */
     int    obs_f32;          /* 1: obstacle radius/downwash pass through a float32 message field */
+    int    world_dimension;  /* world/dimension (src/param.cpp:12): 2 = planar goal grid at z = world_z_2d; anything else = 3 */
+    double world_z_2d;       /* world/z_2d (src/param.cpp:15)                                                  */
 } orc_params;
 
 /* one sparse QP row:  sum val[j]*x[idx[j]]  (sense)  rhs ; sense: 0 '=', 1 '>=', 2 '<=' */

@@ -83,8 +83,9 @@ void grid_info(const orc_params *prm, double res, Grid &g)
     for (int a = 0; a < 3; a++) {
         g.gmin[a] = -std::floor((-(double)prm->world_min[a] + kEps) / res) * res;
         g.gmax[a] = std::floor(((double)prm->world_max[a] + kEps) / res) * res;
-        g.dim[a] = (int)std::round((g.gmax[a] - g.gmin[a]) / res) + 1;
     }
+    if (prm->world_dimension == 2) { g.gmin[2] = prm->world_z_2d; g.gmax[2] = prm->world_z_2d; }   /* :82-85 */
+    for (int a = 0; a < 3; a++) g.dim[a] = (int)std::round((g.gmax[a] - g.gmin[a]) / res) + 1;
 }
 
 struct Node { int i, j, z; double F, g, H; int64_t parent; };
@@ -323,7 +324,8 @@ void orc_goal_prior_based_map(const orc_params *prm, const orc_edt *edt, double 
                 const double px = (double)state[9 * qj], py = (double)state[9 * qj + 1], pz = (double)state[9 * qj + 2];
                 const int oi_ = (int)std::round((px - G.gmin[0] + kEps) / grid_res);
                 const int oj_ = (int)std::round((py - G.gmin[1] + kEps) / grid_res);
-                const int ok_ = (int)std::round((pz - G.gmin[2] + kEps) / grid_res);
+                /* `obs_k = 0` stays when world/dimension is 2 (:127-133) */
+                const int ok_ = prm->world_dimension == 2 ? 0 : (int)std::round((pz - G.gmin[2] + kEps) / grid_res);
                 const int sxy = (int)std::ceil((r_a + r_o) / grid_res);
                 const int sz = (int)std::ceil((r_a * dw_a + r_o * dw_o) / grid_res);
                 const double dwt = (r_a * dw_a + r_o * dw_o) / (r_a + r_o);
@@ -344,14 +346,16 @@ void orc_goal_prior_based_map(const orc_params *prm, const orc_edt *edt, double 
         int s[3], g[3];
         G.cell(pos, s);
         G.cell(goal_i, g);
+        if (prm->world_dimension == 2) { s[2] = 0; g[2] = 0; }     /* :199-202 */
         /* the reference indexes the grid with the start cell unchecked (a position within half a cell of world_max
          * rounds to dim): clamped here and in the product instead of reading out of bounds */
         for (int a = 0; a < 3; a++) s[a] = s[a] < 0 ? 0 : (s[a] > G.dim[a] - 1 ? G.dim[a] - 1 : s[a]);
         if (G.get(s[0], s[1], s[2]) == 1) {
+            const int wdim = prm->world_dimension == 2 ? 2 : 3;
             int best = 1000000000, c[3] = {s[0], s[1], s[2]};
             for (int i = -2; i < 3; i++)
                 for (int j = -2; j < 3; j++)
-                    for (int k = -1; k < 2; k++) {                 /* 2 - dim .. dim - 2, dim = 3 */
+                    for (int k = 2 - wdim; k < wdim - 1; k++) {     /* :204-206: -1..1 in 3-D, 0 in a planar world */
                         const int x = s[0] + i, y = s[1] + j, z = s[2] + k;
                         const bool occupied = x < 0 || x > G.dim[0] - 1 || y < 0 || y > G.dim[1] - 1 || z < 0 || z > G.dim[2] - 1 ||
                                               G.get(x, y, z) == 1;

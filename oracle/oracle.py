@@ -27,6 +27,8 @@ class OrcParams(ctypes.Structure):
         ("reset_threshold", ctypes.c_double),
         ("use_sfc", ctypes.c_int),
         ("obs_f32", ctypes.c_int),
+        ("world_dimension", ctypes.c_int),
+        ("world_z_2d", ctypes.c_double),
     ]
 
 
@@ -163,7 +165,7 @@ def _i(a):
 
 
 def make_params(dt=0.2, w_control=0.01, w_terminal=1.0, world_min=(-10, -10, 0), world_max=(10, 10, 2.5),
-                reset_threshold=0.15, use_sfc=False, obs_f32=False):
+                reset_threshold=0.15, use_sfc=False, obs_f32=False, world_dimension=3, world_z_2d=1.0):
     p = OrcParams()
     p.dt, p.w_control, p.w_terminal = dt, w_control, w_terminal
     for k in range(3):
@@ -172,6 +174,7 @@ def make_params(dt=0.2, w_control=0.01, w_terminal=1.0, world_min=(-10, -10, 0),
     p.reset_threshold = reset_threshold
     p.use_sfc = int(use_sfc)
     p.obs_f32 = int(obs_f32)
+    p.world_dimension, p.world_z_2d = int(world_dimension), float(world_z_2d)
     return p
 
 

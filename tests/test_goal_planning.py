@@ -80,3 +80,26 @@ def test_goal_on_the_forest_map_is_visible_and_within_radius(oracle):
     assert max(len(p) for p in paths) >= 20
     dims, gmin = oracle.grid_dims(prm)
     assert tuple(dims) == (33, 33, 9) and abs(gmin[0] + 4.8) < 1e-9
+
+
+def test_planar_world_has_one_grid_layer_and_no_vertical_moves(oracle):
+    """world/dimension = 2: grid_min[2] = grid_max[2] = world/z_2d, one layer (src/grid_based_planner.cpp:82-88); start and
+    goal cells are forced into it (:199-202) even when the agent has drifted off that height."""
+    from maputil import forest_leaves
+    import lsc_planner_amd as L
+    leaves, res = forest_leaves()
+    wmin, wmax = (-5, -5, 0), (5, 5, 2.5)
+    dm = oracle.DistMap(leaves, res, wmin, wmax)
+    prm = oracle.make_params(world_min=wmin, world_max=wmax, obs_f32=True, world_dimension=2, world_z_2d=0.7)
+    dims, gmin = oracle.grid_dims(prm)
+    assert tuple(dims) == (33, 33, 1) and gmin[2] == 0.7
+    ms = L.random_swarm(12, world=wmin + wmax, seed=5, edt=dm.dist, edt_key_min=dm.key_min)
+    ms.start[:, 2] = ms.goal[:, 2] = np.float32(0.7)
+    state = np.zeros((12, 9), np.float32)
+    state[:, :3] = ms.start
+    state[::2, 2] += np.float32(0.4)                            # half of the agents are 0.4 m above the plane: same cells
+    traj = np.zeros((12, 3, 30), np.float32)
+    goals, paths, flags = oracle.goal_prior_based_map(prm, dm, state, ms.goal, traj, 1, ms.radius, ms.downwash, want_paths=True)
+    assert max(len(p) for p in paths) >= 10
+    for p in paths:
+        assert len(p) == 0 or (p[:, 2] == 0).all()

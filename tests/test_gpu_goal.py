@@ -16,8 +16,8 @@ def L():
     return L
 
 
-def _compare_goal_stage(L, O, ms, dm, dist, key_min, res, state, traj, tick, pl, grid_margin=0.2):
-    prm = O.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+def _compare_goal_stage(L, O, ms, dm, dist, key_min, res, state, traj, tick, pl, grid_margin=0.2, **world):
+    prm = O.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True, **world)
     ref, paths, flags = O.goal_prior_based_map(prm, dm, state, ms.goal, traj, tick, ms.radius, ms.downwash, grid_margin=grid_margin,
                                                want_paths=True)
     g = pl.plan(state, ms.goal, traj)
@@ -55,6 +55,40 @@ def test_forest_goal_planning_bitwise_over_a_mission(L, oracle):
         state = next_state_host(traj)
     pl.close()
     assert longest >= 20 and most >= 500, (longest, most)      # real searches happened
+    assert np.linalg.norm(state[:, :3] - ms.goal, axis=1).mean() < np.linalg.norm(ms.start - ms.goal, axis=1).mean()
+
+
+def test_planar_world_goal_planning(L, oracle):
+    """world/dimension = 2 (src/grid_based_planner.cpp:82-85, 127-133, 199-215; src/mission.cpp:88-112): the planning grid is
+    the single layer z = world/z_2d, starts, goals and the stamped higher-priority agents sit in it whatever their height is,
+    and the search has no vertical moves.  Paths, flags and goals against the oracle, bit for bit; the QP stays 3-D."""
+    from maputil import forest_leaves
+    from lsc_planner_amd.planner import next_state_host
+    leaves, res = forest_leaves()
+    wmin, wmax = (-5, -5, 0), (5, 5, 2.5)
+    z2d = 0.7
+    dm = oracle.DistMap(leaves, res, wmin, wmax)
+    ms = L.random_swarm(20, world=wmin + wmax, seed=12, edt=dm.dist, edt_key_min=dm.key_min)
+    ms.start[:, 2] = ms.goal[:, 2] = np.float32(z2d)          # what Mission::initialize does with world/dimension = 2
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True, goal_mode="prior_based", world_dimension=2, world_z_2d=z2d))
+    pl.set_distmap(dm.dist, dm.key_min, res)
+    pl.set_goal_trace(512)
+    N = ms.qn
+    state = np.zeros((N, 9), np.float32)
+    state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    longest = 0
+    for tick in range(1, 31):
+        g = _compare_goal_stage(L, oracle, ms, dm, dm.dist, dm.key_min, res, state, traj, tick, pl, world_dimension=2, world_z_2d=z2d)
+        tr = pl.goal_trace()
+        assert tr["grid_dims"][2] == 1 and tr["grid_min"][2] == z2d
+        for path in tr["paths"]:
+            assert (path[:, 2] == 0).all()
+        longest = max(longest, int(tr["path_len"].max()))
+        traj = g["traj"]
+        state = next_state_host(traj)
+    pl.close()
+    assert longest >= 15, longest
     assert np.linalg.norm(state[:, :3] - ms.goal, axis=1).mean() < np.linalg.norm(ms.start - ms.goal, axis=1).mean()
 
 

@@ -107,6 +107,35 @@ def test_forest_mission_in_the_default_goal_mode(tmp_path):
     pl.close()
 
 
+def test_forest_mission_in_a_planar_world(tmp_path):
+    """`--dimension 2 --z-2d 0.7` (world/dimension, world/z_2d): the mission's heights are replaced by z_2d, the goal planner
+    searches one layer; the run finishes collision-free, nobody leaves the plane, and the summary says dimension 2."""
+    import lsc_planner_amd as L
+    from maputil import forest_leaves, write_bt
+    leaves, res = forest_leaves()
+    bt = tmp_path / "forest.bt"
+    write_bt(str(bt), leaves, res)
+    world = (-5, -5, 0, 5, 5, 2.5)
+    dist, kmin, r = L.edt_from_bt(str(bt), np.asarray(world[:3], np.float32), np.asarray(world[3:], np.float32))
+    # starts / goals sampled in the plane itself (a slab that shrinks to z = 0.7), free of the trees there; the mission file
+    # then carries other heights, which --dimension 2 must override
+    ms = L.random_swarm(8, world=(-5, -5, 0.2, 5, 5, 1.2), seed=21, edt=dist, edt_key_min=kmin, edt_res=r)
+    assert (ms.start[:, 2] == np.float32(0.7)).all()
+    ms.world_min, ms.world_max = np.asarray(world[:3], np.float32), np.asarray(world[3:], np.float32)
+    ms.start[:, 2] = 1.9
+    ms.goal[:, 2] = 0.3
+    mp = tmp_path / "forest8.json"
+    _write_mission(str(mp), ms)
+    rr = subprocess.run([SIM, "--mission", str(mp), "--world", str(bt), "--csv", str(tmp_path), "--quiet", "--max-iter", "200",
+                         "--dimension", "2", "--z-2d", "0.7"], capture_output=True, text=True, timeout=600)
+    assert rr.returncode == 0, rr.stdout + rr.stderr
+    summ = list(csv.reader(open(tmp_path / "summary_LSC_8agents.csv")))
+    assert summ[1][21] == "2"
+    rows = list(csv.reader(open(tmp_path / "result_LSC_8agents.csv")))[1:]
+    z = np.array([[float(row[15 * q + 4]) for q in range(8)] for row in rows])
+    assert np.abs(z - 0.7).max() < 1e-3, np.abs(z - 0.7).max()
+
+
 def test_simulator_over_the_native_communicator_writes_the_same_run(ticks, tmp_path):
     """lsc_sim --ranks 1 --comm-file: the multi-GPU form (rendezvous file, lsc_comm_init, lsc_replan_tick_all with its
     RCCL all-gather group) must produce the same result CSV as the plain run.  One GPU here, hence world size 1."""

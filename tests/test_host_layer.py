@@ -80,6 +80,9 @@ def test_mission_loader_and_generators(tmp_path):
     ms = L.load_mission(str(p))
     assert ms.qn == 2 and ms.start.dtype == np.float32 and ms.start[0, 1] == np.float32(0.1)
     assert ms.max_acc[0, 2] == 1.0 and ms.world_max[2] == np.float32(2.5)
+    flat = L.load_mission(str(p), world_dimension=2, world_z_2d=0.7)      # src/mission.cpp:88-112
+    assert (flat.start[:, 2] == np.float32(0.7)).all() and (flat.goal[:, 2] == np.float32(0.7)).all()
+    assert np.array_equal(flat.start[:, :2], ms.start[:, :2])
     doc["world"].append(doc["world"][0])
     p.write_text(json.dumps(doc))
     with pytest.raises(ValueError):
