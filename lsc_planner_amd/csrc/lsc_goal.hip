@@ -99,6 +99,7 @@ struct Ctx {
     uint32_t *rowMin;                // [H]  its entry (key | g << 17)
     uint16_t *rowCnt;                // [H]
     int16_t *rowNb;                  // [H]  index into nb_seq, -1: the fresh container's single bucket
+    uint32_t *rowNbv, *rowNbm;       // [H]  the bucket count itself and floor(2^32 / it): one read instead of a dependent pair
     uint32_t *tmp;                   // [cap]
     uint32_t *rows;                  // [H][cap]
     const int *nb_seq;
@@ -178,7 +179,7 @@ __device__ void row_insert(Ctx &c, int i, uint32_t e)
         for (int p = c.lane; p < cnt; p += 64) c.tmp[p] = row[p];
         wsync();
         for (int t = 0; t < cnt; t++) row_place(c, row, t, c.tmp[t], nb, nbm);
-        if (c.lane == 0) c.rowNb[i] = (int16_t)nbi;
+        if (c.lane == 0) { c.rowNb[i] = (int16_t)nbi; c.rowNbv[i] = nb; c.rowNbm[i] = nbm; }
     }
     row_place(c, row, cnt, e, nb, nbm);
     if (c.lane == 0) c.rowCnt[i] = (uint16_t)(cnt + 1);
@@ -218,6 +219,64 @@ __device__ void row_pop(Ctx &c, int i, uint32_t key)
         const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
         const unsigned long long own = __ballot(bf == fmin && bsel == sel);
         const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)bent, __ffsll((long long)own) - 1);
+        if (c.lane == 0) { c.rowMin[i] = ent; c.rowF[i] = fmin; }
+    }
+    if (c.lane == 0) {
+        c.rowCnt[i] = (uint16_t)(cnt - 1);
+        if (cnt == 1) c.rowF[i] = 1e300;                       // empty row: never the minimum
+    }
+    wsync();
+}
+
+// ---- The common cases with one LDS round trip each.  The search is a chain of dependent LDS accesses on a single wave
+// (a third of its cycles were LDS latency), so the paths every node takes read everything they need about a row at once:
+// RowInfo = (count, bucket count and its magic, registered minimum and its F) is one batch of independent loads, and a
+// row of at most 64 entries is read once into registers, searched with a ballot and shifted from registers.
+struct RowInfo { int cnt, nbi; uint32_t nb, nbm, min; double F; };
+__device__ __forceinline__ RowInfo row_info(const Ctx &c, int i)
+{
+    RowInfo r;
+    r.cnt = c.rowCnt[i]; r.nbi = c.rowNb[i]; r.nb = c.rowNbv[i]; r.nbm = c.rowNbm[i]; r.min = c.rowMin[i]; r.F = c.rowF[i];
+    return r;
+}
+
+// row_insert for a row whose state is already known; falls back to the general code for a rehash or a long row
+__device__ __forceinline__ void row_insert_known(Ctx &c, int i, uint32_t e, const RowInfo &ri)
+{
+    const int cnt = ri.cnt;
+    if (ri.nbi < 0 || (uint32_t)(cnt + 1) > ri.nb || cnt >= 64 || cnt + 1 > c.cap) { row_insert(c, i, e); return; }
+    uint32_t *row = c.rows + (size_t)i * c.cap;
+    const uint32_t nb = ri.nb, nbm = ri.nbm;
+    auto bucket = [&](uint32_t k) { return k - div_magic(k, nb, nbm) * nb; };
+    const uint32_t v = c.lane < cnt ? row[c.lane] : 0u;
+    const unsigned long long mask = __ballot(c.lane < cnt && bucket(v & KEY_MASK) == bucket(e & KEY_MASK));
+    const int pos = mask ? __ffsll((long long)mask) - 1 : 0;
+    if (c.lane >= pos && c.lane < cnt) row[c.lane + 1] = v;        // every lane holds its entry: no second read
+    if (c.lane == 0) { row[pos] = e; c.rowCnt[i] = (uint16_t)(cnt + 1); }
+    wsync();
+}
+
+// row_pop for a row of at most 64 entries whose count is known
+__device__ __forceinline__ void row_pop_known(Ctx &c, int i, uint32_t key, int cnt)
+{
+    if (cnt > 64) { row_pop(c, i, key); return; }
+    uint32_t *row = c.rows + (size_t)i * c.cap;
+    const int p = c.lane;
+    uint32_t e = p < cnt ? row[p] : 0u;
+    const uint32_t nxt = p + 1 < cnt ? row[p + 1] : 0u;             // issued with the load above: one round trip
+    const unsigned long long m = __ballot(p < cnt && (e & KEY_MASK) == key);
+    const int pos = __ffsll((long long)m) - 1;
+    const bool moved = p >= pos;
+    if (moved) e = nxt;
+    if (moved && p < cnt - 1) row[p] = e;
+    double bf = 1e300;
+    uint32_t bsel = 0;
+    if (p < cnt - 1) { bf = f_of(c, e); bsel = ((e >> KEY_BITS) << 16) | (uint32_t)p; }
+    if (cnt > 1) {
+        const double fmin = wave_min_d(bf);
+        const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
+        const unsigned long long own = __ballot(bf == fmin && bsel == sel);
+        const uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)e, __ffsll((long long)own) - 1);
         if (c.lane == 0) { c.rowMin[i] = ent; c.rowF[i] = fmin; }
     }
     if (c.lane == 0) {
@@ -304,6 +363,8 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
         c.rowCnt = reinterpret_cast<uint16_t *>(gsm + off); off += sizeof(uint16_t) * (size_t)c.H;
         c.rowNb = reinterpret_cast<int16_t *>(gsm + off); off += sizeof(int16_t) * (size_t)c.H;
         off = (off + 3) & ~(size_t)3;
+        c.rowNbv = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.H;
+        c.rowNbm = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.H;
         int *nbs = reinterpret_cast<int *>(gsm + off); off += sizeof(int) * 16;
         uint32_t *nbm = reinterpret_cast<uint32_t *>(gsm + off);
         if (lane < 16) { nbs[lane] = a.nb_seq[lane]; nbm[lane] = a.nb_magic[lane]; }
@@ -391,7 +452,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     int flags = 0, expansions = 0;
     for (int attempt = 0; attempt < 2 && !found && !c.err; attempt++) {
         for (int p = lane; p < c.C; p += 64) c.st[p] = occ_static[p];
-        for (int i = lane; i < c.H; i += 64) { c.rowCnt[i] = 0; c.rowNb[i] = -1; c.rowF[i] = 1e300; c.rowMin[i] = 0; }
+        for (int i = lane; i < c.H; i += 64) { c.rowCnt[i] = 0; c.rowNb[i] = -1; c.rowNbv[i] = 1u; c.rowNbm[i] = 0u; c.rowF[i] = 1e300; c.rowMin[i] = 0; }
         wsync();
         if (attempt == 0) {
             for (int qj = lane; qj < N; qj += 64) {          // updateGridMap, AGENT branch :163-189
@@ -462,23 +523,27 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             // findMin (:181-209): smallest F over the row minima, then the largest g, then the LAST row
             double bf = 1e300;
             uint32_t bsel = 0, bent = 0;
+            int bcnt = 0;
             for (int i = lane; i < c.H; i += 64) {
                 const double f = c.rowF[i];                    // 1e300 while the row is empty
                 const uint32_t me = c.rowMin[i];
+                const int rc = c.rowCnt[i];                    // (same batch of loads: the pop below needs the winner's count)
                 const uint32_t sel = ((me >> KEY_BITS) << 16) | (uint32_t)i;
-                if (f < 1e300 && (f < bf || (f == bf && sel >= bsel))) { bf = f; bsel = sel; bent = me; }
+                if (f < 1e300 && (f < bf || (f == bf && sel >= bsel))) { bf = f; bsel = sel; bent = me; bcnt = rc; }
             }
             const double fmin = wave_min_d(bf);
             const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
             const int ci = (int)(sel & 0xffffu);
             const unsigned long long owner = __ballot(bf == fmin && bsel == sel);
-            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)bent, __ffsll((long long)owner) - 1);
+            const int own_lane = __ffsll((long long)owner) - 1;
+            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)bent, own_lane);
+            const int ccnt = __builtin_amdgcn_readlane(bcnt, own_lane);
             const uint32_t ckey = ce & KEY_MASK;
             const int cg = (int)(ce >> KEY_BITS);
             int cj, cz, ci2;
             decode(c, ckey, ci2, cj, cz);
             if (lane == 0) atomicOr(reinterpret_cast<unsigned int *>(c.st + (ckey & ~3u)), (unsigned int)ST_CLOSED << (8u * (ckey & 3u)));
-            row_pop(c, ci, ckey);
+            row_pop_known(c, ci, ckey, ccnt);
             nopen--;
             if (ci == c.gi && cj == c.gj) { found = true; end_key = ckey; break; }   // the altitude is not part of the goal test
             if (cg + 1 > G_MAX) { c.err = 1; break; }
@@ -513,10 +578,12 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                 const int ni = ci + di, nj = cj + dj, nz = cz + dz;
                 const uint32_t ne = nkey | ((uint32_t)ng << KEY_BITS);
                 uint32_t *row = c.rows + (size_t)ni * c.cap;
+                const RowInfo ri = row_info(c, ni);            // everything the insertion and the bookkeeping need, one round trip
+                int cnt_after = ri.cnt;
                 bool inserted = false;
                 uint32_t stored = ne;                          // the row's entry for this key after addOpen
                 if ((sv & 3u) == ST_OPEN) {                    // addOpen (:243-283): keep the better of the two; same cell,
-                    const int p = row_find(c, row, c.rowCnt[ni], nkey);   // same H, so "F smaller" is "g smaller"
+                    const int p = row_find(c, row, ri.cnt, nkey);          // same H, so "F smaller" is "g smaller"
                     const uint32_t old = row[p];
                     stored = old;
                     if (ng < (int)(old >> KEY_BITS)) {
@@ -529,23 +596,24 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                         wsync();
                     }
                 } else {
-                    row_insert(c, ni, ne);
+                    row_insert_known(c, ni, ne, ri);
                     if (c.err) break;
                     if (lane == 0) c.st[nkey] = st_open(d, ng);
                     inserted = true;
                     nopen++;
+                    cnt_after = ri.cnt + 1;
                     wsync();
                 }
                 // row minimum bookkeeping of addOpen (:262-282)
                 const int ei = c.gi - ni, ej = c.gj - nj, ez = c.gz - nz;
                 const double fs = 10.0 * (double)(stored >> KEY_BITS) + 10.0 * sqrt((double)(ei * ei + ej * ej + ez * ez));
-                if (c.rowCnt[ni] == 1) {
+                if (cnt_after == 1) {
                     if (lane == 0) { c.rowMin[ni] = stored; c.rowF[ni] = fs; }
                 } else {
-                    const uint32_t me = c.rowMin[ni];
+                    const uint32_t me = ri.min;                // (nothing above touches the row's registered minimum)
                     const bool min_is_this = (me & KEY_MASK) == nkey;
                     // the registered minimum is read AFTER the assignment: if it is this very node it already has the new g
-                    const double fm = min_is_this ? fs : c.rowF[ni];
+                    const double fm = min_is_this ? fs : ri.F;
                     const int gm = min_is_this ? (int)(stored >> KEY_BITS) : (int)(me >> KEY_BITS);
                     if (inserted && (fs < fm || (fs == fm && ng >= gm))) {
                         if (lane == 0) { c.rowMin[ni] = stored; c.rowF[ni] = fs; }
@@ -652,6 +720,7 @@ size_t goal_smem_bytes(int H, int W, int A, int cap)
     b += sizeof(double) * (size_t)H + sizeof(uint32_t) * (size_t)H + sizeof(uint32_t) * (size_t)cap;
     b += sizeof(uint32_t) * (size_t)H * cap + 2 * sizeof(uint16_t) * (size_t)H;
     b += 4 + 2 * 16 * sizeof(int);                            // bucket-count / magic tables
+    b += 2 * sizeof(uint32_t) * (size_t)H;                    // per-row bucket count and magic
     return (b + 15) & ~(size_t)15;
 }
 
