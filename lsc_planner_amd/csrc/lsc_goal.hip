@@ -271,7 +271,15 @@ __device__ __forceinline__ void row_pop_known(Ctx &c, int i, uint32_t key, int c
     if (moved && p < cnt - 1) row[p] = e;
     double bf = 1e300;
     uint32_t bsel = 0;
-    if (p < cnt - 1) { bf = f_of(c, e); bsel = ((e >> KEY_BITS) << 16) | (uint32_t)p; }
+    if (p < cnt - 1) {
+#pragma clang fp contract(off)
+        // f_of with the row index known: key - W i = HW z + j, one division instead of two
+        const uint32_t rem = (e & KEY_MASK) - (uint32_t)(c.W * i);
+        const int z = (int)div_magic(rem, (uint32_t)c.HW, c.mHW), j = (int)(rem - (uint32_t)z * (uint32_t)c.HW);
+        const int di = c.gi - i, dj = c.gj - j, dz = c.gz - z;
+        bf = 10.0 * (double)(e >> KEY_BITS) + 10.0 * sqrt((double)(di * di + dj * dj + dz * dz));
+        bsel = ((e >> KEY_BITS) << 16) | (uint32_t)p;
+    }
     if (cnt > 1) {
         const double fmin = wave_min_d(bf);
         const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
@@ -551,6 +559,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             // neighbour each (bounds, occupancy, closed); only the survivors are then handled one after the other.
             int nkey_l = -1;
             uint32_t sv_l = ST_OCC;
+            double h_l = 0.0;                                  // H of the neighbour: one vector square root for all six
             if (lane < 6) {
                 const int d = lane;
                 const int di = d == 0 ? -1 : (d == 5 ? 1 : 0), dj = d == 1 ? -1 : (d == 4 ? 1 : 0), dz = d == 2 ? -1 : (d == 3 ? 1 : 0);
@@ -559,6 +568,8 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                     nkey_l = (int)key_of(ni, nj, nz);
                     sv_l = c.st[nkey_l];
                 }
+                const int ei = c.gi - ni, ej = c.gj - nj, ez = c.gz - nz;
+                h_l = 10.0 * sqrt((double)(ei * ei + ej * ej + ez * ez));
             }
             // Unseen cells are inserted.  A cell that is already OPEN only matters if the new g is smaller (same cell, same
             // H).  With a consistent heuristic the popped F never decreases, so an OPEN neighbour has
@@ -605,8 +616,8 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                     wsync();
                 }
                 // row minimum bookkeeping of addOpen (:262-282)
-                const int ei = c.gi - ni, ej = c.gj - nj, ez = c.gz - nz;
-                const double fs = 10.0 * (double)(stored >> KEY_BITS) + 10.0 * sqrt((double)(ei * ei + ej * ej + ez * ez));
+                const double hs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(h_l), d), __builtin_amdgcn_readlane(__double2loint(h_l), d));
+                const double fs = 10.0 * (double)(stored >> KEY_BITS) + hs;
                 if (cnt_after == 1) {
                     if (lane == 0) { c.rowMin[ni] = stored; c.rowF[ni] = fs; }
                 } else {
