@@ -227,7 +227,8 @@ int lsc_gjk_batch(lsc_ctx *ctx, const double *pts, int count, double *v, double 
 /* Introspection used by bench.py: name / average device time (ms, HIP events) of the kernels timed since
  * the last reset.  which: 0 = plan kernel (all passes: LSC generation + QP), 1 = dense sweep kernel, 2 = the trajectory
  * all-gather of the sharded ticks, 3 = goal kernel (octomap worlds, mode/goal prior_based), 4 = corridor (SFC) kernel --
- * the per-phase columns of PlanningTimeStatistics (include/sp_const.hpp:89-128) that exist as separate launches. */
+ * the per-phase columns of PlanningTimeStatistics (include/sp_const.hpp:89-128) that exist as separate launches; 5 = host
+ * wall clock of lsc_replan_tick itself, entry to return (PCIe-inclusive: what the reference-side caller waits for). */
 int lsc_kernel_time_ms(lsc_ctx *ctx, int which, double *avg_ms, long *launches);
 int lsc_set_timing(lsc_ctx *ctx, int enabled);
 /* Per-launch device times (ms) of the launches timed since lsc_set_timing(ctx, 1): up to `capacity` values in launch

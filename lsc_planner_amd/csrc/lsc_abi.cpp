@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <algorithm>
 #include <map>
 #include <string>
@@ -255,6 +256,7 @@ struct lsc_ctx {
     hipStream_t stream = nullptr;
     // kernel timing: one HIP event pair per launch, recorded on the launch stream, read back on query
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool[5];   // 0 plan kernel(s), 1 dense sweep, 2 trajectory exchange, 3 goal kernel, 4 corridor kernel
+    std::vector<double> host_tick_ms;    // which = 5: wall clock of every lsc_replan_tick since lsc_set_timing(1), entry to return
     size_t ev_used[5] = {0, 0, 0, 0, 0};
     // agent-sharded multi-GPU: this context is rank `rank` of `world`; every rank owns a block of shard_rows agents of a
     // table padded to table_rows = shard_rows * world rows, so that the exchange is ONE in-place equal-sized all-gather
@@ -863,6 +865,7 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
 {
     if (!c || !state || !goal || !prev_traj || !out_traj || !out_cost || !out_status) return LSC_EINVAL;
     if (c->N == 0) return LSC_ESTATE;
+    const auto t_entry = std::chrono::steady_clock::now();
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t N = c->N, cnt = c->count, first = c->first, nobs = N - 1;
     hipStream_t st = c->stream;
@@ -902,6 +905,8 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
         std::memcpy(out_status, si + sizeof(int) * first, sizeof(int) * cnt);
         if (out_iters) std::memcpy(out_iters, si + sizeof(int) * (Np + first), sizeof(int) * cnt);
     }
+    if (c->timing)
+        c->host_tick_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
     return LSC_OK;
 }
 
@@ -1068,12 +1073,20 @@ int lsc_set_timing(lsc_ctx *c, int enabled)
     if (!c) return LSC_EINVAL;
     c->timing = enabled != 0;
     for (int w = 0; w < 5; w++) c->ev_used[w] = 0;
+    c->host_tick_ms.clear();
     return LSC_OK;
 }
 
 int lsc_kernel_time_ms(lsc_ctx *c, int which, double *avg_ms, long *launches)
 {
-    if (!c || which < 0 || which > 4 || !avg_ms) return LSC_EINVAL;
+    if (!c || which < 0 || which > 5 || !avg_ms) return LSC_EINVAL;
+    if (which == 5) {
+        double t = 0;
+        for (double v : c->host_tick_ms) t += v;
+        *avg_ms = c->host_tick_ms.empty() ? 0.0 : t / (double)c->host_tick_ms.size();
+        if (launches) *launches = (long)c->host_tick_ms.size();
+        return LSC_OK;
+    }
     double tot = 0;
     for (size_t i = 0; i < c->ev_used[which]; i++) {
         auto &p = c->ev_pool[which][i];
@@ -1089,7 +1102,13 @@ int lsc_kernel_time_ms(lsc_ctx *c, int which, double *avg_ms, long *launches)
 
 int lsc_kernel_times_ms(lsc_ctx *c, int which, double *out_ms, long capacity, long *launches)
 {
-    if (!c || which < 0 || which > 4 || (capacity > 0 && !out_ms)) return LSC_EINVAL;
+    if (!c || which < 0 || which > 5 || (capacity > 0 && !out_ms)) return LSC_EINVAL;
+    if (which == 5) {
+        const long nh = (long)c->host_tick_ms.size();
+        for (long i = 0; i < nh && i < capacity; i++) out_ms[i] = c->host_tick_ms[(size_t)i];
+        if (launches) *launches = nh;
+        return LSC_OK;
+    }
     const long n = (long)c->ev_used[which];
     for (long i = 0; i < n && i < capacity; i++) {
         auto &p = c->ev_pool[which][(size_t)i];
