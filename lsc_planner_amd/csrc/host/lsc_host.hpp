@@ -14,6 +14,7 @@
 #include <memory>
 #include <sstream>
 #include <stdexcept>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -119,6 +120,8 @@ struct Param {   // defaults = launch/testall_empty.launch
     double control_input_weight = 0.01, terminal_weight = 1.0;
     double multisim_time_step = 0.2, multisim_record_time_step = 0.1, multisim_reset_threshold = 0.15;
     int multisim_max_planner_iteration = 300;
+    double multisim_max_noise = 0.0;   // multisim/max_noise (src/param.cpp; 0.02 in testall_*.launch): uniform noise on the desired goals
+    unsigned multisim_noise_seed = 0;  // 0 = std::random_device like the reference (src/mission.cpp:387); else reproducible
     bool multisim_save_result = false;
     double goal_threshold = 0.1;
     bool goal_mode_prior_based = true;   // mode/goal (launch/*.launch: prior_based)
@@ -147,6 +150,18 @@ class Mission {
     std::vector<Agent> agents;
     point3d world_min, world_max;
     std::string mission_file_name, world_file_name;
+
+    // Mission::addNoise (src/mission.cpp:386-395): desired_goal(k) += U[0,1) * max_noise for k < dimension, float32 draws
+    void addNoise(double max_noise, int dimension, unsigned seed = 0) {
+        std::random_device rd;
+        std::mt19937 gen(seed ? seed : rd());
+        std::uniform_real_distribution<float> dis(0, 1);
+        for (int qi = 0; qi < qn; qi++) {
+            float g[3] = {agents[qi].desired_goal_position.x(), agents[qi].desired_goal_position.y(), agents[qi].desired_goal_position.z()};
+            for (int k = 0; k < dimension && k < 3; k++) g[k] += dis(gen) * max_noise;   // float += float * double, as there
+            agents[qi].desired_goal_position = point3d(g[0], g[1], g[2]);
+        }
+    }
 
     // world_dimension == 2: every start and goal is put at z = world_z_2d (src/mission.cpp:88-112)
     bool initialize(const std::string &mission_file, const std::string &world_file = "", int world_dimension = 3, double world_z_2d = 1.0) {

@@ -311,12 +311,14 @@ int main(int argc, char **argv)
         else if (a == "--slack") { const std::string v = next(); param.slack_mode = v == "dynamical_limit" ? 1 : (v == "collision_constraint" ? 2 : 0); }
         else if (a == "--constraint-segments") param.N_constraint_segments = std::stoi(next());
         else if (a == "--reset-threshold") param.multisim_reset_threshold = std::stod(next());
+        else if (a == "--max-noise") param.multisim_max_noise = std::stod(next());
+        else if (a == "--noise-seed") param.multisim_noise_seed = (unsigned)std::stoul(next());
         else if (a == "--dimension") param.world_dimension = std::stoi(next());
         else if (a == "--z-2d") param.world_z_2d = std::stod(next());
         else if (a == "--ranks") param.world = std::stoi(next());
         else if (a == "--rank") param.rank = std::stoi(next());
         else if (a == "--comm-file") param.comm_file = next();
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]]\n"); return 2; }
     }
     if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
     // torchrun / mpirun style environment: one process per GPU
@@ -328,6 +330,7 @@ int main(int argc, char **argv)
     try {
         Mission mission;
         mission.initialize(mission_file, world_file, param.world_dimension, param.world_z_2d);
+        if (param.multisim_max_noise > 0.0) mission.addNoise(param.multisim_max_noise, param.world_dimension, param.multisim_noise_seed);   // src/mission.cpp:317
         MultiSyncSimulator sim(param, mission);
         sim.run(quiet);
         return sim.is_collided ? 1 : 0;
