@@ -198,3 +198,40 @@ def test_alternate_mode_qps_vs_highs(oracle, mode):
         state = next_state_host(traj)
     assert checked >= 90
     assert slack_vars == {"bvc": 0, "collision_constraint": 35, "dynamical_limit": 10, "reset": 35}[mode]
+
+
+@pytest.mark.parametrize("seed,agent,highs_cost", [(5023, 2, 1.3618641918561454), (5059, 6, 106.74117597754659)])
+def test_instances_on_which_the_oracle_used_to_give_up(oracle, seed, agent, highs_cost):
+    """Found by tests/test_gpu_fuzz.py: alternate-mode QPs close to a degenerate optimum, where the oracle's normal equations
+    lose definiteness.  It used to answer "infeasible"; HiGHS (cost recorded here, re-derived when HiGHS is importable) and the
+    kernel (cost and plan in the fixture, produced on an MI355X) agree on the optimum.  Inputs: tests/golden/fuzz_found_*.npz
+    (the tick's states, previous plans, persistent slack set and the seeded agents of the fuzzer)."""
+    O = oracle
+    Z = np.load(os.path.join(GOLDEN, "fuzz_found_%d.npz" % seed))
+    modes = [dict(planner="bvc"), dict(slack="collision_constraint"), dict(slack="dynamical_limit"),
+             dict(planner="bvc", n_constraint_segments=2), dict(reset_threshold=0.15)]
+    mk = modes[int(Z["which"])]
+    md = O.make_modes(**mk)
+    state, traj, goal, tick = Z["state"], Z["traj"], Z["goal"], int(Z["tick"])
+    n = len(state)
+    prm = O.make_params(world_min=Z["wmin"], world_max=Z["wmax"], obs_f32=True)
+    sw = O.SwarmEx(prm, md, Z["radius"], Z["dw"], Z["vmax"], Z["amax"], Z["vnom"])
+    sw.slack_set[:] = Z["slack"]
+    sw.stale[:] = Z["stale"]
+    o = sw.tick(state, goal, traj, tick, want_lsc=True, nthreads=2)
+    assert (o["status"] == 0).all() and np.array_equal(o["status"], Z["gstatus"])
+    assert abs(o["cost"][agent] - highs_cost) <= 1e-7 * highs_cost
+    assert abs(Z["gcost"][agent] - highs_cost) <= 1e-8 * highs_cost           # the kernel's answer on the same inputs
+    assert (np.abs(o["cost"] - Z["gcost"]) <= 1e-6 * np.abs(Z["gcost"])).all()
+    if H.available():
+        others = [j for j in range(n) if j != agent]
+        bvc = mk.get("planner") == "bvc"
+        obs = []
+        for j in others:
+            pred = O.shift_traj(traj[j]) if tick >= 2 else O.const_vel_traj(state[j, :3], state[j, 3:6])
+            moved = sw.slack_set[agent, j] and np.linalg.norm(pred[:, 0] - state[j, :3]) > 0.15
+            obs.append(np.repeat(state[j, :3, None], 30, axis=1) if (bvc or moved) else pred)
+        qp = O.qp_assemble_ex(prm, md, state[agent], goal[agent], float(Z["vnom"][agent]), Z["vmax"][agent], Z["amax"][agent],
+                              np.array(obs, np.float32), o["normal"][agent], o["d"][agent], slack_flags=sw.slack_set[agent, others])
+        verdict, _, cost = H.solve_oracle_qp(qp)[:3]
+        assert verdict == "Optimal" and abs(cost - highs_cost) <= 1e-8 * highs_cost
