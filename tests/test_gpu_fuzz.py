@@ -130,3 +130,60 @@ def test_fuzz_alternate_modes(oracle):
             state = next_state_host(traj)
         pl.close()
     assert agent_ticks > 7000, agent_ticks
+
+
+def test_fuzz_octomap_worlds(oracle):
+    """Random block worlds (block size, density, world size), random grid resolution / margin of the goal planner, every
+    fourth one planar (world/dimension = 2): goals and corridor boxes bit-exact, statuses equal, plans within tolerance,
+    20 chained ticks each."""
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import PlannerConfig, next_state_host
+    agent_ticks = 0
+    for trial in range(24):
+        rng = np.random.default_rng(100 + trial)
+        side, top = float(rng.choice([3.0, 4.0, 5.0])), float(rng.choice([1.5, 2.0, 2.5]))
+        wmin, wmax = (-side, -side, 0), (side, side, top)
+        res = 0.1
+        kmin = np.array([np.floor(wmin[k] / res) + 32768 for k in range(3)], np.int32)
+        dims = [int(np.floor(wmax[k] / res) + 32768 - kmin[k] + 1) for k in range(3)]
+        bs, dens = int(rng.choice([3, 5, 7])), float(rng.uniform(0.03, 0.10))
+        coarse = rng.random((dims[0] // bs + 1, dims[1] // bs + 1, dims[2] // bs + 1)) < dens
+        occ = np.kron(coarse, np.ones((bs, bs, bs), bool))[:dims[0], :dims[1], :dims[2]]
+        occ[:, :, :2] = False
+        idx = np.argwhere(occ)
+        if len(idx) == 0:
+            continue
+        leaves = np.concatenate([idx + kmin, np.ones((len(idx), 1), int)], 1).astype(np.int32)
+        dm = oracle.DistMap(leaves, res, wmin, wmax)
+        n = int(rng.integers(2, 14))
+        planar = trial % 4 == 3
+        box = (wmin[0], wmin[1], 0.2, wmax[0], wmax[1], 1.2) if planar else wmin + wmax      # a slab that shrinks to z = 0.7
+        ms = L.random_swarm(n, world=box, seed=int(rng.integers(1, 1 << 30)), edt=dm.dist, edt_key_min=dm.key_min, min_clearance=0.5)
+        ms.world_min, ms.world_max = np.asarray(wmin, np.float32), np.asarray(wmax, np.float32)
+        gm, gr = float(rng.choice([0.05, 0.1, 0.2])), float(rng.choice([0.25, 0.3, 0.5]))
+        kw = dict(world_dimension=2, world_z_2d=0.7) if planar else {}
+        pl = L.SwarmPlanner(ms, PlannerConfig(use_octomap=True, goal_mode="prior_based", grid_margin=gm, grid_resolution=gr, **kw))
+        pl.set_distmap(dm.dist, dm.key_min, res)
+        prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, use_sfc=True, obs_f32=True, **kw)
+        sw = oracle.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+        sw.set_distmap(dm)
+        state = np.zeros((n, 9), np.float32)
+        state[:, :3] = ms.start
+        traj = np.zeros((n, 3, 30), np.float32)
+        stale = np.zeros_like(traj)
+        for tick in range(1, 21):
+            goals_ref = oracle.goal_prior_based_map(prm, dm, state, ms.goal, traj, tick, ms.radius, ms.downwash, grid_margin=gm, grid_res=gr)
+            g = pl.plan(state, ms.goal, traj)
+            where = (trial, n, planar, gm, gr, tick)
+            assert (g["status"] < 4).all(), where
+            assert np.array_equal(pl.last_goals(), goals_ref), where
+            sw.stale[:] = stale
+            o = sw.tick(state, goals_ref, traj, tick, want_lsc=False, nthreads=8)
+            assert np.array_equal(g["sfc"], o["sfc"]), where
+            ok = _check(g, o, where)
+            agent_ticks += n
+            stale = np.where(ok[:, None, None], g["traj"], stale).astype(np.float32)
+            traj = g["traj"]
+            state = next_state_host(traj)
+        pl.close()
+    assert agent_ticks > 2500, agent_ticks
