@@ -87,7 +87,11 @@ def random_swarm(n, world=(-20, -20, 0, 20, 20, 5), seed=20260929, min_sep=0.6, 
 
     def sample():
         pts = []
+        draws = 0
         while len(pts) < n:
+            draws += 1
+            if draws > 20000 + 2000 * n:
+                raise ValueError(f"random_swarm: cannot place {n} agents in this world (separation {min_sep}, clearance {min_clearance})")
             p = rng.uniform(lo, hi)
             ok = True
             if edt is not None:
