@@ -311,3 +311,26 @@ def test_throughput_build_agrees_with_the_latency_build(L, n, world, reset_thres
         traj = gb["traj"]
         state = next_state_host(traj)
     tp.close(); lat.close()
+
+
+def test_throughput_build_through_two_shard_contexts(L):
+    """1 200 agents as two ranks would hold them (600 each: more than two workgroups per CU, so each shard runs the
+    throughput build with its own launch order and the bounding spheres of all 1 200 agents) against one unsharded context:
+    bit for bit."""
+    from lsc_planner_amd.planner import next_state_host
+    n = 1200
+    ms = L.random_swarm(n, world=(-22, -22, 0, 22, 22, 4.0), seed=5)
+    cfg = dict(goal_mode="prior_based", reset_threshold=0.15)
+    full, s0, s1 = (L.SwarmPlanner(ms, L.PlannerConfig(**cfg)) for _ in range(3))
+    s0.set_shard(0, 600)
+    s1.set_shard(600, 600)
+    state, traj = _start(ms)
+    for tick in range(1, 7):
+        g, a, b = full.plan(state, ms.goal, traj), s0.plan(state, ms.goal, traj), s1.plan(state, ms.goal, traj)
+        assert np.array_equal(np.concatenate([a["traj"], b["traj"]]), g["traj"]), tick
+        assert np.array_equal(np.concatenate([a["cost"], b["cost"]]), g["cost"]), tick
+        assert np.array_equal(np.concatenate([a["status"], b["status"]]), g["status"]), tick
+        traj = g["traj"]
+        state = next_state_host(traj)
+    for p in (full, s0, s1):
+        p.close()
