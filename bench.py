@@ -53,6 +53,35 @@ def pmc_traffic(key):
     return None, None
 
 
+def weak_scaling_mission(L, G, per_gpu=64, single_circle=False):
+    """Workload.  One GPU: BASELINE configs[2], the 64-agent circle swap.  Several GPUs, weak scaling = fixed work per GPU: G
+    such circles side by side in ONE world (30 m pitch), rank r owning circle r -- every rank's agents are exactly as hard
+    to plan as the single-GPU case, every agent still sees all 64 G agents of the swarm (the far circles' rows are redundant
+    and culled, as far agents of any large swarm are), and the exchange moves all of them.  single_circle: one circle of
+    64 G agents with R = 8 G instead -- the agents' difficulty then changes with G.
+    Returns (mission, description)."""
+    n_agents = per_gpu * G
+    R = 8.0 * per_gpu / 64.0
+    if G == 1 or single_circle:
+        R = 8.0 * n_agents / 64.0
+        ms = L.circle_swap(n_agents, circle_radius=R, z=1.0, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
+        return ms, f"{n_agents}-agent generated circle swap (R={R:g} m, z=1 m)"
+    from lsc_planner_amd.mission import Mission
+    cell = L.circle_swap(per_gpu, circle_radius=R, z=1.0)
+    cols = int(np.ceil(np.sqrt(G)))
+    rows = (G + cols - 1) // cols
+    pitch = 2.0 * R + 14.0
+    off = np.array([[(c % cols) * pitch, (c // cols) * pitch, 0.0] for c in range(G)], np.float32)
+    start = np.concatenate([cell.start + off[c] for c in range(G)])
+    goal = np.concatenate([cell.goal + off[c] for c in range(G)])
+    ms = Mission(start, goal, np.array([-R - 2, -R - 2, 0], np.float32),
+                 np.array([(cols - 1) * pitch + R + 2, (rows - 1) * pitch + R + 2, 2.5], np.float32),
+                 np.tile(cell.radius, G), np.tile(cell.downwash, G), np.tile(cell.max_vel, (G, 1)), np.tile(cell.max_acc, (G, 1)),
+                 np.tile(cell.nominal_velocity, G), name=f"circle_swap{per_gpu}x{G}")
+    return ms, (f"{G} x {per_gpu}-agent generated circle swaps (R={R:g} m, z=1 m, {pitch:g} m pitch) in one world = "
+                f"{n_agents} agents, one circle per GPU")
+
+
 def algorithmic_flops(n_agents, iters_total):
     """per interior-point iteration per agent ~ (N-1)*1.0 kflop + 0.3 Mflop (fp64)."""
     return float(iters_total) * ((n_agents - 1) * 1.0e3 + 0.3e6)
@@ -164,32 +193,8 @@ def main():
         token = L.comm_unique_id()                       # world-size-1 communicator: the same code path on one GPU
     sharded = token is not None
 
-    # Workload.  One GPU: BASELINE configs[2], the 64-agent circle swap.  Several GPUs, weak scaling = fixed work per GPU: G
-    # such circles side by side in ONE world (30 m pitch), rank r owning circle r -- every rank's agents are exactly as hard
-    # to plan as the single-GPU case, every agent still sees all 64 G agents of the swarm (the far circles' rows are redundant
-    # and culled, as far agents of any large swarm are), and the exchange moves all of them.  (--single-circle: one circle of
-    # 64 G agents with R = 8 G instead -- the agents' difficulty then changes with G)
     n_agents = args.agents_per_gpu * G
-    R = 8.0 * args.agents_per_gpu / 64.0
-    if G == 1 or args.single_circle:
-        R = 8.0 * n_agents / 64.0
-        ms = L.circle_swap(n_agents, circle_radius=R, z=1.0, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
-        layout = f"{n_agents}-agent generated circle swap (R={R:g} m, z=1 m)"
-    else:
-        from lsc_planner_amd.mission import Mission
-        cell = L.circle_swap(args.agents_per_gpu, circle_radius=R, z=1.0)
-        cols = int(np.ceil(np.sqrt(G)))
-        pitch = 2.0 * R + 14.0
-        off = np.array([[(c % cols) * pitch, (c // cols) * pitch, 0.0] for c in range(G)], np.float32)
-        start = np.concatenate([cell.start + off[c] for c in range(G)])
-        goal = np.concatenate([cell.goal + off[c] for c in range(G)])
-        rows = (G + cols - 1) // cols
-        ms = Mission(start, goal, np.array([-R - 2, -R - 2, 0], np.float32),
-                     np.array([(cols - 1) * pitch + R + 2, (rows - 1) * pitch + R + 2, 2.5], np.float32),
-                     np.tile(cell.radius, G), np.tile(cell.downwash, G), np.tile(cell.max_vel, (G, 1)), np.tile(cell.max_acc, (G, 1)),
-                     np.tile(cell.nominal_velocity, G), name=f"circle_swap{args.agents_per_gpu}x{G}")
-        layout = (f"{G} x {args.agents_per_gpu}-agent generated circle swaps (R={R:g} m, z=1 m, {pitch:g} m pitch) in one world = "
-                  f"{n_agents} agents, one circle per GPU")
+    ms, layout = weak_scaling_mission(L, G, args.agents_per_gpu, args.single_circle)
     goal_mode = "static" if args.static_goal else "prior_based"
     def make_planner(comm):
         return L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode,

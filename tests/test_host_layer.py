@@ -167,3 +167,32 @@ def test_sharded_stepping_gloo_equals_single_process(oracle, tmp_path, world):
         state = next_state_host(traj)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"rank{r}.npy").reshape(5, 3, 30), traj), r
+
+
+def test_weak_scaling_workload_of_the_bench_is_one_circle_per_rank():
+    """bench.py --gpus G: G circles of 64 agents in one world, rank r owning circle r (lsc_comm_info's partitioning), each an
+    exact translate of the single-GPU mission and far enough from the others that no row between circles can be active."""
+    import importlib.util
+    import lsc_planner_amd as L
+    from lsc_planner_amd.sharded import shard_bounds
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    one, text1 = bench.weak_scaling_mission(L, 1)
+    assert one.qn == 64 and "64-agent generated circle swap (R=8 m" in text1
+    for G in (2, 4, 8):
+        ms, text = bench.weak_scaling_mission(L, G)
+        assert ms.qn == 64 * G and f"{G} x 64-agent" in text
+        assert (ms.start >= ms.world_min).all() and (ms.start <= ms.world_max).all()
+        assert (ms.goal >= ms.world_min).all() and (ms.goal <= ms.world_max).all()
+        for r in range(G):
+            first, count = shard_bounds(ms.qn, G, r)
+            assert count == 64
+            shift = ms.start[first] - one.start[0]
+            assert np.allclose(ms.start[first:first + 64] - shift, one.start, atol=1e-5)
+            assert np.allclose(ms.goal[first:first + 64] - shift, one.goal, atol=1e-5)
+            others = np.delete(np.arange(ms.qn), np.arange(first, first + 64))
+            d = np.linalg.norm(ms.start[first:first + 64, None, :2] - ms.start[None, others, :2], axis=2).min()
+            assert d >= 14.0 - 1e-3
+    big, text8 = bench.weak_scaling_mission(L, 8, single_circle=True)
+    assert big.qn == 512 and "512-agent generated circle swap (R=64 m" in text8
