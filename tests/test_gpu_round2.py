@@ -334,3 +334,38 @@ def test_throughput_build_through_two_shard_contexts(L):
         state = next_state_host(traj)
     for p in (full, s0, s1):
         p.close()
+
+
+def test_bench_line_contract_and_exchange_paths(tmp_path):
+    """bench.py as the driver runs it (short): exactly one JSON line on stdout carrying the contract's fields, `roofline` and
+    -- at N = 1 -- `cpu_baseline`; the sharded sequence on one GPU through the native communicator and through the
+    torch.distributed fallback both report themselves in `rccl`."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    bench = os.path.join(ROOT, "bench.py")
+
+    def run(*flags):
+        r = subprocess.run([sys.executable, bench, "--steps", "12", "--warmup", "4", "--sweep-agents", "0", *flags],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout[:500]
+        return json.loads(lines[0])
+
+    d = run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 4 and d["value"] > 1e4 and d["vs_baseline"] is None
+    assert abs(d["value"] - 64 * 12 / (d["ms_per_step"] * 12e-3)) < 0.01 * d["value"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]) and d["roofline"]["avg_launch_ms"] <= d["ms_per_step"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert "workload" in d["config"] and "64-agent generated circle swap" in d["config"]["workload"]
+    native = run("--unfused", "--no-cpu-baseline", "--no-latency-leg")
+    assert native["rccl"]["native"] is True and native["rccl"]["world_size"] == 1 and native["rccl"]["exchange_us_per_tick"]["mean"] > 0
+    fallback = run("--unfused", "--torch-exchange", "--no-cpu-baseline", "--no-latency-leg")
+    assert fallback["rccl"]["native"] is False and "torch.distributed" in fallback["rccl"]["collective"]
+    assert abs(fallback["value"] - native["value"]) < 0.2 * native["value"]
