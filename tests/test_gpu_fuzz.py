@@ -187,3 +187,48 @@ def test_fuzz_octomap_worlds(oracle):
             state = next_state_host(traj)
         pl.close()
     assert agent_ticks > 2500, agent_ticks
+
+
+def test_fuzz_configuration_values(oracle):
+    """Parameters the shipped launch files never vary: segment time dt (horizon = 5 dt), the two cost weights, and the three
+    thresholds of the goal rule (goal_threshold, priority_dist_threshold, goal_radius) -- statuses and plans against the oracle,
+    goals bit for bit."""
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import PlannerConfig, next_state_host
+    for dt in (0.1, 0.16, 0.25, 0.3):
+        for wc, wt in ((0.01, 1.0), (0.1, 5.0)):
+            ms = L.circle_swap(8, 2.5, world=(-5, -5, 0, 5, 5, 2.5))
+            pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="prior_based", dt=dt, horizon=5 * dt, control_input_weight=wc, terminal_weight=wt))
+            prm = oracle.make_params(dt=dt, w_control=wc, w_terminal=wt, world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+            sw = oracle.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+            state = np.zeros((8, 9), np.float32)
+            state[:, :3] = ms.start
+            traj = np.zeros((8, 3, 30), np.float32)
+            stale = np.zeros_like(traj)
+            for tick in range(1, 21):
+                g = pl.plan(state, ms.goal, traj)
+                goals = pl.last_goals()
+                assert np.array_equal(goals, oracle.goal_prior_based(state, ms.goal, traj, tick, dt=dt)), (dt, tick)
+                sw.stale[:] = stale
+                o = sw.tick(state, goals, traj, tick, want_lsc=False, nthreads=8)
+                ok = _check(g, o, (dt, wc, wt, tick))
+                stale = np.where(ok[:, None, None], g["traj"], stale).astype(np.float32)
+                traj = g["traj"]
+                state = next_state_host(traj, dt=dt)
+            pl.close()
+    rng = np.random.default_rng(3)
+    for trial in range(30):
+        gt, pd, gr = float(rng.choice([0.05, 0.1, 0.3])), float(rng.choice([0.2, 0.4, 0.8, 1.5])), float(rng.choice([0.5, 1.0, 2.0, 4.0]))
+        n = int(rng.integers(3, 16))
+        ms = L.random_swarm(n, world=(-3, -3, 0, 3, 3, 2.5), seed=int(rng.integers(1, 1 << 30)), min_sep=0.5, shrink=0.3)
+        pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="prior_based", goal_threshold=gt, priority_dist_threshold=pd, goal_radius=gr))
+        state = np.zeros((n, 9), np.float32)
+        state[:, :3] = ms.start
+        traj = np.zeros((n, 3, 30), np.float32)
+        for tick in range(1, 21):
+            ref = oracle.goal_prior_based(state, ms.goal, traj, tick, goal_threshold=gt, priority_dist_threshold=pd, goal_radius=gr)
+            g = pl.plan(state, ms.goal, traj)
+            assert np.array_equal(pl.last_goals(), ref), (trial, tick, gt, pd, gr)
+            traj = g["traj"]
+            state = next_state_host(traj)
+        pl.close()
