@@ -33,13 +33,17 @@ def _check(g, o, where):
     return ok
 
 
-def test_fuzz_lsc_mode(oracle):
+@pytest.mark.parametrize("seed0,trials,options", [(1000, 150, {}), (70000, 40, {"warm_start_mu": 0.0}), (71000, 40, {"prune": 0}),
+                                                  (72000, 40, {"prune": 2}), (73000, 40, {"max_rows_per_cp": 3})])
+def test_fuzz_lsc_mode(oracle, seed0, trials, options):
+    """options: the solver's cold start only / no pruning / box-only pruning / an LDS row capacity of three rows per control
+    point (most agents then take the second pass with their rows in HBM)."""
     import lsc_planner_amd as L
     from lsc_planner_amd.mission import Mission
     from lsc_planner_amd.planner import PlannerConfig, next_state_host
     agent_ticks = failures = 0
-    for trial in range(150):
-        rng = np.random.default_rng(1000 + trial)
+    for trial in range(trials):
+        rng = np.random.default_rng(seed0 + trial)
         n = int(rng.integers(1, 14))
         side, top = float(rng.uniform(0.8, 6.0)), float(rng.uniform(0.6, 3.0))
         wmin, wmax = np.array([-side, -side, 0], np.float32), np.array([side, side, top], np.float32)
@@ -58,7 +62,7 @@ def test_fuzz_lsc_mode(oracle):
         vnom = rng.uniform(0.3, 2.0, n)
         ms = Mission(start, goal, wmin, wmax, radius, dw, vmax, amax, vnom, name="fuzz")
         mode = "prior_based" if trial % 2 else "static"
-        pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode=mode))
+        pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode=mode, **options))
         sw = oracle.Swarm(oracle.make_params(world_min=wmin, world_max=wmax, obs_f32=True), radius, dw, vmax, amax, vnom)
         state = np.zeros((n, 9), np.float32)
         state[:, :3] = start
@@ -78,7 +82,7 @@ def test_fuzz_lsc_mode(oracle):
             traj = g["traj"]
             state = next_state_host(traj)
         pl.close()
-    assert agent_ticks > 7000 and failures > 1000, (agent_ticks, failures)
+    assert agent_ticks > 45 * trials and failures > 6 * trials, (agent_ticks, failures)
 
 
 MODES = [(dict(planner_mode="bvc"), dict(planner="bvc")),
