@@ -236,3 +236,58 @@ def test_fuzz_configuration_values(oracle):
             traj = g["traj"]
             state = next_state_host(traj)
         pl.close()
+
+
+def test_fuzz_device_resident_chain_equals_host_buffer_chain():
+    """lsc_tick_device_fused (what bench.py times: everything stays on the device, one launch per tick, the next ideal state
+    computed in the kernel) chained over ten ticks against lsc_replan_tick + host propagation on the same random missions, with
+    and without the disturbance checks and with a three-row LDS capacity: plans, states, statuses and costs bit for bit."""
+    import torch
+    import lsc_planner_amd as L
+    from lsc_planner_amd.mission import Mission
+    from lsc_planner_amd.planner import PlannerConfig, next_state_host
+    dev = torch.device("cuda", 0)
+    agent_ticks = 0
+    for trial in range(40):
+        rng = np.random.default_rng(90000 + trial)
+        n = int(rng.integers(1, 40))
+        side, top = float(rng.uniform(1.0, 6.0)), float(rng.uniform(0.8, 3.0))
+        wmin, wmax = np.array([-side, -side, 0], np.float32), np.array([side, side, top], np.float32)
+        start = rng.uniform(wmin + 0.05, wmax - 0.05, (n, 3)).astype(np.float32)
+        goal = rng.uniform(wmin - 0.2, wmax + 0.2, (n, 3)).astype(np.float32)
+        radius, dw = rng.uniform(0.05, 0.3, n), rng.uniform(1.0, 3.0, n)
+        vmax, amax = np.repeat(rng.uniform(0.3, 2.5, (n, 1)), 3, 1), np.repeat(rng.uniform(0.5, 5.0, (n, 1)), 3, 1)
+        vnom = rng.uniform(0.3, 2.0, n)
+        ms = Mission(start, goal, wmin, wmax, radius, dw, vmax, amax, vnom, name="fuzz")
+        cfg = dict(goal_mode="prior_based" if trial % 2 else "static", reset_threshold=0.15 if trial % 3 == 0 else 0.0,
+                   max_rows_per_cp=3 if trial % 5 == 0 else 0)
+        host, devp = L.SwarmPlanner(ms, PlannerConfig(**cfg)), L.SwarmPlanner(ms, PlannerConfig(**cfg))
+        state = np.zeros((n, 9), np.float32)
+        state[:, :3] = start
+        traj = np.zeros((n, 3, 30), np.float32)
+        f32 = dict(dtype=torch.float32, device=dev)
+        st_d = [torch.tensor(state, device=dev), torch.zeros((n, 9), **f32)]
+        tj_d = [torch.zeros((n, 90), **f32), torch.zeros((n, 90), **f32)]
+        goal_d = torch.tensor(goal, device=dev)
+        cost = torch.zeros(n, dtype=torch.float64, device=dev)
+        status = torch.zeros(n, dtype=torch.int32, device=dev)
+        iters = torch.zeros(n, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        for tick in range(1, 11):
+            g = host.plan(state, goal, traj)
+            devp.tick_device_fused(st_d[0], goal_d, tj_d[0], tj_d[1], st_d[1], cost, status, iters, tick, stream)
+            torch.cuda.synchronize()
+            where = (trial, n, cfg, tick)
+            state = next_state_host(g["traj"])
+            assert np.array_equal(tj_d[1].cpu().numpy().reshape(n, 3, 30), g["traj"]), where
+            assert np.array_equal(status.cpu().numpy(), g["status"]), where
+            assert np.array_equal(st_d[1].cpu().numpy(), state), where
+            ok = g["status"] == 0
+            assert np.array_equal(cost.cpu().numpy()[ok], g["cost"][ok]), where
+            traj = g["traj"]
+            st_d.reverse()
+            tj_d.reverse()
+            agent_ticks += n
+        host.close()
+        devp.close()
+    assert agent_ticks > 5000
