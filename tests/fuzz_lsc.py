@@ -1,5 +1,5 @@
 """Seeded fuzzing of the LSC-mode tick against the oracle (the large-count version of tests/test_gpu_fuzz.py::test_fuzz_lsc_mode).
-    python tools/fuzz_lsc.py SEED0 TRIALS [MAX_AGENTS] ['{"prune": 0}']
+    python tests/fuzz_lsc.py SEED0 TRIALS [MAX_AGENTS] ['{"prune": 0}']
 Needs a GPU and the built oracle (test infrastructure); prints one summary line."""
 import sys, numpy as np, time
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))

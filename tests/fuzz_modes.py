@@ -1,5 +1,5 @@
 """Seeded fuzzing of the alternate planner modes against the oracle (large-count version of test_fuzz_alternate_modes).
-    python tools/fuzz_modes.py SEED0 TRIALS
+    python tests/fuzz_modes.py SEED0 TRIALS
 Mismatching ticks are dumped to gpurun_out/fuzz/ for a HiGHS check on the CPU."""
 import sys, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))

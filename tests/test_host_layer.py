@@ -39,6 +39,12 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 for pat in forbidden:
                     assert pat not in txt, (f, pat)
+    # the helper scripts outside tests/ do not use it either (the fuzzers that do live under tests/)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            for pat in ("from oracle", "import oracle", "liblsc_oracle", "lsc_oracle.h"):
+                assert pat not in txt, (f, pat)
 
 
 def test_device_gjk_header_matches_oracle_on_host(oracle, gjk_golden):
