@@ -202,3 +202,18 @@ def test_weak_scaling_workload_of_the_bench_is_one_circle_per_rank():
             assert d >= 14.0 - 1e-3
     big, text8 = bench.weak_scaling_mission(L, 8, single_circle=True)
     assert big.qn == 512 and "512-agent generated circle swap (R=64 m" in text8
+
+
+def test_the_header_is_plain_c(tmp_path):
+    """include/lsc_planner_amd.h is the C ABI a cgo / JNI / ctypes / C++ caller binds: it must compile as C99 and as C++11
+    with nothing but itself, and a C program must link against the library's exported names."""
+    src = tmp_path / "abi.c"
+    src.write_text('#include "lsc_planner_amd.h"\n'
+                   'int main(void) { lsc_config c; lsc_default_config(&c); return c.device == 0 && c.dt > 0.19 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)])
+    lib = os.path.join(ROOT, "lsc_planner_amd")
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", lib, "-llsc_hip", "-Wl,-rpath," + lib])
+    assert subprocess.run([str(exe)], timeout=120).returncode == 0     # lsc_default_config needs no GPU
