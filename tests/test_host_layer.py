@@ -217,3 +217,20 @@ def test_the_header_is_plain_c(tmp_path):
     exe = tmp_path / "abi"
     subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", lib, "-llsc_hip", "-Wl,-rpath," + lib])
     assert subprocess.run([str(exe)], timeout=120).returncode == 0     # lsc_default_config needs no GPU
+
+
+def test_ctypes_config_struct_matches_the_header(tmp_path):
+    """lsc_planner_amd/_lib.py::LscConfig mirrors `lsc_config` field by field: same size, same offset of every field."""
+    import ctypes
+    from lsc_planner_amd._lib import LscConfig
+    names = [f[0] for f in LscConfig._fields_]
+    src = tmp_path / "layout.c"
+    body = "".join('    printf("%s %%zu\\n", offsetof(lsc_config, %s));\n' % (n, n) for n in names)
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "lsc_planner_amd.h"\n'
+                   'int main(void) {\n    printf("sizeof %zu\\n", sizeof(lsc_config));\n' + body + '    return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(out["sizeof"]) == ctypes.sizeof(LscConfig)
+    for n in names:
+        assert int(out[n]) == getattr(LscConfig, n).offset, n
