@@ -111,3 +111,27 @@ def test_solver_optimality_certificate_and_scipy_cross_check(oracle, ticks):
                                options={"maxiter": 500, "ftol": 1e-14})
                 assert res.fun >= cost - 1e-6 * abs(cost)          # nothing feasible beats the certified optimum
                 assert abs(res.fun - cost) <= 1e-5 * abs(cost)
+
+
+def test_ctypes_mirrors_of_the_oracle_structs_match_the_header(tmp_path):
+    """oracle/oracle.py mirrors orc_params / orc_modes / orc_row of oracle/lsc_oracle.h: same size, same field offsets."""
+    import ctypes
+    import os
+    import subprocess
+    from conftest import ROOT
+    from oracle import oracle as O
+    structs = {"orc_params": O.OrcParams, "orc_modes": O.OrcModes, "orc_row": O.OrcRow}
+    body = ""
+    for cname, cls in structs.items():
+        body += '    printf("%s.sizeof %%zu\\n", sizeof(%s));\n' % (cname, cname)
+        for f in cls._fields_:
+            body += '    printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (cname, f[0], cname, f[0])
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "lsc_oracle.h"\nint main(void) {\n' + body + '    return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "oracle"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in structs.items():
+        assert int(out[cname + ".sizeof"]) == ctypes.sizeof(cls), cname
+        for f in cls._fields_:
+            assert int(out["%s.%s" % (cname, f[0])]) == getattr(cls, f[0]).offset, (cname, f[0])
