@@ -13,9 +13,10 @@ Workload (config.workload): BASELINE.json configs[2], the 64-agent circle swap o
 prior_based: goalPlanningWithPriority runs on the device; on maps without a distance field the reference's grid A*
 has no observable effect on the planned goal, see DESIGN.md -- and multisim/reset_threshold = 0.15: the disturbance checks
 of the reference run every tick, lsc_plan_alt_kernel + the hand-over launch of lsc_general_kernel).
-With --gpus G the swarm is 64*G agents on a circle of radius 8*G (same spacing), agent-sharded 64 per GPU with one
-in-place RCCL all-gather of the new trajectories per tick (native: lsc_tick_device_sharded enqueues plan kernel,
-ncclAllGather and state propagation on one stream): weak scaling.  `python bench.py --gpus G` starts the G ranks itself
+With --gpus G the swarm is G such circles side by side in one world (64*G agents, 30 m pitch; --single-circle: one circle of
+radius 8*G), agent-sharded one circle per GPU with one in-place RCCL all-gather of the new trajectories per tick (native:
+lsc_tick_device_sharded enqueues plan kernel, ncclAllGather and state propagation on one stream; if that communicator
+cannot be created, the torch.distributed all-gather around the same kernels): weak scaling with fixed difficulty per GPU.  `python bench.py --gpus G` starts the G ranks itself
 (re-executes under torch.distributed.run when WORLD_SIZE is not set); torch.distributed is only the control plane
 (rendezvous token, barrier, max-over-ranks of the elapsed time).
 
