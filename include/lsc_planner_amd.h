@@ -89,7 +89,7 @@ typedef struct {
     double priority_dist_threshold; /* plan/priority_dist_threshold 0.4 */
     double goal_radius;        /* plan/goal_radius             2.0 */
     double warm_start_mu;      /* interior-point start: > 0 warm start from the shifted previous plan, every row
-                                  centred on this complementarity value (default 0.05), with the cold (Mehrotra)
+                                  centred on this complementarity value (default 0.03), with the cold (Mehrotra)
                                   start as fallback; 0 = always cold start */
     double grid_resolution;    /* grid/resolution 0.3: cell of the goal planner's search grid (goal_mode 1 + use_octomap) */
     double grid_margin;        /* grid/margin     0.2: a cell is occupied when EDT(centre) < radius + grid_margin        */

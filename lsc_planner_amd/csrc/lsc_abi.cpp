@@ -156,7 +156,7 @@ void build_model(const lsc_config &cfg, HostModel &H)
     m.max_iters = cfg.max_iters > 0 ? cfg.max_iters : 50;
     m.dx_tol = 2e-8;
     m.gap_tol = cfg.gap_tolerance > 0.0 ? cfg.gap_tolerance : 1e-9;
-    m.ws_mu0 = cfg.warm_start_mu >= 0.0 ? cfg.warm_start_mu : 0.05;
+    m.ws_mu0 = cfg.warm_start_mu >= 0.0 ? cfg.warm_start_mu : 0.03;
     int n = 0;
     for (int sl = 0; sl < AXROWS; sl++) {
         const int type = sl / NV, t = (sl % NV) % SEGV, mm = t / NC, i = t % NC;
@@ -346,7 +346,7 @@ void lsc_default_config(lsc_config *cfg)
     cfg->world_min[0] = -10; cfg->world_min[1] = -10; cfg->world_min[2] = 0;
     cfg->world_max[0] = 10; cfg->world_max[1] = 10; cfg->world_max[2] = 2.5f;
     cfg->use_octomap = 0; cfg->world_resolution = 0.1; cfg->device = 0;
-    cfg->max_rows_per_cp = 0; cfg->max_iters = 50; cfg->prune = 1; cfg->warm_start_mu = 0.05;
+    cfg->max_rows_per_cp = 0; cfg->max_iters = 50; cfg->prune = 1; cfg->warm_start_mu = 0.03;
     cfg->goal_mode = 0; cfg->goal_threshold = 0.1; cfg->priority_dist_threshold = 0.4; cfg->goal_radius = 2.0;
     cfg->grid_resolution = 0.3; cfg->grid_margin = 0.2;   // launch/testall_forest.launch:88-89
     cfg->horizon = 1.0; cfg->goal_row_cap = 0;

@@ -25,7 +25,7 @@ class PlannerConfig:
     max_rows_per_cp: int = 0
     max_iters: int = 50
     prune: bool = True
-    warm_start_mu: float = 0.05    # 0 = cold (Mehrotra) start only
+    warm_start_mu: float = 0.03    # 0 = cold (Mehrotra) start only
     goal_mode: str = "static"       # mode/goal: "static" or "prior_based" (the latter: goal input = desired goal)
     goal_threshold: float = 0.1
     priority_dist_threshold: float = 0.4
