@@ -1563,8 +1563,9 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     } else if (attempt == 0) {
         // An agent with few surviving LSC rows (most agents of a sparse swarm) is close to its unconstrained optimum: it
         // starts a third as far from the boundary.  Over 36 missions this takes 10 % off the ticks of random swarms and
-        // leaves crossing swarms where they were (profiles/r02_solver_knob_sweeps.log).
-        prepare_warm(nact < WS_FEW_ROWS ? md.ws_mu0 * (1.0 / 3.0) : md.ws_mu0);
+        // leaves crossing swarms where they were (profiles/r02_solver_knob_sweeps.log).  Not in corridor worlds: there the
+        // box rows, which this count does not see, are what is active (the 256-agent forest loses 2.6 % with the rule).
+        prepare_warm((nact < WS_FEW_ROWS && !md.use_sfc) ? md.ws_mu0 * (1.0 / 3.0) : md.ws_mu0);
         phase = ST_PRED;
     } else {
         prepare_cold();
