@@ -118,6 +118,10 @@ typedef struct {
                                   z = world_z_2d (src/grid_based_planner.cpp:82-85, 127-133, 199-215); the QP stays 3-D as in
                                   the reference (src/traj_optimizer.cpp never looks at the dimension).  0 is read as 3       */
     double world_z_2d;         /* world/z_2d (src/param.cpp:15; 1.0)                                                        */
+    int    goal_search;        /* goal planner's grid search: 0 (default) the register-resident search whenever the grid admits it
+                                  (at most 128 rows, (j, z) of a cell in 17 bits), else the general one; 1 always the general
+                                  single-wave search with the row bookkeeping in LDS; 2 = 0; 3 the cooperative search (four waves
+                                  per agent, one per SIMD; same admission rule).  Same paths in every case (tests compare them) */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);
@@ -267,6 +271,11 @@ int lsc_iterations_total(lsc_ctx *ctx, long long *total, int reset);
  * solves, affine pass, corrector pass, step+update, output.  lsc_solver_residuals: [N][4] last duality gap,
  * primal residual, stationarity residual, objective. */
 int lsc_phase_profile(lsc_ctx *ctx, int enable, long long *out);
+/* The same for the goal planner's register-resident grid search: out gets [N][16] counters, shader cycles unless noted:
+ * prologue (priority / retreat rule), grid set-up, search, path + line-of-sight goal; of the search: findMin, deleteMin,
+ * neighbour screening, insertions; of those: cycles and count of the pops and of the insertions that took the general LDS
+ * routines (rows beyond 64 entries, rehashes); the rest is reserved. */
+int lsc_goal_profile(lsc_ctx *ctx, int enable, long long *out);
 int lsc_solver_residuals(lsc_ctx *ctx, double *out);
 /* Reads the [64][8] per-iteration trace recorded for the agent selected by the PREVIOUS call (out may be NULL),
  * then selects `agent` (-1: off): gap, |rp|, objective, affine step, sigma, step, |dx_aff|, mu. */

@@ -231,6 +231,8 @@ struct lsc_ctx {
     unsigned char *d_occ_static = nullptr;
     int *d_goal_err = nullptr, *d_goal_flags = nullptr, *d_goal_exp = nullptr, *d_goal_path = nullptr, *d_goal_plen = nullptr;
     int goal_path_cap = 0;
+    long long *d_goal_prof = nullptr;
+    bool goal_profiling = false;
     int grid_dims[3] = {0, 0, 0}, grid_row_cap = 0;
     double grid_min[3] = {0, 0, 0};
     std::vector<int> nb_seq;
@@ -353,7 +355,7 @@ void lsc_default_config(lsc_config *cfg)
     cfg->planner_mode = 0; cfg->slack_mode = 0; cfg->slack_collision_weight = 100000.0; cfg->n_constraint_segments = -1;
     cfg->reset_threshold = 0.0;
     cfg->gap_tolerance = 1e-9;
-    cfg->world_dimension = 3; cfg->world_z_2d = 1.0;
+    cfg->world_dimension = 3; cfg->world_z_2d = 1.0; cfg->goal_search = 0;
 }
 
 lsc_ctx *lsc_create(const lsc_config *cfg)
@@ -415,8 +417,9 @@ static void free_agents(lsc_ctx *c)
     if (c->h_in) { (void)hipHostFree(c->h_in); c->h_in = nullptr; }
     if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
     void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
-                  c->d_goal_path, c->d_goal_plen};
+                  c->d_goal_path, c->d_goal_plen, c->d_goal_prof};
     for (void *p : gp) if (p) (void)hipFree(p);
+    c->d_goal_prof = nullptr;
     c->d_edt = c->d_goal_planned = c->d_ray_stack = nullptr; c->d_occ_static = nullptr;
     c->d_goal_err = c->d_goal_flags = c->d_goal_exp = c->d_goal_path = c->d_goal_plen = nullptr;
     c->d_radius = c->d_radius_obs = c->d_downwash = c->d_downwash_obs = c->d_vmax = c->d_amax = c->d_vnom = nullptr;
@@ -722,10 +725,14 @@ static int run_goal(lsc_ctx *c, const float *d_state, const float *&d_goal, cons
         g.nb_magic[k] = k < g.n_nb ? (uint32_t)(0x100000000ull / (uint32_t)c->nb_seq[k]) : 0u;
     }
     g.row_cap = c->grid_row_cap;
+    g.variant = c->cfg.goal_search == 1 ? 0 : goal_fast_slots(g.H, g.W, g.A, &g.jbits);
+    if (g.variant == 0) g.jbits = 0;
+    else if (c->cfg.goal_search == 3) g.variant |= 4;          // cooperative: four waves per search
     g.goal_out = c->d_goal_planned; g.err = c->d_goal_err; g.flags = c->d_goal_flags; g.expansions = c->d_goal_exp;
     g.path_out = c->d_goal_path; g.path_cap = c->goal_path_cap; g.path_len = c->d_goal_plen;
     g.ray_stack = c->d_ray_stack;
     g.reset_thr = c->cfg.planner_mode == 0 ? c->cfg.reset_threshold : 0.0; g.ever = c->d_ever;
+    g.prof = c->goal_profiling ? c->d_goal_prof : nullptr;
     hipEvent_t e1 = nullptr;
     if (c->timing && timing_begin(c, 3, st, &e1) != LSC_OK) return LSC_EHIP;
     HIPCHK(c, launch_goal(g, st));
@@ -1131,6 +1138,26 @@ int lsc_phase_profile(lsc_ctx *c, int enable, long long *out)
     if (enable >= 0) {
         c->profiling = enable != 0;
         HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * PROF_PHASES * (size_t)c->N));
+    }
+    return LSC_OK;
+}
+
+// Diagnostics: section profile of the goal planner's register-resident search.  enable = 1 switches to the instrumented
+// kernel and clears the counters, 0 switches back, < 0 only reads; out (may be null) receives [N][8] shader cycles accumulated
+// since then: prologue (priority / retreat rule), grid set-up, search, path + line-of-sight goal; of the search: findMin,
+// deleteMin, neighbour screening, insertions.
+int lsc_goal_profile(lsc_ctx *c, int enable, long long *out)
+{
+    if (!c || c->N == 0) return LSC_EINVAL;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (!c->d_goal_prof) {
+        HIPCHK(c, hipMalloc(&c->d_goal_prof, sizeof(long long) * 16 * (size_t)c->N));
+        HIPCHK(c, hipMemset(c->d_goal_prof, 0, sizeof(long long) * 16 * (size_t)c->N));
+    }
+    if (out) HIPCHK(c, hipMemcpy(out, c->d_goal_prof, sizeof(long long) * 16 * (size_t)c->N, hipMemcpyDeviceToHost));
+    if (enable >= 0) {
+        c->goal_profiling = enable != 0;
+        HIPCHK(c, hipMemset(c->d_goal_prof, 0, sizeof(long long) * 16 * (size_t)c->N));
     }
     return LSC_OK;
 }

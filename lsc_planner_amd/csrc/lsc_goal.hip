@@ -25,6 +25,8 @@
 
 namespace lsc {
 
+extern __shared__ __align__(16) unsigned char gsm[];   // the workgroup's dynamic LDS
+
 namespace {
 
 constexpr uint32_t KEY_BITS = 17;
@@ -347,16 +349,882 @@ __device__ bool cast_ray(const GoalArgs &a, const float from[3], const float to[
     }
 }
 
-}  // namespace
 
-__global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
+// ---------------------------------------------------------------------------------------------------------------------
+// Register-resident search (round 3).  Same container emulation, same order of operations on every row, far fewer
+// instructions per expanded node (the search is a single dependent chain: its cost is its instruction count plus its LDS
+// round trips).
+//   * the per-row bookkeeping (count, bucket count and its magic, registered minimum and its F) lives in the registers
+//     of lane (i mod 64), slot (i / 64), not in LDS: findMin is a lane-local select plus one wave reduction, an update
+//     is a predicated move;
+//   * an OPEN entry is  j | z << JB | g << 17  (the row index i is implied), so a lane gets (j, z) with two bit-field
+//     extracts instead of two divisions; the reference's key  H W z + W i + j  (what the container hashes) is two
+//     multiply-adds away;
+//   * one batch of LDS loads per node: the popped row (entry p and p + 1 per lane), the cell bytes of the six neighbours
+//     and of the popped cell itself (lane 6); the erase, the rescan and the insertions into the same row work on that
+//     register copy, rows i - 1 / i + 1 are loaded when something is inserted there; all cell bytes of a node (CLOSED for
+//     the popped cell, OPEN + direction + g mod 8 for the unseen neighbours) are one ds_write_b8;
+//   * a row is shifted up by one entry with a DPP wave_shr (no LDS traffic).
+// Rows longer than 64 entries, rehashes and the (practically never taken) "already OPEN with a larger g" case use the
+// chunked LDS routines below -- same results, any length.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct FGeoL {
+    int H, W, A, HW, cap, lane;
+    int JB;                          // bits of j in an entry
+    uint32_t JM;                     // (1 << JB) - 1
+    int gi, gj, gz;
+    uint8_t *st;
+    uint32_t *rows, *tmp;
+    const int *nb_seq;
+    const uint32_t *nb_magic;
+    int n_nb;
+};
+
+__device__ __forceinline__ double f_entry(const FGeoL &c, uint32_t e, int di2)
 {
 #pragma clang fp contract(off)
-    extern __shared__ __align__(16) unsigned char gsm[];
-    const int lane = threadIdx.x;
+    const int j = (int)(e & c.JM), z = (int)((e & KEY_MASK) >> c.JB);
+    const int dj = c.gj - j, dz = c.gz - z;
+    return 10.0 * (double)(e >> KEY_BITS) + 10.0 * sqrt((double)(di2 + dj * dj + dz * dz));
+}
+// the key the reference's container hashes: Node::get_id = H W z + W i + j
+__device__ __forceinline__ uint32_t ref_key(const FGeoL &c, uint32_t e, uint32_t Wi)
+{
+    return (uint32_t)c.HW * ((e & KEY_MASK) >> c.JB) + Wi + (e & c.JM);
+}
+// k mod nb with m = floor(2^32 / nb): the quotient estimate is at most one too small
+__device__ __forceinline__ uint32_t bucket_of(uint32_t k, uint32_t nb, uint32_t m)
+{
+    const uint32_t r = k - __umulhi(k, m) * nb;
+    return min(r, r - nb);
+}
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ double readlane_d(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+__device__ int f_row_find(int lane, const uint32_t *row, int cnt, uint32_t jz)
+{
+    for (int base = 0; base < cnt; base += 64) {
+        const int p = base + lane;
+        const unsigned long long mask = __ballot(p < cnt && (row[p] & KEY_MASK) == jz);
+        if (mask) return base + __ffsll((long long)mask) - 1;
+    }
+    return -1;
+}
+
+// _M_insert_bucket_begin on a row of any length held in LDS (chunks of 64)
+__device__ void f_row_place(const FGeoL &c, uint32_t *row, int cnt, uint32_t e, uint32_t Wi, uint32_t nb, uint32_t nbm)
+{
+    auto bucket = [&](uint32_t v) { const uint32_t k = ref_key(c, v, Wi); return k - div_magic(k, nb, nbm) * nb; };
+    const uint32_t b = bucket(e);
+    int pos = 0;
+    for (int base = 0; base < cnt; base += 64) {
+        const int p = base + c.lane;
+        const bool m = p < cnt && bucket(row[p]) == b;
+        const unsigned long long mask = __ballot(m);
+        if (mask) { pos = base + __ffsll((long long)mask) - 1; break; }
+    }
+    for (int hi = cnt; hi > pos; hi -= 64) {
+        const int lo = hi - 64 > pos ? hi - 64 : pos;
+        const int p = lo + c.lane;
+        const uint32_t v = p < hi ? row[p] : 0u;
+        wsync();
+        if (p < hi) row[p + 1] = v;
+        wsync();
+    }
+    if (c.lane == 0) row[pos] = e;
+    wsync();
+}
+
+// unordered_map::operator[] on a missing key, row in LDS, bookkeeping passed in and out (uniform values)
+__device__ void f_row_insert(const FGeoL &c, int i, uint32_t e, int &cnt, int &nbi, uint32_t &nb, uint32_t &nbm, int &err)
+{
+    uint32_t *row = c.rows + (size_t)i * c.cap;
+    const uint32_t Wi = (uint32_t)(c.W * i);
+    if (cnt + 1 > c.cap) { err = 1; return; }
+    if ((uint32_t)(cnt + 1) > nb || nbi < 0) {
+        nbi++;
+        if (nbi >= c.n_nb) { err = 1; return; }
+        nb = (uint32_t)uni(c.nb_seq[nbi]);                     // (a value loaded from LDS is divergent to the compiler)
+        nbm = (uint32_t)uni((int)c.nb_magic[nbi]);
+        for (int p = c.lane; p < cnt; p += 64) c.tmp[p] = row[p];
+        wsync();
+        for (int t = 0; t < cnt; t++) f_row_place(c, row, t, c.tmp[t], Wi, nb, nbm);
+    }
+    f_row_place(c, row, cnt, e, Wi, nb, nbm);
+    cnt++;
+}
+
+// erase + deleteMin's rescan on a row of any length held in LDS
+__device__ void f_row_pop(const FGeoL &c, int i, uint32_t jz, int cnt, double &Fout, uint32_t &mout)
+{
+    uint32_t *row = c.rows + (size_t)i * c.cap;
+    const int di = c.gi - i, di2 = di * di;
+    int pos = -1;
+    double bf = 1e300;
+    uint32_t bsel = 0, bent = 0;
+    for (int base = 0; base < cnt; base += 64) {
+        const int p = base + c.lane;
+        uint32_t e = p < cnt ? row[p] : 0u;
+        if (pos < 0) {
+            const unsigned long long m = __ballot(p < cnt && (e & KEY_MASK) == jz);
+            if (m) pos = base + __ffsll((long long)m) - 1;
+        }
+        const bool moved = pos >= 0 && p >= pos;
+        if (moved) e = p + 1 < cnt ? row[p + 1] : 0u;
+        wsync();
+        if (moved && p < cnt - 1) row[p] = e;
+        if (p < cnt - 1) {
+            const double f = f_entry(c, e, di2);
+            const uint32_t sel = ((e >> KEY_BITS) << 16) | (uint32_t)p;
+            if (f < bf || (f == bf && sel >= bsel)) { bf = f; bsel = sel; bent = e; }
+        }
+        wsync();
+    }
+    Fout = 1e300; mout = 0;
+    if (cnt > 1) {
+        const double fmin = wave_min_d(bf);
+        const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
+        const unsigned long long own = __ballot(bf == fmin && bsel == sel);
+        mout = (uint32_t)__builtin_amdgcn_readlane((int)bent, __ffsll((long long)own) - 1);
+        Fout = fmin;
+    }
+}
+
+// ---- wave primitives of the register-resident search.  One wave alone on its CU issues an instruction every 5-8 cycles
+// whatever its kind (measured), so the search costs what its instruction count costs: the reductions are
+// 32-bit DPP chains (one fused v_min_u32_dpp per stage) over the two halves of F's bit pattern -- non-negative doubles
+// order like their bit patterns -- instead of v_min_f64 on moved copies.
+using FK = unsigned long long;                  // bit pattern of F (>= 0), ~0 for "no entry"
+constexpr FK FK_NONE = ~0ull;
+__device__ __forceinline__ FK fk_of(double f) { return (FK)__double_as_longlong(f); }
+// (the two wait states in front of every stage are the VALU-write -> DPP-read hazard of gfx9; lanes without a DPP source keep
+// their own value, so no identity is needed)
+__device__ __forceinline__ uint32_t wmin_u32(uint32_t v)
+{
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wmax_u32(uint32_t v)
+{
+    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0"
+        : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// smallest F over the lanes, then the largest sel among those lanes (both uniform)
+__device__ __forceinline__ void argmin_f_sel(FK f, uint32_t sel, FK &fmin, uint32_t &smax)
+{
+    const uint32_t hi = (uint32_t)(f >> 32), lo = (uint32_t)f;
+    const uint32_t mh = wmin_u32(hi);
+    const bool c1 = hi == mh;
+    const uint32_t ml = wmin_u32(c1 ? lo : 0xffffffffu);
+    const bool c2 = c1 && lo == ml;
+    smax = wmax_u32(c2 ? sel : 0u);
+    fmin = ((FK)mh << 32) | ml;
+}
+// sqrt of a non-negative integer-valued double < 2^52: the instruction sequence the compiler emits for sqrt(double) without
+// its range scaling and class checks -- bit-identical to sqrt() on every integer below 2^22 (checked on the device)
+__device__ __forceinline__ double sqrt_int(double x)
+{
+#pragma clang fp contract(off)
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = r * 0.5;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
+    double d = __builtin_fma(-g, g, x); g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x); g = __builtin_fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+// F = g + H of the reference (g = 10 steps, H = 10 sqrt(d2)); 10 steps is exact, so the fused form rounds like the sum
+__device__ __forceinline__ FK fk_entry(uint32_t steps, int d2)
+{
+#pragma clang fp contract(off)
+    const double h = 10.0 * sqrt_int((double)d2);
+    return fk_of(__builtin_fma(10.0, (double)steps, h));
+}
+template <typename T>
+__device__ __forceinline__ T *uni_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
+// ISearch::startSearch on the register-resident rows.  NS = slots of row bookkeeping per lane (H <= 64 NS).  Out of line on
+// purpose: the search loop gets a register allocation of its own (inlined into the kernel, the scalar registers that hold the
+// launch arguments across it were spilled into the loop).  Returns expansions | end_key << 32 | found << 52 | err << 56.
+struct FGeo {
+    int H, W, A, HW, cap;
+    int JB;                          // bits of j in an entry
+    int gi, gj, gz;
+    int s0, s1, s2;                  // start cell
+    int n_nb;
+    int bk_off, mb_off;              // cooperative search: row bookkeeping [H] and mailboxes
+    int st_off, rows_off, tmp_off, nbs_off, nbm_off;     // byte offsets into the workgroup's LDS (a pointer passed through a call loses its address space)
+    long long *prof;                 // PROF: [8] counters of this agent
+};
+
+template <int NS, bool PROF>
+__device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
+{
+#pragma clang fp contract(off)
+    const int lane = (int)threadIdx.x;
+    // everything uniform arrives in vector registers (calling convention): back to scalars
+    const int H = uni(gin.H), W = uni(gin.W), A = uni(gin.A), HW = uni(gin.HW), cap = uni(gin.cap), JB = uni(gin.JB);
+    const int gi = uni(gin.gi), gj = uni(gin.gj), gz = uni(gin.gz), n_nb = uni(gin.n_nb);
+    const uint32_t JM = (1u << JB) - 1u;
+    uint8_t *const st = gsm + uni(gin.st_off);
+    uint32_t *const rows = reinterpret_cast<uint32_t *>(gsm + uni(gin.rows_off)), *const tmp = reinterpret_cast<uint32_t *>(gsm + uni(gin.tmp_off));
+    const int *const nb_seq = reinterpret_cast<const int *>(gsm + uni(gin.nbs_off));
+    const uint32_t *const nb_magic = reinterpret_cast<const uint32_t *>(gsm + uni(gin.nbm_off));
+    FGeoL c;
+    c.H = H; c.W = W; c.A = A; c.HW = HW; c.cap = cap; c.lane = lane; c.JB = JB; c.JM = JM; c.gi = gi; c.gj = gj; c.gz = gz;
+    c.st = st; c.rows = rows; c.tmp = tmp; c.nb_seq = nb_seq; c.nb_magic = nb_magic; c.n_nb = n_nb;
+    int err = 0, expansions = 0;
+    long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0-3 sections; 4/5 cycles / count of general pops; 6/7 of general insertions
+    long long tk = 0;
+    auto tick = [&](int slot) { if constexpr (PROF) { const long long t = (long long)__builtin_readcyclecounter(); pc[slot] += t - tk; tk = t; } };
+    auto done = [&](bool found, uint32_t end_key) {
+        if constexpr (PROF) { long long *pr = uni_ptr(gin.prof); if (lane == 0) for (int k = 0; k < 12; k++) pr[4 + k] += pc[k]; }
+        return (unsigned long long)(unsigned)expansions | ((unsigned long long)end_key << 32) | ((unsigned long long)(found ? 1 : 0) << 52) |
+               ((unsigned long long)err << 56);
+    };
+    // per-row state in registers: lane l, slot t <-> row l + 64 t.   rCn = count | lim << 10 | (nbi + 1) << 20 with
+    // lim = min(bucket count, 64, cap) (0 for a fresh container): the in-register insertion applies while count < lim
+    FK rF[NS];
+    uint32_t rMn[NS], rCn[NS];
+#pragma unroll
+    for (int t = 0; t < NS; t++) { rF[t] = FK_NONE; rMn[t] = 0u; rCn[t] = 0u; }
+    const uint32_t tabNb = lane < 16 ? (uint32_t)nb_seq[lane & 15] : 0u, tabNbm = lane < 16 ? nb_magic[lane & 15] : 0u;   // bucket counts by index
+    auto get_u = [&](const uint32_t (&a)[NS], int i) { uint32_t v = a[0]; if constexpr (NS > 1) { if (i >= 64) v = a[1]; } return (uint32_t)__builtin_amdgcn_readlane((int)v, i & 63); };
+    auto get_f = [&](int i) {
+        FK v = rF[0];
+        if constexpr (NS > 1) { if (i >= 64) v = rF[1]; }
+        return ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), i & 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i & 63);
+    };
+    auto put = [&](int i, FK F, uint32_t mn, uint32_t cn) {
+#pragma unroll
+        for (int t = 0; t < NS; t++) { const bool m = lane + 64 * t == i; rF[t] = m ? F : rF[t]; rMn[t] = m ? mn : rMn[t]; rCn[t] = m ? cn : rCn[t]; }
+    };
+    auto pack_cn = [&](int cnt, int nbi, uint32_t nb) {
+        const uint32_t lim = nbi < 0 ? 0u : min(min(nb, 64u), (uint32_t)cap);
+        return (uint32_t)cnt | (lim << 10) | ((uint32_t)(nbi + 1) << 20);
+    };
+    // lanes 0..5: one neighbour each, in the order of findSuccessors' nested loops; lane 6: the popped cell itself
+    const int l_di = lane == 0 ? -1 : (lane == 5 ? 1 : 0), l_dj = lane == 1 ? -1 : (lane == 4 ? 1 : 0), l_dz = lane == 2 ? -1 : (lane == 3 ? 1 : 0);
+    const int l_dkey = HW * l_dz + W * l_di + l_dj;
+    const uint32_t l_open = (uint32_t)ST_OPEN | ((uint32_t)lane << 2);             // st_open(lane, .) without g
+
+    {   // the start node, g = 0 (parent code 7: none)
+        const int s0 = uni(gin.s0), s1 = uni(gin.s1), s2 = uni(gin.s2);
+        int cnt = 0, nbi = -1;
+        uint32_t nb = 1u, nbm = 0u;
+        const uint32_t e0 = (uint32_t)s1 | ((uint32_t)s2 << JB);
+        f_row_insert(c, s0, e0, cnt, nbi, nb, nbm, err);
+        if (err) return done(false, 0u);
+        if (lane == 0) st[HW * s2 + W * s0 + s1] = st_open(7, 0);
+        const int di = gi - s0, dj = gj - s1, dz = gz - s2;
+        put(s0, fk_entry(0u, di * di + dj * dj + dz * dz), e0, pack_cn(1, nbi, nb));
+        wsync();
+    }
+    auto slow_insert = [&](int i, uint32_t e, int &cnt, int &nbi, uint32_t &nb, uint32_t &nbm) {
+        long long t0 = 0;
+        if constexpr (PROF) t0 = (long long)__builtin_readcyclecounter();
+        f_row_insert(c, i, e, cnt, nbi, nb, nbm, err);
+        if constexpr (PROF) { pc[6] += (long long)__builtin_readcyclecounter() - t0; pc[7]++; }
+    };
+    int nopen = 1;
+    if constexpr (PROF) tk = (long long)__builtin_readcyclecounter();
+    while (nopen > 0) {
+        expansions++;
+        // ---- findMin (:181-209): smallest F over the registered row minima, then the largest g, then the LAST row
+        FK bf = rF[0];
+        uint32_t bsel = ((rMn[0] >> KEY_BITS) << 16) | (uint32_t)lane;
+        if constexpr (NS > 1) {
+            const uint32_t s1 = ((rMn[1] >> KEY_BITS) << 16) | (uint32_t)(lane + 64);
+            const bool take = rF[1] < bf || (rF[1] == bf && s1 >= bsel);
+            bf = take ? rF[1] : bf; bsel = take ? s1 : bsel;
+        }
+        FK fmin;
+        uint32_t sel;
+        argmin_f_sel(bf, bsel, fmin, sel);
+        const int ci = (int)(sel & 0xffffu), cg = (int)(sel >> 16);
+        const uint32_t cjz = get_u(rMn, ci) & KEY_MASK;
+        const uint32_t ccn = get_u(rCn, ci);
+        const int ccnt = (int)(ccn & 1023u);
+        const int cj = (int)(cjz & JM), cz = (int)(cjz >> JB);
+        const int ckey = HW * cz + W * ci + cj;
+        uint32_t *rowc = rows + ci * cap;
+        tick(0);
+        // ---- the loads of this node in one batch (unpredicated: entries past the count are never looked at)
+        const uint32_t e = rowc[lane], nxt = rowc[lane + 1];
+        const int ni = ci + l_di, nj = cj + l_dj, nz = cz + l_dz;
+        const bool inb = lane < 7 && (unsigned)ni < (unsigned)H && (unsigned)nj < (unsigned)W && (unsigned)nz < (unsigned)A;
+        const int ncell = min(max(ckey + l_dkey, 0), HW * A - 1);
+        const uint32_t sv = st[ncell];
+        // ---- deleteMin (:211-241): erase the node, rescan what remains of its row
+        FK Fc = FK_NONE;
+        uint32_t mnc = 0u, R = 0u;
+        int cntc = ccnt - 1;
+        bool rvalid = ccnt <= 64;
+        const int dic = gi - ci, dic2 = dic * dic;
+        if (rvalid) {
+            const unsigned long long m = __ballot(lane < ccnt && (e & KEY_MASK) == cjz);
+            const int pos = __ffsll((long long)m) - 1;
+            R = lane >= pos ? nxt : e;
+            if (lane < cntc) rowc[lane] = R;                                       // (the lanes in front of pos rewrite their own entry)
+            if (cntc > 0) {
+                const int dj = gj - (int)(R & JM), dz = gz - (int)((R & KEY_MASK) >> JB);
+                const FK f = lane < cntc ? fk_entry(R >> KEY_BITS, dic2 + dj * dj + dz * dz) : FK_NONE;
+                uint32_t w;
+                argmin_f_sel(f, ((R >> KEY_BITS) << 16) | (uint32_t)lane, Fc, w);
+                mnc = (uint32_t)__builtin_amdgcn_readlane((int)R, (int)(w & 63u));
+            }
+        } else {
+            double Fd;
+            long long t0 = 0;
+            if constexpr (PROF) t0 = (long long)__builtin_readcyclecounter();
+            f_row_pop(c, ci, cjz, ccnt, Fd, mnc);
+            Fc = cntc > 0 ? fk_of(Fd) : FK_NONE;
+            if constexpr (PROF) { pc[4] += (long long)__builtin_readcyclecounter() - t0; pc[5]++; }
+        }
+        nopen--;
+        tick(1);
+        if (ci == gi && cj == gj) return done(true, (uint32_t)ckey);     // the altitude is not part of the goal test
+        if (cg + 1 > G_MAX) { err = 1; return done(false, 0u); }
+        // ---- findSuccessors (:100-141) + addOpen (:243-283)
+        const int ng = cg + 1;
+        const uint32_t state_l = sv & 3u;
+        const uint32_t gdiff = ((sv >> 5) - (uint32_t)ng) & 7u;           // (g_old - g_new) mod 8: 1, 2 -> improvement (see the general search)
+        const bool isn = lane < 6 && inb;
+        const bool want_new = isn && state_l == ST_FREE;
+        const bool want_imp = isn && state_l == ST_OPEN && (gdiff - 1u) < 2u;
+        FK fs_l;
+        {
+            const int ei = gi - ni, ej = gj - nj, ez = gz - nz;
+            fs_l = fk_entry((uint32_t)ng, ei * ei + ej * ej + ez * ez);
+        }
+        // cell bytes of the node in one store: the popped cell is CLOSED, unseen neighbours are OPEN
+        if ((lane == 6 && inb) || want_new) st[ncell] = (uint8_t)(lane == 6 ? (sv | ST_CLOSED) : (l_open | (((uint32_t)ng & 7u) << 5)));
+        unsigned long long todo = __ballot(want_new || want_imp);
+        const unsigned long long impm = __ballot(want_imp);
+        int ccn_nbi = (int)(ccn >> 20) - 1;
+        uint32_t ccn_lim = (ccn >> 10) & 1023u;
+        tick(2);
+        // in-register insertion (_M_insert_bucket_begin) of `ne` into a row of cnt < lim <= 64 entries held one per lane
+        auto ins_reg = [&](uint32_t V, int cnt, int nbi, uint32_t Wi, uint32_t ne, uint32_t *row) {
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)tabNb, nbi), nbm = (uint32_t)__builtin_amdgcn_readlane((int)tabNbm, nbi);
+            const uint32_t kb = bucket_of(ref_key(c, V, Wi), nb, nbm), eb = bucket_of(ref_key(c, ne, Wi), nb, nbm);
+            const unsigned long long mm = __ballot(lane < cnt && kb == eb);
+            const int pos = mm ? __ffsll((long long)mm) - 1 : 0;
+            const uint32_t up = wave_shr1(V);
+            V = lane < pos ? V : (lane == pos ? ne : up);
+            if (lane <= cnt) row[lane] = V;
+            return V;
+        };
+        if (__builtin_expect(impm == 0ull && rvalid, 1)) {
+            // the usual node: nothing to improve, the popped row in registers.  Row by row, in the reference's order
+            // (d = 0: row ci - 1; d = 1..4: row ci; d = 5: row ci + 1 -- the rows are independent containers)
+            auto other_row = [&](int d, int ri) {
+                const int rj = cj, rz = cz;
+                const uint32_t ne = (uint32_t)rj | ((uint32_t)rz << JB) | ((uint32_t)ng << KEY_BITS);
+                const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fs_l >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fs_l, d);
+                uint32_t *row = rows + ri * cap;
+                uint32_t cn = get_u(rCn, ri);
+                int cnt = (int)(cn & 1023u);
+                const uint32_t lim = (cn >> 10) & 1023u;
+                if (__builtin_expect((uint32_t)cnt < lim, 1)) {
+                    (void)ins_reg(row[lane], cnt, (int)(cn >> 20) - 1, (uint32_t)(W * ri), ne, row);
+                    cn++;
+                    cnt++;
+                } else {
+                    int nbi = (int)(cn >> 20) - 1;
+                    uint32_t nb = nbi < 0 ? 1u : (uint32_t)__builtin_amdgcn_readlane((int)tabNb, nbi & 15), nbm = nbi < 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)tabNbm, nbi & 15);
+                    slow_insert(ri, ne, cnt, nbi, nb, nbm);
+                    cn = pack_cn(cnt, nbi, nb);
+                }
+                nopen++;
+                uint32_t mn = get_u(rMn, ri);
+                FK Fr = get_f(ri);
+                if (cnt == 1 || fs < Fr || (fs == Fr && ng >= (int)(mn >> KEY_BITS))) { Fr = fs; mn = ne; }
+                put(ri, Fr, mn, cn);
+            };
+            if (todo & 1ull) other_row(0, ci - 1);
+            if (err) return done(false, 0u);
+            unsigned mid = (unsigned)(todo >> 1) & 15u;
+            const uint32_t Wc = (uint32_t)(W * ci);
+            while (mid) {
+                const int d = __ffs((int)mid);                       // 1..4
+                mid &= mid - 1;
+                const int rj = cj + __builtin_amdgcn_readlane(l_dj, d), rz = cz + __builtin_amdgcn_readlane(l_dz, d);
+                const uint32_t ne = (uint32_t)rj | ((uint32_t)rz << JB) | ((uint32_t)ng << KEY_BITS);
+                const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fs_l >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fs_l, d);
+                if (__builtin_expect(rvalid && (uint32_t)cntc < ccn_lim, 1)) {
+                    R = ins_reg(R, cntc, ccn_nbi, Wc, ne, rowc);
+                    cntc++;
+                } else {
+                    uint32_t nb = ccn_nbi < 0 ? 1u : (uint32_t)__builtin_amdgcn_readlane((int)tabNb, ccn_nbi & 15), nbm = ccn_nbi < 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)tabNbm, ccn_nbi & 15);
+                    slow_insert(ci, ne, cntc, ccn_nbi, nb, nbm);
+                    if (err) return done(false, 0u);
+                    ccn_lim = ccn_nbi < 0 ? 0u : min(min(nb, 64u), (uint32_t)cap);
+                    rvalid = cntc <= 64;
+                    if (rvalid) R = rowc[lane];
+                }
+                nopen++;
+                if (cntc == 1 || fs < Fc || (fs == Fc && ng >= (int)(mnc >> KEY_BITS))) { Fc = fs; mnc = ne; }
+            }
+            if (todo & 32ull) other_row(5, ci + 1);
+            if (err) return done(false, 0u);
+        } else {
+            while (todo) {
+                const int d = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int ri = ci + __builtin_amdgcn_readlane(l_di, d);
+                const int rj = cj + __builtin_amdgcn_readlane(l_dj, d), rz = cz + __builtin_amdgcn_readlane(l_dz, d);
+                const uint32_t njz = (uint32_t)rj | ((uint32_t)rz << JB);
+                const uint32_t ne = njz | ((uint32_t)ng << KEY_BITS);
+                const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fs_l >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fs_l, d);
+                const bool same = ri == ci;
+                uint32_t *row = rows + ri * cap;
+                const uint32_t Wi = (uint32_t)(W * ri);
+                int cnt, nbi;
+                uint32_t lim, mn;
+                FK Fr;
+                if (same) { cnt = cntc; nbi = ccn_nbi; lim = ccn_lim; mn = mnc; Fr = Fc; }
+                else { const uint32_t cn = get_u(rCn, ri); cnt = (int)(cn & 1023u); lim = (cn >> 10) & 1023u; nbi = (int)(cn >> 20) - 1; mn = get_u(rMn, ri); Fr = get_f(ri); }
+                if ((impm >> d) & 1ull) {
+                    // already OPEN: keep the better of the two (same cell, same H: "F smaller" is "g smaller")
+                    const int p = f_row_find(lane, row, cnt, njz);
+                    const uint32_t old = (uint32_t)uni((int)row[p]);
+                    if (ng < (int)(old >> KEY_BITS)) {
+                        if (lane == 0) { row[p] = ne; st[HW * rz + W * ri + rj] = st_open(d, ng); }
+                        wsync();
+                        if (same && rvalid) R = lane == p ? ne : R;
+                        const bool min_is_this = (mn & KEY_MASK) == njz;
+                        const FK fm = min_is_this ? fs : Fr;
+                        const int gm = min_is_this ? ng : (int)(mn >> KEY_BITS);
+                        if (fs < fm || (fs == fm && ng >= gm)) { Fr = fs; mn = ne; }
+                    }
+                } else {
+                    if ((uint32_t)cnt < lim && (!same || rvalid)) {
+                        const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)tabNb, nbi), nbm = (uint32_t)__builtin_amdgcn_readlane((int)tabNbm, nbi);
+                        uint32_t V = R;
+                        if (!same) V = row[lane];
+                        const uint32_t kb = bucket_of(ref_key(c, V, Wi), nb, nbm), eb = bucket_of(ref_key(c, ne, Wi), nb, nbm);
+                        const unsigned long long mm = __ballot(lane < cnt && kb == eb);
+                        const int pos = mm ? __ffsll((long long)mm) - 1 : 0;
+                        const uint32_t up = wave_shr1(V);
+                        V = lane < pos ? V : (lane == pos ? ne : up);
+                        if (lane <= cnt) row[lane] = V;
+                        if (same) R = V;
+                        cnt++;
+                    } else {
+                        uint32_t nb = nbi < 0 ? 1u : (uint32_t)__builtin_amdgcn_readlane((int)tabNb, nbi & 15), nbm = nbi < 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)tabNbm, nbi & 15);
+                        slow_insert(ri, ne, cnt, nbi, nb, nbm);
+                        if (err) return done(false, 0u);
+                        lim = nbi < 0 ? 0u : min(min(nb, 64u), (uint32_t)cap);
+                        if (same) {
+                            rvalid = cnt <= 64;
+                            if (rvalid) R = row[lane];
+                            ccn_nbi = nbi; ccn_lim = lim;
+                        }
+                    }
+                    nopen++;
+                    if (cnt == 1 || fs < Fr || (fs == Fr && ng >= (int)(mn >> KEY_BITS))) { Fr = fs; mn = ne; }
+                }
+                const uint32_t cn = (uint32_t)cnt | (lim << 10) | ((uint32_t)(nbi + 1) << 20);
+                if (same) { cntc = cnt; Fc = Fr; mnc = mn; }
+                else put(ri, Fr, mn, cn);
+            }
+        }
+        put(ci, cntc > 0 ? Fc : FK_NONE, mnc, (uint32_t)cntc | (ccn_lim << 10) | ((uint32_t)(ccn_nbi + 1) << 20));
+        wsync();
+        tick(3);
+    }
+    return done(false, 0u);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Cooperative search: the same container emulation on the four waves of a 256-lane workgroup, one per SIMD.
+// Why: a wave alone on its SIMD issues one instruction every 5.7 (independent) to 8.5 (dependent) cycles whatever the
+// instruction is -- there is no instruction-level parallelism to be had inside a wave, only across waves -- while a
+// workgroup barrier costs 12-48 cycles and an LDS hand-over about 150 (tools/microbench).  The work of one
+// expanded node splits into pieces that touch different containers:
+//     wave 0   deleteMin's rescan of the popped row (F of every remaining entry + the wave reduction)
+//     wave 1   the erase itself, the cell bytes, and the insertions into the popped row (j -+ 1, z -+ 1)
+//     wave 2   the insertion into row i - 1            wave 3   the insertion into row i + 1
+// The rescan runs on the row as it is right after the erase while wave 1 goes on inserting: insertions shift entries
+// but never reorder the old ones, and addOpen's rule "the new node replaces the registered minimum when its F is not
+// larger (and, on equal F, its g not smaller)" makes the final registered minimum the fold of the rescan result and the
+// best inserted node, in that order -- which the next node's phase 1 computes from two mailboxes.
+// Row bookkeeping lives in LDS (BK, 16 B per row: any number of rows); every wave reads all of it once per node and
+// runs findMin redundantly, so all waves take identical decisions without talking.  Two barriers per node:
+//     A  everything written for node k is visible            (reads of node k + 1 follow)
+//     M  every wave has read what it needs of node k + 1      (writes follow)
+// A node with more than 64 entries in the popped row, or with an already-OPEN neighbour to improve, is handled by wave 1
+// alone with the general routines (about 8 % of the nodes on the forest worlds).
+struct BK { FK F; uint32_t mn, cn; };
+enum { MB_RES = 0, MB_INS = 4, MB_ERR = 8 };      // mailbox words: rescan (F lo, F hi, entry, -), insertions (F lo, F hi, entry, cn), errors [4]
+
+template <int NS, bool PROF>
+__device__ __attribute__((noinline)) unsigned long long search_coop(FGeo gin)
+{
+#pragma clang fp contract(off)
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    const int H = uni(gin.H), W = uni(gin.W), A = uni(gin.A), HW = uni(gin.HW), cap = uni(gin.cap), JB = uni(gin.JB);
+    const int gi = uni(gin.gi), gj = uni(gin.gj), gz = uni(gin.gz), n_nb = uni(gin.n_nb);
+    const uint32_t JM = (1u << JB) - 1u;
+    uint8_t *const st = gsm + uni(gin.st_off);
+    uint32_t *const rows = reinterpret_cast<uint32_t *>(gsm + uni(gin.rows_off));
+    uint32_t *const tmp = reinterpret_cast<uint32_t *>(gsm + uni(gin.tmp_off)) + (wave > 1 ? (wave - 1) * cap : 0);   // one rehash scratch per inserting wave
+    const int *const nb_seq = reinterpret_cast<const int *>(gsm + uni(gin.nbs_off));
+    const uint32_t *const nb_magic = reinterpret_cast<const uint32_t *>(gsm + uni(gin.nbm_off));
+    BK *const bk = reinterpret_cast<BK *>(gsm + uni(gin.bk_off));
+    uint32_t *const mb = reinterpret_cast<uint32_t *>(gsm + uni(gin.mb_off));
+    FGeoL c;
+    c.H = H; c.W = W; c.A = A; c.HW = HW; c.cap = cap; c.lane = lane; c.JB = JB; c.JM = JM; c.gi = gi; c.gj = gj; c.gz = gz;
+    c.st = st; c.rows = rows; c.tmp = tmp; c.nb_seq = nb_seq; c.nb_magic = nb_magic; c.n_nb = n_nb;
+    int err = 0, expansions = 0;
+    long long pc[3] = {0, 0, 0};                  // PROF, per wave: phase 1, work of phase 2, waiting at barrier A
+    long long tk = 0;
+    auto tick = [&](int slot) { if constexpr (PROF) { const long long t = (long long)__builtin_readcyclecounter(); pc[slot] += t - tk; tk = t; } };
+    auto done = [&](bool found, uint32_t end_key) {
+        if constexpr (PROF) { long long *pr = uni_ptr(gin.prof); if (lane == 0) for (int k = 0; k < 3; k++) pr[4 + 3 * wave + k] += pc[k]; }
+        return (unsigned long long)(unsigned)expansions | ((unsigned long long)end_key << 32) | ((unsigned long long)(found ? 1 : 0) << 52) |
+               ((unsigned long long)err << 56);
+    };
+    const uint32_t tabNb = lane < 16 ? (uint32_t)nb_seq[lane & 15] : 0u, tabNbm = lane < 16 ? nb_magic[lane & 15] : 0u;
+    auto pack_cn = [&](int cnt, int nbi, uint32_t nb) {
+        const uint32_t lim = nbi < 0 ? 0u : min(min(nb, 64u), (uint32_t)cap);
+        return (uint32_t)cnt | (lim << 10) | ((uint32_t)(nbi + 1) << 20);
+    };
+    auto nb_of = [&](int nbi, uint32_t &nb, uint32_t &nbm) {
+        nb = nbi < 0 ? 1u : (uint32_t)__builtin_amdgcn_readlane((int)tabNb, nbi & 15);
+        nbm = nbi < 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)tabNbm, nbi & 15);
+    };
+    const int l_di = lane == 0 ? -1 : (lane == 5 ? 1 : 0), l_dj = lane == 1 ? -1 : (lane == 4 ? 1 : 0), l_dz = lane == 2 ? -1 : (lane == 3 ? 1 : 0);
+    const int l_dkey = HW * l_dz + W * l_di + l_dj;
+    const uint32_t l_open = (uint32_t)ST_OPEN | ((uint32_t)lane << 2);
+
+    // ---- empty containers, empty mailboxes; wave 1 inserts the start node (g = 0, parent code 7: none)
+    for (int i = tid; i < H; i += 256) { BK b; b.F = FK_NONE; b.mn = 0u; b.cn = 0u; bk[i] = b; }
+    if (tid < 12) mb[tid] = tid < 8 ? (tid == 2 || tid == 3 || tid == 6 || tid == 7 ? 0u : 0xffffffffu) : 0u;
+    __syncthreads();
+    if (wave == 1) {
+        const int s0 = uni(gin.s0), s1 = uni(gin.s1), s2 = uni(gin.s2);
+        int cnt = 0, nbi = -1;
+        uint32_t nb = 1u, nbm = 0u;
+        const uint32_t e0 = (uint32_t)s1 | ((uint32_t)s2 << JB);
+        f_row_insert(c, s0, e0, cnt, nbi, nb, nbm, err);
+        const int di = gi - s0, dj = gj - s1, dz = gz - s2;
+        if (lane == 0) {
+            st[HW * s2 + W * s0 + s1] = st_open(7, 0);
+            BK b; b.F = fk_entry(0u, di * di + dj * dj + dz * dz); b.mn = e0; b.cn = pack_cn(1, nbi, nb);
+            bk[s0] = b;
+            if (err) mb[MB_ERR + 1] = (uint32_t)err;
+        }
+    }
+    int nopen = 1, cp = -1;
+    if constexpr (PROF) tk = (long long)__builtin_readcyclecounter();
+    while (nopen > 0) {
+        expansions++;
+        __syncthreads();                                                            // ---- barrier A
+        tick(2);
+        // ---- phase 1: every wave reads the bookkeeping and the two mailboxes, folds the previous node's row, runs findMin
+        FK bF[NS];
+        uint32_t bMn[NS], bCn[NS];
+#pragma unroll
+        for (int t = 0; t < NS; t++) {
+            const int i = lane + 64 * t;
+            BK b; b.F = FK_NONE; b.mn = 0u; b.cn = 0u;
+            if (i < H) b = bk[i];
+            bF[t] = b.F; bMn[t] = b.mn; bCn[t] = b.cn;
+        }
+        const uint4 mres = *reinterpret_cast<const uint4 *>(mb + MB_RES), mins = *reinterpret_cast<const uint4 *>(mb + MB_INS), merr = *reinterpret_cast<const uint4 *>(mb + MB_ERR);
+        const int anyerr = uni((int)(merr.x | merr.y | merr.z | merr.w));
+        if (anyerr) { err = anyerr; return done(false, 0u); }
+        if (cp >= 0) {
+            const FK Fres = ((FK)(uint32_t)uni((int)mres.y) << 32) | (uint32_t)uni((int)mres.x), Fins = ((FK)(uint32_t)uni((int)mins.y) << 32) | (uint32_t)uni((int)mins.x);
+            const uint32_t eres = (uint32_t)uni((int)mres.z), eins = (uint32_t)uni((int)mins.z), cnp = (uint32_t)uni((int)mins.w);
+            const bool take = Fins < Fres || (Fins == Fres && (eins >> KEY_BITS) >= (eres >> KEY_BITS));
+            const FK Fp = take ? Fins : Fres;
+            const uint32_t mnp = take ? eins : eres;
+#pragma unroll
+            for (int t = 0; t < NS; t++) { const bool m = lane + 64 * t == cp; bF[t] = m ? Fp : bF[t]; bMn[t] = m ? mnp : bMn[t]; bCn[t] = m ? cnp : bCn[t]; }
+            if (wave == 2 && lane == 0) { BK b; b.F = Fp; b.mn = mnp; b.cn = cnp; bk[cp] = b; }   // (nobody trusts bk[cp] during this node)
+        }
+        auto get_u = [&](const uint32_t (&a)[NS], int i) { uint32_t v = a[0]; if constexpr (NS > 1) { if (i >= 64) v = a[1]; } return (uint32_t)__builtin_amdgcn_readlane((int)v, i & 63); };
+        auto get_f = [&](int i) {
+            FK v = bF[0];
+            if constexpr (NS > 1) { if (i >= 64) v = bF[1]; }
+            return ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), i & 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i & 63);
+        };
+        FK bf = bF[0];
+        uint32_t bsel = ((bMn[0] >> KEY_BITS) << 16) | (uint32_t)lane;
+        if constexpr (NS > 1) {
+            const uint32_t s1 = ((bMn[1] >> KEY_BITS) << 16) | (uint32_t)(lane + 64);
+            const bool take = bF[1] < bf || (bF[1] == bf && s1 >= bsel);
+            bf = take ? bF[1] : bf; bsel = take ? s1 : bsel;
+        }
+        FK fmin;
+        uint32_t sel;
+        argmin_f_sel(bf, bsel, fmin, sel);
+        const int ci = (int)(sel & 0xffffu), cg = (int)(sel >> 16);
+        const uint32_t cjz = get_u(bMn, ci) & KEY_MASK;
+        const uint32_t ccn = get_u(bCn, ci);
+        const int ccnt = (int)(ccn & 1023u);
+        const int cj = (int)(cjz & JM), cz = (int)(cjz >> JB);
+        const int ckey = HW * cz + W * ci + cj;
+        uint32_t *rowc = rows + ci * cap;
+        const uint32_t e = rowc[lane], nxt = rowc[lane + 1];
+        const int ni = ci + l_di, nj = cj + l_dj, nz = cz + l_dz;
+        const bool inb = lane < 7 && (unsigned)ni < (unsigned)H && (unsigned)nj < (unsigned)W && (unsigned)nz < (unsigned)A;
+        const int ncell = min(max(ckey + l_dkey, 0), HW * A - 1);
+        const uint32_t sv = st[ncell];
+        tick(0);
+        __syncthreads();                                                            // ---- barrier M
+        // ---- phase 2.  What every wave derives for itself: the goal test, the screening of the six neighbours
+        nopen--;
+        if (ci == gi && cj == gj) return done(true, (uint32_t)ckey);                // the altitude is not part of the goal test
+        if (cg + 1 > G_MAX) { err = 1; return done(false, 0u); }
+        const int ng = cg + 1;
+        const uint32_t state_l = sv & 3u;
+        const uint32_t gdiff = ((sv >> 5) - (uint32_t)ng) & 7u;
+        const bool isn = lane < 6 && inb;
+        const bool want_new = isn && state_l == ST_FREE;
+        const bool want_imp = isn && state_l == ST_OPEN && (gdiff - 1u) < 2u;
+        const unsigned long long newm = __ballot(want_new), impm = __ballot(want_imp);
+        unsigned long long todo = newm | impm;
+        nopen += __popcll(newm);
+        const int cntc0 = ccnt - 1;
+        const int dic = gi - ci, dic2 = dic * dic;
+        const bool slow = ccnt > 64 || impm != 0ull;
+        auto neighbour_f = [&]() {
+            const int ei = gi - ni, ej = gj - nj, ez = gz - nz;
+            return fk_entry((uint32_t)ng, ei * ei + ej * ej + ez * ez);
+        };
+        auto erase_reg = [&]() {                                                   // the popped row without the popped node, one entry per lane
+            const unsigned long long m = __ballot(lane < ccnt && (e & KEY_MASK) == cjz);
+            const int pos = __ffsll((long long)m) - 1;
+            return lane >= pos ? nxt : e;
+        };
+        auto rescan_reg = [&](uint32_t R, int cnt, FK &Fo, uint32_t &mo) {         // deleteMin's rescan (:216-240)
+            Fo = FK_NONE; mo = 0u;
+            if (cnt > 0) {
+                const int dj = gj - (int)(R & JM), dz = gz - (int)((R & KEY_MASK) >> JB);
+                const FK f = lane < cnt ? fk_entry(R >> KEY_BITS, dic2 + dj * dj + dz * dz) : FK_NONE;
+                uint32_t w;
+                argmin_f_sel(f, ((R >> KEY_BITS) << 16) | (uint32_t)lane, Fo, w);
+                mo = (uint32_t)__builtin_amdgcn_readlane((int)R, (int)(w & 63u));
+            }
+        };
+        auto ins_reg = [&](uint32_t V, int cnt, int nbi, uint32_t Wi, uint32_t ne, uint32_t *row) {
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)tabNb, nbi), nbm = (uint32_t)__builtin_amdgcn_readlane((int)tabNbm, nbi);
+            const uint32_t kb = bucket_of(ref_key(c, V, Wi), nb, nbm), eb = bucket_of(ref_key(c, ne, Wi), nb, nbm);
+            const unsigned long long mm = __ballot(lane < cnt && kb == eb);
+            const int pos = mm ? __ffsll((long long)mm) - 1 : 0;
+            const uint32_t up = wave_shr1(V);
+            V = lane < pos ? V : (lane == pos ? ne : up);
+            if (lane <= cnt) row[lane] = V;
+            return V;
+        };
+        auto write_cells = [&]() {   // the popped cell is CLOSED, unseen neighbours are OPEN (direction, g mod 8): one store
+            if ((lane == 6 && inb) || want_new) st[ncell] = (uint8_t)(lane == 6 ? (sv | ST_CLOSED) : (l_open | (((uint32_t)ng & 7u) << 5)));
+        };
+        auto other_row = [&](int d, int ri) {                                      // a new node in row ci -+ 1 (addOpen :243-283)
+            const uint32_t ne = (uint32_t)cj | ((uint32_t)cz << JB) | ((uint32_t)ng << KEY_BITS);
+            const FK fsv = neighbour_f();
+            const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fsv >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fsv, d);
+            uint32_t *row = rows + ri * cap;
+            uint32_t cn = get_u(bCn, ri);
+            int cnt = (int)(cn & 1023u);
+            const uint32_t lim = (cn >> 10) & 1023u;
+            if (__builtin_expect((uint32_t)cnt < lim, 1)) {
+                (void)ins_reg(row[lane], cnt, (int)(cn >> 20) - 1, (uint32_t)(W * ri), ne, row);
+                cn++;
+                cnt++;
+            } else {
+                int nbi = (int)(cn >> 20) - 1;
+                uint32_t nb, nbm;
+                nb_of(nbi, nb, nbm);
+                f_row_insert(c, ri, ne, cnt, nbi, nb, nbm, err);
+                cn = pack_cn(cnt, nbi, nb);
+            }
+            uint32_t mn = get_u(bMn, ri);
+            FK Fr = get_f(ri);
+            if (cnt == 1 || fs < Fr || (fs == Fr && ng >= (int)(mn >> KEY_BITS))) { Fr = fs; mn = ne; }
+            if (lane == 0) { BK b; b.F = Fr; b.mn = mn; b.cn = cn; bk[ri] = b; }
+        };
+        if (!slow) {
+            if (wave == 0) {
+                FK Fo;
+                uint32_t mo;
+                rescan_reg(erase_reg(), cntc0, Fo, mo);
+                if (lane == 0) { mb[MB_RES] = (uint32_t)Fo; mb[MB_RES + 1] = (uint32_t)(Fo >> 32); mb[MB_RES + 2] = mo; }
+            } else if (wave == 1) {
+                uint32_t R = erase_reg();
+                if (lane < cntc0) rowc[lane] = R;
+                write_cells();
+                int cntc = cntc0, nbic = (int)(ccn >> 20) - 1;
+                uint32_t limc = (ccn >> 10) & 1023u;
+                bool rvalid = true;
+                FK Fi = FK_NONE;                                                    // best inserted node so far (all share g = ng: the later one wins a tie)
+                uint32_t ei = 0u;
+                unsigned mid = (unsigned)(todo >> 1) & 15u;
+                const uint32_t Wc = (uint32_t)(W * ci);
+                const FK fsv = mid ? neighbour_f() : FK_NONE;
+                while (mid) {
+                    const int d = __ffs((int)mid);                                  // 1..4
+                    mid &= mid - 1;
+                    const int rj = cj + __builtin_amdgcn_readlane(l_dj, d), rz = cz + __builtin_amdgcn_readlane(l_dz, d);
+                    const uint32_t ne = (uint32_t)rj | ((uint32_t)rz << JB) | ((uint32_t)ng << KEY_BITS);
+                    const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fsv >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fsv, d);
+                    if (__builtin_expect(rvalid && (uint32_t)cntc < limc, 1)) {
+                        R = ins_reg(R, cntc, nbic, Wc, ne, rowc);
+                        cntc++;
+                    } else {
+                        uint32_t nb, nbm;
+                        nb_of(nbic, nb, nbm);
+                        f_row_insert(c, ci, ne, cntc, nbic, nb, nbm, err);
+                        if (err) break;
+                        limc = nbic < 0 ? 0u : min(min(nb, 64u), (uint32_t)cap);
+                        rvalid = cntc <= 64;
+                        if (rvalid) R = rowc[lane];
+                    }
+                    if (fs <= Fi) { Fi = fs; ei = ne; }
+                }
+                if (lane == 0) {
+                    mb[MB_INS] = (uint32_t)Fi; mb[MB_INS + 1] = (uint32_t)(Fi >> 32); mb[MB_INS + 2] = ei;
+                    mb[MB_INS + 3] = (uint32_t)cntc | (limc << 10) | ((uint32_t)(nbic + 1) << 20);
+                }
+            } else if (wave == 2) {
+                if (todo & 1ull) other_row(0, ci - 1);
+            } else {
+                if (todo & 32ull) other_row(5, ci + 1);
+            }
+        } else if (wave == 1) {
+            // ---- the whole node on one wave, general routines where a row is long
+            FK Fc = FK_NONE;
+            uint32_t mnc = 0u, R = 0u;
+            int cntc = cntc0, nbic = (int)(ccn >> 20) - 1;
+            uint32_t limc = (ccn >> 10) & 1023u;
+            bool rvalid = ccnt <= 64;
+            if (rvalid) {
+                R = erase_reg();
+                if (lane < cntc0) rowc[lane] = R;
+                rescan_reg(R, cntc0, Fc, mnc);
+            } else {
+                double Fd;
+                f_row_pop(c, ci, cjz, ccnt, Fd, mnc);
+                Fc = cntc0 > 0 ? fk_of(Fd) : FK_NONE;
+            }
+            write_cells();
+            const FK fsv = neighbour_f();
+            while (todo && !err) {
+                const int d = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int ri = ci + __builtin_amdgcn_readlane(l_di, d);
+                const int rj = cj + __builtin_amdgcn_readlane(l_dj, d), rz = cz + __builtin_amdgcn_readlane(l_dz, d);
+                const uint32_t njz = (uint32_t)rj | ((uint32_t)rz << JB);
+                const uint32_t ne = njz | ((uint32_t)ng << KEY_BITS);
+                const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fsv >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fsv, d);
+                const bool same = ri == ci;
+                uint32_t *row = rows + ri * cap;
+                int cnt, nbi;
+                uint32_t lim, mn;
+                FK Fr;
+                if (same) { cnt = cntc; nbi = nbic; lim = limc; mn = mnc; Fr = Fc; }
+                else { const uint32_t cn = get_u(bCn, ri); cnt = (int)(cn & 1023u); lim = (cn >> 10) & 1023u; nbi = (int)(cn >> 20) - 1; mn = get_u(bMn, ri); Fr = get_f(ri); }
+                if ((impm >> d) & 1ull) {
+                    // already OPEN: keep the better of the two (same cell, same H: "F smaller" is "g smaller")
+                    const int p = f_row_find(lane, row, cnt, njz);
+                    const uint32_t old = (uint32_t)uni((int)row[p]);
+                    if (ng < (int)(old >> KEY_BITS)) {
+                        if (lane == 0) { row[p] = ne; st[HW * rz + W * ri + rj] = st_open(d, ng); }
+                        wsync();
+                        if (same && rvalid) R = lane == p ? ne : R;
+                        const bool min_is_this = (mn & KEY_MASK) == njz;
+                        const FK fm = min_is_this ? fs : Fr;
+                        const int gm = min_is_this ? ng : (int)(mn >> KEY_BITS);
+                        if (fs < fm || (fs == fm && ng >= gm)) { Fr = fs; mn = ne; }
+                    }
+                } else {
+                    if ((uint32_t)cnt < lim && (!same || rvalid)) {
+                        uint32_t V = R;
+                        if (!same) V = row[lane];
+                        V = ins_reg(V, cnt, nbi, (uint32_t)(W * ri), ne, row);
+                        if (same) R = V;
+                        cnt++;
+                    } else {
+                        uint32_t nb, nbm;
+                        nb_of(nbi, nb, nbm);
+                        f_row_insert(c, ri, ne, cnt, nbi, nb, nbm, err);
+                        if (err) break;
+                        lim = nbi < 0 ? 0u : min(min(nb, 64u), (uint32_t)cap);
+                        if (same) { rvalid = cnt <= 64; if (rvalid) R = row[lane]; }
+                    }
+                    if (cnt == 1 || fs < Fr || (fs == Fr && ng >= (int)(mn >> KEY_BITS))) { Fr = fs; mn = ne; }
+                }
+                if (same) { cntc = cnt; nbic = nbi; limc = lim; Fc = Fr; mnc = mn; }
+                else if (lane == 0) { BK b; b.F = Fr; b.mn = mn; b.cn = (uint32_t)cnt | (lim << 10) | ((uint32_t)(nbi + 1) << 20); bk[ri] = b; }
+            }
+            if (lane == 0) {
+                const FK Fo = cntc > 0 ? Fc : FK_NONE;
+                mb[MB_RES] = (uint32_t)Fo; mb[MB_RES + 1] = (uint32_t)(Fo >> 32); mb[MB_RES + 2] = mnc;
+                mb[MB_INS] = 0xffffffffu; mb[MB_INS + 1] = 0xffffffffu; mb[MB_INS + 2] = 0u;
+                mb[MB_INS + 3] = (uint32_t)cntc | (limc << 10) | ((uint32_t)(nbic + 1) << 20);
+            }
+        }
+        if (err && lane == 0) mb[MB_ERR + wave] = (uint32_t)err;
+        err = 0;                                                                    // (reported through the mailbox: every wave leaves at the same point)
+        cp = ci;
+        tick(1);
+    }
+    __syncthreads();                                                                // the last node's errors
+    {
+        const uint4 merr = *reinterpret_cast<const uint4 *>(mb + MB_ERR);
+        err = uni((int)(merr.x | merr.y | merr.z | merr.w));
+    }
+    return done(false, 0u);
+}
+
+}  // namespace
+
+// NS = 0: the general search on one wave; NS > 0: register-resident search on one wave (COOP false) or the cooperative search on
+// the four waves of a 256-lane workgroup (COOP true).  With four waves the set-up is shared (grid copy, stamping) or done
+// redundantly (priority rule, start cell: same inputs, same result in every wave); the path and the line-of-sight goal are wave 0's.
+template <int NS, bool PROF, bool COOP>
+__global__ __launch_bounds__(COOP ? 256 : 64) void lsc_goal_kernel(GoalArgs a)
+{
+#pragma clang fp contract(off)
+    constexpr int NT = COOP ? 256 : 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    auto ksync = [&]() { if constexpr (COOP) __syncthreads(); else wsync(); };
     const int al = blockIdx.x;
     const int qi = a.first + al;
     const int N = a.N;
+    long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // PROF: cycles of prologue, grid set-up, search, path + line of sight; findMin, pop, screening, insertions
+    long long tk0 = 0;
+    auto ktick = [&](int slot) { if constexpr (PROF) { const long long t = (long long)__builtin_readcyclecounter(); pc[slot] += t - tk0; tk0 = t; } };
+    if constexpr (PROF) tk0 = (long long)__builtin_readcyclecounter();
+    int bk_off = 0, mb_off = 0;
     Ctx c;
     c.H = a.H; c.W = a.W; c.A = a.A; c.HW = a.H * a.W; c.C = a.H * a.W * a.A; c.cap = a.row_cap; c.lane = lane;
     c.nb_seq = a.nb_seq; c.nb_magic = a.nb_magic; c.n_nb = a.n_nb; c.err = 0;
@@ -366,7 +1234,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
         c.st = gsm; off += ((size_t)c.C + 15) & ~(size_t)15;
         c.rowF = reinterpret_cast<double *>(gsm + off); off += sizeof(double) * (size_t)c.H;
         c.rowMin = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.H;
-        c.tmp = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.cap;
+        c.tmp = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.cap * 3;   // one rehash scratch per inserting wave
         c.rows = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.H * c.cap;
         c.rowCnt = reinterpret_cast<uint16_t *>(gsm + off); off += sizeof(uint16_t) * (size_t)c.H;
         c.rowNb = reinterpret_cast<int16_t *>(gsm + off); off += sizeof(int16_t) * (size_t)c.H;
@@ -374,9 +1242,12 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
         c.rowNbv = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.H;
         c.rowNbm = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.H;
         int *nbs = reinterpret_cast<int *>(gsm + off); off += sizeof(int) * 16;
-        uint32_t *nbm = reinterpret_cast<uint32_t *>(gsm + off);
-        if (lane < 16) { nbs[lane] = a.nb_seq[lane]; nbm[lane] = a.nb_magic[lane]; }
+        uint32_t *nbm = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * 16;
+        if (tid < 16) { nbs[tid] = a.nb_seq[tid]; nbm[tid] = a.nb_magic[tid]; }
         c.nb_seq = nbs; c.nb_magic = nbm;
+        off = (off + 15) & ~(size_t)15;
+        bk_off = (int)off; off += 16 * (size_t)c.H;           // cooperative search: row bookkeeping
+        mb_off = (int)off;                                    // and its mailboxes (64 B)
     }
     const float *pos = a.state + 9 * qi;
     const float *goal_i = a.goal + 3 * qi;
@@ -425,7 +1296,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
         const double dmin = wave_min_d(best);
         const int q = wave_min_i(best == dmin ? bq : 0x7fffffff);
         if (dmin < a.priority_dist_threshold) {
-            if (lane == 0) {
+            if (tid == 0) {
                 const float *opos = a.state + 9 * q;
                 float dx = opos[0] - pos[0], dy = opos[1] - pos[1], dz = opos[2] - pos[2];
                 const float n2 = dx * dx + dy * dy + dz * dz;
@@ -458,12 +1329,14 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     bool found = false;
     uint32_t end_key = 0;
     int flags = 0, expansions = 0;
+    ktick(0);
     for (int attempt = 0; attempt < 2 && !found && !c.err; attempt++) {
-        for (int p = lane; p < c.C; p += 64) c.st[p] = occ_static[p];
-        for (int i = lane; i < c.H; i += 64) { c.rowCnt[i] = 0; c.rowNb[i] = -1; c.rowNbv[i] = 1u; c.rowNbm[i] = 0u; c.rowF[i] = 1e300; c.rowMin[i] = 0; }
-        wsync();
+        if (attempt > 0) ksync();                              // (everybody is done with the first attempt's grid)
+        for (int p = tid; p < c.C; p += NT) c.st[p] = occ_static[p];
+        if constexpr (NS == 0) for (int i = lane; i < c.H; i += 64) { c.rowCnt[i] = 0; c.rowNb[i] = -1; c.rowNbv[i] = 1u; c.rowNbm[i] = 0u; c.rowF[i] = 1e300; c.rowMin[i] = 0; }
+        ksync();
         if (attempt == 0) {
-            for (int qj = lane; qj < N; qj += 64) {          // updateGridMap, AGENT branch :163-189
+            for (int qj = tid; qj < N; qj += NT) {           // updateGridMap, AGENT branch :163-189
                 if (qj == qi) continue;
                 double d;
                 if (!in_slack(qj) && !has_priority(qj, d)) continue;
@@ -487,7 +1360,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                             if (dist < r_a + r_o) c.st[key_of(i, j, k)] = ST_OCC;
                         }
             }
-            wsync();
+            ksync();
         } else {
             flags |= 2;
         }
@@ -512,131 +1385,153 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                         }
                     }
             s[0] = bc[0]; s[1] = bc[1]; s[2] = bc[2];
-            wsync();
-            if (lane == 0 && (c.st[key_of(s[0], s[1], s[2])] & 3) == ST_OCC) c.st[key_of(s[0], s[1], s[2])] = ST_FREE;
-            wsync();
+            ksync();
+            if (tid == 0 && (c.st[key_of(s[0], s[1], s[2])] & 3) == ST_OCC) c.st[key_of(s[0], s[1], s[2])] = ST_FREE;
+            ksync();
         }
-        // ---- ISearch::startSearch
-        const uint32_t skey = key_of(s[0], s[1], s[2]);
-        row_insert(c, s[0], skey);                            // g = 0
-        if (lane == 0) {
-            c.st[skey] = st_open(7, 0);                       // parent code 7: none
-            c.rowMin[s[0]] = skey;
-            c.rowF[s[0]] = f_of(c, skey);
-        }
-        wsync();
-        int nopen = 1;
-        while (nopen > 0 && !c.err) {
-            expansions++;
-            // findMin (:181-209): smallest F over the row minima, then the largest g, then the LAST row
-            double bf = 1e300;
-            uint32_t bsel = 0, bent = 0;
-            int bcnt = 0;
-            for (int i = lane; i < c.H; i += 64) {
-                const double f = c.rowF[i];                    // 1e300 while the row is empty
-                const uint32_t me = c.rowMin[i];
-                const int rc = c.rowCnt[i];                    // (same batch of loads: the pop below needs the winner's count)
-                const uint32_t sel = ((me >> KEY_BITS) << 16) | (uint32_t)i;
-                if (f < 1e300 && (f < bf || (f == bf && sel >= bsel))) { bf = f; bsel = sel; bent = me; bcnt = rc; }
+        ktick(1);
+        if constexpr (NS > 0) {
+            // register-resident search; rows hold (j | z << JB | g << 17)
+            FGeo f;
+            f.H = c.H; f.W = c.W; f.A = c.A; f.HW = c.HW; f.cap = c.cap; f.JB = a.jbits;
+            f.gi = c.gi; f.gj = c.gj; f.gz = c.gz; f.s0 = s[0]; f.s1 = s[1]; f.s2 = s[2]; f.n_nb = c.n_nb;
+            f.st_off = (int)(c.st - gsm); f.rows_off = (int)(reinterpret_cast<unsigned char *>(c.rows) - gsm);
+            f.tmp_off = (int)(reinterpret_cast<unsigned char *>(c.tmp) - gsm);
+            f.nbs_off = (int)(reinterpret_cast<const unsigned char *>(c.nb_seq) - gsm); f.nbm_off = (int)(reinterpret_cast<const unsigned char *>(c.nb_magic) - gsm);
+            f.prof = PROF ? a.prof + (size_t)qi * 16 : nullptr;
+            f.bk_off = bk_off; f.mb_off = mb_off;
+            unsigned long long r;
+            if constexpr (COOP) r = search_coop<NS, PROF>(f);
+            else r = search_fast<NS, PROF>(f);
+            expansions += (int)(unsigned)r;
+            end_key = (uint32_t)(r >> 32) & KEY_MASK;
+            found = ((r >> 52) & 1ull) != 0;
+            if ((int)(r >> 56)) c.err = (int)(r >> 56);
+            ktick(2);
+        } else {
+            // ---- ISearch::startSearch
+            const uint32_t skey = key_of(s[0], s[1], s[2]);
+            row_insert(c, s[0], skey);                            // g = 0
+            if (lane == 0) {
+                c.st[skey] = st_open(7, 0);                       // parent code 7: none
+                c.rowMin[s[0]] = skey;
+                c.rowF[s[0]] = f_of(c, skey);
             }
-            const double fmin = wave_min_d(bf);
-            const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
-            const int ci = (int)(sel & 0xffffu);
-            const unsigned long long owner = __ballot(bf == fmin && bsel == sel);
-            const int own_lane = __ffsll((long long)owner) - 1;
-            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)bent, own_lane);
-            const int ccnt = __builtin_amdgcn_readlane(bcnt, own_lane);
-            const uint32_t ckey = ce & KEY_MASK;
-            const int cg = (int)(ce >> KEY_BITS);
-            int cj, cz, ci2;
-            decode(c, ckey, ci2, cj, cz);
-            if (lane == 0) atomicOr(reinterpret_cast<unsigned int *>(c.st + (ckey & ~3u)), (unsigned int)ST_CLOSED << (8u * (ckey & 3u)));
-            row_pop_known(c, ci, ckey, ccnt);
-            nopen--;
-            if (ci == c.gi && cj == c.gj) { found = true; end_key = ckey; break; }   // the altitude is not part of the goal test
-            if (cg + 1 > G_MAX) { c.err = 1; break; }
-            // findSuccessors (:100-141): the six axis moves in the order of its nested loops.  Lanes 0..5 look at one
-            // neighbour each (bounds, occupancy, closed); only the survivors are then handled one after the other.
-            int nkey_l = -1;
-            uint32_t sv_l = ST_OCC;
-            double h_l = 0.0;                                  // H of the neighbour: one vector square root for all six
-            if (lane < 6) {
-                const int d = lane;
-                const int di = d == 0 ? -1 : (d == 5 ? 1 : 0), dj = d == 1 ? -1 : (d == 4 ? 1 : 0), dz = d == 2 ? -1 : (d == 3 ? 1 : 0);
-                const int ni = ci + di, nj = cj + dj, nz = cz + dz;
-                if (ni >= 0 && ni < c.H && nj >= 0 && nj < c.W && nz >= 0 && nz < c.A) {
-                    nkey_l = (int)key_of(ni, nj, nz);
-                    sv_l = c.st[nkey_l];
+            wsync();
+            int nopen = 1;
+            while (nopen > 0 && !c.err) {
+                expansions++;
+                // findMin (:181-209): smallest F over the row minima, then the largest g, then the LAST row
+                double bf = 1e300;
+                uint32_t bsel = 0, bent = 0;
+                int bcnt = 0;
+                for (int i = lane; i < c.H; i += 64) {
+                    const double f = c.rowF[i];                    // 1e300 while the row is empty
+                    const uint32_t me = c.rowMin[i];
+                    const int rc = c.rowCnt[i];                    // (same batch of loads: the pop below needs the winner's count)
+                    const uint32_t sel = ((me >> KEY_BITS) << 16) | (uint32_t)i;
+                    if (f < 1e300 && (f < bf || (f == bf && sel >= bsel))) { bf = f; bsel = sel; bent = me; bcnt = rc; }
                 }
-                const int ei = c.gi - ni, ej = c.gj - nj, ez = c.gz - nz;
-                h_l = 10.0 * sqrt((double)(ei * ei + ej * ej + ez * ez));
-            }
-            // Unseen cells are inserted.  A cell that is already OPEN only matters if the new g is smaller (same cell, same
-            // H).  With a consistent heuristic the popped F never decreases, so an OPEN neighbour has
-            // g_old >= g_cur - 1 step, and it was reached from a cell adjacent to it, so g_old <= g_cur + 3 steps: the
-            // difference g_old - g_new lies in [-2, 2] and its sign can be read from g modulo 8 kept in the cell byte.
-            const int ng = cg + 1;
-            const int state_l = (int)(sv_l & 3u);
-            const int gdiff = (int)(((sv_l >> 5) - (uint32_t)ng) & 7u);          // (g_old - g_new) mod 8: 1, 2 -> improvement
-            const bool want = nkey_l >= 0 && (state_l == ST_FREE || (state_l == ST_OPEN && (gdiff == 1 || gdiff == 2)));
-            unsigned long long todo = __ballot(want);
-            while (todo) {
-                const int d = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const uint32_t nkey = (uint32_t)__builtin_amdgcn_readlane(nkey_l, d);
-                const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)sv_l, d);
-                const int di = d == 0 ? -1 : (d == 5 ? 1 : 0), dj = d == 1 ? -1 : (d == 4 ? 1 : 0), dz = d == 2 ? -1 : (d == 3 ? 1 : 0);
-                const int ni = ci + di, nj = cj + dj, nz = cz + dz;
-                const uint32_t ne = nkey | ((uint32_t)ng << KEY_BITS);
-                uint32_t *row = c.rows + (size_t)ni * c.cap;
-                const RowInfo ri = row_info(c, ni);            // everything the insertion and the bookkeeping need, one round trip
-                int cnt_after = ri.cnt;
-                bool inserted = false;
-                uint32_t stored = ne;                          // the row's entry for this key after addOpen
-                if ((sv & 3u) == ST_OPEN) {                    // addOpen (:243-283): keep the better of the two; same cell,
-                    const int p = row_find(c, row, ri.cnt, nkey);          // same H, so "F smaller" is "g smaller"
-                    const uint32_t old = row[p];
-                    stored = old;
-                    if (ng < (int)(old >> KEY_BITS)) {
-                        if (lane == 0) {
-                            row[p] = ne;
-                            c.st[nkey] = st_open(d, ng);
+                const double fmin = wave_min_d(bf);
+                const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
+                const int ci = (int)(sel & 0xffffu);
+                const unsigned long long owner = __ballot(bf == fmin && bsel == sel);
+                const int own_lane = __ffsll((long long)owner) - 1;
+                const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)bent, own_lane);
+                const int ccnt = __builtin_amdgcn_readlane(bcnt, own_lane);
+                const uint32_t ckey = ce & KEY_MASK;
+                const int cg = (int)(ce >> KEY_BITS);
+                int cj, cz, ci2;
+                decode(c, ckey, ci2, cj, cz);
+                if (lane == 0) atomicOr(reinterpret_cast<unsigned int *>(c.st + (ckey & ~3u)), (unsigned int)ST_CLOSED << (8u * (ckey & 3u)));
+                row_pop_known(c, ci, ckey, ccnt);
+                nopen--;
+                if (ci == c.gi && cj == c.gj) { found = true; end_key = ckey; break; }   // the altitude is not part of the goal test
+                if (cg + 1 > G_MAX) { c.err = 1; break; }
+                // findSuccessors (:100-141): the six axis moves in the order of its nested loops.  Lanes 0..5 look at one
+                // neighbour each (bounds, occupancy, closed); only the survivors are then handled one after the other.
+                int nkey_l = -1;
+                uint32_t sv_l = ST_OCC;
+                double h_l = 0.0;                                  // H of the neighbour: one vector square root for all six
+                if (lane < 6) {
+                    const int d = lane;
+                    const int di = d == 0 ? -1 : (d == 5 ? 1 : 0), dj = d == 1 ? -1 : (d == 4 ? 1 : 0), dz = d == 2 ? -1 : (d == 3 ? 1 : 0);
+                    const int ni = ci + di, nj = cj + dj, nz = cz + dz;
+                    if (ni >= 0 && ni < c.H && nj >= 0 && nj < c.W && nz >= 0 && nz < c.A) {
+                        nkey_l = (int)key_of(ni, nj, nz);
+                        sv_l = c.st[nkey_l];
+                    }
+                    const int ei = c.gi - ni, ej = c.gj - nj, ez = c.gz - nz;
+                    h_l = 10.0 * sqrt((double)(ei * ei + ej * ej + ez * ez));
+                }
+                // Unseen cells are inserted.  A cell that is already OPEN only matters if the new g is smaller (same cell, same
+                // H).  With a consistent heuristic the popped F never decreases, so an OPEN neighbour has
+                // g_old >= g_cur - 1 step, and it was reached from a cell adjacent to it, so g_old <= g_cur + 3 steps: the
+                // difference g_old - g_new lies in [-2, 2] and its sign can be read from g modulo 8 kept in the cell byte.
+                const int ng = cg + 1;
+                const int state_l = (int)(sv_l & 3u);
+                const int gdiff = (int)(((sv_l >> 5) - (uint32_t)ng) & 7u);          // (g_old - g_new) mod 8: 1, 2 -> improvement
+                const bool want = nkey_l >= 0 && (state_l == ST_FREE || (state_l == ST_OPEN && (gdiff == 1 || gdiff == 2)));
+                unsigned long long todo = __ballot(want);
+                while (todo) {
+                    const int d = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const uint32_t nkey = (uint32_t)__builtin_amdgcn_readlane(nkey_l, d);
+                    const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)sv_l, d);
+                    const int di = d == 0 ? -1 : (d == 5 ? 1 : 0), dj = d == 1 ? -1 : (d == 4 ? 1 : 0), dz = d == 2 ? -1 : (d == 3 ? 1 : 0);
+                    const int ni = ci + di, nj = cj + dj, nz = cz + dz;
+                    const uint32_t ne = nkey | ((uint32_t)ng << KEY_BITS);
+                    uint32_t *row = c.rows + (size_t)ni * c.cap;
+                    const RowInfo ri = row_info(c, ni);            // everything the insertion and the bookkeeping need, one round trip
+                    int cnt_after = ri.cnt;
+                    bool inserted = false;
+                    uint32_t stored = ne;                          // the row's entry for this key after addOpen
+                    if ((sv & 3u) == ST_OPEN) {                    // addOpen (:243-283): keep the better of the two; same cell,
+                        const int p = row_find(c, row, ri.cnt, nkey);          // same H, so "F smaller" is "g smaller"
+                        const uint32_t old = row[p];
+                        stored = old;
+                        if (ng < (int)(old >> KEY_BITS)) {
+                            if (lane == 0) {
+                                row[p] = ne;
+                                c.st[nkey] = st_open(d, ng);
+                            }
+                            stored = ne;
+                            inserted = true;
+                            wsync();
                         }
-                        stored = ne;
+                    } else {
+                        row_insert_known(c, ni, ne, ri);
+                        if (c.err) break;
+                        if (lane == 0) c.st[nkey] = st_open(d, ng);
                         inserted = true;
+                        nopen++;
+                        cnt_after = ri.cnt + 1;
                         wsync();
                     }
-                } else {
-                    row_insert_known(c, ni, ne, ri);
-                    if (c.err) break;
-                    if (lane == 0) c.st[nkey] = st_open(d, ng);
-                    inserted = true;
-                    nopen++;
-                    cnt_after = ri.cnt + 1;
+                    // row minimum bookkeeping of addOpen (:262-282)
+                    const double hs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(h_l), d), __builtin_amdgcn_readlane(__double2loint(h_l), d));
+                    const double fs = 10.0 * (double)(stored >> KEY_BITS) + hs;
+                    if (cnt_after == 1) {
+                        if (lane == 0) { c.rowMin[ni] = stored; c.rowF[ni] = fs; }
+                    } else {
+                        const uint32_t me = ri.min;                // (nothing above touches the row's registered minimum)
+                        const bool min_is_this = (me & KEY_MASK) == nkey;
+                        // the registered minimum is read AFTER the assignment: if it is this very node it already has the new g
+                        const double fm = min_is_this ? fs : ri.F;
+                        const int gm = min_is_this ? (int)(stored >> KEY_BITS) : (int)(me >> KEY_BITS);
+                        if (inserted && (fs < fm || (fs == fm && ng >= gm))) {
+                            if (lane == 0) { c.rowMin[ni] = stored; c.rowF[ni] = fs; }
+                        } else if (min_is_this && lane == 0) {
+                            c.rowMin[ni] = stored; c.rowF[ni] = fs;
+                        }
+                    }
                     wsync();
                 }
-                // row minimum bookkeeping of addOpen (:262-282)
-                const double hs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(h_l), d), __builtin_amdgcn_readlane(__double2loint(h_l), d));
-                const double fs = 10.0 * (double)(stored >> KEY_BITS) + hs;
-                if (cnt_after == 1) {
-                    if (lane == 0) { c.rowMin[ni] = stored; c.rowF[ni] = fs; }
-                } else {
-                    const uint32_t me = ri.min;                // (nothing above touches the row's registered minimum)
-                    const bool min_is_this = (me & KEY_MASK) == nkey;
-                    // the registered minimum is read AFTER the assignment: if it is this very node it already has the new g
-                    const double fm = min_is_this ? fs : ri.F;
-                    const int gm = min_is_this ? (int)(stored >> KEY_BITS) : (int)(me >> KEY_BITS);
-                    if (inserted && (fs < fm || (fs == fm && ng >= gm))) {
-                        if (lane == 0) { c.rowMin[ni] = stored; c.rowF[ni] = fs; }
-                    } else if (min_is_this && lane == 0) {
-                        c.rowMin[ni] = stored; c.rowF[ni] = fs;
-                    }
-                }
-                wsync();
             }
         }
     }
 
+    if constexpr (COOP) { if (tid >= 64) return; }            // the rest is wave 0's (no workgroup barrier below this line)
     // ---- primary path (makePrimaryPath :143-151): parents back from the popped goal node, stored start -> goal
     uint32_t *path = c.rows;                                   // the OPEN rows are dead now: reuse them
     const int path_cap = c.H * c.cap;
@@ -723,21 +1618,48 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
         if (a.expansions) a.expansions[qi] = expansions;
         if (a.path_len) a.path_len[al] = n_path;
     }
+    if constexpr (PROF) {
+        ktick(3);
+        if (lane == 0) for (int k = 0; k < 4; k++) a.prof[(size_t)qi * 16 + k] += pc[k];
+    }
 }
 
 size_t goal_smem_bytes(int H, int W, int A, int cap)
 {
     size_t b = ((size_t)H * W * A + 15) & ~(size_t)15;
-    b += sizeof(double) * (size_t)H + sizeof(uint32_t) * (size_t)H + sizeof(uint32_t) * (size_t)cap;
+    b += sizeof(double) * (size_t)H + sizeof(uint32_t) * (size_t)H + sizeof(uint32_t) * (size_t)cap * 3;
     b += sizeof(uint32_t) * (size_t)H * cap + 2 * sizeof(uint16_t) * (size_t)H;
     b += 4 + 2 * 16 * sizeof(int);                            // bucket-count / magic tables
+    b += 512;                                                 // the register-resident search reads 65 entries of a row unpredicated
+    b += 16 + 16 * (size_t)H + 64;                            // cooperative search: row bookkeeping + mailboxes
     b += 2 * sizeof(uint32_t) * (size_t)H;                    // per-row bucket count and magic
     return (b + 15) & ~(size_t)15;
 }
 
+// register-resident search: row bookkeeping slots per lane (1: H <= 64, 2: H <= 128) and the bits of j in an OPEN entry;
+// 0 when the grid does not fit that layout (more than 128 rows, or (j, z) does not pack into 17 bits)
+int goal_fast_slots(int H, int W, int A, int *jbits)
+{
+    int jb = 0;
+    while ((1 << jb) < W) jb++;
+    *jbits = jb;
+    if (H > 128) return 0;
+    if ((((unsigned)(A - 1)) << jb | (unsigned)(W - 1)) > KEY_MASK) return 0;
+    return H <= 64 ? 1 : 2;
+}
+
 hipError_t init_device_goal_kernel()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_goal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const void *k[] = {reinterpret_cast<const void *>(&lsc_goal_kernel<0, false, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, false, false>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, false, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, true, false>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, true, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, false, true>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, false, true>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, true, true>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, true, true>)};
+    for (const void *f : k) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_goal(const GoalArgs &a, hipStream_t st)
@@ -745,7 +1667,21 @@ hipError_t launch_goal(const GoalArgs &a, hipStream_t st)
     if (a.count == 0) return hipSuccess;
     const size_t smem = goal_smem_bytes(a.H, a.W, a.A, a.row_cap);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lsc_goal_kernel, dim3(a.count), dim3(64), smem, st, a);
+    // variant: 0 the general search (row bookkeeping in LDS, any grid), 1 / 2 the register-resident search (H <= 64 / 128
+    // rows and (j, z) packed into 17 bits: goal_fast_slots() says which one a grid admits)
+    // a.prof != null selects the instrumented build of the register-resident search (section cycle counters)
+    const int slots = a.variant & 3;
+    if (a.variant & 4) {                                      // cooperative: four waves per search
+        if (slots == 2 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<2, true, true>), dim3(a.count), dim3(256), smem, st, a);
+        else if (slots == 1 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<1, true, true>), dim3(a.count), dim3(256), smem, st, a);
+        else if (slots == 2) hipLaunchKernelGGL((lsc_goal_kernel<2, false, true>), dim3(a.count), dim3(256), smem, st, a);
+        else hipLaunchKernelGGL((lsc_goal_kernel<1, false, true>), dim3(a.count), dim3(256), smem, st, a);
+    }
+    else if (slots == 2 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<2, true, false>), dim3(a.count), dim3(64), smem, st, a);
+    else if (slots == 1 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<1, true, false>), dim3(a.count), dim3(64), smem, st, a);
+    else if (slots == 2) hipLaunchKernelGGL((lsc_goal_kernel<2, false, false>), dim3(a.count), dim3(64), smem, st, a);
+    else if (slots == 1) hipLaunchKernelGGL((lsc_goal_kernel<1, false, false>), dim3(a.count), dim3(64), smem, st, a);
+    else hipLaunchKernelGGL((lsc_goal_kernel<0, false, false>), dim3(a.count), dim3(64), smem, st, a);
     return hipGetLastError();
 }
 

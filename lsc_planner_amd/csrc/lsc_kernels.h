@@ -119,6 +119,7 @@ struct GoalArgs {
     int nb_seq[16];
     uint32_t nb_magic[16];                      // floor(2^32 / nb_seq[k])
     int row_cap;                                // LDS capacity of one OPEN row (entries)
+    int variant, jbits;                         // search variant (see launch_goal) and the bits of j in a register-search entry
     float *goal_out;                            // [N][3] current_goal_position
     int *err;                                   // [N] 0 ok, 1 capacity (row / path / g overflow), 2 ray stack overflow
     int *flags;                                 // optional [N]: bit 0 retreat rule, bit 1 search without priorities used
@@ -129,8 +130,10 @@ struct GoalArgs {
     float *ray_stack;                           // [count][64][24][6] bisection stacks of castRay
     double reset_thr;                           // disturbance checks (multisim/reset_threshold; <= 0 off)
     const unsigned char *ever;                  // [N] persistent "was seen off its plan" flags
+    long long *prof;                            // optional [N][8] section cycle counters (selects the instrumented kernel)
 };
 size_t goal_smem_bytes(int H, int W, int A, int cap);
+int goal_fast_slots(int H, int W, int A, int *jbits);
 hipError_t launch_goal(const GoalArgs &a, hipStream_t st);
 
 size_t general_ws_bytes(int N);

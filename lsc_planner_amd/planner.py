@@ -42,6 +42,7 @@ class PlannerConfig:
     gap_tolerance: float = 1e-9     # interior point: relative duality gap at the optimum
     world_dimension: int = 3        # world/dimension: 2 = planar goal grid at z = world_z_2d
     world_z_2d: float = 1.0         # world/z_2d
+    goal_search: str = "auto"      # goal planner's grid search: "auto" (register-resident when the grid admits it), "general", "single_wave", "cooperative" (four waves per agent)
     comm: tuple = None              # (world_size, rank, id bytes from comm_unique_id()): agent-sharded multi-GPU over RCCL
 
 
@@ -88,6 +89,7 @@ class SwarmPlanner:
         c.reset_threshold = self.cfg.reset_threshold
         c.gap_tolerance = self.cfg.gap_tolerance
         c.world_dimension, c.world_z_2d = int(self.cfg.world_dimension), float(self.cfg.world_z_2d)
+        c.goal_search = {"auto": 0, "general": 1, "single_wave": 2, "cooperative": 3}[self.cfg.goal_search]
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:
@@ -291,6 +293,14 @@ class SwarmPlanner:
     def phase_profile(self, enable=-1):
         out = np.zeros((self.N, 12), np.int64)
         self._check(self.L.lsc_phase_profile(self.ctx, enable, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
+        return out
+
+    GOAL_SECTIONS = ("prologue", "grid_setup", "search", "path_los", "find_min", "delete_min", "screening", "insertions",
+                     "general_pop_cycles", "general_pops", "general_insert_cycles", "general_inserts")
+
+    def goal_profile(self, enable=-1):
+        out = np.zeros((self.N, 16), np.int64)
+        self._check(self.L.lsc_goal_profile(self.ctx, enable, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
         return out
 
     def solver_residuals(self):

@@ -147,3 +147,56 @@ def test_open_row_overflow_is_reported_as_status_5(L):
     assert np.array_equal(goals[~over], goals_ref[~over])
     assert np.array_equal(g["traj"][~over], g_ref["traj"][~over])
     assert (g["traj"][over] == 0).all()
+
+
+@pytest.mark.parametrize("search", ["single_wave", "cooperative"])
+def test_search_variants_return_the_general_search(L, search):
+    """The register-resident search (one wave) and the cooperative search (four waves per agent) emulate the same containers
+    as the general search: goals, paths, flags and the number of expanded nodes must be identical, tick after tick -- on a
+    3-D forest (rows up to ~60 entries), on the 2 x 2 tiled forest (67 rows: two bookkeeping slots per lane, rows beyond 64
+    entries, rehashes) and with a tiny row capacity (the capacity error must surface in the same agents)."""
+    from maputil import forest_leaves, write_bt
+    from lsc_planner_amd.planner import next_state_host
+    import os
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from config_runs import forest_tiles
+    cases = []
+    leaves, res = forest_leaves()
+    bt1 = os.path.join(tempfile.mkdtemp(), "f.bt")
+    write_bt(bt1, leaves, res)
+    cases.append((bt1, (-5, -5, 0, 5, 5, 2.5), 40, 4, 12, {}))
+    bt2, world2 = forest_tiles(2)
+    cases.append((bt2, world2, 96, 7, 6, {}))
+    cases.append((bt1, (-5, -5, 0, 5, 5, 2.5), 16, 4, 1, {"goal_row_cap": 30}))
+    for bt, world, n, seed, ticks, extra in cases:
+        dist, kmin, r = L.edt_from_bt(bt, np.asarray(world[:3], np.float32), np.asarray(world[3:], np.float32))
+        ms = L.random_swarm(n, world=world, seed=seed, edt=dist, edt_key_min=kmin, edt_res=r)
+        pls = [L.SwarmPlanner(ms, L.PlannerConfig(use_octomap=True, goal_mode="prior_based", goal_search=s, **extra)) for s in ("general", search)]
+        for pl in pls:
+            pl.load_octomap(bt)
+            pl.set_goal_trace(1024)
+        state = np.zeros((n, 9), np.float32)
+        state[:, :3] = ms.start
+        traj = np.zeros((n, 3, 30), np.float32)
+        most = 0
+        for tick in range(1, ticks + 1):
+            out = [pl.plan(state, ms.goal, traj) for pl in pls]
+            tr = [pl.goal_trace() for pl in pls]
+            assert np.array_equal(out[0]["status"], out[1]["status"]), (search, tick)
+            ok = out[0]["status"] != 5
+            if extra and tick == 1:
+                assert (~ok).any() and ok.any()
+            assert np.array_equal(tr[0]["flags"][ok], tr[1]["flags"][ok]), (search, tick)
+            assert np.array_equal(tr[0]["expansions"][ok], tr[1]["expansions"][ok]), (search, tick)
+            for q in np.nonzero(ok)[0]:
+                assert np.array_equal(tr[0]["paths"][q], tr[1]["paths"][q]), (search, tick, q)
+            assert np.array_equal(pls[0].last_goals()[ok], pls[1].last_goals()[ok]), (search, tick)
+            assert np.array_equal(out[0]["traj"], out[1]["traj"]), (search, tick)
+            most = max(most, int(tr[0]["expansions"].max()))
+            traj = out[0]["traj"]
+            state = next_state_host(traj)
+        for pl in pls:
+            pl.close()
+        assert extra or most >= 1000, most
