@@ -20,6 +20,10 @@ cannot be created, the torch.distributed all-gather around the same kernels): we
 (re-executes under torch.distributed.run when WORLD_SIZE is not set); torch.distributed is only the control plane
 (rendezvous token, barrier, max-over-ranks of the elapsed time).
 
+--workload random1024 / forest256 time BASELINE configs[4] / configs[3] as SURVEY 8(d) writes them (seeded samplers, the forest
+from the committed leaf fixture) as ONE swarm sharded over the G ranks: strong scaling, every cross-rank LSC row active; the line
+then carries the per-rank plan-kernel time and the all-gather time, which is where the latency floor shows.
+
 One JSON line on rank 0 with `roofline` (plan kernel), `roofline_sweep` (dense LSC sweep, HBM-bound) and
 `cpu_baseline` (the oracle = CPU restatement of the reference path, timed on this box's host cores).
 """
@@ -83,6 +87,21 @@ def weak_scaling_mission(L, G, per_gpu=64, single_circle=False):
                 f"{n_agents} agents, one circle per GPU")
 
 
+def forest256_mission(L):
+    """BASELINE configs[3] as SURVEY 8(d)#4 writes it.  The occupancy is the committed leaf fixture of the reference's data
+    file world/simple_forest.bt (tests/golden/simple_forest_leaves.npz), written out as a .bt and read back by the product's
+    own reader."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from maputil import forest_leaves, write_bt
+    leaves, res = forest_leaves()
+    bt = os.path.join(tempfile.mkdtemp(prefix="lsc_forest_"), "simple_forest.bt")
+    write_bt(bt, leaves, res)
+    world = (-5.0, -5.0, 0.0, 5.0, 5.0, 2.5)
+    dist, kmin, r = L.edt_from_bt(bt, np.asarray(world[:3], np.float32), np.asarray(world[3:], np.float32))
+    return L.random_swarm(256, world=world, seed=20260928, edt=dist, edt_key_min=kmin, edt_res=r), bt
+
+
 def algorithmic_flops(n_agents, iters_total):
     """per interior-point iteration per agent ~ (N-1)*1.0 kflop + 0.3 Mflop (fp64)."""
     return float(iters_total) * ((n_agents - 1) * 1.0e3 + 0.3e6)
@@ -144,6 +163,10 @@ def main():
                     help="several GPUs: one circle of 64 G agents (R = 8 G) instead of G circles of 64")
     ap.add_argument("--torch-exchange", action="store_true",
                     help="several GPUs (or --unfused): exchange through torch.distributed instead of the library's own communicator")
+    ap.add_argument("--workload", default="circle64", choices=["circle64", "random1024", "forest256"],
+                    help="circle64: BASELINE configs[2], weak scaling (64 agents per GPU); random1024: configs[4], one 1024-agent "
+                         "swarm (seed 20260929) sharded over the GPUs, strong scaling; forest256: configs[3] as written (256 agents, "
+                         "simple_forest, world [-5,5]^2 x [0,2.5], seed 20260928), strong scaling")
     ap.add_argument("--sweep-agents", type=int, default=1024,
                     help="extra leg: dense LSC sweep at this swarm size (HBM-meaningful working set); 0 = skip")
     args = ap.parse_args()
@@ -194,13 +217,26 @@ def main():
         token = L.comm_unique_id()                       # world-size-1 communicator: the same code path on one GPU
     sharded = token is not None
 
-    n_agents = args.agents_per_gpu * G
-    ms, layout = weak_scaling_mission(L, G, args.agents_per_gpu, args.single_circle)
+    strong = args.workload != "circle64"
+    bt_path = None
+    if args.workload == "random1024":
+        ms = L.random_swarm(1024, seed=20260929)
+        layout = "1024-agent random swarm (world [-20,20]^2 x [0,5], seed 20260929: BASELINE configs[4])"
+    elif args.workload == "forest256":
+        ms, bt_path = forest256_mission(L)
+        layout = ("256-agent random swarm in world/simple_forest.bt (world [-5,5]^2 x [0,2.5], seed 20260928: BASELINE configs[3] as "
+                  "written), EDT + SFC + grid-search goals")
+    else:
+        ms, layout = weak_scaling_mission(L, G, args.agents_per_gpu, args.single_circle)
+    n_agents = ms.qn
     goal_mode = "static" if args.static_goal else "prior_based"
     def make_planner(comm):
-        return L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode,
-                                                  reset_threshold=args.reset_threshold, planner_mode=args.planner,
-                                                  slack_mode=args.slack, comm=comm))
+        p = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode,
+                                               reset_threshold=args.reset_threshold, planner_mode=args.planner,
+                                               slack_mode=args.slack, use_octomap=bt_path is not None, comm=comm))
+        if bt_path is not None:
+            p.load_octomap(bt_path)
+        return p
 
     # Several GPUs: the exchange is the library's own RCCL all-gather (lsc_comm_init).  Should that communicator not come
     # up on this node, the ranks agree on it and the run falls back to the torch.distributed all-gather of
@@ -290,6 +326,16 @@ def main():
         dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     iters_total = float(it_t.item())
+    # per-rank device times of the tick's launches (HIP events): where a sharded tick's time goes
+    g_all = pl.kernel_times_ms(3) if bt_path is not None and goal_mode == "prior_based" else np.zeros(0)
+    c_all = pl.kernel_times_ms(4) if bt_path is not None else np.zeros(0)
+    mine = torch.tensor([float(k_all.mean()) if len(k_all) else 0.0, float(np.percentile(k_all, 99)) if len(k_all) else 0.0,
+                         float(g_all.mean()) if len(g_all) else 0.0, float(c_all.mean()) if len(c_all) else 0.0,
+                         1e3 * float(x_all.mean()) if len(x_all) else 0.0, float(count)], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(G)]
+    if G > 1:
+        dist.all_gather(per_rank, mine)
+    per_rank = [[round(float(v), 4) for v in r.tolist()] for r in per_rank]
 
     result = None
     if rank == 0:
@@ -297,20 +343,24 @@ def main():
         flops = algorithmic_flops(n_agents, iters_total / G) / max(k_n, 1)   # per launch of this rank's kernel
         ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         kname = "lsc_plan_kernel" if (args.reset_threshold <= 0 and args.planner == "lsc" and args.slack == "none") else "lsc_plan_alt_kernel"
+        if count > torch.cuda.get_device_properties(dev).multi_processor_count:
+            kname = kname.replace("_kernel", "_tp_kernel")       # more agents in the shard than CUs: the throughput build"
         traffic, traffic_src = pmc_traffic(kname + "@grid32768") if n_agents == 64 else (None, None)
         result = {
             "metric": "agent-replans/sec (whole node)", "value": round(value, 1), "unit": "agent-replans/s",
             "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "tick_solve_ms": {"p50": round(float(np.percentile(k_all, 50)), 4), "p99": round(float(np.percentile(k_all, 99)), 4),
                               "max": round(float(k_all.max()), 4),
                               "note": "device time of the per-tick launch (HIP events, rank 0) over the timed steps"},
-            "config": {"workload": f"{layout}, empty map, LSC mode, "
-                                   f"dt 0.2 s, M=5 n=5, mode/goal={goal_mode}, {args.agents_per_gpu} agents per GPU, "
-                                   "device-resident ticks ("
+            "config": {"workload": f"{layout}, " + ("" if bt_path is not None else "empty map, ") + "LSC mode, "
+                                   f"dt 0.2 s, M=5 n=5, mode/goal={goal_mode}, "
+                                   + (f"one swarm sharded over {G} GPU(s), {-(-n_agents // G)} agents per rank, " if strong else f"{args.agents_per_gpu} agents per GPU, ")
+                                   + "device-resident ticks ("
                                    + ("plan kernel -> in-place RCCL all-gather of the new trajectories -> state propagation, "
                                       "one stream, per tick)" if sharded else
-                                      "one fused launch per tick: goal planning + LSC + QP + state propagation)"),
+                                      ("goal search, corridor and plan launches per tick, states propagated in the plan launch)" if bt_path is not None else
+                                       "one fused launch per tick: goal planning + LSC + QP + state propagation)")),
                        "agents": n_agents, "parallelism": f"agent-shard x{G}", "prune_redundant_rows": not args.no_prune,
                        "planner_mode": args.planner, "slack_mode": args.slack, "reset_threshold": args.reset_threshold},
             "qp": {"mean_ip_iterations": round(iters_total / (n_agents * args.steps), 2), "failed_agents_last_tick": bad,
@@ -328,6 +378,10 @@ def main():
                                  "kernel executes only the non-redundant ones (executed_rows_mean, last tick); neither HBM nor "
                                  "MFMA bounds this kernel"},
         }
+        result["per_rank"] = {"columns": ["plan_kernel_ms_mean", "plan_kernel_ms_p99", "goal_kernel_ms_mean", "corridor_kernel_ms_mean",
+                                          "allgather_us_mean", "agents"], "ranks": per_rank,
+                              "note": "device time per tick of each rank's launches (HIP events on the tick's stream); the tick of a sharded swarm "
+                                      "ends with its slowest rank plus the all-gather"}
         if sharded:
             result["rccl"] = {"world_size": G, "native": native,
                               "collective": "ncclAllGather, in place, on the tick's stream" if native else
@@ -365,7 +419,7 @@ def main():
 
     # ---- the same sweep at a swarm size whose output does not fit the caches (only N = 1024 is a
     # meaningful HBM measurement): 1024-agent seeded random swarm, tick-2 inputs (shifted previous plans)
-    if args.sweep_agents > 1 and rank == 0 and G == 1:
+    if args.sweep_agents > 1 and rank == 0 and G == 1 and not strong:
         from lsc_planner_amd.planner import next_state_host
         n2 = args.sweep_agents
         ms2 = L.random_swarm(n2, seed=20260929) if n2 >= 512 else L.circle_swap(n2, 8.0 * n2 / 64)
@@ -400,7 +454,7 @@ def main():
         del nrm2, dd2
 
     # ---- per-tick latency through the host-buffer ABI (H2D + kernel + D2H, PCIe-inclusive): p50 / p99
-    if not args.no_latency_leg and rank == 0 and G == 1:
+    if not args.no_latency_leg and rank == 0 and G == 1 and not strong:
         from lsc_planner_amd.planner import next_state_host
         pl2 = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode))
         st = np.zeros((n_agents, 9), np.float32)
@@ -427,7 +481,7 @@ def main():
                                  "device_resident": result["tick_solve_ms"]["p99"]}
         pl2.close()
 
-    if rank == 0 and G == 1 and not args.no_cpu_baseline:
+    if rank == 0 and G == 1 and not args.no_cpu_baseline and not strong:
         result["cpu_baseline"] = cpu_baseline(ms, static_goal=args.static_goal)
     elif rank == 0:
         result["cpu_baseline"] = None

@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
 BENCH="python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-latency-leg"
-FOREST="python $ROOT/tools/config_runs.py --only forest256p,forest256 --ticks 30 --warmup 5"
+FOREST="python $ROOT/tools/config_runs.py --only forest256p,forest256,forest256x4p,forest256x4 --ticks 30 --warmup 5"
 LARGE="python $ROOT/tools/config_runs.py --only random1024 --ticks 30 --warmup 5"
 cd /tmp
 # 1. kernel trace + stats (no counters)
