@@ -21,6 +21,10 @@ class MultiSyncSimulator {
         lsc_default_config(&cfg);
         cfg.dt = param.dt; cfg.control_weight = param.control_input_weight; cfg.terminal_weight = param.terminal_weight;
         cfg.horizon = param.horizon;
+        if (param.planner_mode == 0 && param.slack_mode != 0) {   // TrajPlanner::checkPlannerMode, src/traj_planner.cpp:445-448
+            std::fprintf(stderr, "[TrajPlanner] LSC does not need slack variables, fix to none\n");
+            param.slack_mode = 0;
+        }
         cfg.planner_mode = param.planner_mode; cfg.slack_mode = param.slack_mode;
         cfg.slack_collision_weight = param.slack_collision_weight; cfg.n_constraint_segments = param.N_constraint_segments;
         cfg.reset_threshold = param.multisim_reset_threshold;   // the disturbance checks of every shipped launch file (0.15)

@@ -12,6 +12,7 @@
 #include <chrono>
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -216,6 +217,7 @@ struct lsc_ctx {
     unsigned char *d_ever = nullptr, *d_gen_ws = nullptr;
     size_t gen_stride = 0;
     int gen_slots = 0;
+    bool h_ever_stale = false;           // device-resident ticks ran since h_ever was last in step with d_ever
     std::vector<unsigned char> h_ever;   // host mirror for the host-buffer ticks (they decide on the host whether anybody is off plan)
     unsigned char *d_spill = nullptr;    // HBM row workspaces of the second pass (agents beyond the LDS row capacity)
     size_t spill_stride = 0;
@@ -280,18 +282,22 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
+static bool rccl_bind(RcclApi &api);
 static const RcclApi *rccl_api()
 {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.h ? &api : nullptr;
-    tried = true;
+    static std::once_flag once;                               // contexts may be created from several threads
+    std::call_once(once, [] { (void)rccl_bind(api); });
+    return api.h ? &api : nullptr;
+}
+static bool rccl_bind(RcclApi &api)
+{
     const char *names[] = {"librccl.so.1", "librccl.so"};
     void *h = nullptr;
     for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);   // the copy the process already has
     for (const char *n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return nullptr;
+    if (!h) return false;
     api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
@@ -301,9 +307,9 @@ static const RcclApi *rccl_api()
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GroupStart || !api.GroupEnd ||
         !api.GetErrorString)
-        return nullptr;
+        return false;
     api.h = h;
-    return &api;
+    return true;
 }
 
 #define NCCLCHK(ctx, api, call)                                                               \
@@ -385,6 +391,13 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
     }
     lsc_ctx *c = new lsc_ctx();
     c->cfg = *cfg;
+    if (c->cfg.planner_mode == 0 && c->cfg.slack_mode != 0) {
+        // TrajPlanner::checkPlannerMode (src/traj_planner.cpp:445-448): "LSC does not need slack variables, fix to none".  The
+        // slack rows of LSC mode are the ones a disturbance reset leaves behind (obs_slack_indices), nothing else.
+        std::fprintf(stderr, "lsc_create: LSC does not need slack variables, slack_mode fixed to none\n");
+        c->cfg.slack_mode = 0;
+        c->err = "note: planner_mode lsc with a slack mode: slack_mode fixed to none (src/traj_planner.cpp:445-448)";
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -815,6 +828,13 @@ static bool want_general(const lsc_ctx *c, int general_hint)
 static int host_disturbance_hint(lsc_ctx *c, const float *state, const float *prev_traj, int planner_seq)
 {
     if (!(c->cfg.reset_threshold > 0.0) || c->cfg.planner_mode != 0) return 0;
+    if (c->h_ever_stale) {
+        // device-resident ticks have run since the mirror was last in step: they flag agents on the device only
+        if (c->d_ever && !c->h_ever.empty() &&
+            (hipDeviceSynchronize() != hipSuccess ||
+             hipMemcpy(c->h_ever.data(), c->d_ever, c->h_ever.size(), hipMemcpyDeviceToHost) != hipSuccess)) return 1;   // when in doubt, launch
+        c->h_ever_stale = false;
+    }
     int any = 0;
     for (int q = 0; q < c->N; q++) {
         if (planner_seq >= 2) {
@@ -853,6 +873,7 @@ int lsc_tick_device(lsc_ctx *c, const float *d_state, const float *d_goal, const
     a.state_next = c->fused_state_next;
     rc = run_sfc(c, d_state, d_goal, d_traj_prev, planner_seq, (hipStream_t)hip_stream);
     if (rc) return rc;
+    if (c->cfg.reset_threshold > 0.0) c->h_ever_stale = true;   // the device may flag agents the host mirror does not see
     return run_plan(c, a, (hipStream_t)hip_stream);
 }
 
@@ -911,6 +932,11 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
         const unsigned char *si = o + (sizeof(double) + sizeof(float) * NV) * Np;
         std::memcpy(out_status, si + sizeof(int) * first, sizeof(int) * cnt);
         if (out_iters) std::memcpy(out_iters, si + sizeof(int) * (Np + first), sizeof(int) * cnt);
+        for (size_t q = 0; q < cnt; q++)
+            if (out_status[q] == LSC_STATUS_GENERAL_K) {      // handed to the general kernel and never solved: an internal error, not a report
+                c->err = "internal: an agent was handed to the alternate-mode kernel, which did not run";
+                return LSC_ESTATE;
+            }
     }
     if (c->timing)
         c->host_tick_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
@@ -1012,12 +1038,16 @@ int lsc_replan_tick_all(lsc_ctx *c, const float *state, const float *goal, const
     hipEvent_t e1 = nullptr;
     if (c->timing && timing_begin(c, 2, st, &e1) != LSC_OK) return LSC_EHIP;
     NCCLCHK(c, api, api->GroupStart());
-    if ((rc = exchange_rows(c, api, c->d_next, sizeof(float) * NV, st))) return rc;
-    if ((rc = exchange_rows(c, api, c->d_cost, sizeof(double), st))) return rc;
-    if ((rc = exchange_rows(c, api, c->d_status, sizeof(int), st))) return rc;
-    if ((rc = exchange_rows(c, api, c->d_iters, sizeof(int), st))) return rc;
-    if ((rc = exchange_rows(c, api, c->d_goal_cur, sizeof(float) * 3, st))) return rc;
-    NCCLCHK(c, api, api->GroupEnd());
+    {   // the group is closed on every path: a communicator left inside an open group is unusable
+        rc = exchange_rows(c, api, c->d_next, sizeof(float) * NV, st);
+        if (!rc) rc = exchange_rows(c, api, c->d_cost, sizeof(double), st);
+        if (!rc) rc = exchange_rows(c, api, c->d_status, sizeof(int), st);
+        if (!rc) rc = exchange_rows(c, api, c->d_iters, sizeof(int), st);
+        if (!rc) rc = exchange_rows(c, api, c->d_goal_cur, sizeof(float) * 3, st);
+        const ncclResult_t ge = api->GroupEnd();
+        if (rc) return rc;
+        if (ge != ncclSuccess) { c->err = std::string("ncclGroupEnd: ") + api->GetErrorString(ge); return LSC_ECOMM; }
+    }
     if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
     const size_t out_bytes = (sizeof(double) + sizeof(float) * NV + 2 * sizeof(int)) * Np;
     HIPCHK(c, hipMemcpyAsync(c->h_out, c->d_cost, out_bytes, hipMemcpyDeviceToHost, st));
@@ -1029,6 +1059,11 @@ int lsc_replan_tick_all(lsc_ctx *c, const float *state, const float *goal, const
     const unsigned char *si = o + (sizeof(double) + sizeof(float) * NV) * Np;
     std::memcpy(out_status, si, sizeof(int) * N);
     if (out_iters) std::memcpy(out_iters, si + sizeof(int) * Np, sizeof(int) * N);
+    for (size_t q = 0; q < N; q++)
+        if (out_status[q] == LSC_STATUS_GENERAL_K) {
+            c->err = "internal: an agent was handed to the alternate-mode kernel, which did not run";
+            return LSC_ESTATE;
+        }
     return LSC_OK;
 }
 

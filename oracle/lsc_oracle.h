@@ -173,12 +173,11 @@ int  orc_tick_ex(const orc_params *prm, const orc_modes *md, int N, const float 
 long orc_astar_last_expansions(void);
 void orc_grid_dims(const orc_params *prm, double grid_res, int dims[3], double gmin[3]);
 int  orc_astar(const unsigned char *occ, const int dims[3], const int start[3], const int goal[3], int *path_out, int max_len);
-void orc_goal_map_set_slack(const unsigned char *slack_row, int own_reset);
 void orc_goal_prior_based_map(const orc_params *prm, const orc_edt *edt, double world_res, double grid_res, double grid_margin,
                               int N, int qi, const float *state, const float *desired_goal, const float *prev_traj,
                               int planner_seq, double goal_threshold, double priority_dist_threshold, double goal_radius,
-                              const double *radius, const double *downwash, float out_goal[3], int *path_out, int max_path,
-                              int *path_len, int *flags);
+                              const double *radius, const double *downwash, const unsigned char *slack_row /* [N] or NULL */,
+                              int own_reset, float out_goal[3], int *path_out, int max_path, int *path_len, int *flags);
 
 #ifdef __cplusplus
 }

@@ -245,17 +245,14 @@ int orc_astar(const unsigned char *occ, const int dims[3], const int start[3], c
  * prm->obs_f32 the obstacle copies pass through float32 (dynamic_msgs::Obstacle).  path_out (optional, [max][3]
  * grid cells) receives the grid path that findLOSFreeGoal walks; *path_len its length; flags bit 0: retreat rule
  * fired, bit 1: the prioritised search failed and the search without priorities was used. */
-/* disturbance reset (src/traj_planner.cpp:547-551, 866-878, 1047-1061): slack obstacles of the NEXT orc_goal_prior_based_map
- * call (row of the agent's slack set, indexed by agent; may be NULL) and whether its own initial trajectory was reset */
-static const unsigned char *g_slack_row = nullptr;
-static int g_own_reset = 0;
-void orc_goal_map_set_slack(const unsigned char *slack_row, int own_reset) { g_slack_row = slack_row; g_own_reset = own_reset; }
-
+/* disturbance reset (src/traj_planner.cpp:547-551, 866-878, 1047-1061): the slack obstacles are stamped as higher priority */
+/* slack_row [N] (may be NULL): the agent's slack set, indexed by agent; own_reset: its own initial trajectory was reset.  Explicit
+ * arguments, no process-wide state: a threaded caller (the QP stage already is) must not pick up another agent's slack set. */
 void orc_goal_prior_based_map(const orc_params *prm, const orc_edt *edt, double world_res, double grid_res, double grid_margin,
                               int N, int qi, const float *state, const float *desired_goal, const float *prev_traj,
                               int planner_seq, double goal_threshold, double priority_dist_threshold, double goal_radius,
-                              const double *radius, const double *downwash, float out_goal[3], int *path_out, int max_path,
-                              int *path_len, int *flags)
+                              const double *radius, const double *downwash, const unsigned char *slack_row, int own_reset,
+                              float out_goal[3], int *path_out, int max_path, int *path_len, int *flags)
 {
     const float *pos = state + 9 * qi;
     const float *goal_i = desired_goal + 3 * qi;
@@ -267,7 +264,7 @@ void orc_goal_prior_based_map(const orc_params *prm, const orc_edt *edt, double 
     if (flags) *flags = 0;
     for (int qj = 0; qj < N; qj++) {              /* :547-577 */
         if (qj == qi) continue;
-        if (g_slack_row && g_slack_row[qj]) { high[qj] = 1; continue; }   /* :548-551 */
+        if (slack_row && slack_row[qj]) { high[qj] = 1; continue; }   /* :548-551 */
         const float *opos = state + 9 * qj, *ogoal = desired_goal + 3 * qj;
         const double obs_dist_to_goal = f32_dist(opos, ogoal);
         const double dist_to_obs = f32_dist(opos, pos);
@@ -376,7 +373,7 @@ void orc_goal_prior_based_map(const orc_params *prm, const orc_edt *edt, double 
 
     /* ---- findLOSFreeGoal(initial_traj[M-1][n], desired goal, ...) :350-407 */
     float cur[3];
-    if (g_own_reset) {
+    if (own_reset) {
         for (int k = 0; k < 3; k++) cur[k] = pos[k];               /* initial trajectory reset to the current position */
     } else if (planner_seq < 2) {
         float tmp[ORC_NV];

@@ -125,8 +125,8 @@ def lib():
         L.orc_goal_prior_based_map.restype = None
         L.orc_goal_prior_based_map.argtypes = [ctypes.POINTER(OrcParams), ctypes.POINTER(OrcEdt), ctypes.c_double, ctypes.c_double,
                                                ctypes.c_double, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,
-                                               ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp, _fp, _ip, ctypes.c_int,
-                                               _ip, _ip]
+                                               ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp, ctypes.POINTER(ctypes.c_ubyte),
+                                               ctypes.c_int, _fp, _ip, ctypes.c_int, _ip, _ip]
         _ubp = ctypes.POINTER(ctypes.c_ubyte)
         pm, pp = ctypes.POINTER(OrcModes), ctypes.POINTER(OrcParams)
         L.orc_qp_solve_n.restype = ctypes.c_int
@@ -143,8 +143,6 @@ def lib():
         L.orc_goal_prior_based_ex.restype = None
         L.orc_goal_prior_based_ex.argtypes = [ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                               ctypes.c_double, ctypes.c_double, _ubp, ctypes.c_int, _fp]
-        L.orc_goal_map_set_slack.restype = None
-        L.orc_goal_map_set_slack.argtypes = [_ubp, ctypes.c_int]
         L.orc_tick_ex.restype = ctypes.c_int
         L.orc_tick_ex.argtypes = [pp, pm, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _fp, _ubp,
                                   ctypes.POINTER(OrcEdt), ctypes.c_double, _fp, _ip, _fp, _dp, _ip, _ip, _fp, _dp, ctypes.c_int]
@@ -479,14 +477,12 @@ def goal_prior_based_map(prm, dm, state, desired_goal, prev_traj, planner_seq, r
     ubp = ctypes.POINTER(ctypes.c_ubyte)
     for qi in range(N):
         n, fl = ctypes.c_int(), ctypes.c_int()
-        if slack_set is not None:
-            row = np.ascontiguousarray(slack_set[qi], np.uint8)
-            lib().orc_goal_map_set_slack(row.ctypes.data_as(ubp), int(own_reset[qi]) if own_reset is not None else 0)
-        else:
-            lib().orc_goal_map_set_slack(None, 0)
+        row = np.ascontiguousarray(slack_set[qi], np.uint8) if slack_set is not None else None
         lib().orc_goal_prior_based_map(ctypes.byref(prm), ctypes.byref(dm.edt), world_res, grid_res, grid_margin, N, qi, _f(state),
                                        _f(dg), _f(pt), planner_seq, goal_threshold, priority_dist_threshold, goal_radius, _d(r),
-                                       _d(dw), _f(out[qi]), _i(buf), len(buf), ctypes.byref(n), ctypes.byref(fl))
+                                       _d(dw), row.ctypes.data_as(ubp) if row is not None else None,
+                                       int(own_reset[qi]) if (own_reset is not None and row is not None) else 0,
+                                       _f(out[qi]), _i(buf), len(buf), ctypes.byref(n), ctypes.byref(fl))
         flags[qi] = fl.value
         if want_paths:
             paths.append(buf[:n.value].copy())

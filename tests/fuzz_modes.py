@@ -11,8 +11,8 @@ COST_RTOL, COST_ATOL, TRAJ_ATOL = 1e-6, 1e-8, 5e-5
 seed0=int(sys.argv[1]); ntr=int(sys.argv[2])
 bad=0; tot=0; fails=0
 MODES=[(dict(planner_mode="bvc"), dict(planner="bvc")),
-       (dict(slack_mode="collision_constraint"), dict(slack="collision_constraint")),
-       (dict(slack_mode="dynamical_limit"), dict(slack="dynamical_limit")),
+       (dict(planner_mode="bvc", slack_mode="collision_constraint"), dict(planner="bvc", slack="collision_constraint")),
+       (dict(planner_mode="bvc", slack_mode="dynamical_limit"), dict(planner="bvc", slack="dynamical_limit")),
        (dict(planner_mode="bvc", n_constraint_segments=2), dict(planner="bvc", n_constraint_segments=2)),
        (dict(reset_threshold=0.15), dict(reset_threshold=0.15))]
 for trial in range(ntr):

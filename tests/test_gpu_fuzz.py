@@ -86,8 +86,8 @@ def test_fuzz_lsc_mode(oracle, seed0, trials, options):
 
 
 MODES = [(dict(planner_mode="bvc"), dict(planner="bvc")),
-         (dict(slack_mode="collision_constraint"), dict(slack="collision_constraint")),
-         (dict(slack_mode="dynamical_limit"), dict(slack="dynamical_limit")),
+         (dict(planner_mode="bvc", slack_mode="collision_constraint"), dict(planner="bvc", slack="collision_constraint")),   # (LSC fixes the slack
+         (dict(planner_mode="bvc", slack_mode="dynamical_limit"), dict(planner="bvc", slack="dynamical_limit")),             #  mode to none)
          (dict(planner_mode="bvc", n_constraint_segments=2), dict(planner="bvc", n_constraint_segments=2)),
          (dict(reset_threshold=0.15), dict(reset_threshold=0.15))]
 

@@ -88,14 +88,34 @@ def test_bvc_with_fewer_constraint_segments_and_heterogeneous_agents(L, oracle):
 
 @pytest.mark.parametrize("slack", ["collision_constraint", "dynamical_limit"])
 def test_slack_modes_match_the_oracle(L, oracle, slack):
+    """SlackMode is a BVC matter: in LSC mode the reference fixes it to none (TrajPlanner::checkPlannerMode,
+    src/traj_planner.cpp:445-448), so the combination the reference can reach is mode/planner = bvc with slack variables."""
     ms = L.circle_swap(8, 1.2, world=(-5, -5, 0, 5, 5, 2.5))
-    _run(L, oracle, ms, dict(slack_mode=slack), oracle.make_modes(slack=slack), 20)
+    _run(L, oracle, ms, dict(planner_mode="bvc", slack_mode=slack), oracle.make_modes(planner="bvc", slack=slack), 20)
+
+
+def test_lsc_mode_fixes_the_slack_mode_to_none(L):
+    """`LSC does not need slack variables, fix to none` (src/traj_planner.cpp:445-448): asking for a slack mode in LSC mode
+    must plan exactly what LSC without slack plans -- on the fast path -- and say so."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(8, 1.2, world=(-5, -5, 0, 5, 5, 2.5))
+    a = L.SwarmPlanner(ms, L.PlannerConfig(slack_mode="collision_constraint"))
+    assert b"slack_mode fixed to none" in a.L.lsc_last_error(a.ctx)
+    b = L.SwarmPlanner(ms)
+    state = np.zeros((8, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((8, 3, 30), np.float32)
+    for tick in range(1, 9):
+        ga, gb = a.plan(state, ms.goal, traj), b.plan(state, ms.goal, traj)
+        for k in ("traj", "cost", "status", "iters"):
+            assert np.array_equal(ga[k], gb[k]), (tick, k)
+        traj = gb["traj"]; state = next_state_host(traj)
+    a.close(); b.close()
 
 
 def test_slack_variables_keep_an_otherwise_infeasible_swarm_planning(L, oracle):
     """The scene of the reference's log/QPmodel.lp (agent 3's QP is infeasible under the hard LSC rows -- CPLEX failed
-    on it, HiGHS certifies it): with collision_constraint slack variables the same tick is solvable for every agent, and the
-    GPU agrees with the oracle."""
+    on it, HiGHS certifies it).  Where the reference puts slack variables on collision rows (mode/planner = bvc,
+    SlackMode::COLLISIONCONSTRAINT) the same swarm keeps planning tick after tick, and the GPU agrees with the oracle."""
     import json, os
     from conftest import GOLDEN
     sc = json.load(open(os.path.join(GOLDEN, "qpmodel_lp.json")))["scene"]
@@ -111,8 +131,8 @@ def test_slack_variables_keep_an_otherwise_infeasible_swarm_planning(L, oracle):
     hard.close()
     assert g["status"][sc["agent"]] == 1
     from lsc_planner_amd.planner import next_state_host
-    pl = L.SwarmPlanner(ms, L.PlannerConfig(slack_mode="collision_constraint"))
-    prm, sw = _swarm_ex(oracle, ms, oracle.make_modes(slack="collision_constraint"))
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(planner_mode="bvc", slack_mode="collision_constraint"))
+    prm, sw = _swarm_ex(oracle, ms, oracle.make_modes(planner="bvc", slack="collision_constraint"))
     traj = np.zeros((N, 3, 30), np.float32)
     for tick in range(1, 7):
         g = pl.plan(state, goal, traj, want_constraints=True)
@@ -180,6 +200,44 @@ def test_device_resident_ticks_take_the_general_kernel_after_a_disturbance(L, or
         assert np.array_equal(status.cpu().numpy(), g["status"]) and (g["status"] == 0).all(), tick
         traj = g["traj"]; state = next_state_host(traj)
     h.close(); d.close()
+
+
+def test_host_tick_after_device_ticks_that_saw_a_disturbance(L):
+    """A context may mix the two kinds of tick.  The device-resident ticks flag an off-plan agent on the device only; a later
+    host-buffer tick on the same context must still launch the alternate-mode kernel for the agents whose rows carry slack
+    variables (the host mirror of the flags is refreshed), and must never hand internal status 6 to the caller.  Reference
+    for the result: a context that ran every tick through the host-buffer entry point."""
+    import torch
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(8, 1.5, world=(-5, -5, 0, 5, 5, 2.5))
+    N = 8
+    cfg = L.PlannerConfig(reset_threshold=0.15)
+    h, m = L.SwarmPlanner(ms, cfg), L.SwarmPlanner(ms, cfg)
+    dev = torch.device("cuda", 0)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    goal = torch.from_numpy(ms.goal).to(dev)
+    cost = torch.zeros(N, dtype=torch.float64, device=dev)
+    status = torch.zeros(N, dtype=torch.int32, device=dev)
+    iters = torch.zeros(N, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for tick in range(1, 13):
+        if tick == 5:
+            state[3, :3] += np.float32([0.25, -0.2, 0.0])      # the gust arrives during the device-resident stretch
+        g = h.plan(state, ms.goal, traj)
+        if tick < 8:
+            b_d = torch.zeros((N, 90), device=dev)
+            m.planner_seq += 1
+            m.tick_device(torch.from_numpy(state).to(dev), goal, torch.from_numpy(traj.reshape(N, 90)).to(dev), b_d, cost, status, iters, tick, st)
+            torch.cuda.synchronize()
+            got, gst = b_d.cpu().numpy().reshape(N, 3, 30), status.cpu().numpy()
+        else:
+            r = m.plan(state, ms.goal, traj)                    # no disturbance in THIS tick's inputs: the mirror must know about tick 5
+            got, gst = r["traj"], r["status"]
+        assert np.array_equal(gst, g["status"]) and (gst == 0).all(), (tick, gst, g["status"])
+        assert np.array_equal(got, g["traj"]), tick
+        traj = g["traj"]; state = next_state_host(traj)
+    h.close(); m.close()
 
 
 def test_disturbance_reinitialises_the_corridor_on_octomap_worlds(L, oracle):

@@ -163,8 +163,9 @@ def test_alternate_mode_qps_vs_highs(oracle, mode):
     import lsc_planner_amd as L
     from lsc_planner_amd.planner import next_state_host
     O = oracle
-    md = {"bvc": O.make_modes(planner="bvc"), "collision_constraint": O.make_modes(slack="collision_constraint"),
-          "dynamical_limit": O.make_modes(slack="dynamical_limit"), "reset": O.make_modes(reset_threshold=0.15)}[mode]
+    # slack modes with mode/planner = bvc: in LSC mode the reference fixes SlackMode to none (src/traj_planner.cpp:445-448)
+    md = {"bvc": O.make_modes(planner="bvc"), "collision_constraint": O.make_modes(planner="bvc", slack="collision_constraint"),
+          "dynamical_limit": O.make_modes(planner="bvc", slack="dynamical_limit"), "reset": O.make_modes(reset_threshold=0.15)}[mode]
     ms = L.circle_swap(8, 1.2, world=(-5, -5, 0, 5, 5, 2.5))
     N = ms.qn
     prm = O.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
@@ -182,7 +183,7 @@ def test_alternate_mode_qps_vs_highs(oracle, mode):
             others = [j for j in range(N) if j != a]
             obs = []
             for j in others:
-                if mode == "bvc" or sw.slack_set[a, j] and np.linalg.norm(
+                if mode in ("bvc", "collision_constraint", "dynamical_limit") or sw.slack_set[a, j] and np.linalg.norm(
                         (O.shift_traj(traj[j]) if tick >= 2 else O.const_vel_traj(state[j, :3], state[j, 3:6]))[:, 0] - state[j, :3]) > 0.15:
                     obs.append(np.repeat(state[j, :3, None], 30, axis=1))
                 else:
