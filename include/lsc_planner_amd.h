@@ -277,6 +277,11 @@ int lsc_phase_profile(lsc_ctx *ctx, int enable, long long *out);
  * routines (rows beyond 64 entries, rehashes); the rest is reserved. */
 int lsc_goal_profile(lsc_ctx *ctx, int enable, long long *out);
 int lsc_solver_residuals(lsc_ctx *ctx, double *out);
+/* QP failure forensics (TrajOptimizer::solve exports the model it could not solve: log/QPmodel.lp, src/traj_optimizer.cpp:99-153).
+ * Writes the QP of `agent` as the LAST host-buffer tick (lsc_replan_tick / lsc_replan_tick_all) posed it, in CPLEX LP format with
+ * the reference's variable names (x_m_i, y_m_i, z_m_i) and populatebyrow's row order (c1, c2, ...), so that it can be diffed against a
+ * reference dump or fed to any LP/QP solver.  LSC mode, rows without slack variables. */
+int lsc_dump_qp(lsc_ctx *ctx, int agent, const char *path);
 /* Reads the [64][8] per-iteration trace recorded for the agent selected by the PREVIOUS call (out may be NULL),
  * then selects `agent` (-1: off): gap, |rp|, objective, affine step, sigma, step, |dx_aff|, mu. */
 int lsc_solver_trace(lsc_ctx *ctx, int agent, double *out);

@@ -156,6 +156,16 @@ class MultiSyncSimulator {
             agents[qi]->acceptPlan(h_next.data() + 90 * qi, h_cost[qi], h_status[qi], last_tick_ms * 1e-3 / N);
         }
         total_ticks++; total_tick_ms += last_tick_ms;
+        // TrajOptimizer::solve exports the model of a failed solve (log/QPmodel.lp, src/traj_optimizer.cpp:99-102); like there the
+        // file is overwritten by every failure, so it holds the last one.  Best effort: a swarm with slack rows is not dumped.
+        if (!param.log_dir.empty() && param.rank == 0)
+            for (int qi = 0; qi < N; qi++)
+                if (h_status[qi] == LSC_STATUS_INFEASIBLE) {
+                    if (lsc_dump_qp(ctx, qi, (param.log_dir + "/QPmodel.lp").c_str()) == LSC_OK)
+                        std::fprintf(stderr, "[TrajOptimizer] QP of agent %d failed at tick %d: model written to %s/QPmodel.lp\n", qi,
+                                     total_ticks, param.log_dir.c_str());
+                    break;
+                }
         for (int qi = 0; qi < N; qi++) {
             // what the reference's plan() does with these outcomes: the corridor's exception leaves the simulator
             // (include/corridor_constructor.hpp:35-38); nothing else stops a run (:323-328 only tests QPFAILED, which

@@ -217,6 +217,7 @@ struct lsc_ctx {
     unsigned char *d_ever = nullptr, *d_gen_ws = nullptr;
     size_t gen_stride = 0;
     int gen_slots = 0;
+    int last_host_seq = 0;               // planner_seq of the last host-buffer tick (lsc_dump_qp reads its inputs back)
     bool h_ever_stale = false;           // device-resident ticks ran since h_ever was last in step with d_ever
     std::vector<unsigned char> h_ever;   // host mirror for the host-buffer ticks (they decide on the host whether anybody is off plan)
     unsigned char *d_spill = nullptr;    // HBM row workspaces of the second pass (agents beyond the LDS row capacity)
@@ -897,6 +898,7 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t N = c->N, cnt = c->count, first = c->first, nobs = N - 1;
     hipStream_t st = c->stream;
+    c->last_host_seq = planner_seq;
     std::memcpy(c->h_in, state, sizeof(float) * 9 * N);
     std::memcpy(c->h_in + 9 * N, goal, sizeof(float) * 3 * N);
     std::memcpy(c->h_in + 12 * N, prev_traj, sizeof(float) * NV * N);
@@ -1021,6 +1023,7 @@ int lsc_replan_tick_all(lsc_ctx *c, const float *state, const float *goal, const
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t N = c->N, Np = (size_t)c->table_rows;
     hipStream_t st = c->stream;
+    c->last_host_seq = planner_seq;
     std::memcpy(c->h_in, state, sizeof(float) * 9 * N);
     std::memcpy(c->h_in + 9 * N, goal, sizeof(float) * 3 * N);
     std::memcpy(c->h_in + 12 * N, prev_traj, sizeof(float) * NV * N);
@@ -1194,6 +1197,212 @@ int lsc_goal_profile(lsc_ctx *c, int enable, long long *out)
         c->goal_profiling = enable != 0;
         HIPCHK(c, hipMemset(c->d_goal_prof, 0, sizeof(long long) * 16 * (size_t)c->N));
     }
+    return LSC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// QP failure forensics.  On a solver failure the reference exports the model it could not solve (log/QPmodel.lp, CPLEX LP
+// format, src/traj_optimizer.cpp:99-153); lsc_dump_qp writes the same file for one agent of the LAST host-buffer tick: variables
+// x_m_i / y_m_i / z_m_i, rows c1.. in populatebyrow's order (:394-536: 15 equalities per axis, corridor rows, LSC rows of
+// every obstacle, velocity / acceleration rows per axis, stop-at-horizon equalities), bounds (:274-303), objective as
+// "linear + [ quadratic ] / 2 + constant".  Numbers are what the kernels used: LSC normals / margins from the dense sweep
+// kernel on the tick's inputs, corridor boxes and planned goal from the context's device state.  LSC mode without slack
+// rows (an agent whose rows carry slack variables after a disturbance has an alternate-mode QP: LSC_EINVAL).
+int lsc_dump_qp(lsc_ctx *c, int agent, const char *path)
+{
+    if (!c || !path || c->N < 1 || agent < 0 || agent >= c->N) return LSC_EINVAL;
+    if (c->last_host_seq < 1 || !c->h_in) { c->err = "lsc_dump_qp: no host-buffer tick has run on this context"; return LSC_ESTATE; }
+    if (c->cfg.planner_mode != 0) { c->err = "lsc_dump_qp: LSC mode only"; return LSC_EINVAL; }
+    const int N = c->N, nobs = N - 1, seq = c->last_host_seq;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->cfg.reset_threshold > 0.0 && c->d_ever) {
+        std::vector<unsigned char> ever(N);
+        HIPCHK(c, hipMemcpy(ever.data(), c->d_ever, N, hipMemcpyDeviceToHost));
+        for (int q = 0; q < N; q++)
+            if (ever[q]) { c->err = "lsc_dump_qp: the swarm carries slack rows of a disturbance reset (alternate-mode QP)"; return LSC_EINVAL; }
+    }
+    const float *state = c->h_in, *prev = c->h_in + 12 * (size_t)N;
+    // the agent's LSC (generateLSC) from the sweep kernel, its corridor and planned goal from the context
+    std::vector<float> normal((size_t)std::max(nobs, 1) * M * 3), sfc(M * 6), goal(3);
+    std::vector<double> dd((size_t)std::max(nobs, 1) * M * NC), vmax(3), amax(3);
+    double vnom = 1.0;
+    if (nobs > 0) {
+        float *d_n = nullptr;
+        double *d_d = nullptr;
+        HIPCHK(c, hipMalloc(&d_n, sizeof(float) * normal.size()));
+        HIPCHK(c, hipMalloc(&d_d, sizeof(double) * dd.size()));
+        SweepArgs s;
+        s.N = N; s.first = agent; s.count = 1; s.planner_seq = seq; s.dtf = (float)c->cfg.dt;
+        s.state = c->d_state; s.traj_prev = c->d_prev;
+        s.radius = c->d_radius; s.radius_obs = c->d_radius_obs; s.downwash = c->d_downwash; s.downwash_obs = c->d_downwash_obs;
+        s.out_normal = d_n; s.out_d = d_d;
+        hipError_t e = launch_sweep(s, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(normal.data(), d_n, sizeof(float) * normal.size(), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(dd.data(), d_d, sizeof(double) * dd.size(), hipMemcpyDeviceToHost);
+        (void)hipFree(d_n); (void)hipFree(d_d);
+        if (e != hipSuccess) { c->err = std::string("lsc_dump_qp: ") + hipGetErrorString(e); return LSC_EHIP; }
+    }
+    HIPCHK(c, hipMemcpy(goal.data(), c->d_goal_cur + 3 * (size_t)agent, sizeof(float) * 3, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(vmax.data(), c->d_vmax + 3 * (size_t)agent, sizeof(double) * 3, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(amax.data(), c->d_amax + 3 * (size_t)agent, sizeof(double) * 3, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&vnom, c->d_vnom + agent, sizeof(double), hipMemcpyDeviceToHost));
+    if (c->cfg.use_octomap) HIPCHK(c, hipMemcpy(sfc.data(), c->d_sfc + (size_t)agent * M * 6, sizeof(float) * M * 6, hipMemcpyDeviceToHost));
+    FILE *f = std::fopen(path, "w");
+    if (!f) { c->err = std::string("lsc_dump_qp: cannot write ") + path; return LSC_EINVAL; }
+    const char ax[3] = {'x', 'y', 'z'};
+    const int n = DEG, phi = 3;
+    const double dt = c->cfg.dt, wc = c->cfg.control_weight, wt = c->cfg.terminal_weight;
+    auto var = [&](int k, int m, int i) { char b[32]; std::snprintf(b, sizeof b, "%c_%d_%d", ax[k], m, i); return std::string(b); };
+    struct Term { double v; std::string name; };
+    auto emit = [&](const std::vector<Term> &t) {       // " - 25 x_0_0 + 25 x_0_1"; unit coefficients are left out like CPLEX does
+        bool first = true;
+        for (const Term &q : t) {
+            if (q.v == 0.0) continue;
+            const double m = std::fabs(q.v);
+            std::fprintf(f, "%s", q.v < 0 ? (first ? " - " : " - ") : (first ? " " : " + "));
+            if (m != 1.0) std::fprintf(f, "%.15g ", m);
+            std::fprintf(f, "%s", q.name.c_str());
+            first = false;
+        }
+        if (first) std::fprintf(f, " 0 %s", var(0, 0, 0).c_str());
+    };
+    // ---- objective: w_c sum x^T Q_base x + w_t sum_{m >= M - T} |c_{m,n} - goal|^2   (:329-372)
+    const float *sa = state + 9 * (size_t)agent;
+    int T;
+    {
+        const float dx = goal[0] - sa[0], dy = goal[1] - sa[1], dz = goal[2] - sa[2];
+        const float n2 = dx * dx + dy * dy + dz * dz;
+        const double ideal = std::sqrt((double)n2) / vnom;       // octomath norm: float32 sum of squares, double sqrt
+        T = std::max((int)((M * dt - ideal + 1e-9) / dt), 1);
+    }
+    double Q[NC * NC];
+    build_qbase(dt, Q);
+    std::fprintf(f, "\\ENCODING=ISO-8859-1\n\\Problem name: lsc_planner_amd (agent %d, planner_seq %d)\n\nMinimize\n obj1:", agent, seq);
+    {
+        std::vector<Term> lin;
+        for (int k = 2; k >= 0; k--)
+            for (int m = M - 1; m >= M - T; m--) lin.push_back({-2.0 * wt * (double)goal[k], var(k, m, n)});
+        emit(lin);
+        std::fprintf(f, " + [");
+        bool first = true;
+        for (int k = 2; k >= 0; k--)
+            for (int m = M - 1; m >= 0; m--)
+                for (int i = n; i >= 0; i--)
+                    for (int j = i; j >= 0; j--) {
+                        // "[ ... ] / 2": the bracket holds twice the objective's quadratic coefficients
+                        double v = i == j ? 2.0 * wc * Q[i * NC + i] : 2.0 * wc * (Q[i * NC + j] + Q[j * NC + i]);
+                        if (i == j && i == n && m >= M - T) v += 2.0 * wt;
+                        if (v == 0.0) continue;
+                        std::fprintf(f, "%s%.15g %s", v < 0 ? " - " : (first ? " " : " + "), std::fabs(v), var(k, m, i).c_str());
+                        if (i == j) std::fprintf(f, " ^2"); else std::fprintf(f, " * %s", var(k, m, j).c_str());
+                        first = false;
+                    }
+        double cst = 0.0;
+        for (int k = 0; k < 3; k++) cst += wt * T * (double)goal[k] * (double)goal[k];
+        std::fprintf(f, " ] / 2 + %.15g\nSubject To\n", cst);
+    }
+    int row = 0;
+    auto begin_row = [&]() { std::fprintf(f, " c%d:", ++row); };
+    // ---- equalities (:394-405, Aeq_base :186-236, deq :239-259)
+    const double A0[3][3] = {{1, 0, 0}, {-1, 1, 0}, {1, -2, 1}};       // A_0 rows 0..2, columns 0..2
+    const double AT[3][3] = {{0, 0, 1}, {0, -1, 1}, {1, -2, 1}};       // A_T rows 0..2, columns n-2..n
+    for (int k = 0; k < 3; k++) {
+        int nn = 1;
+        for (int i = 0; i < phi; i++) {
+            std::vector<Term> t;
+            for (int j = 0; j < 3; j++) t.push_back({std::pow(dt, -i) * nn * A0[i][j], var(k, 0, j)});
+            begin_row(); emit(t);
+            std::fprintf(f, " = %.15g\n", (double)sa[3 * i + k]);
+            nn *= n - i;
+        }
+        for (int m = 1; m < M; m++) {
+            nn = 1;
+            for (int j = 0; j < phi; j++) {
+                std::vector<Term> t;
+                for (int q = 0; q < 3; q++) t.push_back({-std::pow(dt, -j) * nn * A0[j][q], var(k, m, q)});
+                for (int q = 2; q >= 0; q--) t.push_back({std::pow(dt, -j) * nn * AT[j][q], var(k, m - 1, n - 2 + q)});
+                begin_row(); emit(t);
+                std::fprintf(f, " = 0\n");
+                nn *= n - j;
+            }
+        }
+    }
+    const int ncs = c->cfg.n_constraint_segments > 0 ? std::min(c->cfg.n_constraint_segments, (int)M) : (int)M;
+    // ---- corridor rows (:409-434; Box::convertToLSCs src/collision_constraints.cpp:37-59)
+    if (c->cfg.use_octomap)
+        for (int m = 0; m < ncs; m++)
+            for (int k = 0; k < 3; k++)
+                for (int side = 0; side < 2; side++)
+                    for (int j = 0; j <= n; j++) {
+                        if (m == 0 && j < phi) continue;
+                        begin_row();
+                        emit({{side == 0 ? 1.0 : -1.0, var(k, m, j)}});
+                        std::fprintf(f, " >= %.15g\n", side == 0 ? (double)sfc[m * 6 + k] : -(double)sfc[m * 6 + 3 + k]);
+                    }
+    // ---- LSC rows (:437-466): n . (c_{m,i} - q_i) - d_i >= 0, q = the obstacle's predicted control point
+    for (int oi = 0; oi < nobs; oi++) {
+        const int qj = oi < agent ? oi : oi + 1;
+        for (int m = 0; m < ncs; m++)
+            for (int i = 0; i <= n; i++) {
+                if (m == 0 && i < phi) continue;
+                float q[3];
+                if (seq < 2) {
+                    const float *s = state + 9 * (size_t)qj;
+                    const float mi = (float)((double)m + (double)i / (double)n), dtf = (float)dt;
+                    for (int k = 0; k < 3; k++) { const float a1 = s[3 + k] * mi; const float a2 = a1 * dtf; q[k] = s[k] + a2; }
+                } else {
+                    const float *t = prev + (size_t)qj * NV;
+                    const int cc = m < M - 1 ? (m + 1) * NC + i : (M - 1) * NC + n;
+                    for (int k = 0; k < 3; k++) q[k] = t[k * SEGV + cc];
+                }
+                const float *nv = normal.data() + ((size_t)oi * M + m) * 3;
+                double rhs = dd[((size_t)oi * M + m) * NC + i];
+                std::vector<Term> t;
+                for (int k = 2; k >= 0; k--) { t.push_back({(double)nv[k], var(k, m, i)}); }
+                for (int k = 0; k < 3; k++) rhs += (double)nv[k] * (double)q[k];
+                begin_row(); emit(t);
+                std::fprintf(f, " >= %.15g\n", rhs);
+            }
+    }
+    // ---- velocity / acceleration rows (:469-523)
+    for (int k = 0; k < 3; k++)
+        for (int m = 0; m < M; m++) {
+            const double cv = std::pow(dt, -1) * n, ca = std::pow(dt, -2) * n * (n - 1);
+            for (int i = 0; i < n; i++) {
+                if (m == 0 && (i == 0 || i == 1)) continue;
+                for (int sg = 1; sg >= -1; sg -= 2) {
+                    begin_row(); emit({{sg * cv, var(k, m, i + 1)}, {-sg * cv, var(k, m, i)}});
+                    std::fprintf(f, " <= %.15g\n", vmax[k]);
+                }
+            }
+            for (int i = 0; i < n - 1; i++) {
+                if (m == 0 && i == 0) continue;
+                for (int sg = 1; sg >= -1; sg -= 2) {
+                    begin_row(); emit({{sg * ca, var(k, m, i + 2)}, {-2.0 * sg * ca, var(k, m, i + 1)}, {sg * ca, var(k, m, i)}});
+                    std::fprintf(f, " <= %.15g\n", amax[k]);
+                }
+            }
+        }
+    // ---- stop at the horizon (:529-536)
+    for (int k = 0; k < 3; k++)
+        for (int i = 1; i < phi; i++) {
+            begin_row(); emit({{1.0, var(k, M - 1, n)}, {-1.0, var(k, M - 1, n - i)}});
+            std::fprintf(f, " = 0\n");
+        }
+    // ---- bounds (:274-303)
+    std::fprintf(f, "Bounds\n");
+    for (int k = 2; k >= 0; k--)
+        for (int m = M - 1; m >= 0; m--)
+            for (int i = n; i >= 0; i--) {
+                if (m == 0 && i < 3) continue;
+                std::fprintf(f, " %.15g <= %s <= %.15g\n", (double)c->cfg.world_min[k], var(k, m, i).c_str(), (double)c->cfg.world_max[k]);
+            }
+    for (int k = 2; k >= 0; k--)
+        for (int i = 0; i < 3; i++) std::fprintf(f, "      %s Free\n", var(k, 0, i).c_str());
+    std::fprintf(f, "End\n");
+    std::fclose(f);
     return LSC_OK;
 }
 

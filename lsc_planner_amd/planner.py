@@ -303,6 +303,10 @@ class SwarmPlanner:
         self._check(self.L.lsc_goal_profile(self.ctx, enable, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
         return out
 
+    def dump_qp(self, agent, path):
+        """TrajOptimizer::solve's failure export (log/QPmodel.lp): the agent's QP of the last plan() call as a CPLEX LP file."""
+        self._check(self.L.lsc_dump_qp(self.ctx, int(agent), str(path).encode()))
+
     def solver_residuals(self):
         out = np.zeros((self.N, 4))
         self._check(self.L.lsc_solver_residuals(self.ctx, _dp(out)))

@@ -12,63 +12,14 @@ import sys
 REF = "/root/reference"
 
 
-def var_index(name):
-    k = "xyz".index(name[0])
-    _, m, i = name.split("_")
-    return k * 30 + int(m) * 6 + int(i)
-
-
-def parse_expr(txt):
-    """'- 25 x_0_0 + 25 x_0_1' -> {idx: coef}"""
-    out = {}
-    toks = txt.replace("+", " + ").replace("-", " - ").split()
-    sign, coef = 1.0, None
-    for t in toks:
-        if t == "+":
-            sign, coef = 1.0, None
-        elif t == "-":
-            sign, coef = -1.0, None
-        elif re.match(r"^[xyz]_\d+_\d+$", t):
-            out[var_index(t)] = out.get(var_index(t), 0.0) + sign * (coef if coef is not None else 1.0)
-            coef = None
-        else:
-            coef = float(t)
-    return out
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), ".."))
+from lp_parse import parse_lp  # noqa: E402
 
 
 def main():
     txt = open(f"{REF}/log/QPmodel.lp", encoding="latin-1").read()
-    obj_txt = txt[txt.index("obj1:") + 5: txt.index("Subject To")]
-    lin_txt, quad_txt = obj_txt.split("[", 1)
-    quad_txt = quad_txt[: quad_txt.index("]")]
-    lin = parse_expr(lin_txt)
-    # quadratic section is "[ ... ] / 2"
-    assert "/ 2" in obj_txt[obj_txt.index("]"):]
-    quad = []
-    for sign, coef, a, b in re.findall(r"([+-]?)\s*([\d.e+-]+)\s+([xyz]_\d+_\d+)\s*(?:\^2|\*\s*([xyz]_\d+_\d+))", quad_txt):
-        v = float(coef) * (-1.0 if sign == "-" else 1.0)
-        ia = var_index(a)
-        ib = var_index(b) if b else ia
-        quad.append([ia, ib, v])
-    cons_txt = txt[txt.index("Subject To") + 10: txt.index("Bounds")]
-    rows = []
-    for name, body in re.findall(r"(c\d+):\s*(.*?)(?=\n c\d+:|\Z)", cons_txt, flags=re.S):
-        body = " ".join(body.split())
-        m = re.match(r"(.*?)(>=|<=|=)\s*([-\d.e+]+)$", body)
-        expr, sense, rhs = m.group(1), m.group(2), float(m.group(3))
-        e = parse_expr(expr)
-        rows.append({"name": name, "idx": list(e.keys()), "val": list(e.values()), "sense": sense, "rhs": rhs})
-    b_txt = txt[txt.index("Bounds") + 6: txt.index("End")]
-    bounds = {}
-    for line in b_txt.strip().splitlines():
-        line = line.strip()
-        m = re.match(r"([-\d.e+]+)\s*<=\s*([xyz]_\d+_\d+)\s*<=\s*([-\d.e+]+)", line)
-        if m:
-            bounds[var_index(m.group(2))] = [float(m.group(1)), float(m.group(3))]
-            continue
-        m = re.match(r"([xyz]_\d+_\d+)\s+Free", line)
-        if m:
-            bounds[var_index(m.group(1))] = [None, None]
+    P = parse_lp(txt)
+    lin, quad, rows, bounds = P["lin"], P["quad"], P["rows"], P["bounds"]
     mission = json.load(open(f"{REF}/missions/empty/10agents/multi_random_10agents_1.json"))
     starts = [[a["start"][0], a["start"][1], 0.7] for a in mission["agents"]]
     quad_t = mission["quadrotors"]["crazyflie"]
