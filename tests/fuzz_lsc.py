@@ -1,13 +1,14 @@
 """Seeded fuzzing of the LSC-mode tick against the oracle (the large-count version of tests/test_gpu_fuzz.py::test_fuzz_lsc_mode).
     python tests/fuzz_lsc.py SEED0 TRIALS [MAX_AGENTS] ['{"prune": 0}']
 Needs a GPU and the built oracle (test infrastructure); prints one summary line."""
-import sys, numpy as np, time
+import os, sys, numpy as np, time
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import lsc_planner_amd as L
 from lsc_planner_amd.planner import PlannerConfig, next_state_host
 from lsc_planner_amd.mission import Mission
 from oracle import oracle
-COST_RTOL, COST_ATOL, TRAJ_ATOL = 1e-6, 1e-8, 5e-5
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tolerances import COST_ATOL, COST_RTOL, FUZZ_TRAJ_ATOL as TRAJ_ATOL
 seed0=int(sys.argv[1]); ntr=int(sys.argv[2])
 bad=0; tot=0; fails=0
 for trial in range(ntr):

@@ -1,13 +1,14 @@
 """Seeded fuzzing of the alternate planner modes against the oracle (large-count version of test_fuzz_alternate_modes).
     python tests/fuzz_modes.py SEED0 TRIALS
 Mismatching ticks are dumped to gpurun_out/fuzz/ for a HiGHS check on the CPU."""
-import sys, numpy as np
+import os, sys, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import lsc_planner_amd as L
 from lsc_planner_amd.planner import PlannerConfig, next_state_host
 from lsc_planner_amd.mission import Mission
 from oracle import oracle as O
-COST_RTOL, COST_ATOL, TRAJ_ATOL = 1e-6, 1e-8, 5e-5
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tolerances import COST_ATOL, COST_RTOL, FUZZ_TRAJ_ATOL as TRAJ_ATOL
 seed0=int(sys.argv[1]); ntr=int(sys.argv[2])
 bad=0; tot=0; fails=0
 MODES=[(dict(planner_mode="bvc"), dict(planner="bvc")),

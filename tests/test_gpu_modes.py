@@ -13,9 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-COST_RTOL = 1e-6
-COST_ATOL = 1e-8
-TRAJ_ATOL = 2e-5
+from tolerances import COST_ATOL, COST_RTOL, TRAJ_ATOL
 
 
 @pytest.fixture(scope="module")

@@ -11,8 +11,7 @@ from conftest import golden_mission, oracle_swarm
 
 pytestmark = pytest.mark.gpu
 
-COST_RTOL = 1e-6
-TRAJ_ATOL = 2e-5
+from tolerances import COST_ATOL, COST_RTOL, TRAJ_ATOL
 
 
 @pytest.fixture(scope="module")
@@ -298,7 +297,7 @@ def test_prior_based_goal_planning_bitwise_and_mission_completes(L, oracle):
             sw.stale[:] = traj if tick > 1 else 0
             o = sw.tick(state, og, traj, tick, nthreads=8)
             assert np.array_equal(g["status"], o["status"])
-            assert (np.abs(g["cost"] - o["cost"]) <= COST_RTOL * np.abs(o["cost"]) + 1e-8).all(), (tick, g["cost"], o["cost"])   # costs -> 0 near the goal: absolute floor
+            assert (np.abs(g["cost"] - o["cost"]) <= COST_RTOL * np.abs(o["cost"]) + COST_ATOL).all(), (tick, g["cost"], o["cost"])   # costs -> 0 near the goal: absolute floor
             assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL, tick
         assert (g["status"] == 0).all()
         traj = g["traj"]

@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from tolerances import COST_RTOL, LARGE_SWARM_COST_ATOL, TRAJ_ATOL
+
 pytestmark = pytest.mark.gpu
 
 
@@ -101,8 +103,8 @@ def test_relabelling_agents_permutes_the_plans(L):
     for _ in range(6):
         ga = a.plan(sa, ms.goal, ta)
         gb = b.plan(sa[perm], ms.goal[perm], ta[perm])
-        assert (np.abs(ga["cost"][perm] - gb["cost"]) <= 1e-6 * np.abs(gb["cost"])).all()
-        assert np.abs(ga["traj"][perm] - gb["traj"]).max() <= 2e-5
+        assert (np.abs(ga["cost"][perm] - gb["cost"]) <= COST_RTOL * np.abs(gb["cost"])).all()
+        assert np.abs(ga["traj"][perm] - gb["traj"]).max() <= TRAJ_ATOL
         ta = ga["traj"]; sa = next_state_host(ta)
     a.close(); b.close()
 
@@ -250,15 +252,17 @@ def test_1024_agent_mission_against_the_oracle(L, oracle):
         g = pl.plan(state, ms.goal, traj)
         if tick in (1, 2, 15, 30, 60):
             sw.stale[:] = stale
-            o = sw.tick(state, pl.last_goals(), traj, tick, want_lsc=False, nthreads=32)
+            goals = oracle.goal_prior_based(state, ms.goal, traj, tick)     # the oracle's own goals; the GPU's must equal them
+            assert np.array_equal(pl.last_goals(), goals), tick
+            o = sw.tick(state, goals, traj, tick, want_lsc=False, nthreads=32)
             assert np.array_equal(g["status"], o["status"]), tick
             ok = o["status"] == 0
             # absolute floor: both solvers stop at a primal residual of 1e-9 * (world extent = 20 m), which moves a
             # near-zero cost of an agent that has almost arrived by a few 1e-8
             dc = np.abs(g["cost"] - o["cost"])[ok]
-            bad = dc > 1e-6 * np.abs(o["cost"])[ok] + 1e-7
+            bad = dc > COST_RTOL * np.abs(o["cost"])[ok] + LARGE_SWARM_COST_ATOL
             assert not bad.any(), (tick, dc[bad], o["cost"][ok][bad], g["iters"][ok][bad])
-            assert np.abs(g["traj"] - o["traj"]).max() <= 2e-5, tick
+            assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL, tick
         stale = np.where((g["status"] == 0)[:, None, None], g["traj"], stale).astype(np.float32)
         traj = g["traj"]
         state = next_state_host(traj)

@@ -72,3 +72,46 @@ def test_qp_dump_of_the_reference_scene_equals_the_reference_dump(L, tmp_path):
     for i in range(90):
         lo, hi = lp["bounds"][str(i)]
         assert P["bounds"][i] == [lo, hi] or (lo is not None and abs(P["bounds"][i][0] - lo) < 1e-14 and abs(P["bounds"][i][1] - hi) < 1e-14), i
+
+
+def test_kernel_statuses_and_costs_against_highs_verdicts(L):
+    """The kernel against the INDEPENDENT solver, no oracle in between: 32 ticks of eight dense seeded soak missions
+    (tests/golden/qp_pin_ticks.npz, made by tests/golden/make_qp_pin_ticks.py in the build container) hold, per agent, HiGHS's
+    verdict on the agent's QP -- infeasible (151 of them, each with a phase-1 certificate: the minimal uniform violation of
+    the rows is strictly positive) or optimal with a cost (369).  Same inputs through the C ABI: status 1 exactly where HiGHS
+    certifies infeasibility, status 0 and HiGHS's cost elsewhere."""
+    from tolerances import COST_ATOL, COST_RTOL
+    Z = np.load(os.path.join(GOLDEN, "qp_pin_ticks.npz"))
+    n_inf = n_opt = 0
+    for t in range(int(Z["count"])):
+        g = lambda k: Z[f"t{t}_{k}"]
+        ms = L.Mission(g("start"), g("goal"), g("world_min"), g("world_max"), g("radius"), g("downwash"), g("max_vel"), g("max_acc"),
+                       g("nominal_velocity"))
+        pl = L.SwarmPlanner(ms)
+        pl.planner_seq = int(g("tick")) - 1                       # plan() advances it: the tick's own planner_seq
+        r = pl.plan(g("state"), g("goal"), g("traj"))
+        pl.close()
+        v, c = g("verdict"), g("cost")
+        known = v >= 0
+        assert np.array_equal(r["status"][known], (v[known] == 1).astype(np.int32)), (t, r["status"], v)
+        opt = v == 0
+        assert (np.abs(r["cost"][opt] - c[opt]) <= COST_RTOL * np.abs(c[opt]) + COST_ATOL).all(), (t, r["cost"][opt], c[opt])
+        ub = v == 2                                                 # HiGHS stopped short: its cost is an upper bound (a few 1e-6 relative)
+        assert (r["cost"][ub] <= c[ub] + COST_ATOL).all() and (r["cost"][ub] >= c[ub] * (1 - 1e-5) - COST_ATOL).all(), (t, r["cost"][ub], c[ub])
+        n_inf += int((v == 1).sum()); n_opt += int(opt.sum() + ub.sum())
+    assert n_inf >= 140 and n_opt >= 300, (n_inf, n_opt)
+
+
+def test_fuzz_found_instance_through_the_kernel_against_highs(L):
+    """tests/golden/fuzz_found_5023.npz: the alternate-mode QP (BVC, two constraint segments) on which the oracle used to give
+    up and HiGHS found the optimum 1.3618641918561454 (tests/test_oracle_pins.py re-derives it when HiGHS is importable).  The
+    current kernel on the recorded inputs, against that number directly."""
+    Z = np.load(os.path.join(GOLDEN, "fuzz_found_5023.npz"))
+    assert int(Z["which"]) == 3
+    ms = L.Mission(Z["state"][:, :3].copy(), Z["goal"], Z["wmin"], Z["wmax"], Z["radius"], Z["dw"], Z["vmax"], Z["amax"], Z["vnom"])
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(planner_mode="bvc", n_constraint_segments=2))
+    pl.planner_seq = int(Z["tick"]) - 1
+    r = pl.plan(Z["state"], Z["goal"], Z["traj"])
+    pl.close()
+    assert (r["status"] == 0).all() and np.array_equal(r["status"], Z["gstatus"])
+    assert abs(r["cost"][2] - 1.3618641918561454) <= 1e-8 * 1.3618641918561454

@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-COST_RTOL, COST_ATOL, TRAJ_ATOL = 1e-6, 1e-8, 2e-5
+from tolerances import COST_ATOL, COST_RTOL, TRAJ_ATOL
 
 
 @pytest.mark.parametrize("dense", [False, True])
@@ -37,7 +37,10 @@ def test_random_missions_tick_by_tick(oracle, dense):
         stale = np.zeros_like(traj)               # TrajOptimizer::trajectory of every agent (kept on failure)
         for tick in range(1, 49):
             g = pl.plan(state, ms.goal, traj)
-            goals = pl.last_goals() if mode == "prior_based" else ms.goal
+            goals = ms.goal
+            if mode == "prior_based":                              # the oracle's own goals feed the oracle; the GPU's must equal them
+                goals = oracle.goal_prior_based(state, ms.goal, traj, tick)
+                assert np.array_equal(pl.last_goals(), goals), (trial, n, tick)
             sw.stale[:] = stale
             o = sw.tick(state, goals, traj, tick, want_lsc=False, nthreads=16)
             assert np.array_equal(g["status"], o["status"]), (trial, n, tick)

@@ -1,0 +1,21 @@
+"""The one table of parity tolerances.  Integer / byte / index work -- LSC normals and margins, corridor
+boxes, distance fields, grid paths, planned goals, propagated states, statuses -- is compared bit for bit and has no entry
+here.  The QP solve is floating point: north_star allows 1e-3 relative cost; the tests hold the kernel to
+
+    cost          |gpu - oracle| <= COST_RTOL |oracle| + COST_ATOL
+    control point |gpu - oracle| <= TRAJ_ATOL   (metres; float32 storage + flat directions of the cost; measured <= 1.5e-5)
+
+Exceptions, each used by name where it applies:
+"""
+COST_RTOL = 1e-6
+COST_ATOL = 1e-8
+TRAJ_ATOL = 2e-5
+
+# Seeded fuzzing of tiny swarms with extreme parameters (vmax 0.2..3, amax 0.5..6, radii 0.05..0.4, goals outside the world,
+# coincident agents): optima with nearly flat directions -- the plan may move 3-4e-5 m at 1e-9 relative cost.
+FUZZ_TRAJ_ATOL = 5e-5
+# ... and with the 1e5 slack penalty a grossly violated limit makes |f| ~ 1e7; both solvers stop on criteria relative to |f|
+# and their plans may then differ by centimetres at 4e-8 relative cost: plans are compared below this objective only.
+FUZZ_PLAN_COMPARED_BELOW_COST = 1e4
+# 1024-agent swarms near their goals: costs approach 0 (1e-6..1e-5), so the absolute floor is what binds.
+LARGE_SWARM_COST_ATOL = 1e-7
