@@ -266,9 +266,10 @@ int lsc_last_bucket_max(lsc_ctx *ctx, int *rows);
 int lsc_iterations_total(lsc_ctx *ctx, long long *total, int reset);
 
 /* Diagnostics.  lsc_phase_profile: enable=1 selects the instrumented plan kernel and clears its counters, 0 goes
- * back to the production kernel, -1 only reads; out (may be NULL) gets [N][12] cycle counts (100 MHz wall clock)
+ * back to the production kernel, -1 only reads; out (may be NULL) gets [N][16] counts (100 MHz wall clock)
  * per phase: setup, LSC build, IP init, residual pass, row reduction, Hessian assembly, Cholesky, triangular
- * solves, affine pass, corrector pass, step+update, output.  lsc_solver_residuals: [N][4] last duality gap,
+ * solves, affine pass, corrector pass, step+update, output; then two parts of the row reduction (the LSC-bucket sums as wave 0
+ * sees them, the axis-row gather as the last lane sees it) and two spare slots.  lsc_solver_residuals: [N][4] last duality gap,
  * primal residual, stationarity residual, objective. */
 int lsc_phase_profile(lsc_ctx *ctx, int enable, long long *out);
 /* The same for the goal planner's register-resident grid search: out gets [N][16] counters, shader cycles unless noted:

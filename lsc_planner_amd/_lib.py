@@ -63,7 +63,8 @@ EXPORTS = [
 
 
 def lib_path():
-    return os.path.join(_HERE, "liblsc_hip.so")
+    """liblsc_hip.so next to this file; LSC_HIP_LIB overrides it (A/B runs of two builds on the same GPU box)."""
+    return os.environ.get("LSC_HIP_LIB") or os.path.join(_HERE, "liblsc_hip.so")
 
 
 def load_library():

@@ -48,7 +48,7 @@ struct PlanArgs {
     float *out_normal;         // optional dense dump [count][N-1][M][3]
     double *out_d;             // optional dense dump [count][N-1][M][6]
     double *dbg;               // optional [N][4]: last (gap, |rp|, |rd|, objective) seen by the solver
-    long long *prof;           // optional [N][12] phase cycle counters (selects the instrumented kernel)
+    long long *prof;           // optional [N][PROF_PHASES] phase counters (selects the instrumented kernel)
     double *trace;             // optional [64][8] per-iteration trace of agent trace_agent (diagnostics)
     int trace_agent;
     unsigned char *spill_ws;   // second pass only: HBM row workspaces, one of spill_stride bytes per workgroup
@@ -65,7 +65,7 @@ struct PlanArgs {
     unsigned char *gen_ws;     // HBM workspaces of lsc_general_kernel, gen_stride bytes per workgroup
     size_t gen_stride;
 };
-constexpr int PROF_PHASES = 12;
+constexpr int PROF_PHASES = 16;
 
 struct SweepArgs {
     int N, first, count, planner_seq;

@@ -407,6 +407,11 @@ __global__ __launch_bounds__(64) void lsc_sfc_kernel(SfcArgs a)
 // The per-agent planning kernel
 // ---------------------------------------------------------------------------------------------------
 constexpr int NB = 27;        // control points that carry LSC rows: all but (m=0, i<3)
+// Row reduction (reduce_rows): a lane sums all components over a few consecutive rows of one control point's bucket, a second
+// step adds the parts of a bucket in order.  Slots = lanes of the first step; their partial sums are staged in LDS that is dead
+// at that point: K (NY x KLD doubles, 12 components per slot) before a factorisation, the factorisation's scratch (colbuf, mid2,
+// xch: 388 doubles, 6 components per slot) in a corrector pass.
+constexpr int RSLOT_P = (NY * KLD) / 12, RSLOT_C = 64;
 constexpr int AXVALID = 414;  // 162 bound + 138 velocity + 114 acceleration rows (src/traj_optimizer.cpp:274-303, 468-525)
 
 // SMALL = the throughput build's variant: what can be recomputed or read from L2 (right-hand sides of the axis rows, the
@@ -452,9 +457,13 @@ struct SmemT {
     int offs[32];               // exclusive prefix of cnt over the 27 buckets
     uint32_t offcnt[32];        // offs | cnt << 16 per bucket (LDS pass: both below 65536), one load per reduction unit
     int wcnt[NWAVE][32];
+    // row reduction: slots = (bucket, part) pairs, one lane each; two granularities (predictor / corrector staging sizes differ)
+    uint32_t slotP[RSLOT_P], slotC[RSLOT_C];   // first row | rows << 16 | bucket << 24
+    unsigned short soffP[NB + 1], soffC[NB + 1];   // first slot of every bucket (+ total)
     double cullB[M];            // phase B pre-cull: per segment max_i(|c_{0,2} - p_{m,i}| + reach radius of c_{m,i})
     double cullA[2];            // obstacle-level cull: rho_a = max |c_{0,2} - p| over the own points, max_m cullB[m]
     int cullc[NWAVE + 1];       // survivors of the pre-cull per wave (compaction)
+    int rpl[2];                 // rows per slot of the row reduction (predictor / corrector granularity)
     int ntmp;                   // rows appended in phase B (arrival order), listfull: the pre-cull list overflowed
     int listfull;
     int tseg;                   // terminal segments
@@ -609,7 +618,10 @@ __device__ __forceinline__ void bwd_steps(const double (&c)[CNT], double &b)
 }
 
 // phase stamps (PROF variant only): cycles of lane 0 spent per phase, accumulated per agent
-enum { PH_SETUP = 0, PH_LSC, PH_INIT, PH_P1, PH_REDUCE, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_P2, PH_P3, PH_P45, PH_OUT, PH_COUNT };
+enum { PH_SETUP = 0, PH_LSC, PH_INIT, PH_P1, PH_REDUCE, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_P2, PH_P3, PH_P45, PH_OUT,
+       PH_RED_BUCKETS /* part of PH_REDUCE: the LSC-bucket sums of wave 0, before the barrier */, PH_RED_GATHER /* the axis-row gather, clocked by the last lane */,
+       PH_SPARE0, PH_SPARE1, PH_COUNT };
+static_assert(PH_COUNT == PROF_PHASES, "lsc_phase_profile copies PROF_PHASES counters per agent");
 
 
 // One agent's replan on one 512-lane workgroup.
@@ -1150,6 +1162,31 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         S.nact = o;
     }
     __syncthreads();
+    if constexpr (!SPILL) {
+        // slot tables of the row reduction: bucket b is cut into parts of rpl rows; rpl is the smallest that fits the staging
+        if (tid < 2) {
+            const int cap_slots = tid == 0 ? RSLOT_P : RSLOT_C, min_rpl = tid == 0 ? 4 : 8;
+            const int na_ = S.nact;
+            int rpl = (na_ + (cap_slots - NB) - 1) / (cap_slots - NB);
+            rpl = rpl < min_rpl ? min_rpl : rpl;
+            unsigned short *so = tid == 0 ? S.soffP : S.soffC;
+            int o = 0;
+            for (int b = 0; b < NB; b++) { so[b] = (unsigned short)o; o += (S.cnt[b + 3] + rpl - 1) / rpl; }
+            so[NB] = (unsigned short)o;
+            S.rpl[tid] = rpl;
+        }
+        __syncthreads();
+        for (int q = tid; q < 2 * NB; q += NT) {
+            const int which = q >= NB, b = which ? q - NB : q;
+            const unsigned short *so = which ? S.soffC : S.soffP;
+            uint32_t *sl = which ? S.slotC : S.slotP;
+            const int rpl = S.rpl[which], cnt = S.cnt[b + 3], r0 = S.offs[b];
+            for (int p = 0, s = so[b]; p * rpl < cnt; p++, s++) {
+                const int n = cnt - p * rpl < rpl ? cnt - p * rpl : rpl;
+                sl[s] = (uint32_t)(r0 + p * rpl) | ((uint32_t)n << 16) | ((uint32_t)b << 24);
+            }
+        }
+    }
     // scatter from arrival order to the compact, bucket-sorted layout
     for (int k = tid; k < S.nact; k += NT) {
         const TmpRow t = tmp_rows[k];
@@ -1278,8 +1315,58 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             }
             S.gx[b] = cg + g;
             S.gz[b] = cg + gzv;
+            if constexpr (PROF) { if (tid == NT - 1) t_acc[PH_RED_GATHER] += wall_clock64() - t_last; }
         }
-        // LSC buckets: unit (bucket, c): c 0..5 -> sum w n n^T, 6..8 -> -sum v n and -sum z n  (row vector a_r = -n).
+        // LSC buckets: per control point  sum w n n^T (six components), -sum v n and -sum z n (three each; row vector a_r = -n).
+        if constexpr (!SPILL) {
+            // Row-major: one lane per slot = a few consecutive rows of one bucket; it loads each row once and accumulates all
+            // twelve (corrector pass: six) components in registers -- about two instructions per product where one lane per
+            // (bucket, component) spent ten -- and no lane waits for the fullest bucket (that wait was four fifths of this phase).
+            // Partial sums go to LDS that is dead right now (see RSLOT_P); a second step adds the parts of a bucket in slot order.
+            static_assert(offsetof(SmemT<!TABLES_IN_LDS>, xmid) - offsetof(SmemT<!TABLES_IN_LDS>, colbuf) >= sizeof(double) * RSLOT_C * 6,
+                          "corrector-pass staging of the bucket sums");
+            static_assert(RSLOT_P <= NT - NV && RSLOT_C <= NT - NV, "slot lanes and the axis-row gather lanes do not overlap");
+            const int ncomp = with_w ? 12 : 6;
+            double *stage = with_w ? S.K : &S.colbuf[0][0];
+            const unsigned short *soff = with_w ? S.soffP : S.soffC;
+            if (tid < soff[NB]) {
+                const uint32_t e = with_w ? S.slotP[tid] : S.slotC[tid];
+                const int r0 = (int)(e & 0xffffu), n = (int)((e >> 16) & 0xffu);
+                double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, t0 = 0, t1 = 0, t2 = 0, u0 = 0, u1 = 0, u2 = 0;
+                for (int q = 0; q < n; q++) {
+                    const int r = r0 + q;
+                    const double nx = (double)rn[r], ny = (double)rn[R + r], nz = (double)rn[2 * R + r];
+                    const double zv = rz[r], vv = rt2[r];
+                    t0 = fma(vv, nx, t0); t1 = fma(vv, ny, t1); t2 = fma(vv, nz, t2);
+                    u0 = fma(zv, nx, u0); u1 = fma(zv, ny, u1); u2 = fma(zv, nz, u2);
+                    if (with_w) {
+                        const double w = unit_w ? 1.0 : zv * rt1[r];
+                        const double wx = w * nx, wy = w * ny, wz = w * nz;
+                        s0 = fma(wx, nx, s0); s1 = fma(wx, ny, s1); s2 = fma(wx, nz, s2);
+                        s3 = fma(wy, ny, s3); s4 = fma(wy, nz, s4); s5 = fma(wz, nz, s5);
+                    }
+                }
+                double *o = stage + tid * ncomp;
+                if (with_w) { o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = s5; o += 6; }
+                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = u0; o[4] = u1; o[5] = u2;
+            }
+            if constexpr (PROF) { if (tid == 0) t_acc[PH_RED_BUCKETS] += wall_clock64() - t_last; }
+            __syncthreads();
+            for (int o = tid; o < NB * ncomp; o += NT) {
+                const int b = o / ncomp, c = o - b * ncomp, cp = b + 3;
+                double sum = 0.0;
+                for (int sl = soff[b]; sl < soff[b + 1]; sl++) {
+                    double *e = stage + sl * ncomp + c;
+                    sum += *e;
+                    *e = 0.0;                                      // (K must not keep anything assemble() does not overwrite)
+                }
+                const int j = with_w ? c : c + 6;
+                if (j < 6) S.W[W_S + cp * 6 + j] = sum;
+                else if (j < 9) S.Tv[cp * 3 + (j - 6)] = -sum;
+                else S.Tz[cp * 3 + (j - 9)] = -sum;
+            }
+        } else {
+        // rows in HBM, up to 27 (N-1) of them: unit (bucket, c) loops over its bucket, c 0..5 -> sum w n n^T, 6..8 -> v n and z n
         // Two lanes per unit take the even / odd rows of the bucket and combine through a lane-pair shuffle.
         const int nunits = with_w ? NB * 9 : NB * 3;
         for (int ub = 0; ub < 2 * nunits; ub += NT) {      // one trip with 512 lanes, two with 256
@@ -1324,6 +1411,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 else { S.Tv[cp * 3 + (c - 6)] = -sa; S.Tz[cp * 3 + (c - 6)] = -sz; }
             }
         }
+        }
+        if constexpr (PROF && SPILL) { if (tid == 0) t_acc[PH_RED_BUCKETS] += wall_clock64() - t_last; }
         __syncthreads();
     };
 
@@ -1839,6 +1928,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int i = 0; i < PH_COUNT; i++) a.prof[(size_t)qi * PH_COUNT + i] += t_acc[i];
         }
     }
+    if constexpr (PROF) { if (tid == NT - 1 && a.prof) a.prof[(size_t)qi * PH_COUNT + PH_RED_GATHER] += t_acc[PH_RED_GATHER]; }
 }
 
 template <bool PROF>

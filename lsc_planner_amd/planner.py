@@ -288,10 +288,11 @@ class SwarmPlanner:
                                             d.data_ptr(), stream))
 
     PHASES = ("setup", "lsc_build", "ip_init", "residual_pass", "row_reduce", "assemble", "cholesky", "tri_solves",
-              "affine_pass", "corrector_pass", "step_update", "output")
+              "affine_pass", "corrector_pass", "step_update", "output", "(row_reduce: buckets, wave 0)", "(row_reduce: axis gather, last lane)",
+              "(spare)", "(spare)")
 
     def phase_profile(self, enable=-1):
-        out = np.zeros((self.N, 12), np.int64)
+        out = np.zeros((self.N, 16), np.int64)
         self._check(self.L.lsc_phase_profile(self.ctx, enable, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
         return out
 
