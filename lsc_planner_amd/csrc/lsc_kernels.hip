@@ -47,10 +47,35 @@ __device__ __forceinline__ double lane_value(double v, int lane_const)
 // OP: 0 sum, 1 max, 2 min
 template <int OP>
 __device__ __forceinline__ double red_op(double a, double b) { return OP == 0 ? a + b : (OP == 1 ? fmax(a, b) : fmin(a, b)); }
+// max / min: the moved copy needs no identity.  A lane without a DPP source keeps what its temporary held before -- a value of
+// this same reduction (its own, or an earlier stage's) -- and taking an element twice does not change a maximum.  Two moves and
+// one v_max_f64 / v_min_f64 per stage instead of four moves, two canonicalisations and the operation.
+template <int OP>
+__device__ __forceinline__ double hw_extreme(double a, double b)       // v_max_f64 / v_min_f64 as they are (no NaN quieting round trip)
+{
+    double r;
+    if (OP == 1) asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int OP>
+__device__ __forceinline__ double wave_extreme(double v)
+{
+    static_assert(OP == 1 || OP == 2, "max or min");
+    int tlo = __double2loint(v), thi = __double2hiint(v);
+#define LSC_STAGE(CTRL)                                                                                   \
+    tlo = __builtin_amdgcn_update_dpp(tlo, __double2loint(v), CTRL, 0xf, 0xf, false);                     \
+    thi = __builtin_amdgcn_update_dpp(thi, __double2hiint(v), CTRL, 0xf, 0xf, false);                     \
+    v = hw_extreme<OP>(v, __hiloint2double(thi, tlo));
+    LSC_STAGE(0x111) LSC_STAGE(0x112) LSC_STAGE(0x114) LSC_STAGE(0x118)
+#undef LSC_STAGE
+    return hw_extreme<OP>(hw_extreme<OP>(lane_value(v, 15), lane_value(v, 31)), hw_extreme<OP>(lane_value(v, 47), lane_value(v, 63)));
+}
 template <int OP>
 __device__ __forceinline__ double wave_reduce(double v)
 {
-    const double id = OP == 0 ? 0.0 : (OP == 1 ? -1.7976931348623157e308 : 1.7976931348623157e308);
+    if constexpr (OP != 0) return wave_extreme<OP>(v);
+    const double id = 0.0;
     v = red_op<OP>(v, dpp_move<0x111>(v, id));   // row_shr:1
     v = red_op<OP>(v, dpp_move<0x112>(v, id));   // row_shr:2
     v = red_op<OP>(v, dpp_move<0x114>(v, id));   // row_shr:4
@@ -1252,12 +1277,20 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     };
     // block reduction of up to 5 values: op 0 sum, 1 max, 2 min ; results in S.sc[0..4] (one barrier pair; the
     // per-wave partials are combined by five lanes)
+    // (op < 0: slot unused -- its wave reduction, ~45 instructions on every wave, is not emitted)
     auto block_reduce = [&](double v0, double v1, double v2, double v3, double v4, int op0, int op1, int op2, int op3, int op4) {
-        auto wr = [&](double v, int op) { return op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v)); };
+        auto wr = [&](double v, int op) { return op < 0 ? 0.0 : (op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v))); };
         double r0 = wr(v0, op0), r1 = wr(v1, op1), r2 = wr(v2, op2), r3 = wr(v3, op3), r4 = wr(v4, op4);
-        if (lane == 0) { S.red[0][wave] = r0; S.red[1][wave] = r1; S.red[2][wave] = r2; S.red[3][wave] = r3; S.red[4][wave] = r4; }
+        if (lane == 0) {
+            S.red[0][wave] = r0;
+            if (op1 >= 0) S.red[1][wave] = r1;
+            if (op2 >= 0) S.red[2][wave] = r2;
+            if (op3 >= 0) S.red[3][wave] = r3;
+            if (op4 >= 0) S.red[4][wave] = r4;
+        }
         __syncthreads();
-        if (tid < 5) {
+        const int nused = op4 >= 0 ? 5 : (op3 >= 0 ? 4 : (op2 >= 0 ? 3 : (op1 >= 0 ? 2 : 1)));
+        if (tid < nused) {
             const int op = tid == 0 ? op0 : (tid == 1 ? op1 : (tid == 2 ? op2 : (tid == 3 ? op3 : op4)));
             double t = S.red[tid][0];
 #pragma unroll
@@ -1697,7 +1730,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     objp = 0.5 * cost_grad() * S.x[tid];
                     if (xterm) { double e = S.x[tid] - S.goal[xk]; objp += md.w_t * e * e; }
                 }
-                block_reduce(gp, rpm, objp, 0.0, 0.0, 0, 1, 0, 0, 0);
+                block_reduce(gp, rpm, objp, 0.0, 0.0, 0, 1, 0, -1, -1);
                 gap = S.sc[0]; rpmax = S.sc[1]; obj = S.sc[2];
                 mu = gap / nrow;
                 gap_ok = gap <= md.gap_tol * (1.0 + fabs(obj));
@@ -1737,7 +1770,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             if (phase == ST_PRED) {
                 // cheap exit before the factorisation: primal residual, gap and stationarity all at tolerance
                 const double rda = (tid < NY) ? fabs(S.dy[tid]) : 0.0;
-                block_reduce(rda, 0.0, 0.0, 0.0, 0.0, 1, 0, 0, 0, 0);
+                block_reduce(rda, 0.0, 0.0, 0.0, 0.0, 1, -1, -1, -1, -1);
                 if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
             }
             if (with_w) {
@@ -1777,7 +1810,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     rs[r] = sv; rz[r] = -sv;
                     mins = fmin(mins, sv); minz = fmin(minz, -sv);
                 }
-                block_reduce(mins, minz, 0.0, 0.0, 0.0, 2, 2, 0, 0, 0);
+                block_reduce(mins, minz, 0.0, 0.0, 0.0, 2, 2, -1, -1, -1);
                 const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0;
                 const double shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
                 // the shift enters the loop as a "step" of length 1 (t1 = ds, t2 = dz) applied by the first fused pass
@@ -1855,7 +1888,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     if (dz < 0.0) amin = fmin(amin, -zv / dz);
                     rt1[r] = ds; rt2[r] = dz;
                 }
-                block_reduce(amin, 0.0, 0.0, 0.0, 0.0, 2, 0, 0, 0, 0);
+                block_reduce(amin, 0.0, 0.0, 0.0, 0.0, 2, -1, -1, -1, -1);
                 alpha = fmin(1.0, tau * S.sc[0]);
                 if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) a.trace[iters * 8 + 5] = alpha;
                 if (tid < NY) S.y[tid] += alpha * S.dy[tid];
