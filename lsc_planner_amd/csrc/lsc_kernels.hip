@@ -435,8 +435,8 @@ constexpr int NB = 27;        // control points that carry LSC rows: all but (m=
 // Row reduction (reduce_rows): a lane sums all components over a few consecutive rows of one control point's bucket, a second
 // step adds the parts of a bucket in order.  Slots = lanes of the first step; their partial sums are staged in LDS that is dead
 // at that point: K (NY x KLD doubles, 12 components per slot) before a factorisation, the factorisation's scratch (colbuf, mid2,
-// xch: 388 doubles, 6 components per slot) in a corrector pass.
-constexpr int RSLOT_P = (NY * KLD) / 12, RSLOT_C = 64;
+// xch: 388 doubles, 3 components per slot: a corrector pass only needs sum v n) in a corrector pass.
+constexpr int RSLOT_P = (NY * KLD) / 12, RSLOT_C = 128;
 constexpr int AXVALID = 414;  // 162 bound + 138 velocity + 114 acceleration rows (src/traj_optimizer.cpp:274-303, 468-525)
 
 // SMALL = the throughput build's variant: what can be recomputed or read from L2 (right-hand sides of the axis rows, the
@@ -1190,7 +1190,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     if constexpr (!SPILL) {
         // slot tables of the row reduction: bucket b is cut into parts of rpl rows; rpl is the smallest that fits the staging
         if (tid < 2) {
-            const int cap_slots = tid == 0 ? RSLOT_P : RSLOT_C, min_rpl = tid == 0 ? 4 : 8;
+            const int cap_slots = tid == 0 ? RSLOT_P : RSLOT_C, min_rpl = 4;
             const int na_ = S.nact;
             int rpl = (na_ + (cap_slots - NB) - 1) / (cap_slots - NB);
             rpl = rpl < min_rpl ? min_rpl : rpl;
@@ -1356,10 +1356,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             // twelve (corrector pass: six) components in registers -- about two instructions per product where one lane per
             // (bucket, component) spent ten -- and no lane waits for the fullest bucket (that wait was four fifths of this phase).
             // Partial sums go to LDS that is dead right now (see RSLOT_P); a second step adds the parts of a bucket in slot order.
-            static_assert(offsetof(SmemT<!TABLES_IN_LDS>, xmid) - offsetof(SmemT<!TABLES_IN_LDS>, colbuf) >= sizeof(double) * RSLOT_C * 6,
+            static_assert(offsetof(SmemT<!TABLES_IN_LDS>, xmid) - offsetof(SmemT<!TABLES_IN_LDS>, colbuf) >= sizeof(double) * RSLOT_C * 3,
                           "corrector-pass staging of the bucket sums");
             static_assert(RSLOT_P <= NT - NV && RSLOT_C <= NT - NV, "slot lanes and the axis-row gather lanes do not overlap");
-            const int ncomp = with_w ? 12 : 6;
+            // (a corrector pass only needs -sum v n: the stationarity residual, which -sum z n feeds, is tested in predictor passes)
+            const int ncomp = with_w ? 12 : 3;
             double *stage = with_w ? S.K : &S.colbuf[0][0];
             const unsigned short *soff = with_w ? S.soffP : S.soffC;
             if (tid < soff[NB]) {
@@ -1369,10 +1370,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int q = 0; q < n; q++) {
                     const int r = r0 + q;
                     const double nx = (double)rn[r], ny = (double)rn[R + r], nz = (double)rn[2 * R + r];
-                    const double zv = rz[r], vv = rt2[r];
+                    const double vv = rt2[r];
                     t0 = fma(vv, nx, t0); t1 = fma(vv, ny, t1); t2 = fma(vv, nz, t2);
-                    u0 = fma(zv, nx, u0); u1 = fma(zv, ny, u1); u2 = fma(zv, nz, u2);
                     if (with_w) {
+                        const double zv = rz[r];
+                        u0 = fma(zv, nx, u0); u1 = fma(zv, ny, u1); u2 = fma(zv, nz, u2);
                         const double w = unit_w ? 1.0 : zv * rt1[r];
                         const double wx = w * nx, wy = w * ny, wz = w * nz;
                         s0 = fma(wx, nx, s0); s1 = fma(wx, ny, s1); s2 = fma(wx, nz, s2);
@@ -1380,8 +1382,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     }
                 }
                 double *o = stage + tid * ncomp;
-                if (with_w) { o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = s5; o += 6; }
-                o[0] = t0; o[1] = t1; o[2] = t2; o[3] = u0; o[4] = u1; o[5] = u2;
+                if (with_w) { o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = s5; o[9] = u0; o[10] = u1; o[11] = u2; o += 6; }
+                o[0] = t0; o[1] = t1; o[2] = t2;
             }
             if constexpr (PROF) { if (tid == 0) t_acc[PH_RED_BUCKETS] += wall_clock64() - t_last; }
             __syncthreads();
