@@ -501,17 +501,17 @@ struct SmemT {
 };
 using Smem = SmemT<false>;
 
+// Row `type` of variable (k, t) applied to x: bound (x_t), velocity (x_{t+1} - x_t) or acceleration (x_{t+2} - 2 x_{t+1} + x_t)
+// difference, odd types negated.  Branch-free on purpose: the lanes of a wave hold rows of all six types, and a switch runs
+// every case one after the other; three loads (x has room behind its 90 entries) and three multiply-adds with coefficients
+// selected by the type cost less than one of its cases did.
 __device__ __forceinline__ double ax_row(const double *x, int type, int k, int t)
 {
-    const double *xk = x + k * SEGV;
-    switch (type) {
-    case 0: return xk[t];
-    case 1: return -xk[t];
-    case 2: return xk[t + 1] - xk[t];
-    case 3: return -(xk[t + 1] - xk[t]);
-    case 4: return xk[t + 2] - 2.0 * xk[t + 1] + xk[t];
-    default: return -(xk[t + 2] - 2.0 * xk[t + 1] + xk[t]);
-    }
+    const double *xk = x + k * SEGV + t;
+    const int kind = type >> 1;                                       // 0 bound, 1 velocity, 2 acceleration
+    const double a0 = kind == 1 ? -1.0 : 1.0, a1 = kind == 0 ? 0.0 : (kind == 1 ? 1.0 : -2.0), a2 = kind == 2 ? 1.0 : 0.0;
+    const double v = fma(a2, xk[2], fma(a1, xk[1], a0 * xk[0]));
+    return (type & 1) ? -v : v;
 }
 
 // value of lane L (compile-time) broadcast to the wave: two v_readlane_b32, no LDS round trip
