@@ -462,7 +462,7 @@ struct SmemT {
     // axis rows: slot = type*90 + k*30 + t ; type 0 x<=hi, 1 -x<=-lo, 2/3 +-velocity, 4/5 +-acceleration
     double as_[AXROWS], az[AXROWS], at1[AXROWS], at2[AXROWS], ah[SMALL ? 2 : AXROWS];
     double vlim[3], alim[3];    // right-hand sides of the velocity / acceleration rows (SMALL: ah is computed from these)
-    unsigned short amap[AXVALID + 2];   // valid slots, compact
+    uint32_t amap[AXVALID + 2];   // valid slots, compact: slot | type << 10 | axis k << 13 | t << 15 (decoded by shifts: the row passes visit every row four times an iteration)
     // solver constants addressed per lane (LDS tables instead of ~40 long-lived registers per lane, which the
     // register allocator would otherwise park in scratch for the whole kernel)
     double xtc[SEGV][3];        // x_t = sum xtc[t][j] * y[xgp byte j]   (zero beyond the stencil length)
@@ -871,7 +871,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         int T = (int)((M * md.dt - flight + 1e-9) / md.dt);
         S.tseg = T > 1 ? T : 1;
     }
-    for (int i = tid; i < AXVALID; i += NT) S.amap[i] = md.amap[i];
+    for (int i = tid; i < AXVALID; i += NT) {
+        const uint32_t sl = md.amap[i], type = sl / NV, kt = sl % NV;
+        S.amap[i] = sl | (type << 10) | ((kt / SEGV) << 13) | ((kt % SEGV) << 15);
+    }
     // per-lane solver constants -> LDS tables (see Smem)
     const int vq = tid < NV ? tid : (tid >= NT - NV ? tid - (NT - NV) : -1);  // lanes 0..89 (x / objective) and the last 90 (row gather)
     const int xk = vq >= 0 ? vq / SEGV : 0, xt = vq >= 0 ? vq % SEGV : 0;
@@ -1634,8 +1637,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         compute_x(S.y, S.x, true);
         __syncthreads();
         for (int c = tid; c < AXVALID; c += NT) {
-            const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
-            S.at2[sl] = ax_row(S.x, type, kt / SEGV, kt % SEGV) - AH(sl);
+            const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
+            S.at2[sl] = ax_row(S.x, type, ak, at) - AH(sl);
         }
         for (int c = tid; c < nact; c += NT) {
             const uint32_t e = cmap[c];
@@ -1655,11 +1658,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         __syncthreads();
         const double smin = sqrt(mu0);
         for (int c = tid; c < AXVALID; c += NT) {
-            const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
+            const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
             // velocity / acceleration rows are stored divided by n/dt and n(n-1)/dt^2: scale the floor with them so that
             // the start equals the one of the reference's row scaling
             const double floor_s = type < 2 ? smin : (type < 4 ? smin * md.hv_scale : smin * md.ha_scale);
-            const double sv = fmax(AH(sl) - ax_row(S.x, type, kt / SEGV, kt % SEGV), floor_s);
+            const double sv = fmax(AH(sl) - ax_row(S.x, type, ak, at), floor_s);
             S.as_[sl] = sv; S.az[sl] = mu0 / sv; S.at1[sl] = 0.0; S.at2[sl] = 0.0;
         }
         for (int c = tid; c < nact; c += NT) {
@@ -1706,9 +1709,9 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 // P1 (fused with the previous step): s += alpha ds, z += alpha dz, then residuals, 1/s, v = w rp
                 double gp = 0.0, rpm = 0.0;
                 for (int c = tid; c < AXVALID; c += NT) {
-                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
+                    const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
                     double sv = S.as_[sl] + alpha * S.at1[sl], zv = S.az[sl] + alpha * S.at2[sl];
-                    double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - AH(sl);
+                    double rp = ax_row(S.x, type, ak, at) + sv - AH(sl);
                     double is = 1.0 / sv;
                     S.as_[sl] = sv; S.az[sl] = zv;
                     S.at1[sl] = is;
@@ -1748,9 +1751,9 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         } else if (phase == ST_CORR) {
             // P3: corrector right-hand side  v = w rp - (ds dz - sigma mu)/s
             for (int c = tid; c < AXVALID; c += NT) {
-                const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
+                const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
                 double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl];
-                double rp = ax_row(S.x, type, kt / SEGV, kt % SEGV) + sv - AH(sl);
+                double rp = ax_row(S.x, type, ak, at) + sv - AH(sl);
                 S.at2[sl] = zv * is * rp - (S.at2[sl] - smu) * is;
             }
             for (int c = tid; c < nact; c += NT) {
@@ -1800,8 +1803,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 __syncthreads();
                 double mins = 1e300, minz = 1e300;
                 for (int c = tid; c < AXVALID; c += NT) {
-                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV;
-                    double sv = AH(sl) - ax_row(S.x, type, kt / SEGV, kt % SEGV);
+                    const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
+                    double sv = AH(sl) - ax_row(S.x, type, ak, at);
                     S.as_[sl] = sv; S.az[sl] = -sv;
                     mins = fmin(mins, sv); minz = fmin(minz, -sv);
                 }
@@ -1816,7 +1819,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0;
                 const double shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
                 // the shift enters the loop as a "step" of length 1 (t1 = ds, t2 = dz) applied by the first fused pass
-                for (int c = tid; c < AXVALID; c += NT) { const int sl = S.amap[c]; S.at1[sl] = shs; S.at2[sl] = shz; }
+                for (int c = tid; c < AXVALID; c += NT) { const int sl = S.amap[c] & 1023; S.at1[sl] = shs; S.at2[sl] = shz; }
                 for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt1[r] = shs; rt2[r] = shz; }
                 __syncthreads();
                 alpha = 1.0;
@@ -1826,7 +1829,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 // P2: affine step length and centring statistics (+ the Newton-step convergence test)
                 double amin = 1.0, s1 = 0.0, s2 = 0.0;
                 for (int c = tid; c < AXVALID; c += NT) {
-                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
+                    const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, k = (am >> 13) & 3, t = am >> 15;
                     double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
                     double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
                     double adx = ax_row(S.dx, type, k, t);
@@ -1870,7 +1873,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 // P4: step length; the step itself stays in t1 = ds, t2 = dz for the fused pass of the next round
                 double amin = 1e300;
                 for (int c = tid; c < AXVALID; c += NT) {
-                    const int sl = S.amap[c], type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
+                    const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, k = (am >> 13) & 3, t = am >> 15;
                     double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
                     double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
                     double adx = ax_row(S.dx, type, k, t);
