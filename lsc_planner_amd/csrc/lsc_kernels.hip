@@ -1462,9 +1462,17 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 double v;
                 if constexpr (TABLES_IN_LDS) v = kconst[e];
                 else v = kconst_of(id);
-                for (uint32_t q = t0; q < t1; q++) {
-                    const uint32_t tm = terms[q];
-                    v += (double)((int)(tm & 0xff) - 128) * S.W[(tm >> 8) & 0x3ff];
+                // four terms per trip: the term words first, then the weights they point at (two LDS round trips per trip instead of
+                // two per term); terms past the entry's end get coefficient zero
+                for (uint32_t q = t0; q < t1; q += 4) {
+                    uint32_t tm[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) tm[u] = terms[q + u < t1 ? q + u : t0];
+                    double w[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) w[u] = S.W[(tm[u] >> 8) & 0x3ff];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v += (q + u < t1 ? (double)((int)(tm[u] & 0xff) - 128) : 0.0) * w[u];
                 }
                 S.K[(id >> 16) * KLD + (id & 0xffff)] = v;
             }
