@@ -120,8 +120,7 @@ typedef struct {
     double world_z_2d;         /* world/z_2d (src/param.cpp:15; 1.0)                                                        */
     int    goal_search;        /* goal planner's grid search: 0 (default) the register-resident search whenever the grid admits it
                                   (at most 128 rows, (j, z) of a cell in 17 bits), else the general one; 1 always the general
-                                  single-wave search with the row bookkeeping in LDS; 2 = 0; 3 the cooperative search (four waves
-                                  per agent, one per SIMD; same admission rule).  Same paths in every case (tests compare them) */
+                                  search with the row bookkeeping in LDS.  Same paths either way (tests compare them)          */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);

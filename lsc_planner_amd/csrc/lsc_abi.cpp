@@ -741,7 +741,6 @@ static int run_goal(lsc_ctx *c, const float *d_state, const float *&d_goal, cons
     g.row_cap = c->grid_row_cap;
     g.variant = c->cfg.goal_search == 1 ? 0 : goal_fast_slots(g.H, g.W, g.A, &g.jbits);
     if (g.variant == 0) g.jbits = 0;
-    else if (c->cfg.goal_search == 3) g.variant |= 4;          // cooperative: four waves per search
     g.goal_out = c->d_goal_planned; g.err = c->d_goal_err; g.flags = c->d_goal_flags; g.expansions = c->d_goal_exp;
     g.path_out = c->d_goal_path; g.path_cap = c->goal_path_cap; g.path_len = c->d_goal_plen;
     g.ray_stack = c->d_ray_stack;

@@ -575,7 +575,6 @@ struct FGeo {
     int gi, gj, gz;
     int s0, s1, s2;                  // start cell
     int n_nb;
-    int bk_off, mb_off;              // cooperative search: row bookkeeping [H] and mailboxes
     int st_off, rows_off, tmp_off, nbs_off, nbm_off;     // byte offsets into the workgroup's LDS (a pointer passed through a call loses its address space)
     long long *prof;                 // PROF: [8] counters of this agent
 };
@@ -861,362 +860,19 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Cooperative search: the same container emulation on the four waves of a 256-lane workgroup, one per SIMD.
-// Why: a wave alone on its SIMD issues one instruction every 5.7 (independent) to 8.5 (dependent) cycles whatever the
-// instruction is -- there is no instruction-level parallelism to be had inside a wave, only across waves -- while a
-// workgroup barrier costs 12-48 cycles and an LDS hand-over about 150 (tools/microbench).  The work of one
-// expanded node splits into pieces that touch different containers:
-//     wave 0   deleteMin's rescan of the popped row (F of every remaining entry + the wave reduction)
-//     wave 1   the erase itself, the cell bytes, and the insertions into the popped row (j -+ 1, z -+ 1)
-//     wave 2   the insertion into row i - 1            wave 3   the insertion into row i + 1
-// The rescan runs on the row as it is right after the erase while wave 1 goes on inserting: insertions shift entries
-// but never reorder the old ones, and addOpen's rule "the new node replaces the registered minimum when its F is not
-// larger (and, on equal F, its g not smaller)" makes the final registered minimum the fold of the rescan result and the
-// best inserted node, in that order -- which the next node's phase 1 computes from two mailboxes.
-// Row bookkeeping lives in LDS (BK, 16 B per row: any number of rows); every wave reads all of it once per node and
-// runs findMin redundantly, so all waves take identical decisions without talking.  Two barriers per node:
-//     A  everything written for node k is visible            (reads of node k + 1 follow)
-//     M  every wave has read what it needs of node k + 1      (writes follow)
-// A node with more than 64 entries in the popped row, or with an already-OPEN neighbour to improve, is handled by wave 1
-// alone with the general routines (about 8 % of the nodes on the forest worlds).
-struct BK { FK F; uint32_t mn, cn; };
-enum { MB_RES = 0, MB_INS = 4, MB_ERR = 8 };      // mailbox words: rescan (F lo, F hi, entry, -), insertions (F lo, F hi, entry, cn), errors [4]
-
-template <int NS, bool PROF>
-__device__ __attribute__((noinline)) unsigned long long search_coop(FGeo gin)
-{
-#pragma clang fp contract(off)
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
-    const int H = uni(gin.H), W = uni(gin.W), A = uni(gin.A), HW = uni(gin.HW), cap = uni(gin.cap), JB = uni(gin.JB);
-    const int gi = uni(gin.gi), gj = uni(gin.gj), gz = uni(gin.gz), n_nb = uni(gin.n_nb);
-    const uint32_t JM = (1u << JB) - 1u;
-    uint8_t *const st = gsm + uni(gin.st_off);
-    uint32_t *const rows = reinterpret_cast<uint32_t *>(gsm + uni(gin.rows_off));
-    uint32_t *const tmp = reinterpret_cast<uint32_t *>(gsm + uni(gin.tmp_off)) + (wave > 1 ? (wave - 1) * cap : 0);   // one rehash scratch per inserting wave
-    const int *const nb_seq = reinterpret_cast<const int *>(gsm + uni(gin.nbs_off));
-    const uint32_t *const nb_magic = reinterpret_cast<const uint32_t *>(gsm + uni(gin.nbm_off));
-    BK *const bk = reinterpret_cast<BK *>(gsm + uni(gin.bk_off));
-    uint32_t *const mb = reinterpret_cast<uint32_t *>(gsm + uni(gin.mb_off));
-    FGeoL c;
-    c.H = H; c.W = W; c.A = A; c.HW = HW; c.cap = cap; c.lane = lane; c.JB = JB; c.JM = JM; c.gi = gi; c.gj = gj; c.gz = gz;
-    c.st = st; c.rows = rows; c.tmp = tmp; c.nb_seq = nb_seq; c.nb_magic = nb_magic; c.n_nb = n_nb;
-    int err = 0, expansions = 0;
-    long long pc[3] = {0, 0, 0};                  // PROF, per wave: phase 1, work of phase 2, waiting at barrier A
-    long long tk = 0;
-    auto tick = [&](int slot) { if constexpr (PROF) { const long long t = (long long)__builtin_readcyclecounter(); pc[slot] += t - tk; tk = t; } };
-    auto done = [&](bool found, uint32_t end_key) {
-        if constexpr (PROF) { long long *pr = uni_ptr(gin.prof); if (lane == 0) for (int k = 0; k < 3; k++) pr[4 + 3 * wave + k] += pc[k]; }
-        return (unsigned long long)(unsigned)expansions | ((unsigned long long)end_key << 32) | ((unsigned long long)(found ? 1 : 0) << 52) |
-               ((unsigned long long)err << 56);
-    };
-    const uint32_t tabNb = lane < 16 ? (uint32_t)nb_seq[lane & 15] : 0u, tabNbm = lane < 16 ? nb_magic[lane & 15] : 0u;
-    auto pack_cn = [&](int cnt, int nbi, uint32_t nb) {
-        const uint32_t lim = nbi < 0 ? 0u : min(min(nb, 64u), (uint32_t)cap);
-        return (uint32_t)cnt | (lim << 10) | ((uint32_t)(nbi + 1) << 20);
-    };
-    auto nb_of = [&](int nbi, uint32_t &nb, uint32_t &nbm) {
-        nb = nbi < 0 ? 1u : (uint32_t)__builtin_amdgcn_readlane((int)tabNb, nbi & 15);
-        nbm = nbi < 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)tabNbm, nbi & 15);
-    };
-    const int l_di = lane == 0 ? -1 : (lane == 5 ? 1 : 0), l_dj = lane == 1 ? -1 : (lane == 4 ? 1 : 0), l_dz = lane == 2 ? -1 : (lane == 3 ? 1 : 0);
-    const int l_dkey = HW * l_dz + W * l_di + l_dj;
-    const uint32_t l_open = (uint32_t)ST_OPEN | ((uint32_t)lane << 2);
-
-    // ---- empty containers, empty mailboxes; wave 1 inserts the start node (g = 0, parent code 7: none)
-    for (int i = tid; i < H; i += 256) { BK b; b.F = FK_NONE; b.mn = 0u; b.cn = 0u; bk[i] = b; }
-    if (tid < 12) mb[tid] = tid < 8 ? (tid == 2 || tid == 3 || tid == 6 || tid == 7 ? 0u : 0xffffffffu) : 0u;
-    __syncthreads();
-    if (wave == 1) {
-        const int s0 = uni(gin.s0), s1 = uni(gin.s1), s2 = uni(gin.s2);
-        int cnt = 0, nbi = -1;
-        uint32_t nb = 1u, nbm = 0u;
-        const uint32_t e0 = (uint32_t)s1 | ((uint32_t)s2 << JB);
-        f_row_insert(c, s0, e0, cnt, nbi, nb, nbm, err);
-        const int di = gi - s0, dj = gj - s1, dz = gz - s2;
-        if (lane == 0) {
-            st[HW * s2 + W * s0 + s1] = st_open(7, 0);
-            BK b; b.F = fk_entry(0u, di * di + dj * dj + dz * dz); b.mn = e0; b.cn = pack_cn(1, nbi, nb);
-            bk[s0] = b;
-            if (err) mb[MB_ERR + 1] = (uint32_t)err;
-        }
-    }
-    int nopen = 1, cp = -1;
-    if constexpr (PROF) tk = (long long)__builtin_readcyclecounter();
-    while (nopen > 0) {
-        expansions++;
-        __syncthreads();                                                            // ---- barrier A
-        tick(2);
-        // ---- phase 1: every wave reads the bookkeeping and the two mailboxes, folds the previous node's row, runs findMin
-        FK bF[NS];
-        uint32_t bMn[NS], bCn[NS];
-#pragma unroll
-        for (int t = 0; t < NS; t++) {
-            const int i = lane + 64 * t;
-            BK b; b.F = FK_NONE; b.mn = 0u; b.cn = 0u;
-            if (i < H) b = bk[i];
-            bF[t] = b.F; bMn[t] = b.mn; bCn[t] = b.cn;
-        }
-        const uint4 mres = *reinterpret_cast<const uint4 *>(mb + MB_RES), mins = *reinterpret_cast<const uint4 *>(mb + MB_INS), merr = *reinterpret_cast<const uint4 *>(mb + MB_ERR);
-        const int anyerr = uni((int)(merr.x | merr.y | merr.z | merr.w));
-        if (anyerr) { err = anyerr; return done(false, 0u); }
-        if (cp >= 0) {
-            const FK Fres = ((FK)(uint32_t)uni((int)mres.y) << 32) | (uint32_t)uni((int)mres.x), Fins = ((FK)(uint32_t)uni((int)mins.y) << 32) | (uint32_t)uni((int)mins.x);
-            const uint32_t eres = (uint32_t)uni((int)mres.z), eins = (uint32_t)uni((int)mins.z), cnp = (uint32_t)uni((int)mins.w);
-            const bool take = Fins < Fres || (Fins == Fres && (eins >> KEY_BITS) >= (eres >> KEY_BITS));
-            const FK Fp = take ? Fins : Fres;
-            const uint32_t mnp = take ? eins : eres;
-#pragma unroll
-            for (int t = 0; t < NS; t++) { const bool m = lane + 64 * t == cp; bF[t] = m ? Fp : bF[t]; bMn[t] = m ? mnp : bMn[t]; bCn[t] = m ? cnp : bCn[t]; }
-            if (wave == 2 && lane == 0) { BK b; b.F = Fp; b.mn = mnp; b.cn = cnp; bk[cp] = b; }   // (nobody trusts bk[cp] during this node)
-        }
-        auto get_u = [&](const uint32_t (&a)[NS], int i) { uint32_t v = a[0]; if constexpr (NS > 1) { if (i >= 64) v = a[1]; } return (uint32_t)__builtin_amdgcn_readlane((int)v, i & 63); };
-        auto get_f = [&](int i) {
-            FK v = bF[0];
-            if constexpr (NS > 1) { if (i >= 64) v = bF[1]; }
-            return ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), i & 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i & 63);
-        };
-        FK bf = bF[0];
-        uint32_t bsel = ((bMn[0] >> KEY_BITS) << 16) | (uint32_t)lane;
-        if constexpr (NS > 1) {
-            const uint32_t s1 = ((bMn[1] >> KEY_BITS) << 16) | (uint32_t)(lane + 64);
-            const bool take = bF[1] < bf || (bF[1] == bf && s1 >= bsel);
-            bf = take ? bF[1] : bf; bsel = take ? s1 : bsel;
-        }
-        FK fmin;
-        uint32_t sel;
-        argmin_f_sel(bf, bsel, fmin, sel);
-        const int ci = (int)(sel & 0xffffu), cg = (int)(sel >> 16);
-        const uint32_t cjz = get_u(bMn, ci) & KEY_MASK;
-        const uint32_t ccn = get_u(bCn, ci);
-        const int ccnt = (int)(ccn & 1023u);
-        const int cj = (int)(cjz & JM), cz = (int)(cjz >> JB);
-        const int ckey = HW * cz + W * ci + cj;
-        uint32_t *rowc = rows + ci * cap;
-        const uint32_t e = rowc[lane], nxt = rowc[lane + 1];
-        const int ni = ci + l_di, nj = cj + l_dj, nz = cz + l_dz;
-        const bool inb = lane < 7 && (unsigned)ni < (unsigned)H && (unsigned)nj < (unsigned)W && (unsigned)nz < (unsigned)A;
-        const int ncell = min(max(ckey + l_dkey, 0), HW * A - 1);
-        const uint32_t sv = st[ncell];
-        tick(0);
-        __syncthreads();                                                            // ---- barrier M
-        // ---- phase 2.  What every wave derives for itself: the goal test, the screening of the six neighbours
-        nopen--;
-        if (ci == gi && cj == gj) return done(true, (uint32_t)ckey);                // the altitude is not part of the goal test
-        if (cg + 1 > G_MAX) { err = 1; return done(false, 0u); }
-        const int ng = cg + 1;
-        const uint32_t state_l = sv & 3u;
-        const uint32_t gdiff = ((sv >> 5) - (uint32_t)ng) & 7u;
-        const bool isn = lane < 6 && inb;
-        const bool want_new = isn && state_l == ST_FREE;
-        const bool want_imp = isn && state_l == ST_OPEN && (gdiff - 1u) < 2u;
-        const unsigned long long newm = __ballot(want_new), impm = __ballot(want_imp);
-        unsigned long long todo = newm | impm;
-        nopen += __popcll(newm);
-        const int cntc0 = ccnt - 1;
-        const int dic = gi - ci, dic2 = dic * dic;
-        const bool slow = ccnt > 64 || impm != 0ull;
-        auto neighbour_f = [&]() {
-            const int ei = gi - ni, ej = gj - nj, ez = gz - nz;
-            return fk_entry((uint32_t)ng, ei * ei + ej * ej + ez * ez);
-        };
-        auto erase_reg = [&]() {                                                   // the popped row without the popped node, one entry per lane
-            const unsigned long long m = __ballot(lane < ccnt && (e & KEY_MASK) == cjz);
-            const int pos = __ffsll((long long)m) - 1;
-            return lane >= pos ? nxt : e;
-        };
-        auto rescan_reg = [&](uint32_t R, int cnt, FK &Fo, uint32_t &mo) {         // deleteMin's rescan (:216-240)
-            Fo = FK_NONE; mo = 0u;
-            if (cnt > 0) {
-                const int dj = gj - (int)(R & JM), dz = gz - (int)((R & KEY_MASK) >> JB);
-                const FK f = lane < cnt ? fk_entry(R >> KEY_BITS, dic2 + dj * dj + dz * dz) : FK_NONE;
-                uint32_t w;
-                argmin_f_sel(f, ((R >> KEY_BITS) << 16) | (uint32_t)lane, Fo, w);
-                mo = (uint32_t)__builtin_amdgcn_readlane((int)R, (int)(w & 63u));
-            }
-        };
-        auto ins_reg = [&](uint32_t V, int cnt, int nbi, uint32_t Wi, uint32_t ne, uint32_t *row) {
-            const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)tabNb, nbi), nbm = (uint32_t)__builtin_amdgcn_readlane((int)tabNbm, nbi);
-            const uint32_t kb = bucket_of(ref_key(c, V, Wi), nb, nbm), eb = bucket_of(ref_key(c, ne, Wi), nb, nbm);
-            const unsigned long long mm = __ballot(lane < cnt && kb == eb);
-            const int pos = mm ? __ffsll((long long)mm) - 1 : 0;
-            const uint32_t up = wave_shr1(V);
-            V = lane < pos ? V : (lane == pos ? ne : up);
-            if (lane <= cnt) row[lane] = V;
-            return V;
-        };
-        auto write_cells = [&]() {   // the popped cell is CLOSED, unseen neighbours are OPEN (direction, g mod 8): one store
-            if ((lane == 6 && inb) || want_new) st[ncell] = (uint8_t)(lane == 6 ? (sv | ST_CLOSED) : (l_open | (((uint32_t)ng & 7u) << 5)));
-        };
-        auto other_row = [&](int d, int ri) {                                      // a new node in row ci -+ 1 (addOpen :243-283)
-            const uint32_t ne = (uint32_t)cj | ((uint32_t)cz << JB) | ((uint32_t)ng << KEY_BITS);
-            const FK fsv = neighbour_f();
-            const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fsv >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fsv, d);
-            uint32_t *row = rows + ri * cap;
-            uint32_t cn = get_u(bCn, ri);
-            int cnt = (int)(cn & 1023u);
-            const uint32_t lim = (cn >> 10) & 1023u;
-            if (__builtin_expect((uint32_t)cnt < lim, 1)) {
-                (void)ins_reg(row[lane], cnt, (int)(cn >> 20) - 1, (uint32_t)(W * ri), ne, row);
-                cn++;
-                cnt++;
-            } else {
-                int nbi = (int)(cn >> 20) - 1;
-                uint32_t nb, nbm;
-                nb_of(nbi, nb, nbm);
-                f_row_insert(c, ri, ne, cnt, nbi, nb, nbm, err);
-                cn = pack_cn(cnt, nbi, nb);
-            }
-            uint32_t mn = get_u(bMn, ri);
-            FK Fr = get_f(ri);
-            if (cnt == 1 || fs < Fr || (fs == Fr && ng >= (int)(mn >> KEY_BITS))) { Fr = fs; mn = ne; }
-            if (lane == 0) { BK b; b.F = Fr; b.mn = mn; b.cn = cn; bk[ri] = b; }
-        };
-        if (!slow) {
-            if (wave == 0) {
-                FK Fo;
-                uint32_t mo;
-                rescan_reg(erase_reg(), cntc0, Fo, mo);
-                if (lane == 0) { mb[MB_RES] = (uint32_t)Fo; mb[MB_RES + 1] = (uint32_t)(Fo >> 32); mb[MB_RES + 2] = mo; }
-            } else if (wave == 1) {
-                uint32_t R = erase_reg();
-                if (lane < cntc0) rowc[lane] = R;
-                write_cells();
-                int cntc = cntc0, nbic = (int)(ccn >> 20) - 1;
-                uint32_t limc = (ccn >> 10) & 1023u;
-                bool rvalid = true;
-                FK Fi = FK_NONE;                                                    // best inserted node so far (all share g = ng: the later one wins a tie)
-                uint32_t ei = 0u;
-                unsigned mid = (unsigned)(todo >> 1) & 15u;
-                const uint32_t Wc = (uint32_t)(W * ci);
-                const FK fsv = mid ? neighbour_f() : FK_NONE;
-                while (mid) {
-                    const int d = __ffs((int)mid);                                  // 1..4
-                    mid &= mid - 1;
-                    const int rj = cj + __builtin_amdgcn_readlane(l_dj, d), rz = cz + __builtin_amdgcn_readlane(l_dz, d);
-                    const uint32_t ne = (uint32_t)rj | ((uint32_t)rz << JB) | ((uint32_t)ng << KEY_BITS);
-                    const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fsv >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fsv, d);
-                    if (__builtin_expect(rvalid && (uint32_t)cntc < limc, 1)) {
-                        R = ins_reg(R, cntc, nbic, Wc, ne, rowc);
-                        cntc++;
-                    } else {
-                        uint32_t nb, nbm;
-                        nb_of(nbic, nb, nbm);
-                        f_row_insert(c, ci, ne, cntc, nbic, nb, nbm, err);
-                        if (err) break;
-                        limc = nbic < 0 ? 0u : min(min(nb, 64u), (uint32_t)cap);
-                        rvalid = cntc <= 64;
-                        if (rvalid) R = rowc[lane];
-                    }
-                    if (fs <= Fi) { Fi = fs; ei = ne; }
-                }
-                if (lane == 0) {
-                    mb[MB_INS] = (uint32_t)Fi; mb[MB_INS + 1] = (uint32_t)(Fi >> 32); mb[MB_INS + 2] = ei;
-                    mb[MB_INS + 3] = (uint32_t)cntc | (limc << 10) | ((uint32_t)(nbic + 1) << 20);
-                }
-            } else if (wave == 2) {
-                if (todo & 1ull) other_row(0, ci - 1);
-            } else {
-                if (todo & 32ull) other_row(5, ci + 1);
-            }
-        } else if (wave == 1) {
-            // ---- the whole node on one wave, general routines where a row is long
-            FK Fc = FK_NONE;
-            uint32_t mnc = 0u, R = 0u;
-            int cntc = cntc0, nbic = (int)(ccn >> 20) - 1;
-            uint32_t limc = (ccn >> 10) & 1023u;
-            bool rvalid = ccnt <= 64;
-            if (rvalid) {
-                R = erase_reg();
-                if (lane < cntc0) rowc[lane] = R;
-                rescan_reg(R, cntc0, Fc, mnc);
-            } else {
-                double Fd;
-                f_row_pop(c, ci, cjz, ccnt, Fd, mnc);
-                Fc = cntc0 > 0 ? fk_of(Fd) : FK_NONE;
-            }
-            write_cells();
-            const FK fsv = neighbour_f();
-            while (todo && !err) {
-                const int d = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int ri = ci + __builtin_amdgcn_readlane(l_di, d);
-                const int rj = cj + __builtin_amdgcn_readlane(l_dj, d), rz = cz + __builtin_amdgcn_readlane(l_dz, d);
-                const uint32_t njz = (uint32_t)rj | ((uint32_t)rz << JB);
-                const uint32_t ne = njz | ((uint32_t)ng << KEY_BITS);
-                const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fsv >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fsv, d);
-                const bool same = ri == ci;
-                uint32_t *row = rows + ri * cap;
-                int cnt, nbi;
-                uint32_t lim, mn;
-                FK Fr;
-                if (same) { cnt = cntc; nbi = nbic; lim = limc; mn = mnc; Fr = Fc; }
-                else { const uint32_t cn = get_u(bCn, ri); cnt = (int)(cn & 1023u); lim = (cn >> 10) & 1023u; nbi = (int)(cn >> 20) - 1; mn = get_u(bMn, ri); Fr = get_f(ri); }
-                if ((impm >> d) & 1ull) {
-                    // already OPEN: keep the better of the two (same cell, same H: "F smaller" is "g smaller")
-                    const int p = f_row_find(lane, row, cnt, njz);
-                    const uint32_t old = (uint32_t)uni((int)row[p]);
-                    if (ng < (int)(old >> KEY_BITS)) {
-                        if (lane == 0) { row[p] = ne; st[HW * rz + W * ri + rj] = st_open(d, ng); }
-                        wsync();
-                        if (same && rvalid) R = lane == p ? ne : R;
-                        const bool min_is_this = (mn & KEY_MASK) == njz;
-                        const FK fm = min_is_this ? fs : Fr;
-                        const int gm = min_is_this ? ng : (int)(mn >> KEY_BITS);
-                        if (fs < fm || (fs == fm && ng >= gm)) { Fr = fs; mn = ne; }
-                    }
-                } else {
-                    if ((uint32_t)cnt < lim && (!same || rvalid)) {
-                        uint32_t V = R;
-                        if (!same) V = row[lane];
-                        V = ins_reg(V, cnt, nbi, (uint32_t)(W * ri), ne, row);
-                        if (same) R = V;
-                        cnt++;
-                    } else {
-                        uint32_t nb, nbm;
-                        nb_of(nbi, nb, nbm);
-                        f_row_insert(c, ri, ne, cnt, nbi, nb, nbm, err);
-                        if (err) break;
-                        lim = nbi < 0 ? 0u : min(min(nb, 64u), (uint32_t)cap);
-                        if (same) { rvalid = cnt <= 64; if (rvalid) R = row[lane]; }
-                    }
-                    if (cnt == 1 || fs < Fr || (fs == Fr && ng >= (int)(mn >> KEY_BITS))) { Fr = fs; mn = ne; }
-                }
-                if (same) { cntc = cnt; nbic = nbi; limc = lim; Fc = Fr; mnc = mn; }
-                else if (lane == 0) { BK b; b.F = Fr; b.mn = mn; b.cn = (uint32_t)cnt | (lim << 10) | ((uint32_t)(nbi + 1) << 20); bk[ri] = b; }
-            }
-            if (lane == 0) {
-                const FK Fo = cntc > 0 ? Fc : FK_NONE;
-                mb[MB_RES] = (uint32_t)Fo; mb[MB_RES + 1] = (uint32_t)(Fo >> 32); mb[MB_RES + 2] = mnc;
-                mb[MB_INS] = 0xffffffffu; mb[MB_INS + 1] = 0xffffffffu; mb[MB_INS + 2] = 0u;
-                mb[MB_INS + 3] = (uint32_t)cntc | (limc << 10) | ((uint32_t)(nbic + 1) << 20);
-            }
-        }
-        if (err && lane == 0) mb[MB_ERR + wave] = (uint32_t)err;
-        err = 0;                                                                    // (reported through the mailbox: every wave leaves at the same point)
-        cp = ci;
-        tick(1);
-    }
-    __syncthreads();                                                                // the last node's errors
-    {
-        const uint4 merr = *reinterpret_cast<const uint4 *>(mb + MB_ERR);
-        err = uni((int)(merr.x | merr.y | merr.z | merr.w));
-    }
-    return done(false, 0u);
-}
-
 }  // namespace
 
-// NS = 0: the general search on one wave; NS > 0: register-resident search on one wave (COOP false) or the cooperative search on
-// the four waves of a 256-lane workgroup (COOP true).  With four waves the set-up is shared (grid copy, stamping) or done
-// redundantly (priority rule, start cell: same inputs, same result in every wave); the path and the line-of-sight goal are wave 0's.
-template <int NS, bool PROF, bool COOP>
-__global__ __launch_bounds__(COOP ? 256 : 64) void lsc_goal_kernel(GoalArgs a)
+// NS = 0: the general search; NS > 0: the register-resident search with NS slots of row bookkeeping per lane.  One wave per agent.
+// (A cooperative variant -- four waves per agent, the rescan, the same-row and the other-row insertions on different SIMDs, two
+// barriers per node -- was built and measured in round 3: it returned the same paths at the same 28.5 ms per tick on the tiled
+// forest, because every wave has to repeat findMin and the hand-overs cost what the split saves; commit cda8913)
+template <int NS, bool PROF>
+__global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
 {
 #pragma clang fp contract(off)
-    constexpr int NT = COOP ? 256 : 64;
+    constexpr int NT = 64;
     const int tid = threadIdx.x, lane = tid & 63;
-    auto ksync = [&]() { if constexpr (COOP) __syncthreads(); else wsync(); };
+    auto ksync = [&]() { wsync(); };
     const int al = blockIdx.x;
     const int qi = a.first + al;
     const int N = a.N;
@@ -1224,7 +880,6 @@ __global__ __launch_bounds__(COOP ? 256 : 64) void lsc_goal_kernel(GoalArgs a)
     long long tk0 = 0;
     auto ktick = [&](int slot) { if constexpr (PROF) { const long long t = (long long)__builtin_readcyclecounter(); pc[slot] += t - tk0; tk0 = t; } };
     if constexpr (PROF) tk0 = (long long)__builtin_readcyclecounter();
-    int bk_off = 0, mb_off = 0;
     Ctx c;
     c.H = a.H; c.W = a.W; c.A = a.A; c.HW = a.H * a.W; c.C = a.H * a.W * a.A; c.cap = a.row_cap; c.lane = lane;
     c.nb_seq = a.nb_seq; c.nb_magic = a.nb_magic; c.n_nb = a.n_nb; c.err = 0;
@@ -1234,7 +889,7 @@ __global__ __launch_bounds__(COOP ? 256 : 64) void lsc_goal_kernel(GoalArgs a)
         c.st = gsm; off += ((size_t)c.C + 15) & ~(size_t)15;
         c.rowF = reinterpret_cast<double *>(gsm + off); off += sizeof(double) * (size_t)c.H;
         c.rowMin = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.H;
-        c.tmp = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.cap * 3;   // one rehash scratch per inserting wave
+        c.tmp = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.cap;
         c.rows = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * (size_t)c.H * c.cap;
         c.rowCnt = reinterpret_cast<uint16_t *>(gsm + off); off += sizeof(uint16_t) * (size_t)c.H;
         c.rowNb = reinterpret_cast<int16_t *>(gsm + off); off += sizeof(int16_t) * (size_t)c.H;
@@ -1245,9 +900,6 @@ __global__ __launch_bounds__(COOP ? 256 : 64) void lsc_goal_kernel(GoalArgs a)
         uint32_t *nbm = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * 16;
         if (tid < 16) { nbs[tid] = a.nb_seq[tid]; nbm[tid] = a.nb_magic[tid]; }
         c.nb_seq = nbs; c.nb_magic = nbm;
-        off = (off + 15) & ~(size_t)15;
-        bk_off = (int)off; off += 16 * (size_t)c.H;           // cooperative search: row bookkeeping
-        mb_off = (int)off;                                    // and its mailboxes (64 B)
     }
     const float *pos = a.state + 9 * qi;
     const float *goal_i = a.goal + 3 * qi;
@@ -1399,10 +1051,7 @@ __global__ __launch_bounds__(COOP ? 256 : 64) void lsc_goal_kernel(GoalArgs a)
             f.tmp_off = (int)(reinterpret_cast<unsigned char *>(c.tmp) - gsm);
             f.nbs_off = (int)(reinterpret_cast<const unsigned char *>(c.nb_seq) - gsm); f.nbm_off = (int)(reinterpret_cast<const unsigned char *>(c.nb_magic) - gsm);
             f.prof = PROF ? a.prof + (size_t)qi * 16 : nullptr;
-            f.bk_off = bk_off; f.mb_off = mb_off;
-            unsigned long long r;
-            if constexpr (COOP) r = search_coop<NS, PROF>(f);
-            else r = search_fast<NS, PROF>(f);
+            const unsigned long long r = search_fast<NS, PROF>(f);
             expansions += (int)(unsigned)r;
             end_key = (uint32_t)(r >> 32) & KEY_MASK;
             found = ((r >> 52) & 1ull) != 0;
@@ -1531,7 +1180,6 @@ __global__ __launch_bounds__(COOP ? 256 : 64) void lsc_goal_kernel(GoalArgs a)
         }
     }
 
-    if constexpr (COOP) { if (tid >= 64) return; }            // the rest is wave 0's (no workgroup barrier below this line)
     // ---- primary path (makePrimaryPath :143-151): parents back from the popped goal node, stored start -> goal
     uint32_t *path = c.rows;                                   // the OPEN rows are dead now: reuse them
     const int path_cap = c.H * c.cap;
@@ -1627,11 +1275,10 @@ __global__ __launch_bounds__(COOP ? 256 : 64) void lsc_goal_kernel(GoalArgs a)
 size_t goal_smem_bytes(int H, int W, int A, int cap)
 {
     size_t b = ((size_t)H * W * A + 15) & ~(size_t)15;
-    b += sizeof(double) * (size_t)H + sizeof(uint32_t) * (size_t)H + sizeof(uint32_t) * (size_t)cap * 3;
+    b += sizeof(double) * (size_t)H + sizeof(uint32_t) * (size_t)H + sizeof(uint32_t) * (size_t)cap;
     b += sizeof(uint32_t) * (size_t)H * cap + 2 * sizeof(uint16_t) * (size_t)H;
     b += 4 + 2 * 16 * sizeof(int);                            // bucket-count / magic tables
     b += 512;                                                 // the register-resident search reads 65 entries of a row unpredicated
-    b += 16 + 16 * (size_t)H + 64;                            // cooperative search: row bookkeeping + mailboxes
     b += 2 * sizeof(uint32_t) * (size_t)H;                    // per-row bucket count and magic
     return (b + 15) & ~(size_t)15;
 }
@@ -1650,11 +1297,9 @@ int goal_fast_slots(int H, int W, int A, int *jbits)
 
 hipError_t init_device_goal_kernel()
 {
-    const void *k[] = {reinterpret_cast<const void *>(&lsc_goal_kernel<0, false, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, false, false>),
-                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, false, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, true, false>),
-                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, true, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, false, true>),
-                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, false, true>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, true, true>),
-                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, true, true>)};
+    const void *k[] = {reinterpret_cast<const void *>(&lsc_goal_kernel<0, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, false>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, true>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, true>)};
     for (const void *f : k) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1668,20 +1313,14 @@ hipError_t launch_goal(const GoalArgs &a, hipStream_t st)
     const size_t smem = goal_smem_bytes(a.H, a.W, a.A, a.row_cap);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     // variant: 0 the general search (row bookkeeping in LDS, any grid), 1 / 2 the register-resident search (H <= 64 / 128
-    // rows and (j, z) packed into 17 bits: goal_fast_slots() says which one a grid admits)
-    // a.prof != null selects the instrumented build of the register-resident search (section cycle counters)
+    // rows and (j, z) packed into 17 bits: goal_fast_slots() says which one a grid admits); a.prof != null selects the
+    // instrumented build of the register-resident search (section cycle counters)
     const int slots = a.variant & 3;
-    if (a.variant & 4) {                                      // cooperative: four waves per search
-        if (slots == 2 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<2, true, true>), dim3(a.count), dim3(256), smem, st, a);
-        else if (slots == 1 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<1, true, true>), dim3(a.count), dim3(256), smem, st, a);
-        else if (slots == 2) hipLaunchKernelGGL((lsc_goal_kernel<2, false, true>), dim3(a.count), dim3(256), smem, st, a);
-        else hipLaunchKernelGGL((lsc_goal_kernel<1, false, true>), dim3(a.count), dim3(256), smem, st, a);
-    }
-    else if (slots == 2 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<2, true, false>), dim3(a.count), dim3(64), smem, st, a);
-    else if (slots == 1 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<1, true, false>), dim3(a.count), dim3(64), smem, st, a);
-    else if (slots == 2) hipLaunchKernelGGL((lsc_goal_kernel<2, false, false>), dim3(a.count), dim3(64), smem, st, a);
-    else if (slots == 1) hipLaunchKernelGGL((lsc_goal_kernel<1, false, false>), dim3(a.count), dim3(64), smem, st, a);
-    else hipLaunchKernelGGL((lsc_goal_kernel<0, false, false>), dim3(a.count), dim3(64), smem, st, a);
+    if (slots == 2 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<2, true>), dim3(a.count), dim3(64), smem, st, a);
+    else if (slots == 1 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<1, true>), dim3(a.count), dim3(64), smem, st, a);
+    else if (slots == 2) hipLaunchKernelGGL((lsc_goal_kernel<2, false>), dim3(a.count), dim3(64), smem, st, a);
+    else if (slots == 1) hipLaunchKernelGGL((lsc_goal_kernel<1, false>), dim3(a.count), dim3(64), smem, st, a);
+    else hipLaunchKernelGGL((lsc_goal_kernel<0, false>), dim3(a.count), dim3(64), smem, st, a);
     return hipGetLastError();
 }
 

@@ -54,14 +54,6 @@ def main():
             def split(idx):
                 n = max(e[idx].sum(), 1.0)
                 return {k: round(float(prof[idx, 4 + i].sum() / n), 1) for i, k in enumerate(("find_min", "delete_min", "screening", "insertions"))}
-            coop = a.search == "cooperative"
-            if coop:
-                n8 = max(e[top].sum(), 1.0)
-                waves = {f"wave{w}": {k: round(float(prof[top, 4 + 3 * w + i].sum() / n8), 1) for i, k in enumerate(("phase1", "work", "wait"))} for w in range(4)}
-                print(json.dumps({"tick": t, "expansions_max": int(e.max()), "cycles_per_node_top8": round(float(prof[top, 2].sum() / n8), 1),
-                                  "per_wave_cycles_per_node_top8": waves,
-                                  "phases_of_slowest": {k: int(prof[int(np.argmax(tot)), i]) for i, k in enumerate(("prologue", "grid_setup", "search", "path_los"))}}), flush=True)
-                continue
             line = {"tick": t, "grid": [int(v) for v in tr["grid_dims"]], "expansions_mean": round(float(e.mean()), 1), "expansions_max": int(e.max()),
                     "kernel_cycles_max": int(tot.max()), "cycles_per_node_top8": round(float(prof[top, 2].sum() / max(e[top].sum(), 1)), 1),
                     "split_top8": split(top), "split_all": split(np.arange(N)),
