@@ -119,8 +119,9 @@ typedef struct {
                                   the reference (src/traj_optimizer.cpp never looks at the dimension).  0 is read as 3       */
     double world_z_2d;         /* world/z_2d (src/param.cpp:15; 1.0)                                                        */
     int    goal_search;        /* goal planner's grid search: 0 (default) the register-resident search whenever the grid admits it
-                                  (at most 128 rows, (j, z) of a cell in 17 bits), else the general one; 1 always the general
-                                  search with the row bookkeeping in LDS.  Same paths either way (tests compare them)          */
+                                  (at most 128 rows, (j, z) of a cell in 17 bits), with 32-bit search keys when their table fits
+                                  LDS (else the double itself as key); 1 always the general search with the row bookkeeping in
+                                  LDS; 2 the register-resident search with 64-bit keys.  Same paths in every case (tests)      */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);

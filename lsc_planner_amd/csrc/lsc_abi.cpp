@@ -234,6 +234,9 @@ struct lsc_ctx {
     unsigned char *d_occ_static = nullptr;
     int *d_goal_err = nullptr, *d_goal_flags = nullptr, *d_goal_exp = nullptr, *d_goal_path = nullptr, *d_goal_plen = nullptr;
     int goal_path_cap = 0;
+    std::vector<uint32_t> h_fcode;       // Key32 table of the goal search (empty: Key64)
+    uint32_t *d_fcode = nullptr;
+    int fcode_rb = 0;
     long long *d_goal_prof = nullptr;
     bool goal_profiling = false;
     int grid_dims[3] = {0, 0, 0}, grid_row_cap = 0;
@@ -431,9 +434,9 @@ static void free_agents(lsc_ctx *c)
     if (c->h_in) { (void)hipHostFree(c->h_in); c->h_in = nullptr; }
     if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
     void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
-                  c->d_goal_path, c->d_goal_plen, c->d_goal_prof};
+                  c->d_goal_path, c->d_goal_plen, c->d_goal_prof, c->d_fcode};
     for (void *p : gp) if (p) (void)hipFree(p);
-    c->d_goal_prof = nullptr;
+    c->d_goal_prof = nullptr; c->d_fcode = nullptr;
     c->d_edt = c->d_goal_planned = c->d_ray_stack = nullptr; c->d_occ_static = nullptr;
     c->d_goal_err = c->d_goal_flags = c->d_goal_exp = c->d_goal_path = c->d_goal_plen = nullptr;
     c->d_radius = c->d_radius_obs = c->d_downwash = c->d_downwash_obs = c->d_vmax = c->d_amax = c->d_vnom = nullptr;
@@ -611,6 +614,57 @@ static int build_goal_grid(lsc_ctx *c, const std::vector<double> &radii)
     int cap = W * A;
     while (cap > 16 && goal_smem_bytes(H, W, A, cap) > 158 * 1024) cap--;
     if (goal_smem_bytes(H, W, A, cap) > 158 * 1024) { c->err = "goal planner: search grid does not fit LDS"; return LSC_EINVAL; }
+    // ---- Key32: the search key as one 32-bit word (lsc_goal.hip).  The A* key is F = 10 (g + sqrt(d2)), g = steps, d2 = squared cell
+    // distance to the goal: integers.  The search only ever ORDERS keys and tests them for EQUALITY, so any map of (g, d2) that
+    // preserves both is as good as the double the reference computes.  Write sqrt(d2) = q + f, q = floor.  Then
+    //     key = ((g + q) << rb) | rank(f),      rank = position of f among the distinct fractional parts of sqrt(0 .. D)
+    // orders like g + sqrt(d2): integer parts first (f < 1), fractional parts by rank; and key equality <=> (g + q, f) equal <=>
+    // the reals are equal.  The reference's doubles order the same way: equal reals mean equal d2 (same double) or two perfect
+    // squares (every operation exact), and distinct reals differ by at least the smallest gap between distinct fractional parts,
+    // which is CHECKED below to exceed the rounding error of the reference's three roundings (a few ulp of F < 2^19) by orders
+    // of magnitude.  If the check fails, or the table does not fit next to a useful row capacity, Key64 (the double itself) is used.
+    c->h_fcode.clear();
+    c->fcode_rb = 0;
+    {
+        const long long D = (long long)(H - 1) * (H - 1) + (long long)(W - 1) * (W - 1) + (long long)(A - 1) * (A - 1);
+        int cap32 = W * A;
+        const int words = D < (1 << 16) ? (int)D + 1 : 0;
+        if (words > 0) {
+            while (cap32 > 16 && goal_smem_bytes(H, W, A, cap32, words) > 158 * 1024) cap32--;
+            if (goal_smem_bytes(H, W, A, cap32, words) > 158 * 1024 || cap32 < std::min(W * A, 192)) cap32 = 0;
+        }
+        if (words > 0 && cap32 > 0 && c->cfg.goal_search != 2) {
+            std::vector<std::pair<long double, int>> fr(words);
+            std::vector<uint32_t> q(words);
+            for (int d = 0; d < words; d++) {
+                uint32_t r = (uint32_t)std::sqrt((double)d);
+                while ((long long)r * r > d) r--;
+                while ((long long)(r + 1) * (r + 1) <= d) r++;
+                q[d] = r;
+                fr[d] = {(long long)r * r == d ? 0.0L : sqrtl((long double)d) - (long double)r, d};     // exact 0 for perfect squares
+            }
+            std::sort(fr.begin(), fr.end());
+            std::vector<uint32_t> rank(words);
+            long double min_gap = 1.0L;
+            uint32_t rk = 0;
+            for (int i = 0; i < words; i++) {
+                if (i > 0 && fr[i].first != fr[i - 1].first) { rk++; min_gap = std::min(min_gap, fr[i].first - fr[i - 1].first); }
+                rank[fr[i].second] = rk;
+            }
+            int rb = 1;
+            while ((1u << rb) <= rk) rb++;
+            // gaps are ~1 / D^2 (>= 1e-10 for D < 65536); long double resolves 1e-16 here; the reference's F carries < 1e-9 of rounding
+            // at most (ulp(2^19) = 6e-11, three roundings) against 10 x gap
+            const bool safe = min_gap > 1e-12L && 10.0L * min_gap > 50.0L * 6e-11L && rb <= 16;
+            // (with rb <= 16 and steps <= G_MAX = 32767, (steps + q) << rb stays below 2^32 - 1 = NONE)
+            if (safe) {
+                c->h_fcode.resize(words);
+                for (int d = 0; d < words; d++) c->h_fcode[d] = (q[d] << rb) | rank[d];
+                c->fcode_rb = rb;
+                cap = cap32;
+            }
+        }
+    }
     if (c->cfg.goal_row_cap > 0) cap = std::max(4, std::min(cap, c->cfg.goal_row_cap));   // explicit smaller capacity (tests force the overflow path)
     c->grid_row_cap = cap;
     // bucket counts of a growing std::unordered_map<uint_least32_t, T> (identity hash), from the container itself
@@ -644,10 +698,14 @@ static int build_goal_grid(lsc_ctx *c, const std::vector<double> &radii)
                                         (float)(c->grid_min[2] + k * res)};
                     if ((double)edt_at(p) < radii[r] + (double)margin) occ[r * C + (size_t)H * W * k + (size_t)W * i + j] = 1;
                 }
-    void *old[] = {c->d_edt, c->d_occ_static, c->d_goal_planned, c->d_goal_err, c->d_goal_flags, c->d_goal_exp, c->d_ray_stack};
+    void *old[] = {c->d_edt, c->d_occ_static, c->d_goal_planned, c->d_goal_err, c->d_goal_flags, c->d_goal_exp, c->d_ray_stack, c->d_fcode};
     for (void *p : old) if (p) (void)hipFree(p);
     c->d_edt = c->d_goal_planned = c->d_ray_stack = nullptr; c->d_occ_static = nullptr;
-    c->d_goal_err = c->d_goal_flags = c->d_goal_exp = nullptr;
+    c->d_goal_err = c->d_goal_flags = c->d_goal_exp = nullptr; c->d_fcode = nullptr;
+    if (!c->h_fcode.empty()) {
+        HIPCHK(c, hipMalloc(&c->d_fcode, sizeof(uint32_t) * c->h_fcode.size()));
+        HIPCHK(c, hipMemcpy(c->d_fcode, c->h_fcode.data(), sizeof(uint32_t) * c->h_fcode.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMalloc(&c->d_edt, sizeof(float) * c->h_edt.size()));
     HIPCHK(c, hipMemcpy(c->d_edt, c->h_edt.data(), sizeof(float) * c->h_edt.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_occ_static, occ.size()));
@@ -741,6 +799,8 @@ static int run_goal(lsc_ctx *c, const float *d_state, const float *&d_goal, cons
     g.row_cap = c->grid_row_cap;
     g.variant = c->cfg.goal_search == 1 ? 0 : goal_fast_slots(g.H, g.W, g.A, &g.jbits);
     if (g.variant == 0) g.jbits = 0;
+    g.fcode = nullptr; g.fcode_n = 0; g.fcode_rb = 0;
+    if (g.variant != 0 && c->d_fcode) { g.variant |= 8; g.fcode = c->d_fcode; g.fcode_n = (int)c->h_fcode.size(); g.fcode_rb = c->fcode_rb; }
     g.goal_out = c->d_goal_planned; g.err = c->d_goal_err; g.flags = c->d_goal_flags; g.expansions = c->d_goal_exp;
     g.path_out = c->d_goal_path; g.path_cap = c->goal_path_cap; g.path_len = c->d_goal_plen;
     g.ray_stack = c->d_ray_stack;

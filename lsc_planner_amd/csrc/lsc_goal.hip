@@ -20,6 +20,7 @@
 // minima are reduced with one lane per row, the line-of-sight tests of the path points run one point per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "lsc_kernels.h"
 
@@ -381,13 +382,6 @@ struct FGeoL {
     int n_nb;
 };
 
-__device__ __forceinline__ double f_entry(const FGeoL &c, uint32_t e, int di2)
-{
-#pragma clang fp contract(off)
-    const int j = (int)(e & c.JM), z = (int)((e & KEY_MASK) >> c.JB);
-    const int dj = c.gj - j, dz = c.gz - z;
-    return 10.0 * (double)(e >> KEY_BITS) + 10.0 * sqrt((double)(di2 + dj * dj + dz * dz));
-}
 // the key the reference's container hashes: Node::get_id = H W z + W i + j
 __device__ __forceinline__ uint32_t ref_key(const FGeoL &c, uint32_t e, uint32_t Wi)
 {
@@ -458,49 +452,10 @@ __device__ void f_row_insert(const FGeoL &c, int i, uint32_t e, int &cnt, int &n
     cnt++;
 }
 
-// erase + deleteMin's rescan on a row of any length held in LDS
-__device__ void f_row_pop(const FGeoL &c, int i, uint32_t jz, int cnt, double &Fout, uint32_t &mout)
-{
-    uint32_t *row = c.rows + (size_t)i * c.cap;
-    const int di = c.gi - i, di2 = di * di;
-    int pos = -1;
-    double bf = 1e300;
-    uint32_t bsel = 0, bent = 0;
-    for (int base = 0; base < cnt; base += 64) {
-        const int p = base + c.lane;
-        uint32_t e = p < cnt ? row[p] : 0u;
-        if (pos < 0) {
-            const unsigned long long m = __ballot(p < cnt && (e & KEY_MASK) == jz);
-            if (m) pos = base + __ffsll((long long)m) - 1;
-        }
-        const bool moved = pos >= 0 && p >= pos;
-        if (moved) e = p + 1 < cnt ? row[p + 1] : 0u;
-        wsync();
-        if (moved && p < cnt - 1) row[p] = e;
-        if (p < cnt - 1) {
-            const double f = f_entry(c, e, di2);
-            const uint32_t sel = ((e >> KEY_BITS) << 16) | (uint32_t)p;
-            if (f < bf || (f == bf && sel >= bsel)) { bf = f; bsel = sel; bent = e; }
-        }
-        wsync();
-    }
-    Fout = 1e300; mout = 0;
-    if (cnt > 1) {
-        const double fmin = wave_min_d(bf);
-        const uint32_t sel = wave_max_u(bf == fmin ? bsel : 0u);
-        const unsigned long long own = __ballot(bf == fmin && bsel == sel);
-        mout = (uint32_t)__builtin_amdgcn_readlane((int)bent, __ffsll((long long)own) - 1);
-        Fout = fmin;
-    }
-}
-
 // ---- wave primitives of the register-resident search.  One wave alone on its CU issues an instruction every 5-8 cycles
 // whatever its kind (measured), so the search costs what its instruction count costs: the reductions are
 // 32-bit DPP chains (one fused v_min_u32_dpp per stage) over the two halves of F's bit pattern -- non-negative doubles
 // order like their bit patterns -- instead of v_min_f64 on moved copies.
-using FK = unsigned long long;                  // bit pattern of F (>= 0), ~0 for "no entry"
-constexpr FK FK_NONE = ~0ull;
-__device__ __forceinline__ FK fk_of(double f) { return (FK)__double_as_longlong(f); }
 // (the two wait states in front of every stage are the VALU-write -> DPP-read hazard of gfx9; lanes without a DPP source keep
 // their own value, so no identity is needed)
 __device__ __forceinline__ uint32_t wmin_u32(uint32_t v)
@@ -527,17 +482,6 @@ __device__ __forceinline__ uint32_t wmax_u32(uint32_t v)
         : "+v"(v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-// smallest F over the lanes, then the largest sel among those lanes (both uniform)
-__device__ __forceinline__ void argmin_f_sel(FK f, uint32_t sel, FK &fmin, uint32_t &smax)
-{
-    const uint32_t hi = (uint32_t)(f >> 32), lo = (uint32_t)f;
-    const uint32_t mh = wmin_u32(hi);
-    const bool c1 = hi == mh;
-    const uint32_t ml = wmin_u32(c1 ? lo : 0xffffffffu);
-    const bool c2 = c1 && lo == ml;
-    smax = wmax_u32(c2 ? sel : 0u);
-    fmin = ((FK)mh << 32) | ml;
-}
 // sqrt of a non-negative integer-valued double < 2^52: the instruction sequence the compiler emits for sqrt(double) without
 // its range scaling and class checks -- bit-identical to sqrt() on every integer below 2^22 (checked on the device)
 __device__ __forceinline__ double sqrt_int(double x)
@@ -551,19 +495,96 @@ __device__ __forceinline__ double sqrt_int(double x)
     d = __builtin_fma(-g, g, x); g = __builtin_fma(d, h, g);
     return x == 0.0 ? 0.0 : g;
 }
-// F = g + H of the reference (g = 10 steps, H = 10 sqrt(d2)); 10 steps is exact, so the fused form rounds like the sum
-__device__ __forceinline__ FK fk_entry(uint32_t steps, int d2)
-{
+// ---- the search key.  F = 10 (g + sqrt(d2)) with g = steps and d2 = squared cell distance to the goal, both integers; only its
+// ORDER and its TIES matter to the search (findMin, the rescan, addOpen's "not larger").  Two exact representations:
+//   Key64 : the bit pattern of the double the reference computes (non-negative doubles order like their bit patterns);
+//   Key32 : ((g + floor sqrt d2) << RB) + rank of frac(sqrt d2) among all d2 of the grid -- a table of one word per d2 in LDS,
+//           built on the host (lsc_abi.cpp: build_goal_grid, where the argument is spelled out and the minimal gap between
+//           distinct keys is checked): integer part first, fractional part by rank; two keys are equal exactly when the
+//           reals are, and then the doubles are too (equal d2, or two perfect squares).  Half the reduction work, no sqrt.
+struct Key64 {
+    using T = unsigned long long;
+    static constexpr T NONE = ~0ull;
+    __device__ __forceinline__ T entry(uint32_t steps, int d2) const
+    {
 #pragma clang fp contract(off)
-    const double h = 10.0 * sqrt_int((double)d2);
-    return fk_of(__builtin_fma(10.0, (double)steps, h));
-}
+        return (T)__double_as_longlong(__builtin_fma(10.0, (double)steps, 10.0 * sqrt_int((double)d2)));
+    }
+    // smallest key over the lanes, then the largest sel among those lanes (both uniform)
+    static __device__ __forceinline__ void argmin(T f, uint32_t sel, T &fmin, uint32_t &smax)
+    {
+        const uint32_t hi = (uint32_t)(f >> 32), lo = (uint32_t)f;
+        const uint32_t mh = wmin_u32(hi);
+        const bool c1 = hi == mh;
+        const uint32_t ml = wmin_u32(c1 ? lo : 0xffffffffu);
+        const bool c2 = c1 && lo == ml;
+        smax = wmax_u32(c2 ? sel : 0u);
+        fmin = ((T)mh << 32) | ml;
+    }
+    static __device__ __forceinline__ T lane_value(T v, int l)
+    {
+        return ((T)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    }
+};
+struct Key32 {
+    using T = uint32_t;
+    static constexpr T NONE = ~0u;
+    const uint32_t *tab;             // [d2] floor(sqrt d2) << rb | rank of the fractional part
+    int rb;
+    __device__ __forceinline__ T entry(uint32_t steps, int d2) const { return (steps << rb) + tab[d2]; }
+    static __device__ __forceinline__ void argmin(T f, uint32_t sel, T &fmin, uint32_t &smax)
+    {
+        fmin = wmin_u32(f);
+        smax = wmax_u32(f == fmin ? sel : 0u);
+    }
+    static __device__ __forceinline__ T lane_value(T v, int l) { return (T)__builtin_amdgcn_readlane((int)v, l); }
+};
+// (F = g + H of the reference with g = 10 steps, H = 10 sqrt(d2): 10 steps is exact, so Key64's fused form rounds like the sum)
 template <typename T>
 __device__ __forceinline__ T *uni_ptr(T *p)
 {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
+// erase + deleteMin's rescan on a row of any length held in LDS, in the search's key (the general routine of the register-resident
+// search: rows beyond 64 entries)
+template <typename KP>
+__device__ void f_row_pop_keyed(const FGeoL &c, const KP &key, int i, uint32_t jz, int cnt, typename KP::T &Fout, uint32_t &mout)
+{
+    using FK = typename KP::T;
+    uint32_t *row = c.rows + (size_t)i * c.cap;
+    const int di = c.gi - i, di2 = di * di;
+    int pos = -1;
+    FK bf = KP::NONE;
+    uint32_t bsel = 0, bent = 0;
+    for (int base = 0; base < cnt; base += 64) {
+        const int p = base + c.lane;
+        uint32_t e = p < cnt ? row[p] : 0u;
+        if (pos < 0) {
+            const unsigned long long m = __ballot(p < cnt && (e & KEY_MASK) == jz);
+            if (m) pos = base + __ffsll((long long)m) - 1;
+        }
+        const bool moved = pos >= 0 && p >= pos;
+        if (moved) e = p + 1 < cnt ? row[p + 1] : 0u;
+        wsync();
+        if (moved && p < cnt - 1) row[p] = e;
+        if (p < cnt - 1) {
+            const int dj = c.gj - (int)(e & c.JM), dz = c.gz - (int)((e & KEY_MASK) >> c.JB);
+            const FK f = key.entry(e >> KEY_BITS, di2 + dj * dj + dz * dz);
+            const uint32_t sel = ((e >> KEY_BITS) << 16) | (uint32_t)p;
+            if (f < bf || (f == bf && sel >= bsel)) { bf = f; bsel = sel; bent = e; }
+        }
+        wsync();
+    }
+    Fout = KP::NONE; mout = 0;
+    if (cnt > 1) {
+        uint32_t sel;
+        KP::argmin(bf, bsel, Fout, sel);
+        const unsigned long long own = __ballot(bf == Fout && bsel == sel);
+        mout = (uint32_t)__builtin_amdgcn_readlane((int)bent, __ffsll((long long)own) - 1);
+    }
 }
 
 // ISearch::startSearch on the register-resident rows.  NS = slots of row bookkeeping per lane (H <= 64 NS).  Out of line on
@@ -575,14 +596,18 @@ struct FGeo {
     int gi, gj, gz;
     int s0, s1, s2;                  // start cell
     int n_nb;
+    int tab_off, rb;                 // Key32: the key table in LDS and its rank bits
     int st_off, rows_off, tmp_off, nbs_off, nbm_off;     // byte offsets into the workgroup's LDS (a pointer passed through a call loses its address space)
     long long *prof;                 // PROF: [8] counters of this agent
 };
 
-template <int NS, bool PROF>
+template <int NS, bool PROF, bool C32>
 __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
 {
 #pragma clang fp contract(off)
+    using KP = typename std::conditional<C32, Key32, Key64>::type;
+    using FK = typename KP::T;
+    constexpr FK FK_NONE = KP::NONE;
     const int lane = (int)threadIdx.x;
     // everything uniform arrives in vector registers (calling convention): back to scalars
     const int H = uni(gin.H), W = uni(gin.W), A = uni(gin.A), HW = uni(gin.HW), cap = uni(gin.cap), JB = uni(gin.JB);
@@ -595,6 +620,8 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
     FGeoL c;
     c.H = H; c.W = W; c.A = A; c.HW = HW; c.cap = cap; c.lane = lane; c.JB = JB; c.JM = JM; c.gi = gi; c.gj = gj; c.gz = gz;
     c.st = st; c.rows = rows; c.tmp = tmp; c.nb_seq = nb_seq; c.nb_magic = nb_magic; c.n_nb = n_nb;
+    KP key;
+    if constexpr (C32) { key.tab = reinterpret_cast<const uint32_t *>(gsm + uni(gin.tab_off)); key.rb = uni(gin.rb); }
     int err = 0, expansions = 0;
     long long pc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 0-3 sections; 4/5 cycles / count of general pops; 6/7 of general insertions
     long long tk = 0;
@@ -615,7 +642,7 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
     auto get_f = [&](int i) {
         FK v = rF[0];
         if constexpr (NS > 1) { if (i >= 64) v = rF[1]; }
-        return ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), i & 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i & 63);
+        return KP::lane_value(v, i & 63);
     };
     auto put = [&](int i, FK F, uint32_t mn, uint32_t cn) {
 #pragma unroll
@@ -639,7 +666,7 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
         if (err) return done(false, 0u);
         if (lane == 0) st[HW * s2 + W * s0 + s1] = st_open(7, 0);
         const int di = gi - s0, dj = gj - s1, dz = gz - s2;
-        put(s0, fk_entry(0u, di * di + dj * dj + dz * dz), e0, pack_cn(1, nbi, nb));
+        put(s0, key.entry(0u, di * di + dj * dj + dz * dz), e0, pack_cn(1, nbi, nb));
         wsync();
     }
     auto slow_insert = [&](int i, uint32_t e, int &cnt, int &nbi, uint32_t &nb, uint32_t &nbm) {
@@ -662,7 +689,7 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
         }
         FK fmin;
         uint32_t sel;
-        argmin_f_sel(bf, bsel, fmin, sel);
+        KP::argmin(bf, bsel, fmin, sel);
         const int ci = (int)(sel & 0xffffu), cg = (int)(sel >> 16);
         const uint32_t cjz = get_u(rMn, ci) & KEY_MASK;
         const uint32_t ccn = get_u(rCn, ci);
@@ -690,17 +717,15 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
             if (lane < cntc) rowc[lane] = R;                                       // (the lanes in front of pos rewrite their own entry)
             if (cntc > 0) {
                 const int dj = gj - (int)(R & JM), dz = gz - (int)((R & KEY_MASK) >> JB);
-                const FK f = lane < cntc ? fk_entry(R >> KEY_BITS, dic2 + dj * dj + dz * dz) : FK_NONE;
+                const FK f = lane < cntc ? key.entry(R >> KEY_BITS, dic2 + dj * dj + dz * dz) : FK_NONE;
                 uint32_t w;
-                argmin_f_sel(f, ((R >> KEY_BITS) << 16) | (uint32_t)lane, Fc, w);
+                KP::argmin(f, ((R >> KEY_BITS) << 16) | (uint32_t)lane, Fc, w);
                 mnc = (uint32_t)__builtin_amdgcn_readlane((int)R, (int)(w & 63u));
             }
         } else {
-            double Fd;
             long long t0 = 0;
             if constexpr (PROF) t0 = (long long)__builtin_readcyclecounter();
-            f_row_pop(c, ci, cjz, ccnt, Fd, mnc);
-            Fc = cntc > 0 ? fk_of(Fd) : FK_NONE;
+            f_row_pop_keyed(c, key, ci, cjz, ccnt, Fc, mnc);
             if constexpr (PROF) { pc[4] += (long long)__builtin_readcyclecounter() - t0; pc[5]++; }
         }
         nopen--;
@@ -717,7 +742,7 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
         FK fs_l;
         {
             const int ei = gi - ni, ej = gj - nj, ez = gz - nz;
-            fs_l = fk_entry((uint32_t)ng, ei * ei + ej * ej + ez * ez);
+            fs_l = key.entry((uint32_t)ng, ei * ei + ej * ej + ez * ez);
         }
         // cell bytes of the node in one store: the popped cell is CLOSED, unseen neighbours are OPEN
         if ((lane == 6 && inb) || want_new) st[ncell] = (uint8_t)(lane == 6 ? (sv | ST_CLOSED) : (l_open | (((uint32_t)ng & 7u) << 5)));
@@ -743,7 +768,7 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
             auto other_row = [&](int d, int ri) {
                 const int rj = cj, rz = cz;
                 const uint32_t ne = (uint32_t)rj | ((uint32_t)rz << JB) | ((uint32_t)ng << KEY_BITS);
-                const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fs_l >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fs_l, d);
+                const FK fs = KP::lane_value(fs_l, d);
                 uint32_t *row = rows + ri * cap;
                 uint32_t cn = get_u(rCn, ri);
                 int cnt = (int)(cn & 1023u);
@@ -773,7 +798,7 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
                 mid &= mid - 1;
                 const int rj = cj + __builtin_amdgcn_readlane(l_dj, d), rz = cz + __builtin_amdgcn_readlane(l_dz, d);
                 const uint32_t ne = (uint32_t)rj | ((uint32_t)rz << JB) | ((uint32_t)ng << KEY_BITS);
-                const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fs_l >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fs_l, d);
+                const FK fs = KP::lane_value(fs_l, d);
                 if (__builtin_expect(rvalid && (uint32_t)cntc < ccn_lim, 1)) {
                     R = ins_reg(R, cntc, ccn_nbi, Wc, ne, rowc);
                     cntc++;
@@ -798,7 +823,7 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
                 const int rj = cj + __builtin_amdgcn_readlane(l_dj, d), rz = cz + __builtin_amdgcn_readlane(l_dz, d);
                 const uint32_t njz = (uint32_t)rj | ((uint32_t)rz << JB);
                 const uint32_t ne = njz | ((uint32_t)ng << KEY_BITS);
-                const FK fs = ((FK)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fs_l >> 32), d) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fs_l, d);
+                const FK fs = KP::lane_value(fs_l, d);
                 const bool same = ri == ci;
                 uint32_t *row = rows + ri * cap;
                 const uint32_t Wi = (uint32_t)(W * ri);
@@ -866,7 +891,7 @@ __device__ __attribute__((noinline)) unsigned long long search_fast(FGeo gin)
 // (A cooperative variant -- four waves per agent, the rescan, the same-row and the other-row insertions on different SIMDs, two
 // barriers per node -- was built and measured in round 3: it returned the same paths at the same 28.5 ms per tick on the tiled
 // forest, because every wave has to repeat findMin and the hand-overs cost what the split saves; commit cda8913)
-template <int NS, bool PROF>
+template <int NS, bool PROF, bool C32>
 __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
 {
 #pragma clang fp contract(off)
@@ -880,6 +905,7 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     long long tk0 = 0;
     auto ktick = [&](int slot) { if constexpr (PROF) { const long long t = (long long)__builtin_readcyclecounter(); pc[slot] += t - tk0; tk0 = t; } };
     if constexpr (PROF) tk0 = (long long)__builtin_readcyclecounter();
+    int tab_off = 0;
     Ctx c;
     c.H = a.H; c.W = a.W; c.A = a.A; c.HW = a.H * a.W; c.C = a.H * a.W * a.A; c.cap = a.row_cap; c.lane = lane;
     c.nb_seq = a.nb_seq; c.nb_magic = a.nb_magic; c.n_nb = a.n_nb; c.err = 0;
@@ -900,6 +926,12 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
         uint32_t *nbm = reinterpret_cast<uint32_t *>(gsm + off); off += sizeof(uint32_t) * 16;
         if (tid < 16) { nbs[tid] = a.nb_seq[tid]; nbm[tid] = a.nb_magic[tid]; }
         c.nb_seq = nbs; c.nb_magic = nbm;
+        if constexpr (C32) {                                  // Key32's table: one word per squared distance of the grid
+            off = (off + 512 + 15) & ~(size_t)15;             // (behind the slack the unpredicated row loads may touch)
+            tab_off = (int)off;
+            uint32_t *tab = reinterpret_cast<uint32_t *>(gsm + off);
+            for (int i = tid; i < a.fcode_n; i += NT) tab[i] = a.fcode[i];
+        }
     }
     const float *pos = a.state + 9 * qi;
     const float *goal_i = a.goal + 3 * qi;
@@ -1047,11 +1079,12 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
             FGeo f;
             f.H = c.H; f.W = c.W; f.A = c.A; f.HW = c.HW; f.cap = c.cap; f.JB = a.jbits;
             f.gi = c.gi; f.gj = c.gj; f.gz = c.gz; f.s0 = s[0]; f.s1 = s[1]; f.s2 = s[2]; f.n_nb = c.n_nb;
+            f.tab_off = tab_off; f.rb = a.fcode_rb;
             f.st_off = (int)(c.st - gsm); f.rows_off = (int)(reinterpret_cast<unsigned char *>(c.rows) - gsm);
             f.tmp_off = (int)(reinterpret_cast<unsigned char *>(c.tmp) - gsm);
             f.nbs_off = (int)(reinterpret_cast<const unsigned char *>(c.nb_seq) - gsm); f.nbm_off = (int)(reinterpret_cast<const unsigned char *>(c.nb_magic) - gsm);
             f.prof = PROF ? a.prof + (size_t)qi * 16 : nullptr;
-            const unsigned long long r = search_fast<NS, PROF>(f);
+            const unsigned long long r = search_fast<NS, PROF, C32>(f);
             expansions += (int)(unsigned)r;
             end_key = (uint32_t)(r >> 32) & KEY_MASK;
             found = ((r >> 52) & 1ull) != 0;
@@ -1272,13 +1305,14 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     }
 }
 
-size_t goal_smem_bytes(int H, int W, int A, int cap)
+size_t goal_smem_bytes(int H, int W, int A, int cap, int key_words)
 {
     size_t b = ((size_t)H * W * A + 15) & ~(size_t)15;
     b += sizeof(double) * (size_t)H + sizeof(uint32_t) * (size_t)H + sizeof(uint32_t) * (size_t)cap;
     b += sizeof(uint32_t) * (size_t)H * cap + 2 * sizeof(uint16_t) * (size_t)H;
     b += 4 + 2 * 16 * sizeof(int);                            // bucket-count / magic tables
     b += 512;                                                 // the register-resident search reads 65 entries of a row unpredicated
+    b += 16 + sizeof(uint32_t) * (size_t)key_words;           // Key32's table (0 words: Key64)
     b += 2 * sizeof(uint32_t) * (size_t)H;                    // per-row bucket count and magic
     return (b + 15) & ~(size_t)15;
 }
@@ -1297,9 +1331,11 @@ int goal_fast_slots(int H, int W, int A, int *jbits)
 
 hipError_t init_device_goal_kernel()
 {
-    const void *k[] = {reinterpret_cast<const void *>(&lsc_goal_kernel<0, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, false>),
-                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<1, true>),
-                       reinterpret_cast<const void *>(&lsc_goal_kernel<2, true>)};
+    const void *k[] = {reinterpret_cast<const void *>(&lsc_goal_kernel<0, false, false>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<1, false, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<2, false, false>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<1, true, false>), reinterpret_cast<const void *>(&lsc_goal_kernel<2, true, false>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<1, false, true>), reinterpret_cast<const void *>(&lsc_goal_kernel<2, false, true>),
+                       reinterpret_cast<const void *>(&lsc_goal_kernel<1, true, true>), reinterpret_cast<const void *>(&lsc_goal_kernel<2, true, true>)};
     for (const void *f : k) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -1310,17 +1346,21 @@ hipError_t init_device_goal_kernel()
 hipError_t launch_goal(const GoalArgs &a, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;
-    const size_t smem = goal_smem_bytes(a.H, a.W, a.A, a.row_cap);
+    const size_t smem = goal_smem_bytes(a.H, a.W, a.A, a.row_cap, (a.variant & 8) ? a.fcode_n : 0);
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     // variant: 0 the general search (row bookkeeping in LDS, any grid), 1 / 2 the register-resident search (H <= 64 / 128
     // rows and (j, z) packed into 17 bits: goal_fast_slots() says which one a grid admits); a.prof != null selects the
     // instrumented build of the register-resident search (section cycle counters)
     const int slots = a.variant & 3;
-    if (slots == 2 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<2, true>), dim3(a.count), dim3(64), smem, st, a);
-    else if (slots == 1 && a.prof) hipLaunchKernelGGL((lsc_goal_kernel<1, true>), dim3(a.count), dim3(64), smem, st, a);
-    else if (slots == 2) hipLaunchKernelGGL((lsc_goal_kernel<2, false>), dim3(a.count), dim3(64), smem, st, a);
-    else if (slots == 1) hipLaunchKernelGGL((lsc_goal_kernel<1, false>), dim3(a.count), dim3(64), smem, st, a);
-    else hipLaunchKernelGGL((lsc_goal_kernel<0, false>), dim3(a.count), dim3(64), smem, st, a);
+    const bool prof = a.prof != nullptr, c32 = (a.variant & 8) != 0 && a.fcode != nullptr;
+    const dim3 g(a.count), b(64);
+#define LSC_GOAL_LAUNCH(NS_, PR_, C_) hipLaunchKernelGGL((lsc_goal_kernel<NS_, PR_, C_>), g, b, smem, st, a)
+    if (slots == 0) LSC_GOAL_LAUNCH(0, false, false);
+    else if (slots == 1) { if (c32) { if (prof) LSC_GOAL_LAUNCH(1, true, true); else LSC_GOAL_LAUNCH(1, false, true); }
+                           else { if (prof) LSC_GOAL_LAUNCH(1, true, false); else LSC_GOAL_LAUNCH(1, false, false); } }
+    else { if (c32) { if (prof) LSC_GOAL_LAUNCH(2, true, true); else LSC_GOAL_LAUNCH(2, false, true); }
+           else { if (prof) LSC_GOAL_LAUNCH(2, true, false); else LSC_GOAL_LAUNCH(2, false, false); } }
+#undef LSC_GOAL_LAUNCH
     return hipGetLastError();
 }
 

@@ -119,7 +119,9 @@ struct GoalArgs {
     int nb_seq[16];
     uint32_t nb_magic[16];                      // floor(2^32 / nb_seq[k])
     int row_cap;                                // LDS capacity of one OPEN row (entries)
-    int variant, jbits;                         // search variant (see launch_goal) and the bits of j in a register-search entry
+    int variant, jbits;                         // search variant (see launch_goal: slots | 8 = Key32) and the bits of j in a register-search entry
+    const uint32_t *fcode;                      // Key32 table [fcode_n]: floor(sqrt d2) << fcode_rb | rank of frac(sqrt d2), or null
+    int fcode_n, fcode_rb;
     float *goal_out;                            // [N][3] current_goal_position
     int *err;                                   // [N] 0 ok, 1 capacity (row / path / g overflow), 2 ray stack overflow
     int *flags;                                 // optional [N]: bit 0 retreat rule, bit 1 search without priorities used
@@ -132,7 +134,7 @@ struct GoalArgs {
     const unsigned char *ever;                  // [N] persistent "was seen off its plan" flags
     long long *prof;                            // optional [N][8] section cycle counters (selects the instrumented kernel)
 };
-size_t goal_smem_bytes(int H, int W, int A, int cap);
+size_t goal_smem_bytes(int H, int W, int A, int cap, int key_words = 0);
 int goal_fast_slots(int H, int W, int A, int *jbits);
 hipError_t launch_goal(const GoalArgs &a, hipStream_t st);
 

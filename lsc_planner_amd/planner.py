@@ -42,7 +42,7 @@ class PlannerConfig:
     gap_tolerance: float = 1e-9     # interior point: relative duality gap at the optimum
     world_dimension: int = 3        # world/dimension: 2 = planar goal grid at z = world_z_2d
     world_z_2d: float = 1.0         # world/z_2d
-    goal_search: str = "auto"      # goal planner's grid search: "auto" (register-resident when the grid admits it) or "general"
+    goal_search: str = "auto"      # goal planner's grid search: "auto" (register-resident, 32-bit keys when their table fits), "general", "key64" (register-resident, the double as key)
     comm: tuple = None              # (world_size, rank, id bytes from comm_unique_id()): agent-sharded multi-GPU over RCCL
 
 
@@ -89,7 +89,7 @@ class SwarmPlanner:
         c.reset_threshold = self.cfg.reset_threshold
         c.gap_tolerance = self.cfg.gap_tolerance
         c.world_dimension, c.world_z_2d = int(self.cfg.world_dimension), float(self.cfg.world_z_2d)
-        c.goal_search = {"auto": 0, "general": 1}[self.cfg.goal_search]
+        c.goal_search = {"auto": 0, "general": 1, "key64": 2}[self.cfg.goal_search]
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:

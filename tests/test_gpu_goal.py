@@ -149,7 +149,8 @@ def test_open_row_overflow_is_reported_as_status_5(L):
     assert (g["traj"][over] == 0).all()
 
 
-def test_register_resident_search_returns_the_general_search(L, search="auto"):
+@pytest.mark.parametrize("search", ["auto", "key64"])
+def test_register_resident_search_returns_the_general_search(L, search):
     """The register-resident search emulates the same containers as the general search: goals, paths, flags and the number of expanded nodes must be identical, tick after tick -- on a
     3-D forest (rows up to ~60 entries), on the 2 x 2 tiled forest (67 rows: two bookkeeping slots per lane, rows beyond 64
     entries, rehashes) and with a tiny row capacity (the capacity error must surface in the same agents)."""
