@@ -277,6 +277,11 @@ int lsc_phase_profile(lsc_ctx *ctx, int enable, long long *out);
  * neighbour screening, insertions; of those: cycles and count of the pops and of the insertions that took the general LDS
  * routines (rows beyond 64 entries, rehashes); the rest is reserved. */
 int lsc_goal_profile(lsc_ctx *ctx, int enable, long long *out);
+/* lsc_general_profile: sections of lsc_general_kernel (BVC / slack modes / disturbed agents), collected while
+ * lsc_phase_profile is enabled and cleared with it; out[N][16] shader cycles: set-up, start, residual pass, row reduction,
+ * assembly, factorization, solves, affine pass, corrector right-hand side, its reduction and assembly, step; [12] the
+ * iterations and [13] the solves of the agent. */
+int lsc_general_profile(lsc_ctx *ctx, long long *out);
 int lsc_solver_residuals(lsc_ctx *ctx, double *out);
 /* QP failure forensics (TrajOptimizer::solve exports the model it could not solve: log/QPmodel.lp, src/traj_optimizer.cpp:99-153).
  * Writes the QP of `agent` as the LAST host-buffer tick (lsc_replan_tick / lsc_replan_tick_all) posed it, in CPLEX LP format with

@@ -554,8 +554,8 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMalloc(&c->d_obs_bound, sizeof(float) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * PROF_PHASES * (size_t)N));
-    HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * PROF_PHASES * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));          // [N] plan kernel, [N] general kernel
+    HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_dbg, sizeof(double) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_dbg, 0, sizeof(double) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (size_t)N));
@@ -1234,8 +1234,20 @@ int lsc_phase_profile(lsc_ctx *c, int enable, long long *out)
     if (out) HIPCHK(c, hipMemcpy(out, c->d_prof, sizeof(long long) * PROF_PHASES * (size_t)c->N, hipMemcpyDeviceToHost));
     if (enable >= 0) {
         c->profiling = enable != 0;
-        HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * PROF_PHASES * (size_t)c->N));
+        HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * 2 * PROF_PHASES * (size_t)c->N));
     }
+    return LSC_OK;
+}
+
+// Diagnostics: section profile of lsc_general_kernel (the alternate planner modes), collected while lsc_phase_profile is
+// enabled and cleared with it.  out receives [N][16] shader cycles: set-up, start, then per interior-point section (residual
+// pass, row reduction, assembly, factorization, both solves, affine pass, corrector right-hand side, its reduction and
+// assembly, step), the iteration count and the number of solves of the agent.
+int lsc_general_profile(lsc_ctx *c, long long *out)
+{
+    if (!c || c->N == 0 || !out) return LSC_EINVAL;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, c->d_prof + PROF_PHASES * (size_t)c->N, sizeof(long long) * PROF_PHASES * (size_t)c->N, hipMemcpyDeviceToHost));
     return LSC_OK;
 }
 

@@ -37,7 +37,9 @@ constexpr int GW = GT / 64;
 constexpr int PMAX = 3 * GNYA + 2 * M;      // 45 + 10
 constexpr int KL = PMAX + 1;       // leading dimension of the dense matrices in LDS
 constexpr int NBK = 27;            // control points that carry collision rows
-constexpr int SEG_E = 171;         // symmetric 18 x 18 block of one segment (6 control points x 3 axes)
+constexpr int SEG_E = 171;
+// sections of lsc_general_profile
+enum { GP_SETUP = 0, GP_START, GP_RESID, GP_REDUCE, GP_ASSEMBLE, GP_FACTOR, GP_SOLVE, GP_AFFINE, GP_CORR_RHS, GP_REDUCE2, GP_ASSEMBLE2, GP_STEP, GP_ITERS, GP_AGENTS };         // symmetric 18 x 18 block of one segment (6 control points x 3 axes)
 
 struct GS {
     double x[96], dx[96];
@@ -65,7 +67,9 @@ struct GS {
     float pinit[NV];
     float goalf[3];
     unsigned char avalid[AXROWS];
-    int tseg, ok, any_slack;
+    double reachL[3][28], reachU[3][28];   // per axis: bounds of c_{m,i} - c_{0,2} after K = 5m+i-2 steps (row pruning, as in phase B of lsc_plan_kernel)
+    int wkept[GW];
+    int tseg, ok, any_slack, nk;
 };
 
 __device__ __forceinline__ double wsum(double v)
@@ -144,6 +148,31 @@ __device__ __forceinline__ double ax_x(const double *x, int type, int k, int t)
     }
 }
 
+// Per-workgroup row workspace (per-row state of the interior point, collision rows of all obstacles).  As much of it as
+// fits behind the solver state lives in LDS (all but one array at N = 64), the rest in HBM: the row passes are chains of
+// dependent loads, an order of magnitude shorter out of LDS than out of L2.  The code is the same either way (flat
+// addressing).
+__host__ __device__ inline size_t ws_main_bytes(int N)
+{
+    const size_t nob = N - 1 > 1 ? N - 1 : 1;
+    const size_t RT = AXROWS + 2 * M + NBK * nob + M * nob;
+    size_t b = sizeof(double) * (4 * RT + NBK * nob + 5 * M * nob) + sizeof(float) * 3 * M * nob + nob * (1 + NBK + M) + 16 * 14;
+    return (b + 255) & ~(size_t)255;
+}
+// + the staging area of the row build (rows of all obstacles before the compaction)
+__host__ __device__ inline size_t ws_bytes_of(int N)
+{
+    const size_t nob = N - 1 > 1 ? N - 1 : 1;
+    size_t b = ws_main_bytes(N) + ((12 * M * nob + 15) & ~(size_t)15) + sizeof(double) * NBK * nob + ((NBK * nob + 15) & ~(size_t)15) + 2 * nob + 16;
+    return (b + 255) & ~(size_t)255;
+}
+__host__ __device__ inline size_t gs_bytes() { return (sizeof(GS) + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t ws_lds_bytes(int N)
+{
+    const size_t room = 160 * 1024 - gs_bytes(), all = ws_main_bytes(N);
+    return all < room ? all : room;
+}
+
 }  // namespace
 
 // (noinline: the kernel below must be able to leave before this function's frame -- it keeps part of its state in
@@ -156,7 +185,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     const Model &md = *a.model;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = a.first + al;
-    const int N = a.N, n_obs = N - 1, nob = n_obs > 0 ? n_obs : 1;
+    const int N = a.N, n_all = N - 1, nob_all = n_all > 0 ? n_all : 1;
     const int nya = gm.nya, P0 = 3 * nya;
     const int nu = a.slack_mode == 1 ? 2 * M : 0;
     const int P = P0 + nu;
@@ -164,31 +193,6 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     const bool bvc = a.planner_mode == 1;
     const float dtf = (float)md.dt;
     const double hv = md.hv_scale, ha = md.ha_scale;
-
-    // ---- workspace carve-up (HBM): per-row state of the interior point, collision rows of all obstacles
-    const int NCL = NBK * nob, NGR = M * nob;
-    const int US0 = AXROWS, CL0 = AXROWS + 2 * M, GS0 = CL0 + NCL, RT = GS0 + NGR;
-    // Each array goes to LDS while there is room (most latency-critical first: the ones the per-control-point reductions
-    // walk obstacle by obstacle), else to the workgroup's HBM workspace; the code below only sees flat pointers.
-    auto take = [&](size_t bytes) -> unsigned char * {
-        bytes = (bytes + 15) & ~(size_t)15;
-        unsigned char *p;
-        if (bytes <= lds_ws_bytes) { p = lds_ws; lds_ws += bytes; lds_ws_bytes -= bytes; }
-        else { p = wsb; wsb += bytes; }
-        return p;
-    };
-    float *nrm = reinterpret_cast<float *>(take(sizeof(float) * 3 * NGR));              // [NGR][3]
-    unsigned char *slk = take(nob);                                                     // [nob]
-    double *rt1 = reinterpret_cast<double *>(take(sizeof(double) * RT));
-    double *rt2 = reinterpret_cast<double *>(take(sizeof(double) * RT));
-    double *rz = reinterpret_cast<double *>(take(sizeof(double) * RT));
-    double *crhs = reinterpret_cast<double *>(take(sizeof(double) * NCL));              // [NCL]   d + n.q of a collision row
-    double *ev = reinterpret_cast<double *>(take(sizeof(double) * NGR));                // [NGR]   group slack variables
-    double *dev = reinterpret_cast<double *>(take(sizeof(double) * NGR));
-    double *Dg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
-    double *iDg = reinterpret_cast<double *>(take(sizeof(double) * NGR));               // 1 / D_g
-    double *qg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
-    double *rs = reinterpret_cast<double *>(take(sizeof(double) * RT));
 
     auto block_reduce = [&](double v0, double v1, double v2, double v3, int op0, int op1, int op2, int op3) {
         auto wr = [&](double v, int op) { return op == 0 ? wsum(v) : (op == 1 ? wmax(v) : wmin(v)); };
@@ -205,6 +209,12 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         __syncthreads();
     };
 
+    // optional section profile (lsc_general_profile): shader cycles seen by lane 0 between the stamps
+    long long *const gp = a.prof ? a.prof + ((size_t)N + qi) * PROF_PHASES : nullptr;
+    long long tk = gp ? (long long)__builtin_readcyclecounter() : 0;
+    auto gstamp = [&](int slot) {
+        if (gp && tid == 0) { const long long t = (long long)__builtin_readcyclecounter(); gp[slot] += t - tk; tk = t; }
+    };
     // ------------------------------------------------------------------ setup
     const bool own_now = disturbed_now(a, qi);
     const bool ever_i = a.ever ? (a.ever[qi] != 0) : false;
@@ -272,16 +282,36 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         S.avalid[sl] = valid ? 1 : 0;
         S.ah[sl] = h;
     }
-    // ---- collision rows of every obstacle (no pruning here): LSC via GJK, or the BVC half-space
+    // ---- collision rows of every obstacle: LSC via GJK, or the BVC half-space.  Rows that cannot be active inside the
+    // reachable box of their control point are redundant (the test of lsc_plan_kernel's phase B; it rests on the velocity and
+    // acceleration rows being hard, so not with DYNAMICALLIMIT's slack on them; a slack variable on the row only relaxes it
+    // further).  Obstacles without an active row are left out altogether: the arrays below are per KEPT obstacle, in
+    // increasing order of the obstacle index.
+    const bool prune = md.prune != 0 && a.slack_mode != 1 && !a.out_normal;
+    // staging area (HBM, behind the fallback workspace): rows of all obstacles before the compaction
+    float *t_nrm = reinterpret_cast<float *>(wsb + ws_main_bytes(N));                                  // [n_all * M][3]
+    double *t_crhs = reinterpret_cast<double *>(wsb + ws_main_bytes(N) + (((size_t)12 * M * nob_all + 15) & ~(size_t)15));   // [n_all][NBK]
+    unsigned char *t_act = reinterpret_cast<unsigned char *>(t_crhs + (size_t)NBK * nob_all);         // [n_all][NBK]
+    unsigned short *omap = reinterpret_cast<unsigned short *>(t_act + (((size_t)NBK * nob_all + 15) & ~(size_t)15));   // [kept] -> obstacle
+    if (tid < 3) {
+        const int k = tid;
+        const double V = a.vmax[3 * qi + k] * hv, A = a.amax[3 * qi + k] * ha;
+        const double d0 = S.s0[k][2] - S.s0[k][1];
+        double lo = 0.0, hi = 0.0;
+        S.reachL[k][0] = 0.0; S.reachU[k][0] = 0.0;
+        for (int j = 1; j < 28; j++) {
+            lo += fmax(-V, d0 - (double)j * A) - 1e-9;
+            hi += fmin(V, d0 + (double)j * A) + 1e-9;
+            S.reachL[k][j] = lo; S.reachU[k][j] = hi;
+        }
+    }
+    __syncthreads();
+    auto in_set_of = [&](int qj) {
+        return a.slack_mode == 2 || (a.slack_mode == 0 && (ever_i || own_now || (a.ever && a.ever[qj]) || disturbed_now(a, qj)));
+    };
     {
         const double r_a = a.radius[qi], dw_a = a.downwash[qi];
-        for (int oi = tid; oi < n_obs; oi += GT) {
-            const int qj = oi < qi ? oi : oi + 1;
-            const bool in_set = a.slack_mode == 2 ||
-                                (a.slack_mode == 0 && (ever_i || own_now || (a.ever && a.ever[qj]) || disturbed_now(a, qj)));
-            slk[oi] = in_set ? 1 : 0;
-        }
-        for (int u = tid; u < n_obs * M; u += GT) {
+        for (int u = tid; u < n_all * M; u += GT) {
             const int oi = u / M, m = u % M;
             const int qj = oi < qi ? oi : oi + 1;
             F3 pa[6], po[6];
@@ -307,32 +337,123 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 lsc_segment(pa, po, downwash, r_o + r_a, n, d);
             }
             if (a.out_normal) {
-                size_t o = ((size_t)al * n_obs + oi) * M + m;
+                size_t o = ((size_t)al * n_all + oi) * M + m;
                 a.out_normal[o * 3] = n.x; a.out_normal[o * 3 + 1] = n.y; a.out_normal[o * 3 + 2] = n.z;
 #pragma unroll
                 for (int i = 0; i < 6; i++) a.out_d[o * 6 + i] = d[i];
             }
-            nrm[3 * u] = n.x; nrm[3 * u + 1] = n.y; nrm[3 * u + 2] = n.z;
+            t_nrm[3 * u] = n.x; t_nrm[3 * u + 1] = n.y; t_nrm[3 * u + 2] = n.z;
+            const double nx = (double)n.x, ny = (double)n.y, nz = (double)n.z;
+            const double centre = nx * S.s0[0][2] + ny * S.s0[1][2] + nz * S.s0[2][2];
+            const double (*rx)[28] = nx >= 0.0 ? S.reachL : S.reachU, (*ry)[28] = ny >= 0.0 ? S.reachL : S.reachU,
+                         (*rzb)[28] = nz >= 0.0 ? S.reachL : S.reachU;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const int cp = m * NC + i;
                 if (cp < 3) continue;
                 double r = d[i];
-                r += (double)n.x * (double)po[i].x;
-                r += (double)n.y * (double)po[i].y;
-                r += (double)n.z * (double)po[i].z;
-                crhs[oi * NBK + cp - 3] = r;
+                r += nx * (double)po[i].x;
+                r += ny * (double)po[i].y;
+                r += nz * (double)po[i].z;
+                t_crhs[oi * NBK + cp - 3] = r;
+                bool on = m < ncs;
+                if (on && prune) {
+                    const int K = 5 * m + i - 2;             // smallest n.c over the reachable box of c_{m,i}
+                    const double worst = centre + nx * rx[0][K] + ny * ry[1][K] + nz * rzb[2][K];
+                    if (worst >= r + 1e-6) on = false;
+                }
+                t_act[oi * NBK + cp - 3] = on ? 1 : 0;
             }
         }
     }
+    __threadfence_block();
+    __syncthreads();
+    // kept obstacles, in order: ballot ranks per wave, wave offsets through LDS
+    {
+        int base = 0;
+        for (int o0 = 0; o0 < n_all; o0 += GT) {
+            const int oi = o0 + tid;
+            bool keep = false;
+            if (oi < n_all) {
+                if (!prune) keep = true;
+                else
+                    for (int c = 0; c < NBK; c++) keep |= t_act[oi * NBK + c] != 0;
+            }
+            const unsigned long long mk = __ballot(keep);
+            if (lane == 0) S.wkept[wave] = __popcll(mk);
+            __syncthreads();
+            int off = base;
+            for (int w = 0; w < wave; w++) off += S.wkept[w];
+            if (keep) omap[off + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)oi;
+            int tot = 0;
+            for (int w = 0; w < GW; w++) tot += S.wkept[w];
+            base += tot;
+            __syncthreads();
+        }
+        if (tid == 0) S.nk = base;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int n_obs = S.nk, nob = n_obs > 0 ? n_obs : 1;
+    // ---- workspace carve-up: per-row state of the interior point, collision rows of the kept obstacles
+    const int NCL = NBK * nob, NGR = M * nob;
+    const int US0 = AXROWS, CL0 = AXROWS + 2 * M, GS0 = CL0 + NCL, RT = GS0 + NGR;
+    // Each array goes to LDS while there is room (most latency-critical first: the ones the per-control-point reductions
+    // walk obstacle by obstacle), else to the workgroup's HBM workspace; the code below only sees flat pointers.
+    auto take = [&](size_t bytes) -> unsigned char * {
+        bytes = (bytes + 15) & ~(size_t)15;
+        unsigned char *p;
+        if (bytes <= lds_ws_bytes) { p = lds_ws; lds_ws += bytes; lds_ws_bytes -= bytes; }
+        else { p = wsb; wsb += bytes; }
+        return p;
+    };
+    float *nrm = reinterpret_cast<float *>(take(sizeof(float) * 3 * NGR));              // [NGR][3]
+    unsigned char *slk = take(nob);                                                     // [nob]
+    unsigned char *cact = take((size_t)NBK * nob);                                      // [NCL] row is active
+    unsigned char *gact = take((size_t)M * nob);                                        // [NGR] group has an active row
+    double *rt1 = reinterpret_cast<double *>(take(sizeof(double) * RT));
+    double *rt2 = reinterpret_cast<double *>(take(sizeof(double) * RT));
+    double *rz = reinterpret_cast<double *>(take(sizeof(double) * RT));
+    double *crhs = reinterpret_cast<double *>(take(sizeof(double) * NCL));              // [NCL]   d + n.q of a collision row
+    double *ev = reinterpret_cast<double *>(take(sizeof(double) * NGR));                // [NGR]   group slack variables
+    double *dev = reinterpret_cast<double *>(take(sizeof(double) * NGR));
+    double *Dg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
+    double *iDg = reinterpret_cast<double *>(take(sizeof(double) * NGR));               // 1 / D_g
+    double *qg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
+    double *rs = reinterpret_cast<double *>(take(sizeof(double) * RT));
+
+    for (int oe = tid; oe < n_obs; oe += GT) {
+        const int oi = omap[oe];
+        slk[oe] = in_set_of(oi < qi ? oi : oi + 1) ? 1 : 0;
+    }
+    if (tid == 0 && n_obs == 0) slk[0] = 0;
+    for (int u = tid; u < n_obs * M; u += GT) {
+        const int oe = u / M, m = u % M, oi = omap[oe];
+        const float *tn = t_nrm + 3 * (oi * M + m);
+        nrm[3 * u] = tn[0]; nrm[3 * u + 1] = tn[1]; nrm[3 * u + 2] = tn[2];
+        unsigned char any = 0;
+        for (int i = 0; i < NC; i++) {
+            const int cp = m * NC + i;
+            if (cp >= 3) any |= t_act[oi * NBK + cp - 3];
+        }
+        gact[u] = any;
+    }
+    for (int c = tid; c < NCL; c += GT) {
+        const int oe = c / NBK, cpi = c % NBK;
+        const bool there = oe < n_obs;                                                   // (NCL is 27 even with nobody kept)
+        const int src = there ? omap[oe] * NBK + cpi : 0;
+        crhs[c] = there ? t_crhs[src] : 0.0;
+        cact[c] = there ? t_act[src] : 0;
+        rt1[CL0 + c] = 0.0; rt2[CL0 + c] = 0.0; rz[CL0 + c] = 0.0; rs[CL0 + c] = 1.0;     // rows left out stay zero in every sum
+    }
+    __syncthreads();
     if (tid == 0) {
         int any = 0;
-        for (int oi = 0; oi < n_obs; oi++) any |= (a.slack_mode == 2 || (a.slack_mode == 0 && (ever_i || own_now || (a.ever && a.ever[oi < qi ? oi : oi + 1]) ||
-                                                                                              disturbed_now(a, oi < qi ? oi : oi + 1)))) ? 1 : 0;
+        for (int oe = 0; oe < n_obs; oe++) any |= slk[oe];
         S.any_slack = any;
     }
     if (tid <= PMAX) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
-    for (int g = tid; g < NGR; g += GT) { ev[g] = 0.0; dev[g] = 0.0; }
+    for (int g = tid; g < NGR; g += GT) { ev[g] = 0.0; dev[g] = 0.0; Dg[g] = 1.0; iDg[g] = 0.0; qg[g] = 0.0; if (g >= n_obs * M) gact[g] = 0; }   // (groups without an active row stay like this)
     __syncthreads();
 
     const int tseg = S.tseg;
@@ -348,8 +469,8 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     // row bookkeeping ---------------------------------------------------------------------------------
     // kinds: axis slot sl in [0, AXROWS) (valid mask), slack sign rows US0 + j (DYNAMICALLIMIT), collision rows
     // CL0 + oi*27 + (cp-3) (segment < ncs), group sign rows GS0 + oi*M + m (slack obstacles, segment < ncs)
-    auto coll_valid = [&](int c) { return ((c % NBK + 3) / NC) < ncs; };
-    auto grp_valid = [&](int g) { return slk[g / M] != 0 && (g % M) < ncs; };
+    auto coll_valid = [&](int c) { return cact[c] != 0; };                         // (segment < ncs and not pruned)
+    auto grp_valid = [&](int g) { return slk[g / M] != 0 && gact[g] != 0; };
     // a_r . v for the three variable blocks (xv: control points, uv: explicit slack, gv: group slack)
     auto val_axis = [&](int sl, const double *xv, const double *uv) {
         const int type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV;
@@ -432,7 +553,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
             if (m < ncs)
                 for (int oi = 0; oi < n_obs; oi++) {
                     const float *n = nrm + 3 * (oi * M + m);
-                    const double w = unit_w ? 1.0 : rt1[CL0 + oi * NBK + cpi];
+                    const double w = unit_w ? (double)cact[oi * NBK + cpi] : rt1[CL0 + oi * NBK + cpi];
                     acc += w * (double)n[ia] * (double)n[ib];
                 }
             S.Ws[(cpi + 3) * 6 + c] = acc;
@@ -492,7 +613,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 const int cp = m * NC + i;
                 if (cp < 3) continue;
                 const int r = CL0 + oi * NBK + cp - 3;
-                sw += unit_w ? 1.0 : rt1[r]; svv += rt2[r]; szz += rz[r];
+                sw += unit_w ? (double)cact[r - CL0] : rt1[r]; svv += rt2[r]; szz += rz[r];
             }
             const double hq = wg_base * (double)(M - m);
             if (with_w) { const double dg = hq + sw + (unit_w ? 1.0 : rt1[GS0 + g]); Dg[g] = dg; iDg[g] = 1.0 / dg; }
@@ -514,8 +635,8 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
 #pragma unroll 4
                     for (int oi = 0; oi < n_obs; oi++) {                  // branch-free: the loads of several obstacles in flight
                         const float *n = nrm + 3 * (oi * M + m);
-                        const double w1 = unit_w ? 1.0 : rt1[CL0 + oi * NBK + m * NC + i1 - 3];
-                        const double w2 = unit_w ? 1.0 : rt1[CL0 + oi * NBK + m * NC + i2 - 3];
+                        const double w1 = unit_w ? (double)cact[oi * NBK + m * NC + i1 - 3] : rt1[CL0 + oi * NBK + m * NC + i1 - 3];
+                        const double w2 = unit_w ? (double)cact[oi * NBK + m * NC + i2 - 3] : rt1[CL0 + oi * NBK + m * NC + i2 - 3];
                         const double t = w1 * w2 * (double)n[k1] * (double)n[k2] * iDg[oi * M + m];
                         acc += slk[oi] ? t : 0.0;
                     }
@@ -528,7 +649,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
 #pragma unroll 4
                 for (int oi = 0; oi < n_obs; oi++) {
                     const int g = oi * M + m;
-                    const double w = unit_w ? 1.0 : rt1[CL0 + oi * NBK + cp - 3];
+                    const double w = unit_w ? (double)cact[oi * NBK + cp - 3] : rt1[CL0 + oi * NBK + cp - 3];
                     const double t = -w * (double)nrm[3 * g + k] * qg[g] * iDg[g];
                     acc += slk[oi] ? t : 0.0;
                 }
@@ -679,7 +800,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
             for (int i = 0; i < NC; i++) {
                 const int cp = m * NC + i;
                 if (cp < 3) continue;
-                const double w = S.sc[7] != 0.0 ? 1.0 : rt1[CL0 + oi * NBK + cp - 3];
+                const double w = S.sc[7] != 0.0 ? (double)cact[oi * NBK + cp - 3] : rt1[CL0 + oi * NBK + cp - 3];
                 mdx += -w * ((double)n[0] * S.dx[cp] + (double)n[1] * S.dx[SEGV + cp] + (double)n[2] * S.dx[2 * SEGV + cp]);
             }
             dev[g] = (qg[g] - mdx) / Dg[g];
@@ -711,6 +832,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     // ------------------------------------------------------------------ starts
     // Warm (from the third tick on): y = free control points of the shifted previous plan, every row centred on mu0 -- the
     // start of lsc_plan_kernel -- with the cold start (least-squares point, then shift) as fallback; cold only otherwise.
+    gstamp(GP_SETUP);
     int status = LSC_STATUS_INFEASIBLE_K, iters = 0, spent = 0;
     double obj = 0.0;
     bool can = true;
@@ -778,25 +900,29 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         }
 
         // -------------------------------------------------------------- Mehrotra predictor-corrector
+        gstamp(GP_START);
         const int max_iters = attempt == 0 ? 30 : 80;
         while (run) {
             if (iters >= max_iters) break;
             // residuals, weights, predictor right-hand side
-            double gp = 0.0, rpm = 0.0;
+            double gpart = 0.0, rpm = 0.0;
             for_rows([&](int r, double av, double, double h) {
                 const double sv = rs[r], zv = rz[r];
                 const double rp = av + sv - h, w = zv / sv;
                 rt1[r] = w; rt2[r] = w * rp;
-                gp += sv * zv; rpm = fmax(rpm, fabs(rp));
+                gpart += sv * zv; rpm = fmax(rpm, fabs(rp));
             });
-            block_reduce(gp, rpm, objective(), 0, 0, 1, 0, 0);
+            block_reduce(gpart, rpm, objective(), 0, 0, 1, 0, 0);
+            gstamp(GP_RESID);
             const double gap = S.sc[0], rpmax = S.sc[1];
             obj = S.sc[2];
             const double mu = gap / nrow;
             const bool gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
             if (!(gap == gap) || !(rpmax == rpmax)) break;
             reduce_rows(true, false);
+            gstamp(GP_REDUCE);
             assemble(true);
+            gstamp(GP_ASSEMBLE);
             {
                 double rda = tid < P ? fabs(S.dy[tid]) : 0.0;
                 for (int g = tid; g < NGR; g += GT)
@@ -804,11 +930,14 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 block_reduce(rda, 0, 0, 0, 1, 0, 0, 0);
                 if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
             }
-            if (!factor()) {
+            const bool fok = factor();
+            gstamp(GP_FACTOR);
+            if (!fok) {
                 if (rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj))) status = LSC_STATUS_OK_K;
                 break;
             }
             solve();
+            gstamp(GP_SOLVE);
             // affine step length and centring statistics
             double amin = 1.0, s1 = 0.0, s2 = 0.0;
             for_rows([&](int r, double av, double adv, double h) {
@@ -824,6 +953,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
             block_reduce(amin, s1, s2, dxa, 2, 0, 0, 1);
             const double aaff = S.sc[0], ss1 = S.sc[1], ss2 = S.sc[2], dxn = S.sc[3];
             block_reduce(xa, 0, 0, 0, 1, 0, 0, 0);
+            gstamp(GP_AFFINE);
             if (rpmax <= 1e-9 * hmax && gap_ok && dxn <= 1e-9 * fmax(1.0, S.sc[0])) { status = LSC_STATUS_OK_K; break; }
             const double mu_aff = (gap + aaff * ss1 + aaff * aaff * ss2) / nrow;
             double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
@@ -836,9 +966,13 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 rt2[r] = rt1[r] * rp - (rt2[r] - smu) / sv;
             });
             __syncthreads();
+            gstamp(GP_CORR_RHS);
             reduce_rows(false, false);
+            gstamp(GP_REDUCE2);
             assemble(false);
+            gstamp(GP_ASSEMBLE2);
             solve();
+            gstamp(GP_SOLVE);
             double amax = 1e300;
             for_rows([&](int r, double av, double adv, double h) {
                 const double sv = rs[r], zv = rz[r], w = rt1[r];
@@ -856,6 +990,8 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
             __syncthreads();
             compute_x(S.y, S.x, true);
             __syncthreads();
+            gstamp(GP_STEP);
+            if (gp && tid == 0) gp[GP_ITERS]++;
             iters++;
         }
 
@@ -883,6 +1019,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         const float v0 = ((c1 - c0) * fn) * finv, v1 = ((c2 - c1) * fn) * finv, a0 = ((v1 - v0) * fn1) * finv;
         a.state_next[9 * qi + k] = c0; a.state_next[9 * qi + 3 + k] = v0; a.state_next[9 * qi + 6 + k] = a0;
     }
+    if (gp && tid == 0) gp[GP_AGENTS]++;
     if (tid == 0) {
         if (status == LSC_STATUS_OK_K) a.cost[qi] = obj;
         a.status[qi] = status;
@@ -891,24 +1028,6 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         if (a.nrows) a.nrows[qi] = (int)nrow - 414 - nu;      // collision rows + group sign rows
     }
     __syncthreads();
-}
-
-// Per-workgroup row workspace (per-row state of the interior point, collision rows of all obstacles).  As much of it as
-// fits behind the solver state lives in LDS (all but one array at N = 64), the rest in HBM: the row passes are chains of
-// dependent loads, an order of magnitude shorter out of LDS than out of L2.  The code is the same either way (flat
-// addressing).
-__host__ __device__ inline size_t ws_bytes_of(int N)
-{
-    const size_t nob = N - 1 > 1 ? N - 1 : 1;
-    const size_t RT = AXROWS + 2 * M + NBK * nob + M * nob;
-    size_t b = sizeof(double) * (4 * RT + NBK * nob + 5 * M * nob) + sizeof(float) * 3 * M * nob + nob + 16 * 12;
-    return (b + 255) & ~(size_t)255;
-}
-__host__ __device__ inline size_t gs_bytes() { return (sizeof(GS) + 255) & ~(size_t)255; }
-__host__ __device__ inline size_t ws_lds_bytes(int N)
-{
-    const size_t room = 160 * 1024 - gs_bytes(), all = ws_bytes_of(N);
-    return all < room ? all : room;
 }
 
 // The agents of one workgroup, out of line: the argument block is copied into private memory HERE, not in the kernel's

@@ -304,6 +304,15 @@ class SwarmPlanner:
         self._check(self.L.lsc_goal_profile(self.ctx, enable, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
         return out
 
+    GENERAL_SECTIONS = ("setup", "start", "residual_pass", "row_reduce", "assemble", "factor", "solves", "affine_pass",
+                        "corrector_rhs", "row_reduce_2", "assemble_2", "step", "iterations", "solves_of_agent")
+
+    def general_profile(self):
+        """Sections of lsc_general_kernel, collected while phase_profile is enabled: [N][16] shader cycles / counts."""
+        out = np.zeros((self.N, 16), np.int64)
+        self._check(self.L.lsc_general_profile(self.ctx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
+        return out
+
     def dump_qp(self, agent, path):
         """TrajOptimizer::solve's failure export (log/QPmodel.lp): the agent's QP of the last plan() call as a CPLEX LP file."""
         self._check(self.L.lsc_dump_qp(self.ctx, int(agent), str(path).encode()))
