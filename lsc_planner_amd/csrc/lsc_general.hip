@@ -35,7 +35,7 @@ namespace {
 constexpr int GT = 256;            // lanes per agent
 constexpr int GW = GT / 64;
 constexpr int PMAX = 3 * GNYA + 2 * M;      // 45 + 10
-constexpr int KL = PMAX + 1;       // leading dimension of the dense matrices in LDS
+constexpr int KL = PMAX + 2;       // leading dimension of the dense matrices in LDS (57 doubles: rows of one column fall in different banks)
 constexpr int NBK = 27;            // control points that carry collision rows
 constexpr int SEG_E = 171;
 // sections of lsc_general_profile
@@ -146,6 +146,76 @@ __device__ __forceinline__ double ax_x(const double *x, int type, int k, int t)
     case 4: return xk[t + 2] - 2.0 * xk[t + 1] + xk[t];
     default: return -(xk[t + 2] - 2.0 * xk[t + 1] + xk[t]);
     }
+}
+
+// ---- dense K = L D L^T and the two substitutions, on wave 0 alone and OUT OF LINE: one body each, whatever the number of
+// call sites, with a register allocation of its own (inlined, the unrolled row of the factor pushed the whole kernel into
+// scratch and the scalar registers of the caller into vector lanes).  lane = row.  The factor runs right-looking in registers
+// (av[c] = K[lane][c]; step j: pivot through v_readlane, every later column k takes -l_j l_k d_j with l_k again a v_readlane:
+// ~PU^2/2 readlane + fma pairs, no square roots, no LDS traffic); L (strictly lower, zeros above) and 1/D go back to LDS once.
+// The substitutions hold the row / the column of L in registers -- loaded ahead of the dependent chain readlane -> fma, which
+// is all that remains on it.  PU: compile-time bound of the unrolled loops (45 without, 55 with the explicit slack variables);
+// rows and columns P..PU-1 are the identity (written once at set-up).  K is stored as a full symmetric matrix.
+extern __shared__ __align__(16) unsigned char gsm_general[];
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double lane_value(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+template <int PU>
+__device__ __attribute__((noinline)) void dense_factor_w0()
+{
+    GS &S = *reinterpret_cast<GS *>(gsm_general);
+    const int lane = (int)threadIdx.x & 63;
+    const int lr = lane < PU ? lane : PU - 1;
+    double av[PU];
+#pragma unroll
+    for (int c = 0; c < PU; c++) av[c] = S.K[lr * KL + c];
+    bool ok = true;
+    double myinv = 1.0;
+#pragma unroll
+    for (int j = 0; j < PU; j++) {
+        const double d = lane_value(av[j], j);
+        if (!(d > 0.0)) ok = false;
+        const double inv = 1.0 / (d > 0.0 ? d : 1.0);
+        const double l = av[j] * inv;                      // column j of L
+        if (lane == j) myinv = inv;
+#pragma unroll
+        for (int k = j + 1; k < PU; k++) av[k] = fma(-l, lane_value(av[j], k), av[k]);
+        av[j] = l;
+    }
+    if (lane < PU) {
+#pragma unroll
+        for (int c = 0; c < PU; c++) S.K[lr * KL + c] = c < lane ? av[c] : 0.0;
+        S.invd[lane] = myinv;
+    }
+    if (lane == 0) S.ok = ok ? 1 : 0;
+}
+template <int PU>
+__device__ __attribute__((noinline)) void dense_solve_w0(int P_in)
+{
+    GS &S = *reinterpret_cast<GS *>(gsm_general);
+    const int lane = (int)threadIdx.x & 63;
+    const int P = uni_i(P_in);
+    const int lr = lane < PU ? lane : PU - 1;
+    double b = lane < PU ? S.rhs[lr] : 0.0;
+    const double myinv = S.invd[lr];
+    {
+        double lrow[PU];                                   // L[lane][j], zero for j >= lane
+#pragma unroll
+        for (int j = 0; j < PU; j++) lrow[j] = S.K[lr * KL + j];
+#pragma unroll
+        for (int j = 0; j < PU; j++) b = fma(-lrow[j], lane_value(b, j), b);
+    }
+    b *= myinv;
+    {
+        double lcol[PU];                                   // L[j][lane], zero for j <= lane
+#pragma unroll
+        for (int j = 0; j < PU; j++) lcol[j] = S.K[j * KL + lr];
+#pragma unroll
+        for (int j = PU - 1; j >= 0; j--) b = fma(-lcol[j], lane_value(b, j), b);
+    }
+    if (lane < P) S.dy[lane] = b;
 }
 
 // Per-workgroup row workspace (per-row state of the interior point, collision rows of all obstacles).  As much of it as
@@ -452,13 +522,14 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         for (int oe = 0; oe < n_obs; oe++) any |= slk[oe];
         S.any_slack = any;
     }
-    if (tid <= PMAX) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
+    if (tid <= PMAX) { S.y[tid] = 0.0; S.dy[tid] = 0.0; S.rhs[tid] = 0.0; }
+    for (int e = tid; e < PMAX * KL; e += GT) S.K[e] = (e / KL == e % KL) ? 1.0 : 0.0;      // rows / columns P.. of the factor's bound: identity
     for (int g = tid; g < NGR; g += GT) { ev[g] = 0.0; dev[g] = 0.0; Dg[g] = 1.0; iDg[g] = 0.0; qg[g] = 0.0; if (g >= n_obs * M) gact[g] = 0; }   // (groups without an active row stay like this)
     __syncthreads();
 
     const int tseg = S.tseg;
-    const int xk = tid < NV ? tid / SEGV : 0, xt = tid < NV ? tid % SEGV : 0;
     auto compute_x = [&](const double *yv, double *xv, bool with_const) {
+        const int xk = tid < NV ? tid / SEGV : 0, xt = tid < NV ? tid % SEGV : 0;
         if (tid < NV) {
             double v = (xt < 3 && with_const) ? S.s0[xk][xt] : 0.0;
             if (xt >= 3)
@@ -501,7 +572,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         hmax = S.sc[0];
     }
     const double wg_base = 2.0 * a.slack_w / (double)M;       // Hessian of slack_w (M - m)/M eps^2 is 2 slack_w (M - m)/M
-    auto cost_grad = [&]() -> double {
+    auto cost_grad = [&](int xk, int xt) -> double {
         const double *xs = S.x + xk * SEGV + (xt / NC) * NC;
         double g = 0.0;
         for (int j = 0; j < NC; j++) g += S.Qh[(xt % NC) * NC + j] * xs[j];
@@ -511,6 +582,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     // x-space sums of a per-row coefficient (rt2 = vv, rz = z) and, with_w, of the weights rt1 = w: the only place where
     // the rows meet the unknowns.  Fixed summation orders: results do not depend on scheduling.
     auto reduce_rows = [&](bool with_w, bool unit_w) {
+        const int xk = tid < NV ? tid / SEGV : 0, xt = tid < NV ? tid % SEGV : 0;
         if (tid < NV) {
             const int k = xk, t = xt, i = t % NC, b = tid;
             const int t1i = t >= 1 ? t - 1 : 0, t2i = t >= 2 ? t - 2 : 0;
@@ -521,7 +593,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 return (V(arr, 0, o0) - V(arr, 1, o0)) + (V(arr, 3, o0) - V(arr, 2, o0)) + (V(arr, 4, o0) - V(arr, 5, o0)) +
                        m1 * ((V(arr, 2, o1) - V(arr, 3, o1)) - 2.0 * (V(arr, 4, o1) - V(arr, 5, o1))) + m2 * (V(arr, 4, o2) - V(arr, 5, o2));
             };
-            double cg = cost_grad();
+            double cg = cost_grad(xk, xt);
             if (i == DEG && t / NC >= M - tseg) cg += 2.0 * md.w_t * (S.x[b] - S.goal[k]);
             S.gv[b] = cg + gather(rt2);
             S.gz[b] = cg + gather(rz);
@@ -664,6 +736,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     };
     // dense reduced system: K (lower triangle) and rhs = q_y - sum_g m_g q_g / D_g ; stationarity residual in dy
     auto assemble = [&](bool with_k) {
+        if (with_k && tid >= P && tid < PMAX) S.K[tid * KL + tid] = 1.0;     // identity beyond P (the factor left its L there: zero)
         if (with_k)
             for (int e = tid; e < P * (P + 1) / 2; e += GT) {       // lower triangle, row-major: e = r (r + 1) / 2 + c
                 int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
@@ -703,6 +776,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                     v = S.Huu[r - P0];
                 }
                 S.K[r * KL + c] = v;
+                S.K[c * KL + r] = v;
             }
         if (tid < P0) {
             const int k = tid / nya, aa = tid % nya;
@@ -721,72 +795,22 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         }
         __syncthreads();
     };
-    // dense K = L D L^T (L unit lower), then L D L^T dy = rhs -- both on wave 0 alone, without barriers: lane = row.  The
-    // factor runs right-looking in registers (a[c] = K[lane][c]; column j is scaled by the pivot read through v_readlane, and
-    // every later column k takes l * l_k with l_k again a v_readlane: ~P^2/2 readlane + fma pairs, no LDS traffic), L and 1/D
-    // go back to LDS once; the substitutions chain readlane -> fma per unknown (no division on the chain) with the factor's
-    // entries streaming in from LDS ahead of the chain (they do not depend on it).
-    auto rl = [&](double v, int l) {
-        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-    };
-    // (PU: compile-time bound of the unrolled loops, 45 without and 55 with the explicit slack variables; rows and columns
-    // P..PU-1 are the identity)
-    auto factor_w0 = [&](auto pu) {
-        constexpr int PU = decltype(pu)::value;
-        const int lr = lane < PU ? lane : PU - 1;
-        double av[PU];
-#pragma unroll
-        for (int c = 0; c < PU; c++) av[c] = (lane < P && c <= lane) ? S.K[lr * KL + c] : ((c == lane) ? 1.0 : 0.0);
-        bool ok = true;
-        double myinv = 1.0;
-#pragma unroll
-        for (int j = 0; j < PU; j++) {
-            const double d = rl(av[j], j);
-            if (!(d > 0.0)) ok = false;
-            const double inv = 1.0 / sqrt(d > 0.0 ? d : 1.0);
-            const double l = av[j] * inv;
-            av[j] = l * inv;                               // stored: unit-lower column of K = L D L^T ...
-            if (lane == j) myinv = inv * inv;              // ... and 1 / D: no division on the substitution chains
-#pragma unroll
-            for (int k = j + 1; k < PU; k++) av[k] = fma(-l, rl(l, k), av[k]);
-        }
-        if (lane < P) {
-#pragma unroll
-            for (int c = 0; c < PU; c++) if (c < lane) S.K[lr * KL + c] = av[c];
-            S.invd[lane] = myinv;
-        }
-        if (lane == 0) S.ok = ok ? 1 : 0;
-    };
+    // dense K = L D L^T, then L D L^T dy = rhs: wave 0, out of line (dense_factor_w0 / dense_solve_w0 above)
     auto factor = [&]() -> bool {
         if (wave == 0) {
-            if (P <= 45) factor_w0(std::integral_constant<int, 45>{});
-            else factor_w0(std::integral_constant<int, PMAX>{});
+            if (P <= 45) dense_factor_w0<45>();
+            else dense_factor_w0<PMAX>();
         }
         __syncthreads();
         return S.ok != 0;
     };
-    auto solve_w0 = [&](auto pu) {
-        constexpr int PU = decltype(pu)::value;
-        const int lr = lane < PU ? lane : PU - 1;
-        double b = lane < P ? S.rhs[lane] : 0.0;
-        const double myinv = lane < P ? S.invd[lane] : 1.0;
-#pragma unroll
-        for (int j = 0; j < PU; j++) {
-            const double l = S.K[lr * KL + j];
-            b = (lane > j && lane < P) ? fma(-l, rl(b, j), b) : b;
-        }
-        b *= myinv;
-#pragma unroll
-        for (int j = PU - 1; j >= 0; j--) {
-            const double l = S.K[j * KL + lr];
-            b = (lane < j && j < P) ? fma(-l, rl(b, j), b) : b;
-        }
-        if (lane < P) S.dy[lane] = b;
-    };
     auto solve = [&]() {
         if (wave == 0) {
-            if (P <= 45) solve_w0(std::integral_constant<int, 45>{});
-            else solve_w0(std::integral_constant<int, PMAX>{});
+            long long t0 = 0;
+            if (gp) t0 = (long long)__builtin_readcyclecounter();
+            if (P <= 45) dense_solve_w0<45>(P);
+            else dense_solve_w0<PMAX>(P);
+            if (gp && tid == 0) gp[14] += (long long)__builtin_readcyclecounter() - t0;
         }
         __syncthreads();
         compute_x(S.dy, S.dx, false);
@@ -818,9 +842,10 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
             if (g / M < n_obs && grp_valid(g)) f(GS0 + g, ev[g], dev[g], 0.0);
     };
     auto objective = [&]() -> double {
+        const int xk = tid < NV ? tid / SEGV : 0, xt = tid < NV ? tid % SEGV : 0;
         double o = 0.0;
         if (tid < NV) {
-            o = 0.5 * cost_grad() * S.x[tid];
+            o = 0.5 * cost_grad(xk, xt) * S.x[tid];
             if (xt % NC == DEG && xt / NC >= M - tseg) { const double e = S.x[tid] - S.goal[xk]; o += md.w_t * e * e; }
         }
         if (tid < nu) o += 0.5 * wg_base * (double)(M - tid % M) * S.y[P0 + tid] * S.y[P0 + tid];
@@ -864,6 +889,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
             });
             __syncthreads();
         } else {
+            if (gp && tid == 0) gp[15]++;
             if (tid <= PMAX) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
             for (int g = tid; g < NGR; g += GT) { ev[g] = 0.0; dev[g] = 0.0; }
             __syncthreads();

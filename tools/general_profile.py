@@ -66,8 +66,10 @@ def run(name, cfg, ticks, gust):
     line = {"mode": name, "ticks": ticks, "plan_and_general_kernel_ms": {"mean": round(float(kp.mean()), 4), "p99": round(float(np.percentile(kp, 99)), 4)},
             "agents_on_general_path_per_tick": round(float(g[:, 13].sum()) / ticks, 1),
             "iterations_per_solve": round(float(g[:, 12].sum() / max(g[:, 13].sum(), 1.0)), 2),
+            "cold_starts_per_solve": round(float(g[:, 15].sum() / max(g[:, 13].sum(), 1.0)), 3),
             "busiest_agent": {"us_per_iteration": round(float(tot[worst]) / it / SHADER_MHZ, 2), "iterations": int(g[worst, 12]),
                               "sections_us_per_iteration": sec},
+            "busiest_agent_triangular_solves_alone_us_per_iteration": round(float(g[worst, 14]) / it / SHADER_MHZ, 2),
             "failed_plans": bad}
     pl.close()
     print(json.dumps(line), flush=True)
