@@ -26,13 +26,14 @@
 #include "lsc_gjk.hpp"
 #include "lsc_model.hpp"
 #include "lsc_kernels.h"
+#include "lsc_wave.hpp"
 #include <type_traits>
 
 namespace lsc {
 
 namespace {
 
-constexpr int GT = 256;            // lanes per agent
+constexpr int GT = 512;            // lanes per agent
 constexpr int GW = GT / 64;
 constexpr int PMAX = 3 * GNYA + 2 * M;      // 45 + 10
 constexpr int KL = PMAX + 2;       // leading dimension of the dense matrices in LDS (57 doubles: rows of one column fall in different banks)
@@ -71,25 +72,6 @@ struct GS {
     int wkept[GW];
     int tseg, ok, any_slack, nk;
 };
-
-__device__ __forceinline__ double wsum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wmax(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ double wmin(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
-}
 
 // predicted control points of agent q for segment m in the general modes: current position (BVC, or after a
 // disturbance reset), else like the fast path
@@ -158,10 +140,6 @@ __device__ __forceinline__ double ax_x(const double *x, int type, int k, int t)
 // rows and columns P..PU-1 are the identity (written once at set-up).  K is stored as a full symmetric matrix.
 extern __shared__ __align__(16) unsigned char gsm_general[];
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ double lane_value(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
 template <int PU>
 __device__ __attribute__((noinline)) void dense_factor_w0()
 {
@@ -264,15 +242,24 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     const float dtf = (float)md.dt;
     const double hv = md.hv_scale, ha = md.ha_scale;
 
-    auto block_reduce = [&](double v0, double v1, double v2, double v3, int op0, int op1, int op2, int op3) {
-        auto wr = [&](double v, int op) { return op == 0 ? wsum(v) : (op == 1 ? wmax(v) : wmin(v)); };
-        const double r0 = wr(v0, op0), r1 = wr(v1, op1), r2 = wr(v2, op2), r3 = wr(v3, op3);
+    // block reduction of up to five values: op 0 sum, 1 max, 2 min, < 0 slot unused; results in S.sc[0..4].  DPP wave reductions
+    // (lsc_wave.hpp), one barrier pair, the per-wave partials combined by five lanes.
+    auto block_reduce = [&](double v0, double v1, double v2, double v3, double v4, int op0, int op1, int op2, int op3, int op4) {
+        auto wr = [&](double v, int op) { return op < 0 ? 0.0 : (op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v))); };
+        const double r0 = wr(v0, op0), r1 = wr(v1, op1), r2 = wr(v2, op2), r3 = wr(v3, op3), r4 = wr(v4, op4);
+        if (lane == 0) {
+            S.red[0][wave] = r0;
+            if (op1 >= 0) S.red[1][wave] = r1;
+            if (op2 >= 0) S.red[2][wave] = r2;
+            if (op3 >= 0) S.red[3][wave] = r3;
+            if (op4 >= 0) S.red[4][wave] = r4;
+        }
         __syncthreads();
-        if (lane == 0) { S.red[0][wave] = r0; S.red[1][wave] = r1; S.red[2][wave] = r2; S.red[3][wave] = r3; }
-        __syncthreads();
-        if (tid < 4) {
-            const int op = tid == 0 ? op0 : (tid == 1 ? op1 : (tid == 2 ? op2 : op3));
+        const int nused = op4 >= 0 ? 5 : (op3 >= 0 ? 4 : (op2 >= 0 ? 3 : (op1 >= 0 ? 2 : 1)));
+        if (tid < nused) {
+            const int op = tid == 0 ? op0 : (tid == 1 ? op1 : (tid == 2 ? op2 : (tid == 3 ? op3 : op4)));
             double t = S.red[tid][0];
+#pragma unroll
             for (int w = 1; w < GW; w++) t = op == 0 ? t + S.red[tid][w] : (op == 1 ? fmax(t, S.red[tid][w]) : fmin(t, S.red[tid][w]));
             S.sc[tid] = t;
         }
@@ -561,14 +548,14 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     if (tid < nu) nrow_i++;
     for (int c = tid; c < NCL; c += GT) nrow_i += (c / NBK < n_obs && coll_valid(c)) ? 1 : 0;
     for (int g = tid; g < NGR; g += GT) nrow_i += (g / M < n_obs && grp_valid(g)) ? 1 : 0;
-    block_reduce((double)nrow_i, 0, 0, 0, 0, 0, 0, 0);
+    block_reduce((double)nrow_i, 0, 0, 0, 0, 0, -1, -1, -1, -1);
     const double nrow = S.sc[0];
     double hmax = 1.0;
     {
         double hm = 1.0;
         for (int sl = tid; sl < AXROWS; sl += GT) if (S.avalid[sl]) hm = fmax(hm, fabs(S.ah[sl]));
         for (int c = tid; c < NCL; c += GT) if (c / NBK < n_obs && coll_valid(c)) hm = fmax(hm, fabs(crhs[c]));
-        block_reduce(hm, 0, 0, 0, 1, 0, 0, 0);
+        block_reduce(hm, 0, 0, 0, 0, 1, -1, -1, -1, -1);
         hmax = S.sc[0];
     }
     const double wg_base = 2.0 * a.slack_w / (double)M;       // Hessian of slack_w (M - m)/M eps^2 is 2 slack_w (M - m)/M
@@ -916,7 +903,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                     rs[r] = sl; rz[r] = -sl;
                     mins = fmin(mins, sl); minz = fmin(minz, -sl);
                 });
-                block_reduce(mins, minz, 0, 0, 2, 2, 0, 0);
+                block_reduce(mins, minz, 0, 0, 0, 2, 2, -1, -1, -1);
                 const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0, shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
                 for_rows([&](int r, double, double, double) { rs[r] += shs; rz[r] += shz; });
                 if (tid == 0) S.sc[7] = 0.0;
@@ -938,7 +925,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 rt1[r] = w; rt2[r] = w * rp;
                 gpart += sv * zv; rpm = fmax(rpm, fabs(rp));
             });
-            block_reduce(gpart, rpm, objective(), 0, 0, 1, 0, 0);
+            block_reduce(gpart, rpm, objective(), 0, 0, 0, 1, 0, -1, -1);
             gstamp(GP_RESID);
             const double gap = S.sc[0], rpmax = S.sc[1];
             obj = S.sc[2];
@@ -953,7 +940,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 double rda = tid < P ? fabs(S.dy[tid]) : 0.0;
                 for (int g = tid; g < NGR; g += GT)
                     if (g / M < n_obs && grp_valid(g)) rda = fmax(rda, fabs(dev[g]));
-                block_reduce(rda, 0, 0, 0, 1, 0, 0, 0);
+                block_reduce(rda, 0, 0, 0, 0, 1, -1, -1, -1, -1);
                 if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
             }
             const bool fok = factor();
@@ -976,11 +963,10 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 rt2[r] = ds * dz;
             });
             const double dxa = tid < NV ? fabs(S.dx[tid]) : 0.0, xa = tid < NV ? fabs(S.x[tid]) : 0.0;
-            block_reduce(amin, s1, s2, dxa, 2, 0, 0, 1);
-            const double aaff = S.sc[0], ss1 = S.sc[1], ss2 = S.sc[2], dxn = S.sc[3];
-            block_reduce(xa, 0, 0, 0, 1, 0, 0, 0);
+            block_reduce(amin, s1, s2, dxa, xa, 2, 0, 0, 1, 1);
+            const double aaff = S.sc[0], ss1 = S.sc[1], ss2 = S.sc[2], dxn = S.sc[3], xn = S.sc[4];
             gstamp(GP_AFFINE);
-            if (rpmax <= 1e-9 * hmax && gap_ok && dxn <= 1e-9 * fmax(1.0, S.sc[0])) { status = LSC_STATUS_OK_K; break; }
+            if (rpmax <= 1e-9 * hmax && gap_ok && dxn <= 1e-9 * fmax(1.0, xn)) { status = LSC_STATUS_OK_K; break; }
             const double mu_aff = (gap + aaff * ss1 + aaff * aaff * ss2) / nrow;
             double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
             sigma = sigma * sigma * sigma;
@@ -1008,7 +994,7 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
                 if (dz < 0.0) amax = fmin(amax, -zv / dz);
                 rt1[r] = ds; rt2[r] = dz;
             });
-            block_reduce(amax, 0, 0, 0, 2, 0, 0, 0);
+            block_reduce(amax, 0, 0, 0, 0, 2, -1, -1, -1, -1);
             const double alpha = fmin(1.0, 0.99 * S.sc[0]);
             for_rows([&](int r, double, double, double) { rs[r] += alpha * rt1[r]; rz[r] += alpha * rt2[r]; });
             if (tid < P) S.y[tid] += alpha * S.dy[tid];
