@@ -155,7 +155,10 @@ __device__ __attribute__((noinline)) void dense_factor_w0()
     for (int j = 0; j < PU; j++) {
         const double d = lane_value(av[j], j);
         if (!(d > 0.0)) ok = false;
-        const double inv = 1.0 / (d > 0.0 ? d : 1.0);
+        const double dd = d > 0.0 ? d : 1.0;
+        double inv = __builtin_amdgcn_rcp(dd);               // 1 / d: hardware estimate + two Newton steps (full division is twice the chain)
+        inv = fma(fma(-dd, inv, 1.0), inv, inv);
+        inv = fma(fma(-dd, inv, 1.0), inv, inv);
         const double l = av[j] * inv;                      // column j of L
         if (lane == j) myinv = inv;
 #pragma unroll
@@ -785,7 +788,8 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     // dense K = L D L^T, then L D L^T dy = rhs: wave 0, out of line (dense_factor_w0 / dense_solve_w0 above)
     auto factor = [&]() -> bool {
         if (wave == 0) {
-            if (P <= 45) dense_factor_w0<45>();
+            if (P <= 39) dense_factor_w0<39>();
+            else if (P <= 45) dense_factor_w0<45>();
             else dense_factor_w0<PMAX>();
         }
         __syncthreads();
@@ -795,7 +799,8 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
         if (wave == 0) {
             long long t0 = 0;
             if (gp) t0 = (long long)__builtin_readcyclecounter();
-            if (P <= 45) dense_solve_w0<45>(P);
+            if (P <= 39) dense_solve_w0<39>(P);
+            else if (P <= 45) dense_solve_w0<45>(P);
             else dense_solve_w0<PMAX>(P);
             if (gp && tid == 0) gp[14] += (long long)__builtin_readcyclecounter() - t0;
         }
