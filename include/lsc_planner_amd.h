@@ -219,6 +219,16 @@ int lsc_replan_tick_all(lsc_ctx *ctx, const float *state, const float *goal, con
  * (getFutureStateMsg -> getStateFromControlPoints, include/polynomial.hpp:63-97).  All N agents. */
 int lsc_propagate_device(lsc_ctx *ctx, const float *d_traj, float *d_state, void *hip_stream);
 
+/* MultiSyncSimulator::savePlanningResult's agent-agent accounting (src/multi_sync_simulator.cpp:446-503) on the device, for
+ * the plans of the last lsc_replan_tick / lsc_replan_tick_all.  times[n_times] (n_times <= 64): seconds into the plan at which
+ * the swarm is sampled (the reference: 0, multisim_record_time_step, ... below multisim_time_step).  For every sample and
+ * every agent of this context's shard, the downwash-scaled distance to every other agent over the sum of the two radii
+ * (distBetweenAgents, include/util.hpp:225-229): out_ratio[n_times][count] = the minimum over the partners,
+ * out_partner[n_times][count] = the first partner attaining it (what the reference's collision message names); either may be
+ * NULL.  *out_min = the minimum over everything -- over ALL ranks when the context has a communicator (one ncclAllReduce(min);
+ * collective: every rank must call it).  The reference walks all N^2 pairs on the host after every tick. */
+int lsc_safety_ratio(lsc_ctx *ctx, const double *times, int n_times, double *out_ratio, int *out_partner, double *out_min);
+
 /* Dense LSC sweep only (TrajPlanner::generateLSC for every ordered pair), device buffers:
  *   d_normal [count][N-1][M][3] float, d_d [count][N-1][M][n+1] double. */
 int lsc_sweep_device(lsc_ctx *ctx, const float *d_state, const float *d_traj_prev, int planner_seq,

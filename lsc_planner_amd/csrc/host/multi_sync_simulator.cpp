@@ -190,30 +190,35 @@ class MultiSyncSimulator {
         return true;
     }
 
-    // :408-510
+    // :408-510.  The agent-agent accounting -- every pair of agents at every record step, N^2 distance evaluations per tick on
+    // the reference's host -- runs on the device (lsc_safety_ratio): every rank looks at its own agents against all others,
+    // one all-reduce(min) brings the swarm's safety ratio to every rank.
     void savePlanningResult() {
         const int N = mission.qn;
+        std::vector<double> times;
         for (double ft = 0; ft < param.multisim_time_step - SP_EPSILON_FLOAT; ft += param.multisim_record_time_step) {
-            std::vector<point3d> pos(N);
-            for (int qi = 0; qi < N; qi++) { pos[qi] = agents[qi]->getFutureStateMsg(ft).position; points[qi].push_back(pos[qi]); }
-            for (int qi = 0; qi < N; qi++) {
-                double current = SP_INFINITY; int min_qj = -1;
-                for (int qj = 0; qj < N; qj++) {
-                    if (qi == qj) continue;
-                    const Agent &a = mission.agents[qi], &b = mission.agents[qj];
-                    const double downwash = (a.downwash * a.radius + b.downwash * b.radius) / (a.radius + b.radius);
-                    point3d d = pos[qi] - pos[qj];
-                    d(2) = (float)(d.z() / downwash);             // distBetweenAgents, include/util.hpp:225-229
-                    const double ratio = d.norm() / (a.radius + b.radius);
-                    if (ratio < current) { current = ratio; min_qj = qj; }
-                    if (ratio < safety_ratio_agent) safety_ratio_agent = ratio;
-                }
-                if (current < 1) {
-                    std::fprintf(stderr, "[MultiSyncSimulator] collision with agents, agent_id: (%d,%d), safety_ratio:%g\n", qi, min_qj, current);
-                    is_collided = true;
-                }
-            }
+            times.push_back(ft);
+            for (int qi = 0; qi < N; qi++) points[qi].push_back(agents[qi]->getFutureStateMsg(ft).position);
         }
+        int first = 0, count = N;
+        if (sharded) {
+            int world = 1, rank = 0, shard_rows = N, table_rows = N;
+            check(lsc_comm_info(ctx, &world, &rank, &shard_rows, &table_rows));
+            first = std::min(rank * shard_rows, N);
+            count = std::min(shard_rows, N - first);
+        }
+        const int T = (int)times.size();
+        std::vector<double> ratio((size_t)T * std::max(count, 1));
+        std::vector<int> partner((size_t)T * std::max(count, 1));
+        double tick_min = SP_INFINITY;
+        check(lsc_safety_ratio(ctx, times.data(), T, ratio.data(), partner.data(), &tick_min));
+        if (tick_min < safety_ratio_agent) safety_ratio_agent = tick_min;
+        if (tick_min < 1) is_collided = true;
+        for (int ti = 0; ti < T; ti++)
+            for (int al = 0; al < count; al++)
+                if (ratio[(size_t)ti * count + al] < 1)
+                    std::fprintf(stderr, "[MultiSyncSimulator] collision with agents, agent_id: (%d,%d), safety_ratio:%g\n", first + al,
+                                 partner[(size_t)ti * count + al], ratio[(size_t)ti * count + al]);
         for (int qi = 0; qi < N; qi++) { N_average++; planning_time_sum += agents[qi]->getPlanningTime(); }
     }
 

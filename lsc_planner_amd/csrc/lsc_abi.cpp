@@ -237,6 +237,8 @@ struct lsc_ctx {
     std::vector<uint32_t> h_fcode;       // Key32 table of the goal search (empty: Key64)
     uint32_t *d_fcode = nullptr;
     int fcode_rb = 0;
+    unsigned char *d_safety = nullptr;           // lsc_safety_ratio's buffers
+    int safety_times = 0;
     long long *d_goal_prof = nullptr;
     bool goal_profiling = false;
     int grid_dims[3] = {0, 0, 0}, grid_row_cap = 0;
@@ -281,6 +283,7 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -306,10 +309,11 @@ static bool rccl_bind(RcclApi &api)
     api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
     api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(h, "ncclGroupStart"));
     api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.GroupStart || !api.GroupEnd ||
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce || !api.GroupStart || !api.GroupEnd ||
         !api.GetErrorString)
         return false;
     api.h = h;
@@ -434,9 +438,9 @@ static void free_agents(lsc_ctx *c)
     if (c->h_in) { (void)hipHostFree(c->h_in); c->h_in = nullptr; }
     if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
     void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
-                  c->d_goal_path, c->d_goal_plen, c->d_goal_prof, c->d_fcode};
+                  c->d_goal_path, c->d_goal_plen, c->d_goal_prof, c->d_fcode, c->d_safety};
     for (void *p : gp) if (p) (void)hipFree(p);
-    c->d_goal_prof = nullptr; c->d_fcode = nullptr;
+    c->d_goal_prof = nullptr; c->d_fcode = nullptr; c->d_safety = nullptr; c->safety_times = 0;
     c->d_edt = c->d_goal_planned = c->d_ray_stack = nullptr; c->d_occ_static = nullptr;
     c->d_goal_err = c->d_goal_flags = c->d_goal_exp = c->d_goal_path = c->d_goal_plen = nullptr;
     c->d_radius = c->d_radius_obs = c->d_downwash = c->d_downwash_obs = c->d_vmax = c->d_amax = c->d_vnom = nullptr;
@@ -1126,6 +1130,66 @@ int lsc_replan_tick_all(lsc_ctx *c, const float *state, const float *goal, const
             c->err = "internal: an agent was handed to the alternate-mode kernel, which did not run";
             return LSC_ESTATE;
         }
+    return LSC_OK;
+}
+
+// MultiSyncSimulator::savePlanningResult's agent-agent accounting (src/multi_sync_simulator.cpp:446-503) for the plans of the last
+// host-buffer tick.  Sample time t falls into segment m = (int)(t / dt) at local parameter t / dt - m (getStateFromControlPoints,
+// include/polynomial.hpp); the Bernstein weights are computed here, on the host, with the reference's own expression
+// (nChoosek * pow(t, i) * pow(1 - t, n - i)) so that the device only repeats its multiply-adds.
+int lsc_safety_ratio(lsc_ctx *c, const double *times, int n_times, double *out_ratio, int *out_partner, double *out_min)
+{
+    if (!c || !times || n_times < 1 || n_times > 64 || !out_min) return LSC_EINVAL;
+    if (c->N < 1 || c->last_host_seq < 1) { if (c) c->err = "lsc_safety_ratio: no host-buffer tick was planned yet"; return LSC_ESTATE; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int N = c->N, cnt = c->count;
+    std::vector<double> w((size_t)n_times * NC);
+    std::vector<int> seg(n_times);
+    auto choose = [](int n, int k) { if (k * 2 > n) k = n - k; if (k == 0) return 1; int r = n; for (int i = 2; i <= k; i++) { r *= (n - i + 1); r /= i; } return r; };
+    for (int ti = 0; ti < n_times; ti++) {
+        const double t = times[ti];
+        int m = (int)(t / c->cfg.dt);
+        if (m == M && t < M * c->cfg.dt + 1e-9) m = M - 1;
+        else if (m >= M || t < 0.0) { c->err = "lsc_safety_ratio: sample time outside the planning horizon"; return LSC_EINVAL; }
+        seg[ti] = m;
+        const double tl = t / c->cfg.dt - m;
+        for (int i = 0; i < NC; i++) w[(size_t)ti * NC + i] = choose(DEG, i) * std::pow(tl, i) * std::pow(1 - tl, DEG - i);
+    }
+    if (!c->d_safety || c->safety_times < n_times) {
+        if (c->d_safety) (void)hipFree(c->d_safety);
+        c->d_safety = nullptr;
+        const size_t bytes = (size_t)n_times * (sizeof(double) * NC + sizeof(int) * 2 + sizeof(float) * 3 * (size_t)N + (sizeof(double) + sizeof(int)) * (size_t)cnt) + 64;
+        HIPCHK(c, hipMalloc(&c->d_safety, bytes));
+        c->safety_times = n_times;
+    }
+    // carve-up: ratios, weights, global minimum | positions | partners, segments
+    double *d_ratio = reinterpret_cast<double *>(c->d_safety);
+    double *d_w = d_ratio + (size_t)n_times * cnt;
+    double *d_min = d_w + (size_t)n_times * NC;
+    float *d_pos = reinterpret_cast<float *>(d_min + 1);
+    int *d_partner = reinterpret_cast<int *>(d_pos + (size_t)n_times * 3 * N);
+    int *d_seg = d_partner + (size_t)n_times * cnt;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(d_w, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_seg, seg.data(), sizeof(int) * seg.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, launch_safety(c->d_next, d_w, d_seg, n_times, N, c->first, cnt, c->d_radius, c->d_downwash, d_pos, d_ratio, d_partner, st));
+    std::vector<double> ratio((size_t)n_times * cnt);
+    std::vector<int> partner((size_t)n_times * cnt);
+    HIPCHK(c, hipMemcpyAsync(ratio.data(), d_ratio, sizeof(double) * ratio.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(partner.data(), d_partner, sizeof(int) * partner.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    double mn = 1e300;
+    for (double r : ratio) mn = r < mn ? r : mn;
+    if (c->comm) {                                  // one all-reduce brings the swarm's minimum to every rank
+        const RcclApi *api = rccl_api();
+        HIPCHK(c, hipMemcpyAsync(d_min, &mn, sizeof(double), hipMemcpyHostToDevice, st));
+        NCCLCHK(c, api, api->AllReduce(d_min, d_min, 1, ncclDouble, ncclMin, c->comm, st));
+        HIPCHK(c, hipMemcpyAsync(&mn, d_min, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    if (out_ratio) std::memcpy(out_ratio, ratio.data(), sizeof(double) * ratio.size());
+    if (out_partner) std::memcpy(out_partner, partner.data(), sizeof(int) * partner.size());
+    *out_min = mn;
     return LSC_OK;
 }
 

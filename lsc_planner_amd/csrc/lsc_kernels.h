@@ -149,6 +149,8 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st);
 hipError_t launch_plan_spill(const PlanArgs &a, int slots, size_t smem, hipStream_t st);
 hipError_t launch_sweep(const SweepArgs &a, hipStream_t st);
 hipError_t launch_propagate(const float *traj, float *state, int N, double dt, hipStream_t st);
+hipError_t launch_safety(const float *traj, const double *weights, const int *seg, int n_times, int N, int first, int count,
+                         const double *radius, const double *downwash, float *pos, double *out_ratio, int *out_partner, hipStream_t st);
 hipError_t launch_gjk(const double *pts, int count, double *v, double *dist, hipStream_t st);
 
 }  // namespace lsc

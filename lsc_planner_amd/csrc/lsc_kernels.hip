@@ -2131,6 +2131,80 @@ hipError_t launch_propagate(const float *traj, float *state, int N, double dt, h
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// savePlanningResult's agent-agent accounting (src/multi_sync_simulator.cpp:446-503) on the device.
+//   lsc_sample_kernel : position of every agent at the sample times, getPointFromControlPoints (include/polynomial.hpp) with
+//                       the Bernstein weights of each time computed by the caller in the reference's own arithmetic
+//   lsc_safety_kernel : one workgroup per own agent: downwash-scaled distance to every other agent over the sum of radii
+//                       (distBetweenAgents, include/util.hpp:225-229), minimum and FIRST partner of the minimum per sample time
+// ---------------------------------------------------------------------------------------------------
+__global__ void lsc_sample_kernel(const float *traj, const double *weights, const int *seg, int n_times, int N, float *pos)
+{
+#pragma clang fp contract(off)
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_times * N) return;
+    const int ti = u / N, q = u % N;
+    const float *t = traj + (size_t)q * NV + seg[ti] * NC;
+    const double *b = weights + ti * NC;
+    for (int k = 0; k < 3; k++) {
+        double x = 0.0;
+        for (int i = 0; i < NC; i++) x += (double)t[k * SEGV + i] * b[i];
+        pos[(size_t)u * 3 + k] = (float)x;
+    }
+}
+
+__global__ __launch_bounds__(256) void lsc_safety_kernel(const float *pos, const double *radius, const double *downwash, int n_times, int N,
+                                                           int first, double *out_ratio, int *out_partner)
+{
+#pragma clang fp contract(off)
+    __shared__ double s_r[4];
+    __shared__ int s_q[4];
+    const int al = blockIdx.x, qi = first + al, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double r_a = radius[qi], dw_a = downwash[qi];
+    for (int ti = 0; ti < n_times; ti++) {
+        const float *p = pos + (size_t)ti * N * 3;
+        const float px = p[3 * qi], py = p[3 * qi + 1], pz = p[3 * qi + 2];
+        double best = 1e300;
+        int bq = 0x7fffffff;
+        for (int qj = tid; qj < N; qj += 256) {
+            if (qj == qi) continue;
+            const double r_b = radius[qj];
+            const double dw = (dw_a * r_a + downwash[qj] * r_b) / (r_a + r_b);
+            const float dx = px - p[3 * qj], dy = py - p[3 * qj + 1];
+            const float dz = (float)((double)(pz - p[3 * qj + 2]) / dw);
+            const float n2 = dx * dx + dy * dy + dz * dz;
+            const double ratio = sqrt((double)n2) / (r_a + r_b);
+            if (ratio < best) { best = ratio; bq = qj; }            // (increasing qj per lane: the first partner of a tie stays)
+        }
+        // smallest ratio, then smallest partner index
+        const double wb = wave_min(best);
+        int cand = best == wb ? bq : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        if (lane == 0) { s_r[wave] = wb; s_q[wave] = cand; }
+        __syncthreads();
+        if (tid == 0) {
+            double r = s_r[0];
+            int q = s_q[0];
+            for (int w = 1; w < 4; w++)
+                if (s_r[w] < r || (s_r[w] == r && s_q[w] < q)) { r = s_r[w]; q = s_q[w]; }
+            out_ratio[(size_t)ti * gridDim.x + al] = r;
+            out_partner[(size_t)ti * gridDim.x + al] = q == 0x7fffffff ? -1 : q;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_safety(const float *traj, const double *weights, const int *seg, int n_times, int N, int first, int count,
+                         const double *radius, const double *downwash, float *pos, double *out_ratio, int *out_partner, hipStream_t st)
+{
+    const int n = n_times * N;
+    hipLaunchKernelGGL(lsc_sample_kernel, dim3((n + 127) / 128), dim3(128), 0, st, traj, weights, seg, n_times, N, pos);
+    if (count > 0)
+        hipLaunchKernelGGL(lsc_safety_kernel, dim3(count), dim3(256), 0, st, pos, radius, downwash, n_times, N, first, out_ratio, out_partner);
+    return hipGetLastError();
+}
+
 hipError_t launch_gjk(const double *pts, int count, double *v, double *dist, hipStream_t st)
 {
     hipLaunchKernelGGL(lsc_gjk_kernel, dim3((count + 255) / 256), dim3(256), 0, st, pts, count, v, dist);

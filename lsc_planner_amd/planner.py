@@ -304,6 +304,18 @@ class SwarmPlanner:
         self._check(self.L.lsc_goal_profile(self.ctx, enable, out.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))))
         return out
 
+    def safety_ratio(self, times):
+        """savePlanningResult's agent-agent accounting for the plans of the last plan() call: (ratio [T][count], partner [T][count],
+        minimum over everything -- over all ranks with a communicator)."""
+        t = np.ascontiguousarray(times, np.float64)
+        ratio = np.zeros((len(t), self.count), np.float64)
+        partner = np.zeros((len(t), self.count), np.int32)
+        mn = ctypes.c_double()
+        self._check(self.L.lsc_safety_ratio(self.ctx, t.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), len(t),
+                                            ratio.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                            partner.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(mn)))
+        return ratio, partner, mn.value
+
     GENERAL_SECTIONS = ("setup", "start", "residual_pass", "row_reduce", "assemble", "factor", "solves", "affine_pass",
                         "corrector_rhs", "row_reduce_2", "assemble_2", "step", "iterations", "solves_of_agent")
 

@@ -115,3 +115,58 @@ def test_fuzz_found_instance_through_the_kernel_against_highs(L):
     pl.close()
     assert (r["status"] == 0).all() and np.array_equal(r["status"], Z["gstatus"])
     assert abs(r["cost"][2] - 1.3618641918561454) <= 1e-8 * 1.3618641918561454
+
+
+def _safety_reference(traj, times, dt, radius, downwash):
+    """MultiSyncSimulator::savePlanningResult's pair loop (src/multi_sync_simulator.cpp:446-503) with octomap's float arithmetic."""
+    from math import comb
+    N = traj.shape[0]
+    ratio = np.full((len(times), N), np.inf)
+    partner = np.full((len(times), N), -1, np.int32)
+    for ti, t in enumerate(times):
+        m = min(int(t / dt), 4)
+        tl = t / dt - m
+        w = [comb(5, i) * pow(tl, i) * pow(1 - tl, 5 - i) for i in range(6)]
+        pos = np.zeros((N, 3), np.float32)
+        for q in range(N):
+            for k in range(3):
+                x = 0.0
+                for i in range(6):
+                    x += float(traj[q, k, 6 * m + i]) * w[i]
+                pos[q, k] = np.float32(x)
+        for qi in range(N):
+            for qj in range(N):
+                if qi == qj:
+                    continue
+                ra, rb = radius[qi], radius[qj]
+                dw = (downwash[qi] * ra + downwash[qj] * rb) / (ra + rb)
+                d = pos[qi] - pos[qj]
+                d[2] = np.float32(float(d[2]) / dw)
+                n2 = np.float32(np.float32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+                r = np.sqrt(float(n2)) / (ra + rb)
+                if r < ratio[ti, qi]:
+                    ratio[ti, qi], partner[ti, qi] = r, qj
+    return ratio, partner
+
+
+def test_safety_ratio_accounting_equals_the_reference_pair_loop():
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import PlannerConfig, next_state_host
+    ms = L.random_swarm(48, world=(-3, -3, 0, 3, 3, 2.5), seed=31)
+    ms.radius[:] = np.random.default_rng(3).uniform(0.1, 0.2, 48)
+    ms.downwash[:] = np.random.default_rng(4).uniform(1.0, 2.5, 48)
+    pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="static"))
+    state = np.zeros((48, 9), np.float32)
+    state[:, :3] = ms.start
+    traj = np.zeros((48, 3, 30), np.float32)
+    times = [0.0, 0.1, 0.17]
+    for tick in range(4):
+        g = pl.plan(state, ms.goal, traj)
+        traj = g["traj"]
+        ratio, partner, mn = pl.safety_ratio(times)
+        ref_ratio, ref_partner = _safety_reference(traj, times, 0.2, ms.radius, ms.downwash)
+        assert np.array_equal(ratio, ref_ratio)
+        assert np.array_equal(partner, ref_partner)
+        assert mn == ref_ratio.min()
+        state = next_state_host(traj)
+    pl.close()

@@ -11,26 +11,30 @@ ROOT=$PWD
 BENCH="python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-latency-leg"
 FOREST="python $ROOT/tools/config_runs.py --only forest256p,forest256,forest256x4p,forest256x4 --ticks 30 --warmup 5"
 LARGE="python $ROOT/tools/config_runs.py --only random1024 --ticks 30 --warmup 5"
+GENERAL="python $ROOT/tools/general_profile.py --modes bvc,collision_constraint,gust"      # lsc_general_kernel under load
 cd /tmp
 # 1. kernel trace + stats (no counters)
 rocprofv3 --kernel-trace --stats -d $OUT/stats_bench -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/stats_bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats_forest -o forest -- $FOREST > $OUT/forest_under_rocprof.jsonl 2> $OUT/stats_forest.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats_large -o large -- $LARGE > $OUT/large_under_rocprof.jsonl 2> $OUT/stats_large.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats_general -o general -- $GENERAL --ticks 30 > $OUT/general_under_rocprof.jsonl 2> $OUT/stats_general.err
 # 2. counters, each group in its own pass, kernel trace only
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_bench_$tag -o bench -- $BENCH --steps 30 > /dev/null 2> $OUT/pmc_bench_$tag.err
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_forest_$tag -o forest -- $FOREST --ticks 10 > /dev/null 2> $OUT/pmc_forest_$tag.err
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_large_$tag -o large -- $LARGE --ticks 10 > /dev/null 2> $OUT/pmc_large_$tag.err
+  rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_general_$tag -o general -- $GENERAL --ticks 10 > /dev/null 2> $OUT/pmc_general_$tag.err
 done
 cd $ROOT
-for d in stats_bench stats_forest stats_large; do
+for d in stats_bench stats_forest stats_large stats_general; do
   db=$(find $OUT/$d -name "*.db" | head -1)
   [ -n "$db" ] && python profiles/summarize_rocpd.py stats $db > $OUT/$d.csv
 done
 python profiles/summarize_rocpd.py pmc $(find $OUT/pmc_bench_* -name "*.db") > $OUT/pmc_bench.json
 python profiles/summarize_rocpd.py pmc $(find $OUT/pmc_forest_* -name "*.db") > $OUT/pmc_forest.json
 python profiles/summarize_rocpd.py pmc $(find $OUT/pmc_large_* -name "*.db") > $OUT/pmc_large.json
+python profiles/summarize_rocpd.py pmc $(find $OUT/pmc_general_* -name "*.db") > $OUT/pmc_general.json
 # the databases are large: keep only the summaries
 find $OUT -name "*.db" -delete
 ls -la $OUT
