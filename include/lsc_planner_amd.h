@@ -287,7 +287,7 @@ int lsc_phase_profile(lsc_ctx *ctx, int enable, long long *out);
  * neighbour screening, insertions; of those: cycles and count of the pops and of the insertions that took the general LDS
  * routines (rows beyond 64 entries, rehashes); the rest is reserved. */
 int lsc_goal_profile(lsc_ctx *ctx, int enable, long long *out);
-/* lsc_general_profile: sections of lsc_general_kernel (BVC / slack modes / disturbed agents), collected while
+/* lsc_general_profile: sections of the alternate-mode kernel -- BVC / slack modes / disturbed agents -- collected while
  * lsc_phase_profile is enabled and cleared with it; out[N][16] shader cycles: set-up, start, residual pass, row reduction,
  * assembly, factorization, solves, affine pass, corrector right-hand side, its reduction and assembly, step; [12] the
  * iterations and [13] the solves of the agent. */
