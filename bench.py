@@ -394,7 +394,7 @@ def main():
     # ---- dense LSC sweep kernel (the HBM-class stage of SURVEY 8(d)): N(N-1)*180 B written per launch
     nobs = n_agents - 1
     nrm = torch.empty((count, nobs, 5, 3), **f32)
-    dd = torch.empty((count, nobs, 5, 6), dtype=torch.float64, device=dev)
+    dd = torch.empty((count, nobs, 5, 6), dtype=torch.float32, device=dev)       # float32 margins (lsc_sweep_device_f32)
     for _ in range(3):
         pl.sweep_device(states[0], prev, seq + 1, nrm, dd, stream)
     torch.cuda.synchronize()
@@ -405,8 +405,8 @@ def main():
     s_ms, s_n = pl.kernel_time_ms(1)
     pl.set_timing(False)
     if rank == 0:
-        # bytes as materialised by this implementation: fp32 normal x3 + fp64 d x6 per (pair, segment), plus reads
-        wr = count * nobs * 5 * (3 * 4 + 6 * 8)
+        # bytes as materialised: fp32 normal x3 + fp32 margins x6 per (pair, segment)
+        wr = count * nobs * 5 * (3 * 4 + 6 * 4)
         alg = count * nobs * 180 + n_agents * 404
         result["roofline_sweep"] = {"kernel": "lsc_sweep_kernel", "bound": "hbm",
                                     "achieved": round(alg / (s_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -430,7 +430,7 @@ def main():
         tj2 = torch.from_numpy(g2["traj"].reshape(n2, 90)).to(dev)
         s2 = torch.from_numpy(next_state_host(g2["traj"])).to(dev)
         nrm2 = torch.empty((n2, n2 - 1, 5, 3), **f32)
-        dd2 = torch.empty((n2, n2 - 1, 5, 6), dtype=torch.float64, device=dev)
+        dd2 = torch.empty((n2, n2 - 1, 5, 6), dtype=torch.float32, device=dev)      # float32 margins: the 180 B per pair of SURVEY 8(d)
         for _ in range(2):
             p2.sweep_device(s2, tj2, 2, nrm2, dd2, stream)
         torch.cuda.synchronize()
@@ -441,7 +441,7 @@ def main():
         ms_l, _ = p2.kernel_time_ms(1)
         p2.set_timing(False)
         alg2 = n2 * (n2 - 1) * 180 + n2 * 404
-        wr2 = n2 * (n2 - 1) * 5 * 60
+        wr2 = n2 * (n2 - 1) * 5 * 36
         result["roofline_sweep_large"] = {"kernel": "lsc_sweep_kernel", "agents": n2, "bound": "hbm",
                                           "achieved": round(alg2 / (ms_l * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": round(alg2 / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

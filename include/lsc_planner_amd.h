@@ -233,6 +233,10 @@ int lsc_safety_ratio(lsc_ctx *ctx, const double *times, int n_times, double *out
  *   d_normal [count][N-1][M][3] float, d_d [count][N-1][M][n+1] double. */
 int lsc_sweep_device(lsc_ctx *ctx, const float *d_state, const float *d_traj_prev, int planner_seq,
                      float *d_normal, double *d_d, void *hip_stream);
+/* The same sweep with the margins rounded to float32 (d_d32 [count][N-1][M][n+1] float): 180 B per ordered pair instead of
+ * 300 -- the dump format for swarms whose table is large; the QP itself always reads the doubles. */
+int lsc_sweep_device_f32(lsc_ctx *ctx, const float *d_state, const float *d_traj_prev, int planner_seq,
+                         float *d_normal, float *d_d32, void *hip_stream);
 
 /* GJK distance origin <-> conv(points) for `count` independent 6-point hulls (device kernel; test hook
  * for src/openGJK/openGJK.cpp:674-780).  pts [count][6][3] double (host), v [count][3], dist [count]. */

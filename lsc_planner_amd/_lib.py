@@ -56,7 +56,7 @@ class LscConfig(ctypes.Structure):
 # every symbol include/lsc_planner_amd.h declares
 EXPORTS = [
     "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
-    "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_safety_ratio", "lsc_sweep_device",
+    "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_safety_ratio", "lsc_sweep_device", "lsc_sweep_device_f32",
     "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_kernel_times_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_goal_profile", "lsc_general_profile", "lsc_dump_qp", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals", "lsc_set_goal_trace", "lsc_get_goal_trace",
     "lsc_last_bucket_max", "lsc_row_capacity", "lsc_comm_unique_id", "lsc_comm_init", "lsc_comm_info", "lsc_tick_device_sharded", "lsc_replan_tick_all",
 ]
@@ -108,6 +108,7 @@ def load_library():
     L.lsc_tick_device_sharded.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp]
     L.lsc_replan_tick_all.argtypes = [vp, fp, fp, fp, ctypes.c_int, fp, dp, ip, ip, fp]
     L.lsc_sweep_device.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]
+    L.lsc_sweep_device_f32.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]
     L.lsc_gjk_batch.argtypes = [vp, dp, ctypes.c_int, dp, dp]
     L.lsc_kernel_time_ms.argtypes = [vp, ctypes.c_int, dp, ctypes.POINTER(ctypes.c_long)]
     L.lsc_kernel_times_ms.argtypes = [vp, ctypes.c_int, dp, ctypes.c_long, ctypes.POINTER(ctypes.c_long)]

@@ -1201,22 +1201,34 @@ int lsc_propagate_device(lsc_ctx *c, const float *d_traj, float *d_state, void *
     return LSC_OK;
 }
 
-int lsc_sweep_device(lsc_ctx *c, const float *d_state, const float *d_traj_prev, int planner_seq, float *d_normal,
-                     double *d_d, void *hip_stream)
+static int sweep_device(lsc_ctx *c, const float *d_state, const float *d_traj_prev, int planner_seq, float *d_normal, double *d_d,
+                        float *d_d32, void *hip_stream)
 {
-    if (!c || !d_state || !d_traj_prev || !d_normal || !d_d) return LSC_EINVAL;
+    if (!c || !d_state || !d_traj_prev || !d_normal || (!d_d && !d_d32)) return LSC_EINVAL;
     if (c->N < 2) return LSC_ESTATE;
     SweepArgs a;
     a.N = c->N; a.first = c->first; a.count = c->count; a.planner_seq = planner_seq; a.dtf = (float)c->cfg.dt;
     a.state = d_state; a.traj_prev = d_traj_prev;
     a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
-    a.out_normal = d_normal; a.out_d = d_d;
+    a.out_normal = d_normal; a.out_d = d_d; a.out_d32 = d_d32;
     hipStream_t st = (hipStream_t)hip_stream;
     hipEvent_t e1 = nullptr;
     if (c->timing && timing_begin(c, 1, st, &e1) != LSC_OK) return LSC_EHIP;
     HIPCHK(c, launch_sweep(a, st));
     if (c->timing) HIPCHK(c, hipEventRecord(e1, st));
     return LSC_OK;
+}
+
+int lsc_sweep_device(lsc_ctx *c, const float *d_state, const float *d_traj_prev, int planner_seq, float *d_normal,
+                     double *d_d, void *hip_stream)
+{
+    return sweep_device(c, d_state, d_traj_prev, planner_seq, d_normal, d_d, nullptr, hip_stream);
+}
+
+int lsc_sweep_device_f32(lsc_ctx *c, const float *d_state, const float *d_traj_prev, int planner_seq, float *d_normal,
+                         float *d_d32, void *hip_stream)
+{
+    return sweep_device(c, d_state, d_traj_prev, planner_seq, d_normal, nullptr, d_d32, hip_stream);
 }
 
 int lsc_gjk_batch(lsc_ctx *c, const double *pts, int count, double *v, double *dist)

@@ -72,8 +72,9 @@ struct SweepArgs {
     float dtf;
     const float *state, *traj_prev;
     const double *radius, *radius_obs, *downwash, *downwash_obs;
-    float *out_normal;
-    double *out_d;
+    float *out_normal = nullptr;
+    double *out_d = nullptr;
+    float *out_d32 = nullptr;  // margins as float32 instead (out_d unused)
 };
 
 // Safe Flight Corridor update (TrajPlanner::generateFeasibleSFC), one lane per agent

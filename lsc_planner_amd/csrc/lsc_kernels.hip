@@ -63,6 +63,8 @@ __device__ __forceinline__ void load_segment(const float *__restrict__ state, co
 // Dense LSC sweep: one lane per (agent, obstacle, segment).  Output is what CollisionConstraints holds
 // after generateLSC (normal shared by the 6 rows of a segment, six margins).
 // ---------------------------------------------------------------------------------------------------
+// F32: the six margins as float32 (12 + 24 B per segment: the 180 B per pair of SURVEY 8(d)); else as the doubles the QP reads
+template <bool F32>
 __global__ __launch_bounds__(256) void lsc_sweep_kernel(SweepArgs a)
 {
     const int n_obs = a.N - 1;
@@ -83,9 +85,15 @@ __global__ __launch_bounds__(256) void lsc_sweep_kernel(SweepArgs a)
         lsc_segment(pa, po, downwash, r_o + r_a, n, d);
         float *on = a.out_normal + u * 3;
         on[0] = n.x; on[1] = n.y; on[2] = n.z;
-        double *od = a.out_d + u * 6;
+        if constexpr (F32) {
+            float *od = a.out_d32 + u * 6;
 #pragma unroll
-        for (int i = 0; i < 6; i++) od[i] = d[i];
+            for (int i = 0; i < 6; i++) od[i] = (float)d[i];
+        } else {
+            double *od = a.out_d + u * 6;
+#pragma unroll
+            for (int i = 0; i < 6; i++) od[i] = d[i];
+        }
     }
 }
 
@@ -2120,7 +2128,8 @@ hipError_t launch_sweep(const SweepArgs &a, hipStream_t st)
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(lsc_sweep_kernel, dim3(blocks), dim3(256), 0, st, a);
+    if (a.out_d32) hipLaunchKernelGGL(lsc_sweep_kernel<true>, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lsc_sweep_kernel<false>, dim3(blocks), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -284,8 +284,10 @@ class SwarmPlanner:
         self._check(self.L.lsc_propagate_device(self.ctx, traj.data_ptr(), state.data_ptr(), stream))
 
     def sweep_device(self, state, traj_prev, planner_seq, normal, d, stream=0):
-        self._check(self.L.lsc_sweep_device(self.ctx, state.data_ptr(), traj_prev.data_ptr(), planner_seq, normal.data_ptr(),
-                                            d.data_ptr(), stream))
+        """Dense LSC sweep; d float64 (what the QP reads) or float32 (the compact dump: 180 B per ordered pair)."""
+        import torch
+        fn = self.L.lsc_sweep_device_f32 if d.dtype == torch.float32 else self.L.lsc_sweep_device
+        self._check(fn(self.ctx, state.data_ptr(), traj_prev.data_ptr(), planner_seq, normal.data_ptr(), d.data_ptr(), stream))
 
     PHASES = ("setup", "lsc_build", "ip_init", "residual_pass", "row_reduce", "assemble", "cholesky", "tri_solves",
               "affine_pass", "corrector_pass", "step_update", "output", "(row_reduce: buckets, wave 0)", "(row_reduce: axis gather, last lane)",

@@ -170,3 +170,26 @@ def test_safety_ratio_accounting_equals_the_reference_pair_loop():
         assert mn == ref_ratio.min()
         state = next_state_host(traj)
     pl.close()
+
+
+def test_sweep_with_float32_margins_is_the_rounded_double_sweep():
+    import torch
+    import lsc_planner_amd as L
+    from lsc_planner_amd.planner import PlannerConfig
+    ms = L.circle_swap(24, 4.0)
+    pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="static"))
+    dev = torch.device("cuda", 0)
+    state = torch.zeros((24, 9), dtype=torch.float32, device=dev)
+    state[:, :3] = torch.from_numpy(ms.start).to(dev)
+    state[:, 3:6] = 0.3
+    prev = torch.zeros((24, 90), dtype=torch.float32, device=dev)
+    n64 = torch.empty((24, 23, 5, 3), dtype=torch.float32, device=dev)
+    n32 = torch.empty_like(n64)
+    d64 = torch.empty((24, 23, 5, 6), dtype=torch.float64, device=dev)
+    d32 = torch.empty((24, 23, 5, 6), dtype=torch.float32, device=dev)
+    pl.sweep_device(state, prev, 1, n64, d64)
+    pl.sweep_device(state, prev, 1, n32, d32)
+    torch.cuda.synchronize()
+    assert torch.equal(n64, n32)
+    assert torch.equal(d64.to(torch.float32), d32)
+    pl.close()
