@@ -403,8 +403,8 @@ struct SmemT {
     double K[NY * KLD];         // reduced Hessian (lower band); rows of its Cholesky factor after factor()
     double red[6][NWAVE];
     double colbuf[2][2 * 64];   // column broadcast buffers of the two factorising waves (double-buffered by column parity)
-    double mid2[BAND * BAND];   // Schur contribution of the bottom-up sweep to the middle block (original indices)
-    double xch[BAND], xmid[BAND];   // solve: bottom contribution to the middle right-hand side; middle solution
+    double mid2[BAND * BAND + 7];   // Schur contribution of the bottom-up sweep to the middle block (original indices); + room for the corrector-pass staging
+    double dinv[NY + 1];            // 1 / d of every pivot of K = T D T^T (published by both sweeps of the factorisation)
     double ok2;                 // pivots of the bottom-up sweep all positive
     double sc[8];               // broadcast scalars
     double gap0;                // complementarity gap at the first iteration of the current start (divergence test)
@@ -591,6 +591,31 @@ __device__ __forceinline__ void bwd_steps(const double (&c)[CNT], double &b)
     if constexpr (I > LO) bwd_steps<I - 1, LO, CNT>(c, b);
 }
 
+// Values that must be in registers HERE: an empty volatile statement that names them all.  (The compiler otherwise sinks each
+// load of a "condition ? loaded value : 0" into a branch of its own -- exec mask, load, wait, restore -- and the loads of one
+// group, which are independent, are served one LDS latency after the other.)
+#define LSC_P(a, i) "+v"(a[i])
+__device__ __forceinline__ void pin_values(double (&a)[10])
+{
+    asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7), LSC_P(a, 8), LSC_P(a, 9));
+}
+__device__ __forceinline__ void pin_values(double (&a)[11])
+{
+    asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7), LSC_P(a, 8), LSC_P(a, 9),
+                 LSC_P(a, 10));
+}
+__device__ __forceinline__ void pin_values(double (&a)[13])
+{
+    asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7), LSC_P(a, 8), LSC_P(a, 9),
+                 LSC_P(a, 10), LSC_P(a, 11), LSC_P(a, 12));
+}
+__device__ __forceinline__ void pin_values(double (&a)[14])
+{
+    asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7), LSC_P(a, 8), LSC_P(a, 9),
+                 LSC_P(a, 10), LSC_P(a, 11), LSC_P(a, 12), LSC_P(a, 13));
+}
+#undef LSC_P
+
 // phase stamps (PROF variant only): cycles of lane 0 spent per phase, accumulated per agent
 enum { PH_SETUP = 0, PH_LSC, PH_INIT, PH_P1, PH_REDUCE, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_P2, PH_P3, PH_P45, PH_OUT,
        PH_RED_BUCKETS /* part of PH_REDUCE: the LSC-bucket sums of wave 0, before the barrier */, PH_RED_GATHER /* the axis-row gather, clocked by the last lane */,
@@ -667,6 +692,20 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     double *__restrict__ rt2 = rt1 + R;
     float *__restrict__ rn = reinterpret_cast<float *>(rt2 + R);     // [3][R]
     uint32_t *__restrict__ cmap = reinterpret_cast<uint32_t *>(rn + 3 * R);  // row map: slot | cp << CMAP_SHIFT
+#ifdef LSC_POISON_LDS
+    // debugging aid (not built into the product): every byte of the workgroup's LDS starts as 0xff -- NaN as a double, -1 as an
+    // index -- so that a read of something that was never written shows up as a failed plan or a fault instead of once in a while
+    if constexpr (!SPILL) {
+        uint32_t *pw = reinterpret_cast<uint32_t *>(smem_raw), *pe = cmap + R;
+        const int skip = TABLES_IN_LDS ? (int)(reinterpret_cast<uint32_t *>(rowbase) - pw) : 0;      // (the tables were copied in above)
+        for (uint32_t *q = pw + tid; q < pe; q += NT) {
+            const int i = (int)(q - pw);
+            if (i >= (int)(reinterpret_cast<uint32_t *>(S.dyn) - pw) && i < skip) continue;
+            *q = 0xffffffffu;
+        }
+        __syncthreads();
+    }
+#endif
     // phase B scratch, aliased onto arrays that are first written later: rows in arrival order (rs .. rt2, 32 B per row,
     // written by phase C's start) and the pre-cull's unit list (rrhs .. cmap, written by the scatter that ends phase B)
     struct TmpRow { double rhs; float nx, ny, nz; uint32_t cp_pos; };
@@ -690,6 +729,9 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             val = (m < M - 1) ? t[(m + 1) * NC + i] : t[(M - 1) * NC + DEG];
         }
         S.pinit[tid] = val;
+        // (the branch-free row evaluation, ax_row, reads up to two entries behind the last variable with coefficient zero:
+        // they must be numbers)
+        if (tid < 6) { S.x[NV + tid] = 0.0; S.dx[NV + tid] = 0.0; }
     }
     // ---- disturbance checks (obstaclePredictionCheck / initialTrajPlanningCheck, src/traj_planner.cpp:866-878, 1047-1061):
     // an agent whose state is farther than reset_threshold from where its plan puts it is "disturbed"; every agent then
@@ -1308,7 +1350,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             // twelve (corrector pass: six) components in registers -- about two instructions per product where one lane per
             // (bucket, component) spent ten -- and no lane waits for the fullest bucket (that wait was four fifths of this phase).
             // Partial sums go to LDS that is dead right now (see RSLOT_P); a second step adds the parts of a bucket in slot order.
-            static_assert(offsetof(SmemT<!TABLES_IN_LDS>, xmid) - offsetof(SmemT<!TABLES_IN_LDS>, colbuf) >= sizeof(double) * RSLOT_C * 3,
+            static_assert(offsetof(SmemT<!TABLES_IN_LDS>, dinv) - offsetof(SmemT<!TABLES_IN_LDS>, colbuf) >= sizeof(double) * RSLOT_C * 3,
                           "corrector-pass staging of the bucket sums");
             static_assert(RSLOT_P <= NT - NV && RSLOT_C <= NT - NV, "slot lanes and the axis-row gather lanes do not overlap");
             // (a corrector pass only needs -sum v n: the stationarity residual, which -sum z n feeds, is tested in predictor passes)
@@ -1488,8 +1530,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
 #pragma unroll
             for (int j = 0; j < TW_M1; j++)
                 if (lane < TW_M1 && j < lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
+            if (lane < TW_M1) S.dinv[lane] = dinv_own;
             if (lane == 0) S.sc[7] = ok ? 1.0 : 0.0;
         } else if (wave == 1) {
+            if (lane < TW_A) S.dinv[RV - lane] = dinv_own;
             // multipliers of the bottom-up sweep, reversed (r, c) -> original (RV-r, RV-c), kept at the mirrored band position
 #pragma unroll
             for (int c = 0; c < TW_A; c++)
@@ -1498,68 +1542,89 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         __syncthreads();
         return S.sc[7] != 0.0 && S.ok2 != 0.0;
     };
+    // T D T^T dy = rhs on wave 0 alone (round 3; it ran on two waves with three workgroup barriers and two LDS hand-overs, 2.8 us:
+    // the chains below are as long, but nothing waits for another wave).  lane = unknown.  Every step broadcasts one component
+    // (two v_readlane) and takes coefficient x component off the lanes that follow it in the elimination order; the coefficients
+    // -- entries of T in LDS, zero where the band ends -- do not depend on the chain and are loaded ahead of it.  The top-down
+    // and the bottom-up sweep touch different lanes: they run as two independent chains (two accumulators) side by side.
     auto solve = [&]() {
         constexpr int RV = NY - 1;
-        double b = 0.0;
-        if (wave < 2) {
-            // forward, 14 steps from each end.  rowS: this lane's multipliers (zeros elsewhere, so no lane predicates)
-            double rowS[TW_M1];
-            if (wave == 0) {
+        if (wave == 0) {
+            const int l = lane;
+            // The loads are unconditional (what a lane outside the range reads lies inside this struct and is discarded) and pinned
+            // group by group (pin_values), so that a group is ONE batch of loads ahead of its chain.
+            const int lr = l < NY ? l : NY - 1;
+            const double *Krow = S.K + lr * KLD;            // T[l][.]
+            const double *Kcol = S.K + lr;                  // T[.][l]
+            const double rhs = l < NY ? S.rhs[l] : 0.0;
+            const double dinv = l < NY ? S.dinv[l] : 0.0;
+            double bt = l < TW_M1 ? rhs : 0.0;              // top-down sweep: unknowns 0..13, what it takes off the middle rows
+            double bb = l >= TW_M1 ? rhs : 0.0;             // bottom-up sweep: unknowns 38..25, what it takes off the middle rows
+            {
+                double ct[TW_A], cb[TW_A];
 #pragma unroll
-                for (int j = 0; j < TW_M1; j++) rowS[j] = (lane < TW_M1 && j < lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
-            } else {
+                for (int q = 0; q < TW_A; q++) { ct[q] = Krow[q]; cb[q] = Kcol[(RV - q) * KLD]; }
+                pin_values(ct);
+                pin_values(cb);
 #pragma unroll
-                for (int j = 0; j < TW_M1; j++)
-                    rowS[j] = (lane < TW_M1 && j < TW_A && j < lane && lane - j <= BAND) ? S.K[(RV - j) * KLD + (RV - lane)] : 0.0;
+                for (int q = 0; q < TW_A; q++) {
+                    ct[q] = (l > q && l <= q + BAND) ? ct[q] : 0.0;                      // T[l][q], l in (q, q + BAND] (<= 24: the top sweep ends in the middle block)
+                    cb[q] = (l < RV - q && l >= RV - q - BAND) ? cb[q] : 0.0;            // pivot RV - q: rows above it, stored at the mirrored place
+                }
+#pragma unroll
+                for (int q = 0; q < TW_A; q++) {
+                    bt = fma(-ct[q], lane_value(bt, q), bt);
+                    bb = fma(-cb[q], lane_value(bb, RV - q), bb);
+                }
             }
-            const double b_in = lane < NY ? S.rhs[wave == 0 ? lane : RV - lane] : 0.0;
-            b = b_in;
-            fwd_steps<0, TW_A>(rowS, b);
-            if (wave == 1) {
-                if (lane >= TW_A && lane < TW_M1) S.xch[RV - lane - TW_A] = b - b_in;   // what the bottom sweep takes off the middle rhs
-                b *= dinv_own;                                                          // D^-1 of its own 14 unknowns
-            }
-            __syncthreads();
-            if (wave == 0) {
-                if (lane >= TW_A && lane < TW_M1) b += S.xch[lane - TW_A];
-                fwd_steps<TW_A, TW_M1>(rowS, b);
-                b *= dinv_own;
-                // middle block, backward: lanes 14..23 need column entries T[I][lane], I = 15..24
+            double b = bt + bb;
+            {
                 double cm[BAND - 1];
 #pragma unroll
-                for (int q = 0; q < BAND - 1; q++) {
-                    const int I = TW_A + 1 + q;
-                    cm[q] = (lane >= TW_A && lane < I) ? S.K[I * KLD + lane] : 0.0;
-                }
-                bwd_steps<TW_M1 - 1, TW_A + 1, BAND - 1>(cm, b);
-                if (lane >= TW_A && lane < TW_M1) S.xmid[lane - TW_A] = b;
+                for (int q = 0; q < BAND - 1; q++) cm[q] = Krow[TW_A + q];
+                pin_values(cm);
+#pragma unroll
+                for (int q = 0; q < BAND - 1; q++) cm[q] = (l > TW_A + q && l < TW_M1) ? cm[q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < BAND - 1; q++) b = fma(-cm[q], lane_value(b, TW_A + q), b);
             }
-            __syncthreads();
-            // back out: the middle solution enters the outer unknowns as eleven independent terms, then 13 dependent steps
-            {
-                double acc = 0.0;
+            b *= dinv;
+            {   // back: the middle block first (its solution goes to the rows above AND below it), then outwards
+                double cu[BAND], cd[BAND];
+#pragma unroll
+                for (int q = 0; q < BAND; q++) { const int I = TW_M1 - 1 - q; cu[q] = Kcol[I * KLD]; cd[q] = Krow[I]; }
+                pin_values(cu);
+                pin_values(cd);
 #pragma unroll
                 for (int q = 0; q < BAND; q++) {
-                    const int Im = TW_A + q;                     // middle index in this wave's own numbering
-                    const double coef = (lane < TW_A && Im - lane <= BAND)
-                                            ? (wave == 0 ? S.K[Im * KLD + lane] : S.K[(RV - lane) * KLD + (RV - Im)]) : 0.0;
-                    const double xm = S.xmid[wave == 0 ? q : BAND - 1 - q];
-                    acc = fma(coef, xm, acc);
+                    const int I = TW_M1 - 1 - q;
+                    const double up = (l < I && l >= I - BAND) ? cu[q] : 0.0;                     // T[I][l]: rows above I (middle and top)
+                    cu[q] = (l >= TW_M1 && l < NY && l - I <= BAND) ? cd[q] : up;                 // T[I][l] of a bottom row l, at the mirrored place
                 }
-                if (lane < TW_A) b -= acc;
-                double co[TW_A - 1];
+#pragma unroll
+                for (int q = 0; q < BAND; q++) b = fma(-cu[q], lane_value(b, TW_M1 - 1 - q), b);
+            }
+            bt = b; bb = b;
+            {
+                double co[TW_A - 1], ci[TW_A - 1];
+#pragma unroll
+                for (int q = 0; q < TW_A - 1; q++) { co[q] = Kcol[(TW_A - 1 - q) * KLD]; ci[q] = Krow[TW_M1 + q]; }
+                pin_values(co);
+                pin_values(ci);
 #pragma unroll
                 for (int q = 0; q < TW_A - 1; q++) {
-                    const int I = 1 + q;
-                    co[q] = (lane < I && I - lane <= BAND) ? (wave == 0 ? S.K[I * KLD + lane] : S.K[(RV - lane) * KLD + (RV - I)]) : 0.0;
+                    const int It = TW_A - 1 - q, Ib = TW_M1 + q;
+                    co[q] = (l < It && l >= It - BAND) ? co[q] : 0.0;
+                    ci[q] = (l > Ib && l < NY && l - Ib <= BAND) ? ci[q] : 0.0;
                 }
-                bwd_steps<TW_A - 1, 1, TW_A - 1>(co, b);
+#pragma unroll
+                for (int q = 0; q < TW_A - 1; q++) {
+                    bt = fma(-co[q], lane_value(bt, TW_A - 1 - q), bt);
+                    bb = fma(-ci[q], lane_value(bb, TW_M1 + q), bb);
+                }
             }
-            if (wave == 0) { if (lane < TW_M1) S.dy[lane] = b; }
-            else if (lane < TW_A) S.dy[RV - lane] = b;
-        } else {
-            __syncthreads();
-            __syncthreads();
+            if (l < NY) S.dy[l] = l < TW_M1 ? bt : bb;
+            if constexpr (PROF) { if (tid == 0) t_acc[PH_SPARE0] += wall_clock64() - t_last; }
         }
         __syncthreads();
         compute_x(S.dy, S.dx, false);

@@ -291,7 +291,7 @@ class SwarmPlanner:
 
     PHASES = ("setup", "lsc_build", "ip_init", "residual_pass", "row_reduce", "assemble", "cholesky", "tri_solves",
               "affine_pass", "corrector_pass", "step_update", "output", "(row_reduce: buckets, wave 0)", "(row_reduce: axis gather, last lane)",
-              "(spare)", "(spare)")
+              "(tri_solves: the substitutions of wave 0 alone)", "(spare)")
 
     def phase_profile(self, enable=-1):
         out = np.zeros((self.N, 16), np.int64)
