@@ -33,6 +33,13 @@ namespace lsc {
 
 namespace {
 
+// the kernel's argument block, read where it lies: in the kernarg segment (constant address space => scalar loads, no private copy)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) PlanArgs KArgs;
+#else
+typedef const PlanArgs KArgs;
+#endif
+
 constexpr int GT = 512;            // lanes per agent
 constexpr int GW = GT / 64;
 constexpr int PMAX = 3 * GNYA + 2 * M;      // 45 + 10
@@ -75,7 +82,7 @@ struct GS {
 
 // predicted control points of agent q for segment m in the general modes: current position (BVC, or after a
 // disturbance reset), else like the fast path
-__device__ __forceinline__ void g_segment(const PlanArgs &a, int q, int m, bool at_rest, float dtf, F3 out[6])
+__device__ __forceinline__ void g_segment(KArgs &a, int q, int m, bool at_rest, float dtf, F3 out[6])
 {
 #pragma clang fp contract(off)
     const float *s = a.state + 9 * q;
@@ -106,7 +113,7 @@ __device__ __forceinline__ void g_segment(const PlanArgs &a, int q, int m, bool 
 }
 
 // obstaclePredictionCheck / initialTrajPlanningCheck for agent q: its plan says it should be at traj_prev[q](t = dt) now
-__device__ __forceinline__ bool disturbed_now(const PlanArgs &a, int q)
+__device__ __forceinline__ bool disturbed_now(KArgs &a, int q)
 {
 #pragma clang fp contract(off)
     if (!(a.reset_thr > 0.0) || a.planner_seq < 2 || a.planner_mode != 0) return false;
@@ -228,7 +235,7 @@ __host__ __device__ inline size_t ws_lds_bytes(int N)
 
 // (noinline: the kernel below must be able to leave before this function's frame -- it keeps part of its state in
 // scratch -- is set up; the common launch is the one that finds nobody flagged)
-__device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb,
+__device__ __attribute__((noinline)) void general_agent(KArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb,
                                                          unsigned char *lds_ws, size_t lds_ws_bytes)
 {
     GS &S = *reinterpret_cast<GS *>(smem_raw);
@@ -1047,11 +1054,11 @@ __device__ __attribute__((noinline)) void general_agent(const PlanArgs &a, const
     __syncthreads();
 }
 
-// The agents of one workgroup, out of line: the argument block is copied into private memory HERE, not in the kernel's
-// prologue (see below).
-__device__ __attribute__((noinline)) void general_entry(const PlanArgs *ka, unsigned char *smem_raw)
+// The agents of one workgroup, out of line.  (Round 2 copied the argument block into private memory here: 2.2 KB of scratch per
+// lane, 50 MB of writes per launch in the PMC counters.)
+__device__ __attribute__((noinline)) void general_entry(KArgs *ka, unsigned char *smem_raw)
 {
-    const PlanArgs a = *ka;
+    KArgs &a = *ka;
     unsigned char *ws = a.gen_ws + (size_t)blockIdx.x * a.gen_stride;
     for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
         if (a.status[a.first + al] != LSC_STATUS_GENERAL_K) continue;
@@ -1069,9 +1076,9 @@ __global__ __launch_bounds__(GT) void lsc_general_kernel(PlanArgs)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
 #if defined(__HIP_DEVICE_COMPILE__)
-    const PlanArgs *ka = (const PlanArgs *)__builtin_amdgcn_kernarg_segment_ptr();   // constant -> generic address space
+    KArgs *ka = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
 #else
-    const PlanArgs *ka = nullptr;                                                    // (host pass of the single-source build)
+    KArgs *ka = nullptr;                                                             // (host pass of the single-source build)
 #endif
     bool work = false;
     for (int al = blockIdx.x; al < ka->count; al += gridDim.x) work |= ka->status[ka->first + al] == LSC_STATUS_GENERAL_K;
