@@ -193,3 +193,18 @@ def test_sweep_with_float32_margins_is_the_rounded_double_sweep():
     assert torch.equal(n64, n32)
     assert torch.equal(d64.to(torch.float32), d32)
     pl.close()
+
+
+def test_plans_do_not_depend_on_what_the_lds_held_before():
+    """The parity cases once more through the poison build of the plan kernels (make poison: every byte of the workgroup's LDS is
+    0xff at entry).  A read of LDS that was never written -- harmless while the previous kernel left numbers there -- fails them."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "lsc_planner_amd", "liblsc_hip_poison.so")
+    if not os.path.exists(lib):
+        pytest.skip("liblsc_hip_poison.so not built (make -C lsc_planner_amd/csrc poison)")
+    env = dict(os.environ, LSC_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_edges.py")], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
