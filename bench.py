@@ -42,7 +42,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (guide: half the 157.3 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-PMC_FILE = "profiles/r02_pmc_summary.json"
+PMC_FILE = "profiles/r03_pmc_summary.json"
 
 
 def pmc_traffic(key):
@@ -315,6 +315,8 @@ def main():
     k_ms, k_n = pl.kernel_time_ms(0)
     k_all = pl.kernel_times_ms(0)
     x_all = pl.kernel_times_ms(2) if native else np.zeros(0)
+    g_all = pl.kernel_times_ms(3) if bt_path is not None and goal_mode == "prior_based" else np.zeros(0)
+    c_all = pl.kernel_times_ms(4) if bt_path is not None else np.zeros(0)
     iters_total = pl.iterations_total(reset=False)
     bad = int((status[first:first + count] != 0).sum().item())
     lrows = pl.row_counts()[first:first + count]
@@ -327,8 +329,6 @@ def main():
     elapsed = float(t.item())
     iters_total = float(it_t.item())
     # per-rank device times of the tick's launches (HIP events): where a sharded tick's time goes
-    g_all = pl.kernel_times_ms(3) if bt_path is not None and goal_mode == "prior_based" else np.zeros(0)
-    c_all = pl.kernel_times_ms(4) if bt_path is not None else np.zeros(0)
     mine = torch.tensor([float(k_all.mean()) if len(k_all) else 0.0, float(np.percentile(k_all, 99)) if len(k_all) else 0.0,
                          float(g_all.mean()) if len(g_all) else 0.0, float(c_all.mean()) if len(c_all) else 0.0,
                          1e3 * float(x_all.mean()) if len(x_all) else 0.0, float(count)], dtype=torch.float64, device=dev)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): the measurements DESIGN.md section 5 / 6 quote, into gpurun_out/$TAG/ for copying into profiles/.
+#   tools/round_measurements.sh TAG
+set -u
+TAG=${1:-meas}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+B="python bench.py"
+timeout 900 $B > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 300 $B --reset-threshold 0 --no-cpu-baseline --no-latency-leg --sweep-agents 0 > $OUT/bench_no_checks.json 2>> $OUT/bench_default.err
+timeout 300 $B --unfused --no-cpu-baseline --no-latency-leg --sweep-agents 0 > $OUT/bench_unfused.json 2>> $OUT/bench_default.err
+for mode in "--planner bvc" "--planner bvc --slack collision_constraint" "--planner bvc --slack dynamical_limit"; do
+  timeout 300 $B $mode --no-cpu-baseline --no-latency-leg --sweep-agents 0 2>> $OUT/bench_default.err
+done > $OUT/bench_modes.jsonl
+timeout 600 $B --workload random1024 --steps 60 --warmup 10 > $OUT/bench_random1024.json 2>> $OUT/bench_default.err
+timeout 600 $B --workload forest256 --steps 60 --warmup 10 > $OUT/bench_forest256_prior_based.json 2>> $OUT/bench_default.err
+timeout 600 $B --workload forest256 --static-goal --steps 60 --warmup 10 > $OUT/bench_forest256_static.json 2>> $OUT/bench_default.err
+timeout 900 python tools/config_runs.py > $OUT/config_runs.jsonl 2>> $OUT/bench_default.err
+timeout 600 python tools/shard_emulation.py --workload random1024 > $OUT/shard_emulation_random1024.jsonl 2>> $OUT/bench_default.err
+timeout 600 python tools/shard_emulation.py --workload forest256 > $OUT/shard_emulation_forest256.jsonl 2>> $OUT/bench_default.err
+timeout 600 python tools/general_profile.py > $OUT/general_profile.jsonl 2>> $OUT/bench_default.err
+timeout 600 python tools/phase_profile.py > $OUT/phase_profile_64.log 2>> $OUT/bench_default.err
+timeout 600 python tools/goal_profile.py > $OUT/goal_profile.log 2>> $OUT/bench_default.err
+timeout 600 python tools/multi_eval.py > $OUT/multi_eval.log 2>> $OUT/bench_default.err
+ls -la $OUT
