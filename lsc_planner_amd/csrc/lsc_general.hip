@@ -235,9 +235,21 @@ __host__ __device__ inline size_t ws_lds_bytes(int N)
 
 // (noinline: the kernel below must be able to leave before this function's frame -- it keeps part of its state in
 // scratch -- is set up; the common launch is the one that finds nobody flagged)
-__device__ __attribute__((noinline)) void general_agent(KArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb,
+// LDSP: every row array in LDS, addressed as such (ds_read / ds_write instead of flat accesses through generic pointers: the row
+// passes are chains of dependent loads).  Returns false, before touching anything but its own set-up, when the kept rows do not
+// fit -- the caller then runs the generic-pointer build, which spills the last arrays to the HBM workspace.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LSC_LDS_PTR(T) __attribute__((address_space(3))) T *
+#else
+#define LSC_LDS_PTR(T) T *
+#endif
+template <bool LDSP>
+__device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb,
                                                          unsigned char *lds_ws, size_t lds_ws_bytes)
 {
+    using FP = typename std::conditional<LDSP, LSC_LDS_PTR(float), float *>::type;
+    using BP = typename std::conditional<LDSP, LSC_LDS_PTR(unsigned char), unsigned char *>::type;
+    using DP = typename std::conditional<LDSP, LSC_LDS_PTR(double), double *>::type;
     GS &S = *reinterpret_cast<GS *>(smem_raw);
     const GModel &gm = *a.gmodel;
     const Model &md = *a.model;
@@ -467,27 +479,29 @@ __device__ __attribute__((noinline)) void general_agent(KArgs &a, const int al, 
     const int US0 = AXROWS, CL0 = AXROWS + 2 * M, GS0 = CL0 + NCL, RT = GS0 + NGR;
     // Each array goes to LDS while there is room (most latency-critical first: the ones the per-control-point reductions
     // walk obstacle by obstacle), else to the workgroup's HBM workspace; the code below only sees flat pointers.
+    bool fits = true;
     auto take = [&](size_t bytes) -> unsigned char * {
         bytes = (bytes + 15) & ~(size_t)15;
         unsigned char *p;
         if (bytes <= lds_ws_bytes) { p = lds_ws; lds_ws += bytes; lds_ws_bytes -= bytes; }
-        else { p = wsb; wsb += bytes; }
+        else { p = wsb; wsb += bytes; fits = false; }
         return p;
     };
-    float *nrm = reinterpret_cast<float *>(take(sizeof(float) * 3 * NGR));              // [NGR][3]
-    unsigned char *slk = take(nob);                                                     // [nob]
-    unsigned char *cact = take((size_t)NBK * nob);                                      // [NCL] row is active
-    unsigned char *gact = take((size_t)M * nob);                                        // [NGR] group has an active row
-    double *rt1 = reinterpret_cast<double *>(take(sizeof(double) * RT));
-    double *rt2 = reinterpret_cast<double *>(take(sizeof(double) * RT));
-    double *rz = reinterpret_cast<double *>(take(sizeof(double) * RT));
-    double *crhs = reinterpret_cast<double *>(take(sizeof(double) * NCL));              // [NCL]   d + n.q of a collision row
-    double *ev = reinterpret_cast<double *>(take(sizeof(double) * NGR));                // [NGR]   group slack variables
-    double *dev = reinterpret_cast<double *>(take(sizeof(double) * NGR));
-    double *Dg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
-    double *iDg = reinterpret_cast<double *>(take(sizeof(double) * NGR));               // 1 / D_g
-    double *qg = reinterpret_cast<double *>(take(sizeof(double) * NGR));
-    double *rs = reinterpret_cast<double *>(take(sizeof(double) * RT));
+    FP nrm = (FP)take(sizeof(float) * 3 * NGR);                                          // [NGR][3]
+    BP slk = (BP)take(nob);                                                              // [nob]
+    BP cact = (BP)take((size_t)NBK * nob);                                               // [NCL] row is active
+    BP gact = (BP)take((size_t)M * nob);                                                 // [NGR] group has an active row
+    DP rt1 = (DP)take(sizeof(double) * RT);
+    DP rt2 = (DP)take(sizeof(double) * RT);
+    DP rz = (DP)take(sizeof(double) * RT);
+    DP crhs = (DP)take(sizeof(double) * NCL);                                            // [NCL]   d + n.q of a collision row
+    DP ev = (DP)take(sizeof(double) * NGR);                                              // [NGR]   group slack variables
+    DP dev = (DP)take(sizeof(double) * NGR);
+    DP Dg = (DP)take(sizeof(double) * NGR);
+    DP iDg = (DP)take(sizeof(double) * NGR);                                             // 1 / D_g
+    DP qg = (DP)take(sizeof(double) * NGR);
+    DP rs = (DP)take(sizeof(double) * RT);
+    if (LDSP && !fits) return false;                                                     // (uniform: sizes only)
 
     for (int oe = tid; oe < n_obs; oe += GT) {
         const int oi = omap[oe];
@@ -1052,6 +1066,7 @@ __device__ __attribute__((noinline)) void general_agent(KArgs &a, const int al, 
         if (a.nrows) a.nrows[qi] = (int)nrow - 414 - nu;      // collision rows + group sign rows
     }
     __syncthreads();
+    return true;
 }
 
 // The agents of one workgroup, out of line.  (Round 2 copied the argument block into private memory here: 2.2 KB of scratch per
@@ -1063,7 +1078,10 @@ __device__ __attribute__((noinline)) void general_entry(KArgs *ka, unsigned char
     for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
         if (a.status[a.first + al] != LSC_STATUS_GENERAL_K) continue;
         __syncthreads();
-        general_agent(a, al, smem_raw, ws, smem_raw + gs_bytes(), ws_lds_bytes(a.N));
+        if (!general_agent<true>(a, al, smem_raw, ws, smem_raw + gs_bytes(), ws_lds_bytes(a.N))) {
+            __syncthreads();
+            general_agent<false>(a, al, smem_raw, ws, smem_raw + gs_bytes(), ws_lds_bytes(a.N));
+        }
         __syncthreads();
     }
 }
