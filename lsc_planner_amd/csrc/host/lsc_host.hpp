@@ -121,6 +121,7 @@ struct Param {   // defaults = launch/testall_empty.launch
     double multisim_time_step = 0.2, multisim_record_time_step = 0.1, multisim_reset_threshold = 0.15;
     int multisim_max_planner_iteration = 300;
     double multisim_max_noise = 0.0;   // multisim/max_noise (src/param.cpp; 0.02 in testall_*.launch): uniform noise on the desired goals
+    bool phase_stats = false;          // lsc_sim --phase-stats: per-phase PlanningTimeStatistics from the instrumented plan kernel
     unsigned multisim_noise_seed = 0;  // 0 = std::random_device like the reference (src/mission.cpp:387); else reproducible
     bool multisim_save_result = false;
     double goal_threshold = 0.1;

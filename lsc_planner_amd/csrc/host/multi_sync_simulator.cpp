@@ -37,6 +37,12 @@ class MultiSyncSimulator {
         cfg.grid_resolution = param.grid_resolution; cfg.grid_margin = param.grid_margin;
         ctx = lsc_create(&cfg);
         if (!ctx) throw std::runtime_error("[MultiSyncSimulator] lsc_create failed: no usable MI355X (there is no CPU path)");
+        if (param.phase_stats) {
+            if (param.multisim_reset_threshold > 0 || param.planner_mode != 0)
+                std::fprintf(stderr, "[MultiSyncSimulator] --phase-stats: the instrumented plan kernel has no alternate-mode hooks; use it with "
+                                     "--reset-threshold 0 --planner lsc (the phase columns stay 0 otherwise)\n");
+            phase_stats_on = true;                 // switched on after lsc_set_agents (the counters belong to the swarm)
+        }
         if (param.world > 1 || !param.comm_file.empty()) initComm();
         const int N = mission.qn;
         std::vector<double> r(N), dw(N), vm(3 * N), am(3 * N), vn(N);
@@ -47,6 +53,7 @@ class MultiSyncSimulator {
         }
         check(lsc_set_agents(ctx, N, r.data(), dw.data(), vm.data(), am.data(), vn.data()));
         check(lsc_set_timing(ctx, 1));   // per-kernel device times -> the per-phase columns of the summary
+        if (phase_stats_on) check(lsc_phase_profile(ctx, 1, nullptr));
         if (param.world_use_octomap) setOctomap(mission.world_file_name);
         h_state.resize(9 * N); h_goal.resize(3 * N); h_prev.assign(90 * N, 0.f); h_next.resize(90 * N);
         h_cost.assign(N, 0.0); h_status.assign(N, 0); h_iters.assign(N, 0);
@@ -261,7 +268,31 @@ class MultiSyncSimulator {
             if (lsc_kernel_time_ms(ctx, which, &ms, &n) != LSC_OK || n == 0) return 0.0;
             return ms * 1e-3 / mission.qn;
         };
-        const double t_goal = per_plan(3), t_sfc = per_plan(4), t_plan = per_plan(0);
+        const double t_goal = per_plan(3), t_sfc = per_plan(4);
+        double t_plan = per_plan(0), t_init = 0, t_lsc = 0;
+        if (phase_stats_on && total_ticks > 0) {
+            // instrumented plan kernel: 100 MHz ticks of lane 0 per phase and agent.  initial_traj_planning_time <- the set-up phase (own
+            // initial trajectory, goal stage, constants; the obstacles' predicted segments are loaded inside the LSC build, so
+            // obstacle_prediction_time stays 0), lsc_generation_time <- the LSC build, traj_optimization_time <- the interior point
+            std::vector<long long> ph((size_t)mission.qn * 16);
+            if (lsc_phase_profile(ctx, -1, ph.data()) == LSC_OK) {
+                double s_init = 0, s_lsc = 0, s_qp = 0;
+                int planned = 0;
+                for (int q = 0; q < mission.qn; q++) {
+                    const long long *p = ph.data() + (size_t)q * 16;
+                    long long all = 0;
+                    for (int k = 0; k < 12; k++) all += p[k];
+                    if (all == 0) continue;                                   // not in this rank's shard
+                    planned++;
+                    s_init += (double)p[0]; s_lsc += (double)p[1];
+                    for (int k = 2; k < 12; k++) s_qp += (double)p[k];
+                }
+                if (planned) {
+                    const double per = 1e-8 / ((double)planned * total_ticks);
+                    t_init = s_init * per; t_lsc = s_lsc * per; t_plan = s_qp * per;
+                }
+            }
+        }
         std::printf("[MultiSyncSimulator] total flight time: %g\n[MultiSyncSimulator] total distance: %g\n"
                     "[MultiSyncSimulator] planning time per agent: %g\n[MultiSyncSimulator] safety ratio between agent: %g\n"
                     "[MultiSyncSimulator] collided: %d, ticks: %d, mean tick %.3f ms -> %.1f agent-replans/s (host-buffer ABI)\n",
@@ -278,7 +309,7 @@ class MultiSyncSimulator {
                    "sfc_generation_time,traj_optimization_time,mission_file_name,world_file_name,planner_mode,prediction_mode,"
                    "initial_traj_mode,slack_mode,goal_mode,world_dimension,dt,horizon,N_constraint_segments\n";
         out << sim_start_time << "," << total_flight_time << "," << total_distance << "," << is_collided << "," << safety_ratio_agent << "," << avg
-            << "," << avg << "," << avg << ",0,0," << t_goal << ",0," << t_sfc << "," << t_plan << "," << mission.mission_file_name << "," << mission.world_file_name
+            << "," << avg << "," << avg << "," << t_init << ",0," << t_goal << "," << t_lsc << "," << t_sfc << "," << t_plan << "," << mission.mission_file_name << "," << mission.world_file_name
             // mode strings exactly as the reference's writer produces them, quirks included: "current_posiotion" is its
             // spelling (src/param.cpp:158), and getGoalModeStr() indexes its table with the PLANNER mode (src/param.cpp:168-171),
             // so the goal_mode column reads "static" for LSC and "orca" for BVC whatever mode/goal was
@@ -287,7 +318,7 @@ class MultiSyncSimulator {
             << param.horizon << "," << param.N_constraint_segments << "\n";
     }
 
-    bool is_collided = false;
+    bool is_collided = false, phase_stats_on = false;
     double safety_ratio_agent = SP_INFINITY, total_flight_time = 0, total_distance = 0;
     int total_ticks = 0;
     double total_tick_ms = 0, last_tick_ms = 0;
@@ -325,6 +356,7 @@ int main(int argc, char **argv)
         else if (a == "--csv") { param.log_dir = next(); param.multisim_save_result = true; }
         else if (a == "--device") param.device = std::stoi(next());
         else if (a == "--quiet") quiet = true;
+        else if (a == "--phase-stats") param.phase_stats = true;
         else if (a == "--static-goal") param.goal_mode_prior_based = false;
         else if (a == "--planner") { const std::string v = next(); param.planner_mode = v == "bvc" ? 1 : 0; }
         else if (a == "--slack") { const std::string v = next(); param.slack_mode = v == "dynamical_limit" ? 1 : (v == "collision_constraint" ? 2 : 0); }
@@ -337,7 +369,7 @@ int main(int argc, char **argv)
         else if (a == "--ranks") param.world = std::stoi(next());
         else if (a == "--rank") param.rank = std::stoi(next());
         else if (a == "--comm-file") param.comm_file = next();
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats]\n"); return 2; }
     }
     if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
     // torchrun / mpirun style environment: one process per GPU

@@ -233,3 +233,24 @@ def test_the_one_published_mission_outcome_of_the_reference(tmp_path):
     assert abs(float(summ["total_flight_time"]) - t_pub) <= 0.25 * t_pub, summ["total_flight_time"]
     assert abs(float(summ["total_flight_distance"]) - d_pub) <= 0.10 * d_pub, summ["total_flight_distance"]
     print("lsc_sim:", summ["total_flight_time"], "s,", summ["total_flight_distance"], "m; published:", t_pub, "s,", d_pub, "m")
+
+
+def test_phase_stats_fill_the_planning_time_columns(ticks, tmp_path):
+    """lsc_sim --phase-stats: initial_traj_planning_time / lsc_generation_time / traj_optimization_time of the summary
+    (PlanningTimeStatistics, include/sp_const.hpp:89-128) come from the instrumented plan kernel; the run itself is the same."""
+    ms = golden_mission(ticks, "multi_simple4")
+    mp = tmp_path / "m.json"
+    _write_mission(str(mp), ms)
+    outs = {}
+    for tag, extra in (("plain", []), ("stats", ["--phase-stats"])):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(d), "--quiet", "--reset-threshold", "0"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = list(csv.DictReader(open(d / "summary_LSC_4agents.csv")))[0]
+    plain, stats = outs["plain"], outs["stats"]
+    assert plain["total_flight_time"] == stats["total_flight_time"] and plain["total_flight_distance"] == stats["total_flight_distance"]
+    assert float(plain["lsc_generation_time"]) == 0.0 and float(plain["initial_traj_planning_time"]) == 0.0
+    for col in ("initial_traj_planning_time", "lsc_generation_time", "traj_optimization_time"):
+        assert 1e-7 < float(stats[col]) < 1e-3, (col, stats[col])               # microseconds per agent-plan, in seconds
