@@ -291,6 +291,10 @@ int lsc_phase_profile(lsc_ctx *ctx, int enable, long long *out);
  * neighbour screening, insertions; of those: cycles and count of the pops and of the insertions that took the general LDS
  * routines (rows beyond 64 entries, rehashes); the rest is reserved. */
 int lsc_goal_profile(lsc_ctx *ctx, int enable, long long *out);
+/* Test hook, host only (no device needed): the 32-bit key table of the grid search for squared cell distances 0 .. words-1 --
+ * out[d] = floor(sqrt d) << *rank_bits | rank of frac(sqrt d); a search key is (steps << rank_bits) + out[d2].  LSC_ESTATE when the
+ * table's exactness conditions do not hold for that range (the search then keeps 64-bit keys). */
+int lsc_goal_key_table(int words, unsigned int *out, int *rank_bits);
 /* lsc_general_profile: sections of the alternate-mode kernel -- BVC / slack modes / disturbed agents -- collected while
  * lsc_phase_profile is enabled and cleared with it; out[N][16] shader cycles: set-up, start, residual pass, row reduction,
  * assembly, factorization, solves, affine pass, corrector right-hand side, its reduction and assembly, step; [12] the

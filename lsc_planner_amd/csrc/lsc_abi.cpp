@@ -590,6 +590,57 @@ int lsc_set_shard(lsc_ctx *c, int first, int count)
     return LSC_OK;
 }
 
+// Key32 table of the goal search: word d = floor(sqrt d) << rb | rank of frac(sqrt d) among the distinct fractional parts of
+// sqrt(0 .. words - 1).  Returns false (table empty) when the ranks need more than 16 bits or the smallest gap between two distinct
+// fractional parts -- the wrap-around gap 1 - max included -- is not orders of magnitude above the rounding of the reference's F.
+// (The argument why such keys order and tie exactly like the reference's doubles is spelled out in build_goal_grid.)
+static bool goal_key_table(int words, std::vector<uint32_t> &table, int &rank_bits)
+{
+    table.clear();
+    rank_bits = 0;
+    if (words < 1 || words > (1 << 16)) return false;
+    std::vector<std::pair<long double, int>> fr(words);
+    std::vector<uint32_t> q(words);
+    for (int d = 0; d < words; d++) {
+        uint32_t r = (uint32_t)std::sqrt((double)d);
+        while ((long long)r * r > d) r--;
+        while ((long long)(r + 1) * (r + 1) <= d) r++;
+        q[d] = r;
+        fr[d] = {(long long)r * r == d ? 0.0L : sqrtl((long double)d) - (long double)r, d};     // exact 0 for perfect squares
+    }
+    std::sort(fr.begin(), fr.end());
+    std::vector<uint32_t> rank(words);
+    long double min_gap = 1.0L - fr.back().first;
+    uint32_t rk = 0;
+    for (int i = 0; i < words; i++) {
+        if (i > 0 && fr[i].first != fr[i - 1].first) { rk++; min_gap = std::min(min_gap, fr[i].first - fr[i - 1].first); }
+        rank[fr[i].second] = rk;
+    }
+    int rb = 1;
+    while ((1u << rb) <= rk) rb++;
+    // gaps are ~1 / D^2 (>= 1e-10 for D < 65536); long double resolves 1e-16 here; the reference's F carries < 1e-9 of rounding
+    // at most (ulp(2^19) = 6e-11, three roundings) against 10 x gap
+    const bool safe = min_gap > 1e-12L && 10.0L * min_gap > 50.0L * 6e-11L && rb <= 16;
+    // (with rb <= 16 and steps <= G_MAX = 32767, (steps + q) << rb stays below 2^32 - 1 = NONE)
+    if (!safe) return false;
+    table.resize(words);
+    for (int d = 0; d < words; d++) table[d] = (q[d] << rb) | rank[d];
+    rank_bits = rb;
+    return true;
+}
+
+// test hook (host only, no device needed): the key table for squared distances 0 .. words - 1
+int lsc_goal_key_table(int words, unsigned int *out, int *rank_bits)
+{
+    if (!out || !rank_bits) return LSC_EINVAL;
+    std::vector<uint32_t> t;
+    int rb = 0;
+    if (!goal_key_table(words, t, rb)) return LSC_ESTATE;
+    std::memcpy(out, t.data(), sizeof(uint32_t) * t.size());
+    *rank_bits = rb;
+    return LSC_OK;
+}
+
 // Goal planner inputs derived from the map (GridBasedPlanner::updateGridInfo / updateGridMap, distmap part,
 // src/grid_based_planner.cpp:72-130): grid geometry, one static occupancy grid per distinct radius (indexed by the
 // search key H*W*z + W*i + j), the distance field itself for castRay, and the bucket-count sequence of the
@@ -638,35 +689,8 @@ static int build_goal_grid(lsc_ctx *c, const std::vector<double> &radii)
             if (goal_smem_bytes(H, W, A, cap32, words) > 158 * 1024 || cap32 < std::min(W * A, 192)) cap32 = 0;
         }
         if (words > 0 && cap32 > 0 && c->cfg.goal_search != 2) {
-            std::vector<std::pair<long double, int>> fr(words);
-            std::vector<uint32_t> q(words);
-            for (int d = 0; d < words; d++) {
-                uint32_t r = (uint32_t)std::sqrt((double)d);
-                while ((long long)r * r > d) r--;
-                while ((long long)(r + 1) * (r + 1) <= d) r++;
-                q[d] = r;
-                fr[d] = {(long long)r * r == d ? 0.0L : sqrtl((long double)d) - (long double)r, d};     // exact 0 for perfect squares
-            }
-            std::sort(fr.begin(), fr.end());
-            std::vector<uint32_t> rank(words);
-            long double min_gap = 1.0L;
-            uint32_t rk = 0;
-            for (int i = 0; i < words; i++) {
-                if (i > 0 && fr[i].first != fr[i - 1].first) { rk++; min_gap = std::min(min_gap, fr[i].first - fr[i - 1].first); }
-                rank[fr[i].second] = rk;
-            }
-            int rb = 1;
-            while ((1u << rb) <= rk) rb++;
-            // gaps are ~1 / D^2 (>= 1e-10 for D < 65536); long double resolves 1e-16 here; the reference's F carries < 1e-9 of rounding
-            // at most (ulp(2^19) = 6e-11, three roundings) against 10 x gap
-            const bool safe = min_gap > 1e-12L && 10.0L * min_gap > 50.0L * 6e-11L && rb <= 16;
-            // (with rb <= 16 and steps <= G_MAX = 32767, (steps + q) << rb stays below 2^32 - 1 = NONE)
-            if (safe) {
-                c->h_fcode.resize(words);
-                for (int d = 0; d < words; d++) c->h_fcode[d] = (q[d] << rb) | rank[d];
-                c->fcode_rb = rb;
-                cap = cap32;
-            }
+            int rb = 0;
+            if (goal_key_table(words, c->h_fcode, rb)) { c->fcode_rb = rb; cap = cap32; }
         }
     }
     if (c->cfg.goal_row_cap > 0) cap = std::max(4, std::min(cap, c->cfg.goal_row_cap));   // explicit smaller capacity (tests force the overflow path)

@@ -103,3 +103,27 @@ def test_planar_world_has_one_grid_layer_and_no_vertical_moves(oracle):
     assert max(len(p) for p in paths) >= 10
     for p in paths:
         assert len(p) == 0 or (p[:, 2] == 0).all()
+
+
+@pytest.mark.parametrize("dims", [(34, 34, 9), (67, 67, 9), (128, 100, 5)])
+def test_32_bit_search_keys_order_and_tie_like_the_reference_doubles(dims):
+    """The goal search's Key32 (csrc/lsc_abi.cpp: goal_key_table): (steps << rb) + table[d2] must order AND tie exactly
+    like F = g + H = 10 steps + 10 sqrt(d2) in the reference's double arithmetic (src/Astar-3D/isearch.cpp) for every step count and
+    every squared distance of the grid.  Checked exhaustively: all (steps, d2) sorted by key, F must be non-decreasing along that
+    order and equal exactly where the keys are equal.  Host-only hook of the product library: no GPU involved."""
+    import ctypes
+    from lsc_planner_amd import _lib
+    L = _lib.load_library()
+    H, W, A = dims
+    words = (H - 1) ** 2 + (W - 1) ** 2 + (A - 1) ** 2 + 1
+    tab = np.zeros(words, np.uint32)
+    rb = ctypes.c_int()
+    assert L.lsc_goal_key_table(words, tab.ctypes.data_as(ctypes.POINTER(ctypes.c_uint)), ctypes.byref(rb)) == 0
+    steps = np.arange(0, H + W + A + 400, dtype=np.uint64)                  # longer than any path of these grids
+    key = ((steps[:, None] << np.uint64(rb.value)) + tab[None, :].astype(np.uint64)).ravel()
+    assert key.max() < 2 ** 32 - 1
+    F = (np.float64(10.0) * steps[:, None].astype(np.float64) + np.float64(10.0) * np.sqrt(np.arange(words, dtype=np.float64))[None, :]).ravel()
+    order = np.argsort(key, kind="stable")
+    k, f = key[order], F[order]
+    assert (np.diff(f) >= 0).all()
+    assert np.array_equal(np.diff(k.astype(np.int64)) == 0, np.diff(f) == 0)
