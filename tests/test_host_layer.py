@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     from lsc_planner_amd import _lib
     L = _lib.load_library()                       # loads without a GPU; compute calls are not made here
     hdr = open(os.path.join(ROOT, "include", "lsc_planner_amd.h")).read()
-    declared = set(re.findall(r"\b(lsc_[a-z_]+)\s*\(", hdr)) - {"lsc_ctx"}
+    declared = set(re.findall(r"\b(lsc_[a-z0-9_]+)\s*\(", hdr)) - {"lsc_ctx"}
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     for name in declared:
         assert hasattr(L, name)
