@@ -16,7 +16,9 @@ of the reference run every tick, lsc_plan_alt_kernel + the hand-over launch of l
 With --gpus G the swarm is G such circles side by side in one world (64*G agents, 30 m pitch; --single-circle: one circle of
 radius 8*G), agent-sharded one circle per GPU with one in-place RCCL all-gather of the new trajectories per tick (native:
 lsc_tick_device_sharded enqueues plan kernel, ncclAllGather and state propagation on one stream; if that communicator
-cannot be created, the torch.distributed all-gather around the same kernels): weak scaling with fixed difficulty per GPU.  `python bench.py --gpus G` starts the G ranks itself
+cannot be created, the torch.distributed all-gather around the same kernels): weak scaling with fixed difficulty per GPU -- a BEST
+case, every row between agents of different ranks is culled (config.scaling_note says so; the strong-scaling workloads below keep them).
+`python bench.py --gpus G` starts the G ranks itself
 (re-executes under torch.distributed.run when WORLD_SIZE is not set); torch.distributed is only the control plane
 (rendezvous token, barrier, max-over-ranks of the elapsed time).
 
@@ -362,7 +364,11 @@ def main():
                                       ("goal search, corridor and plan launches per tick, states propagated in the plan launch)" if bt_path is not None else
                                        "one fused launch per tick: goal planning + LSC + QP + state propagation)")),
                        "agents": n_agents, "parallelism": f"agent-shard x{G}", "prune_redundant_rows": not args.no_prune,
-                       "planner_mode": args.planner, "slack_mode": args.slack, "reset_threshold": args.reset_threshold},
+                       "planner_mode": args.planner, "slack_mode": args.slack, "reset_threshold": args.reset_threshold,
+                       "scaling_note": ("one swarm: every agent's rows against agents of other ranks are live" if strong else
+                                        ("weak scaling over disjoint circles: the rows between agents of different ranks are all redundant and culled, so this "
+                                         "curve is a best case (what it shows is the all-gather); --workload random1024 / forest256 shard ONE swarm" if G > 1 else
+                                         "single GPU"))},
             "qp": {"mean_ip_iterations": round(iters_total / (n_agents * args.steps), 2), "failed_agents_last_tick": bad,
                    "active_lsc_rows_last_tick_mean": float(np.mean(lrows)), "active_lsc_rows_last_tick_max": int(np.max(lrows)),
                    "reference_rows_per_agent": 27 * (n_agents - 1)},
