@@ -1074,6 +1074,11 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
 __device__ __attribute__((noinline)) void general_entry(KArgs *ka, unsigned char *smem_raw)
 {
     KArgs &a = *ka;
+#ifdef LSC_POISON_LDS
+    // debugging aid (not built into the product, see lsc_kernels.hip): the workgroup's LDS starts as 0xff bytes
+    for (size_t i = threadIdx.x; i < (gs_bytes() + ws_lds_bytes(a.N)) / 4; i += GT) reinterpret_cast<uint32_t *>(smem_raw)[i] = 0xffffffffu;
+    __syncthreads();
+#endif
     unsigned char *ws = a.gen_ws + (size_t)blockIdx.x * a.gen_stride;
     for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
         if (a.status[a.first + al] != LSC_STATUS_GENERAL_K) continue;

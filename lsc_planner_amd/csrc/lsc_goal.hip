@@ -905,6 +905,11 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
     long long tk0 = 0;
     auto ktick = [&](int slot) { if constexpr (PROF) { const long long t = (long long)__builtin_readcyclecounter(); pc[slot] += t - tk0; tk0 = t; } };
     if constexpr (PROF) tk0 = (long long)__builtin_readcyclecounter();
+#ifdef LSC_POISON_LDS
+    // debugging aid (not built into the product, see lsc_kernels.hip): the workgroup's LDS starts as 0xff bytes
+    for (int i = tid; i < a.smem_bytes / 4; i += NT) reinterpret_cast<uint32_t *>(gsm)[i] = 0xffffffffu;
+    ksync();
+#endif
     int tab_off = 0;
     Ctx c;
     c.H = a.H; c.W = a.W; c.A = a.A; c.HW = a.H * a.W; c.C = a.H * a.W * a.A; c.cap = a.row_cap; c.lane = lane;
@@ -1347,6 +1352,8 @@ hipError_t launch_goal(const GoalArgs &a, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;
     const size_t smem = goal_smem_bytes(a.H, a.W, a.A, a.row_cap, (a.variant & 8) ? a.fcode_n : 0);
+    GoalArgs t = a;
+    t.smem_bytes = (int)smem;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     // variant: 0 the general search (row bookkeeping in LDS, any grid), 1 / 2 the register-resident search (H <= 64 / 128
     // rows and (j, z) packed into 17 bits: goal_fast_slots() says which one a grid admits); a.prof != null selects the
@@ -1354,7 +1361,7 @@ hipError_t launch_goal(const GoalArgs &a, hipStream_t st)
     const int slots = a.variant & 3;
     const bool prof = a.prof != nullptr, c32 = (a.variant & 8) != 0 && a.fcode != nullptr;
     const dim3 g(a.count), b(64);
-#define LSC_GOAL_LAUNCH(NS_, PR_, C_) hipLaunchKernelGGL((lsc_goal_kernel<NS_, PR_, C_>), g, b, smem, st, a)
+#define LSC_GOAL_LAUNCH(NS_, PR_, C_) hipLaunchKernelGGL((lsc_goal_kernel<NS_, PR_, C_>), g, b, smem, st, t)
     if (slots == 0) LSC_GOAL_LAUNCH(0, false, false);
     else if (slots == 1) { if (c32) { if (prof) LSC_GOAL_LAUNCH(1, true, true); else LSC_GOAL_LAUNCH(1, false, true); }
                            else { if (prof) LSC_GOAL_LAUNCH(1, true, false); else LSC_GOAL_LAUNCH(1, false, false); } }

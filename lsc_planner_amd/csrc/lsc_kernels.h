@@ -134,6 +134,7 @@ struct GoalArgs {
     double reset_thr;                           // disturbance checks (multisim/reset_threshold; <= 0 off)
     const unsigned char *ever;                  // [N] persistent "was seen off its plan" flags
     long long *prof;                            // optional [N][8] section cycle counters (selects the instrumented kernel)
+    int smem_bytes;                             // dynamic LDS of the launch (set by launch_goal; the poison build fills it)
 };
 size_t goal_smem_bytes(int H, int W, int A, int cap, int key_words = 0);
 int goal_fast_slots(int H, int W, int A, int *jbits);

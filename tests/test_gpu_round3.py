@@ -196,8 +196,8 @@ def test_sweep_with_float32_margins_is_the_rounded_double_sweep():
 
 
 def test_plans_do_not_depend_on_what_the_lds_held_before():
-    """The parity cases once more through the poison build of the plan kernels (make poison: every byte of the workgroup's LDS is
-    0xff at entry).  A read of LDS that was never written -- harmless while the previous kernel left numbers there -- fails them."""
+    """The parity cases once more through the poison build of the plan, goal and general kernels (make poison: every byte of the
+    workgroup's LDS is 0xff at entry).  A read of LDS that was never written -- harmless while the previous kernel left numbers there -- fails them."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -205,6 +205,7 @@ def test_plans_do_not_depend_on_what_the_lds_held_before():
     if not os.path.exists(lib):
         pytest.skip("liblsc_hip_poison.so not built (make -C lsc_planner_amd/csrc poison)")
     env = dict(os.environ, LSC_HIP_LIB=lib)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        os.path.join(root, "tests", "test_gpu_edges.py")], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    files = [os.path.join(root, "tests", f) for f in ("test_gpu_parity.py", "test_gpu_edges.py", "test_gpu_goal.py", "test_gpu_modes.py")]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu"] + files, env=env, cwd=root, capture_output=True, text=True,
+                       timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:]
