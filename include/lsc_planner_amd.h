@@ -307,7 +307,8 @@ int lsc_solver_residuals(lsc_ctx *ctx, double *out);
  * reference dump or fed to any LP/QP solver.  LSC mode, rows without slack variables. */
 int lsc_dump_qp(lsc_ctx *ctx, int agent, const char *path);
 /* Reads the [64][8] per-iteration trace recorded for the agent selected by the PREVIOUS call (out may be NULL),
- * then selects `agent` (-1: off): gap, |rp|, objective, affine step, sigma, step, |dx_aff|, mu. */
+ * then selects `agent` (-1: off): gap, |rp|, objective, affine step, sigma, step, |dx_aff|, mu.  Agents solved by the
+ * alternate-mode kernel record the same eight values per iteration (the matrices behind the [64][8] block are the fast path's only). */
 int lsc_solver_trace(lsc_ctx *ctx, int agent, double *out);
 
 #ifdef __cplusplus

@@ -957,6 +957,8 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
             obj = S.sc[2];
             const double mu = gap / nrow;
             const bool gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
+            const bool tracing = a.trace && qi == a.trace_agent && tid == 0 && iters + spent < 64;       // lsc_solver_trace
+            if (tracing) { double *tr = a.trace + (iters + spent) * 8; tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = -1; tr[5] = -1; tr[7] = mu; }
             if (!(gap == gap) || !(rpmax == rpmax)) break;
             reduce_rows(true, false);
             gstamp(GP_REDUCE);
@@ -997,6 +999,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
             double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
             sigma = sigma * sigma * sigma;
             const double smu = sigma * mu;
+            if (tracing) { double *tr = a.trace + (iters + spent) * 8; tr[3] = aaff; tr[4] = sigma; tr[6] = dxn; }
             // corrector right-hand side, same factor
             for_rows([&](int r, double av, double, double h) {
                 const double sv = rs[r];
@@ -1021,7 +1024,11 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
                 rt1[r] = ds; rt2[r] = dz;
             });
             block_reduce(amax, 0, 0, 0, 0, 2, -1, -1, -1, -1);
-            const double alpha = fmin(1.0, 0.99 * S.sc[0]);
+            // fraction to the boundary like the fast path's: the closer the affine step came to a full step, the closer the combined
+            // step may go to the boundary (the last iterations then converge faster than the factor 100 a fixed 0.99 allows)
+            const double tau = fmin(1.0 - 1e-5, fmax(0.99, aaff));
+            const double alpha = fmin(1.0, tau * S.sc[0]);
+            if (tracing) a.trace[(iters + spent) * 8 + 5] = alpha;
             for_rows([&](int r, double, double, double) { rs[r] += alpha * rt1[r]; rz[r] += alpha * rt2[r]; });
             if (tid < P) S.y[tid] += alpha * S.dy[tid];
             for (int g = tid; g < NGR; g += GT) ev[g] += alpha * dev[g];
