@@ -114,9 +114,16 @@ typedef struct {
                                   the device-resident ticks                                                                 */
     double gap_tolerance;      /* interior point: duality gap <= gap_tolerance (1 + |objective|) at the optimum; 0 = 1e-9
                                   (CPLEX's barrier default, CPX_PARAM_BAREPCOMP, is 1e-8)                                   */
-    int    world_dimension;    /* world/dimension (src/param.cpp:12; 3).  2 = the goal planner's grid is the single layer
-                                  z = world_z_2d (src/grid_based_planner.cpp:82-85, 127-133, 199-215); the QP stays 3-D as in
-                                  the reference (src/traj_optimizer.cpp never looks at the dimension).  0 is read as 3       */
+    int    world_dimension;    /* world/dimension (src/param.cpp:12; 3).  2 = planar world: the goal planner's grid is the single
+                                  layer z = world_z_2d (src/grid_based_planner.cpp:82-85, 127-133, 199-215) and the QP has the
+                                  x and y variables only -- dim = param.world_dimension, src/traj_optimizer.cpp:8: 60 variables
+                                  (:264-266), cost, equalities, velocity / acceleration rows over k < dim (:330, 394, 469), no z
+                                  term in the terminal cost, the corridor rows (Box::convertToLSCs(dim): 4 half-spaces,
+                                  src/collision_constraints.cpp:37-59) and the collision rows (:367, 423, 450) -- while every
+                                  planned control point gets z = world_z_2d (:87-90).  The whole swarm must sit in that plane
+                                  (states and previous plans at z = (float)world_z_2d, which is what the reference's simulator
+                                  produces: src/mission.cpp:88-112, src/traj_planner.cpp:304-314); the host-buffer ticks return
+                                  LSC_EINVAL otherwise.  0 is read as 3                                                      */
     double world_z_2d;         /* world/z_2d (src/param.cpp:15; 1.0)                                                        */
     int    goal_search;        /* goal planner's grid search: 0 (default) the register-resident search whenever the grid admits it
                                   (at most 128 rows, (j, z) of a cell in 17 bits), with 32-bit search keys when their table fits

@@ -158,13 +158,16 @@ void build_model(const lsc_config &cfg, HostModel &H)
     m.dx_tol = 2e-8;
     m.gap_tol = cfg.gap_tolerance > 0.0 ? cfg.gap_tolerance : 1e-9;
     m.ws_mu0 = cfg.warm_start_mu >= 0.0 ? cfg.warm_start_mu : 0.03;
+    m.dim2 = cfg.world_dimension == 2 ? 1 : 0;
+    m.z2d = (double)(float)cfg.world_z_2d;
     int n = 0;
     for (int sl = 0; sl < AXROWS; sl++) {
-        const int type = sl / NV, t = (sl % NV) % SEGV, mm = t / NC, i = t % NC;
+        const int type = sl / NV, k = (sl % NV) / SEGV, t = (sl % NV) % SEGV, mm = t / NC, i = t % NC;
         const bool valid = type < 2 ? !(mm == 0 && i < 3) : (type < 4 ? (i <= 4 && !(mm == 0 && i < 2)) : (i <= 3 && !(mm == 0 && i == 0)));
-        if (valid) m.amap[n++] = (unsigned short)sl;
+        if (valid && !(m.dim2 && k == 2)) m.amap[n++] = (unsigned short)sl;      // planar world: `for (k < dim)`, src/traj_optimizer.cpp:274, 469
     }
-    if (n != 414) { std::fprintf(stderr, "lsc: axis row count %d != 414\n", n); std::abort(); }
+    if (n != (m.dim2 ? 276 : 414)) { std::fprintf(stderr, "lsc: axis row count %d\n", n); std::abort(); }
+    m.n_ax = n;
     m.sigma_pow = 3;
     // (no environment overrides: everything that changes the solve is an lsc_config field)
 }
@@ -936,6 +939,29 @@ static int host_disturbance_hint(lsc_ctx *c, const float *state, const float *pr
     return any;
 }
 
+// Planar worlds (world/dimension == 2).  The reference reads the planning agent's own position at z = world/z_2d whatever it is told
+// (TrajPlanner::currentStateCallback, src/traj_planner.cpp:304-314), stores z = z_2d in every control point it plans
+// (src/traj_optimizer.cpp:87-90) and drops the z term of every collision row (:450) -- which is only meaningful when the whole swarm
+// sits in that plane, as it does in the reference's simulator (starts at z_2d, src/mission.cpp:88-93; ideal states evaluated from
+// planar plans).  The kernels rely on exactly that, so the host-buffer ticks check it instead of planning something else silently.
+static int planar_inputs_ok(lsc_ctx *c, const float *state, const float *prev_traj, int planner_seq)
+{
+    if (c->cfg.world_dimension != 2) return LSC_OK;
+    const float z = (float)c->cfg.world_z_2d;
+    for (int q = 0; q < c->N; q++) {
+        bool ok = state[9 * (size_t)q + 2] == z;
+        if (planner_seq >= 2) {
+            const float *t = prev_traj + (size_t)q * NV + 2 * SEGV;
+            for (int j = 0; j < SEGV; j++) ok = ok && t[j] == z;
+        }
+        if (!ok) {
+            c->err = "planar world (world_dimension 2): agent " + std::to_string(q) + " is not at z = world_z_2d (state / previous plan)";
+            return LSC_EINVAL;
+        }
+    }
+    return LSC_OK;
+}
+
 static int run_plan(lsc_ctx *c, const PlanArgs &a, hipStream_t st, int general_hint = -1)
 {
     const size_t smem = plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, c->cap);
@@ -982,6 +1008,7 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
     if (!c || !state || !goal || !prev_traj || !out_traj || !out_cost || !out_status) return LSC_EINVAL;
     if (c->N == 0) return LSC_ESTATE;
     const auto t_entry = std::chrono::steady_clock::now();
+    if (int prc = planar_inputs_ok(c, state, prev_traj, planner_seq)) return prc;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t N = c->N, cnt = c->count, first = c->first, nobs = N - 1;
     hipStream_t st = c->stream;
@@ -1106,6 +1133,7 @@ int lsc_replan_tick_all(lsc_ctx *c, const float *state, const float *goal, const
     if (!c || !state || !goal || !prev_traj || !out_traj || !out_cost || !out_status) return LSC_EINVAL;
     if (c->N == 0) return LSC_ESTATE;
     if (!c->comm) { c->err = "lsc_replan_tick_all: lsc_comm_init was not called"; return LSC_ESTATE; }
+    if (int prc = planar_inputs_ok(c, state, prev_traj, planner_seq)) return prc;
     const RcclApi *api = rccl_api();
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const size_t N = c->N, Np = (size_t)c->table_rows;
@@ -1382,6 +1410,11 @@ int lsc_goal_profile(lsc_ctx *c, int enable, long long *out)
 int lsc_dump_qp(lsc_ctx *c, int agent, const char *path)
 {
     if (!c || !path || c->N < 1 || agent < 0 || agent >= c->N) return LSC_EINVAL;
+    if (agent < c->first || agent >= c->first + c->count) {
+        // corridor boxes and plan inputs are only valid for the context's own shard: the owning rank writes the dump
+        c->err = "lsc_dump_qp: the agent is not in this context's shard";
+        return LSC_EINVAL;
+    }
     if (c->last_host_seq < 1 || !c->h_in) { c->err = "lsc_dump_qp: no host-buffer tick has run on this context"; return LSC_ESTATE; }
     if (c->cfg.planner_mode != 0) { c->err = "lsc_dump_qp: LSC mode only"; return LSC_EINVAL; }
     const int N = c->N, nobs = N - 1, seq = c->last_host_seq;
@@ -1424,6 +1457,7 @@ int lsc_dump_qp(lsc_ctx *c, int agent, const char *path)
     if (!f) { c->err = std::string("lsc_dump_qp: cannot write ") + path; return LSC_EINVAL; }
     const char ax[3] = {'x', 'y', 'z'};
     const int n = DEG, phi = 3;
+    const int dim = c->cfg.world_dimension == 2 ? 2 : 3;      // dim = param.world_dimension: a planar world has 60 variables (:8, 264-266)
     const double dt = c->cfg.dt, wc = c->cfg.control_weight, wt = c->cfg.terminal_weight;
     auto var = [&](int k, int m, int i) { char b[32]; std::snprintf(b, sizeof b, "%c_%d_%d", ax[k], m, i); return std::string(b); };
     struct Term { double v; std::string name; };
@@ -1453,12 +1487,12 @@ int lsc_dump_qp(lsc_ctx *c, int agent, const char *path)
     std::fprintf(f, "\\ENCODING=ISO-8859-1\n\\Problem name: lsc_planner_amd (agent %d, planner_seq %d)\n\nMinimize\n obj1:", agent, seq);
     {
         std::vector<Term> lin;
-        for (int k = 2; k >= 0; k--)
+        for (int k = dim - 1; k >= 0; k--)
             for (int m = M - 1; m >= M - T; m--) lin.push_back({-2.0 * wt * (double)goal[k], var(k, m, n)});
         emit(lin);
         std::fprintf(f, " + [");
         bool first = true;
-        for (int k = 2; k >= 0; k--)
+        for (int k = dim - 1; k >= 0; k--)
             for (int m = M - 1; m >= 0; m--)
                 for (int i = n; i >= 0; i--)
                     for (int j = i; j >= 0; j--) {
@@ -1471,7 +1505,7 @@ int lsc_dump_qp(lsc_ctx *c, int agent, const char *path)
                         first = false;
                     }
         double cst = 0.0;
-        for (int k = 0; k < 3; k++) cst += wt * T * (double)goal[k] * (double)goal[k];
+        for (int k = 0; k < dim; k++) cst += wt * T * (double)goal[k] * (double)goal[k];
         std::fprintf(f, " ] / 2 + %.15g\nSubject To\n", cst);
     }
     int row = 0;
@@ -1479,7 +1513,7 @@ int lsc_dump_qp(lsc_ctx *c, int agent, const char *path)
     // ---- equalities (:394-405, Aeq_base :186-236, deq :239-259)
     const double A0[3][3] = {{1, 0, 0}, {-1, 1, 0}, {1, -2, 1}};       // A_0 rows 0..2, columns 0..2
     const double AT[3][3] = {{0, 0, 1}, {0, -1, 1}, {1, -2, 1}};       // A_T rows 0..2, columns n-2..n
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < dim; k++) {
         int nn = 1;
         for (int i = 0; i < phi; i++) {
             std::vector<Term> t;
@@ -1504,7 +1538,7 @@ int lsc_dump_qp(lsc_ctx *c, int agent, const char *path)
     // ---- corridor rows (:409-434; Box::convertToLSCs src/collision_constraints.cpp:37-59)
     if (c->cfg.use_octomap)
         for (int m = 0; m < ncs; m++)
-            for (int k = 0; k < 3; k++)
+            for (int k = 0; k < dim; k++)                         // Box::convertToLSCs(world_dimension): 2 dim half-spaces
                 for (int side = 0; side < 2; side++)
                     for (int j = 0; j <= n; j++) {
                         if (m == 0 && j < phi) continue;
@@ -1531,14 +1565,14 @@ int lsc_dump_qp(lsc_ctx *c, int agent, const char *path)
                 const float *nv = normal.data() + ((size_t)oi * M + m) * 3;
                 double rhs = dd[((size_t)oi * M + m) * NC + i];
                 std::vector<Term> t;
-                for (int k = 2; k >= 0; k--) { t.push_back({(double)nv[k], var(k, m, i)}); }
-                for (int k = 0; k < 3; k++) rhs += (double)nv[k] * (double)q[k];
+                for (int k = dim - 1; k >= 0; k--) { t.push_back({(double)nv[k], var(k, m, i)}); }
+                for (int k = 0; k < dim; k++) rhs += (double)nv[k] * (double)q[k];   // (the z term only `if (dim == 3)`, :450)
                 begin_row(); emit(t);
                 std::fprintf(f, " >= %.15g\n", rhs);
             }
     }
     // ---- velocity / acceleration rows (:469-523)
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < dim; k++)
         for (int m = 0; m < M; m++) {
             const double cv = std::pow(dt, -1) * n, ca = std::pow(dt, -2) * n * (n - 1);
             for (int i = 0; i < n; i++) {
@@ -1557,20 +1591,20 @@ int lsc_dump_qp(lsc_ctx *c, int agent, const char *path)
             }
         }
     // ---- stop at the horizon (:529-536)
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < dim; k++)
         for (int i = 1; i < phi; i++) {
             begin_row(); emit({{1.0, var(k, M - 1, n)}, {-1.0, var(k, M - 1, n - i)}});
             std::fprintf(f, " = 0\n");
         }
     // ---- bounds (:274-303)
     std::fprintf(f, "Bounds\n");
-    for (int k = 2; k >= 0; k--)
+    for (int k = dim - 1; k >= 0; k--)
         for (int m = M - 1; m >= 0; m--)
             for (int i = n; i >= 0; i--) {
                 if (m == 0 && i < 3) continue;
                 std::fprintf(f, " %.15g <= %s <= %.15g\n", (double)c->cfg.world_min[k], var(k, m, i).c_str(), (double)c->cfg.world_max[k]);
             }
-    for (int k = 2; k >= 0; k--)
+    for (int k = dim - 1; k >= 0; k--)
         for (int i = 0; i < 3; i++) std::fprintf(f, "      %s Free\n", var(k, 0, i).c_str());
     std::fprintf(f, "End\n");
     std::fclose(f);

@@ -263,6 +263,9 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     const bool bvc = a.planner_mode == 1;
     const float dtf = (float)md.dt;
     const double hv = md.hv_scale, ha = md.ha_scale;
+    // planar world (world/dimension == 2, src/traj_optimizer.cpp:8): no z variables -- here: the z unknowns stay without any row,
+    // decoupled (every n_z zeroed), resting at z_2d, and are overwritten on output (see lsc_model.hpp)
+    const bool dim2 = md.dim2 != 0;
 
     // block reduction of up to five values: op 0 sum, 1 max, 2 min, < 0 slot unused; results in S.sc[0..4].  DPP wave reductions
     // (lsc_wave.hpp), one barrier pair, the per-wave partials combined by five lanes.
@@ -326,10 +329,11 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     if (tid < 3) {
         const int k = tid;
         const float *s = a.state + 9 * qi;
-        const double c0 = (double)s[k], c1 = c0 + (double)s[3 + k] * hv, c2 = (double)s[6 + k] * ha + 2.0 * c1 - c0;
+        double c0 = (double)s[k], c1 = c0 + (double)s[3 + k] * hv, c2 = (double)s[6 + k] * ha + 2.0 * c1 - c0;
+        if (dim2 && k == 2) c0 = c1 = c2 = md.z2d;
         S.s0[k][0] = c0; S.s0[k][1] = c1; S.s0[k][2] = c2;
         S.goalf[k] = a.goal_out[3 * qi + k];                  // current_goal_position, planned by phase A of lsc_plan_kernel
-        S.goal[k] = (double)S.goalf[k];
+        S.goal[k] = (dim2 && k == 2) ? md.z2d : (double)S.goalf[k];
         for (int m = 0; m < M; m++) {
             double lo = (double)md.world_min[k], hi = (double)md.world_max[k];
             if (md.use_sfc && a.sfc && m < ncs) {
@@ -358,6 +362,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
         if (type < 2) { valid = !(m == 0 && i < 3); h = type == 0 ? S.hi[k][m] : -S.lo[k][m]; }
         else if (type < 4) { valid = i <= 4 && !(m == 0 && i < 2); h = a.vmax[3 * qi + k] * hv; }
         else { valid = i <= 3 && !(m == 0 && i == 0); h = a.amax[3 * qi + k] * ha; }
+        if (dim2 && k == 2) valid = false;                    // `for (k < dim)`: src/traj_optimizer.cpp:274, 469
         S.avalid[sl] = valid ? 1 : 0;
         S.ah[sl] = h;
     }
@@ -421,6 +426,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
 #pragma unroll
                 for (int i = 0; i < 6; i++) a.out_d[o * 6 + i] = d[i];
             }
+            if (dim2) n.z = 0.0f;                              // the row's z term exists only `if (dim == 3)` (:446-453)
             t_nrm[3 * u] = n.x; t_nrm[3 * u + 1] = n.y; t_nrm[3 * u + 2] = n.z;
             const double nx = (double)n.x, ny = (double)n.y, nz = (double)n.z;
             const double centre = nx * S.s0[0][2] + ny * S.s0[1][2] + nz * S.s0[2][2];
@@ -857,7 +863,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     auto objective = [&]() -> double {
         const int xk = tid < NV ? tid / SEGV : 0, xt = tid < NV ? tid % SEGV : 0;
         double o = 0.0;
-        if (tid < NV) {
+        if (tid < NV && !(dim2 && xk == 2)) {
             o = 0.5 * cost_grad(xk, xt) * S.x[tid];
             if (xt % NC == DEG && xt / NC >= M - tseg) { const double e = S.x[tid] - S.goal[xk]; o += md.w_t * e * e; }
         }
@@ -887,7 +893,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
                 const int t = aa < 12 ? (aa / 3) * NC + 3 + aa % 3 : (M - 1) * NC + 3 + (aa - 12);
                 const int m = t / NC, i = t % NC;
                 const float *tp = a.traj_prev + (size_t)qi * NV + k * SEGV;
-                S.y[tid] = (double)((m < M - 1) ? tp[(m + 1) * NC + i] : tp[(M - 1) * NC + DEG]);
+                S.y[tid] = (dim2 && k == 2) ? md.z2d : (double)((m < M - 1) ? tp[(m + 1) * NC + i] : tp[(M - 1) * NC + DEG]);
             } else if (tid < P) S.y[tid] = 0.0;
             for (int g = tid; g < NGR; g += GT) ev[g] = 0.0;
             __syncthreads();
@@ -1051,15 +1057,21 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     float *stale = a.stale + (size_t)qi * NV;
     __syncthreads();
     if (tid < NV) {
-        if (status == LSC_STATUS_OK_K) { const float v = (float)S.x[tid]; out[tid] = v; stale[tid] = v; }
+        if (status == LSC_STATUS_OK_K) {
+            float v = (float)S.x[tid];
+            if (dim2 && tid >= 2 * SEGV) v = (float)md.z2d;   // src/traj_optimizer.cpp:87-90
+            out[tid] = v; stale[tid] = v;
+        }
         else out[tid] = stale[tid];
     }
     if (a.state_next && tid < 3) {
 #pragma clang fp contract(off)
         const int k = tid;
         float c0, c1, c2;
-        if (status == LSC_STATUS_OK_K) { c0 = (float)S.x[k * SEGV + NC]; c1 = (float)S.x[k * SEGV + NC + 1]; c2 = (float)S.x[k * SEGV + NC + 2]; }
-        else { c0 = stale[k * SEGV + NC]; c1 = stale[k * SEGV + NC + 1]; c2 = stale[k * SEGV + NC + 2]; }
+        if (status == LSC_STATUS_OK_K) {
+            c0 = (float)S.x[k * SEGV + NC]; c1 = (float)S.x[k * SEGV + NC + 1]; c2 = (float)S.x[k * SEGV + NC + 2];
+            if (dim2 && k == 2) c0 = c1 = c2 = (float)md.z2d;
+        } else { c0 = stale[k * SEGV + NC]; c1 = stale[k * SEGV + NC + 1]; c2 = stale[k * SEGV + NC + 2]; }
         const float fn = (float)DEG, fn1 = (float)(DEG - 1), finv = a.finv;
         const float v0 = ((c1 - c0) * fn) * finv, v1 = ((c2 - c1) * fn) * finv, a0 = ((v1 - v0) * fn1) * finv;
         a.state_next[9 * qi + k] = c0; a.state_next[9 * qi + 3 + k] = v0; a.state_next[9 * qi + 6 + k] = a0;
@@ -1070,7 +1082,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
         a.status[qi] = status;
         a.iters[qi] = iters;
         if (a.iters_acc) a.iters_acc[qi] += iters;
-        if (a.nrows) a.nrows[qi] = (int)nrow - 414 - nu;      // collision rows + group sign rows
+        if (a.nrows) a.nrows[qi] = (int)nrow - md.n_ax - nu;  // collision rows + group sign rows
     }
     __syncthreads();
     return true;

@@ -666,6 +666,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     // 27 (N-1) rows the reference can add.
     const int R = SPILL ? NB * (n_obs > 1 ? n_obs : 1) : a.cap;
     const int n_terms = md.n_terms, n_entries = md.n_entries;
+    // axis rows that exist: 414, or 276 in a planar world (no z rows: `for (k < dim)`, src/traj_optimizer.cpp:274, 469)
+    const int n_ax = md.n_ax;
+    __builtin_assume(n_ax >= 0 && n_ax <= AXVALID);
+    const bool dim2 = md.dim2 != 0;
 
     // dynamic LDS carve-up.  The throughput build leaves the (agent-independent, 9 KB) assembly tables in HBM/L2 -- its two
     // workgroups per CU hide that latency -- and spends the LDS on row capacity instead.
@@ -837,9 +841,12 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         double c0 = (double)s[k];
         double c1 = c0 + (double)s[3 + k] * md.hv_scale;
         double c2 = (double)s[6 + k] * md.ha_scale + 2.0 * c1 - c0;
+        // planar world: z is not a variable (deq has two columns, src/traj_optimizer.cpp:239-259); the z unknowns of this solver
+        // rest at z_2d -- state constants and terminal target there, no rows -- and are overwritten on output
+        if (dim2 && k == 2) c0 = c1 = c2 = md.z2d;
         S.s0[k][0] = c0; S.s0[k][1] = c1; S.s0[k][2] = c2;
         S.x0c[k * SEGV] = c0; S.x0c[k * SEGV + 1] = c1; S.x0c[k * SEGV + 2] = c2;
-        S.goal[k] = (double)S.goalf[k];
+        S.goal[k] = (dim2 && k == 2) ? md.z2d : (double)S.goalf[k];
         if (a.goal_out) a.goal_out[3 * qi + k] = S.goalf[k];
         for (int m = 0; m < M; m++) {
             double lo = (double)md.world_min[k], hi = (double)md.world_max[k];
@@ -862,7 +869,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         int T = (int)((M * md.dt - flight + 1e-9) / md.dt);
         S.tseg = T > 1 ? T : 1;
     }
-    for (int i = tid; i < AXVALID; i += NT) {
+    for (int i = tid; i < n_ax; i += NT) {
         const uint32_t sl = md.amap[i], type = sl / NV, kt = sl % NV;
         S.amap[i] = sl | (type << 10) | ((kt / SEGV) << 13) | ((kt % SEGV) << 15);
     }
@@ -1098,6 +1105,9 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
 #pragma unroll
                     for (int i = 0; i < 6; i++) a.out_d[o * 6 + i] = d[i];
                 }
+                // planar world: the row is n_x (x - q_x) + n_y (y - q_y) - d >= 0, its z term exists only `if (dim == 3)`
+                // (src/traj_optimizer.cpp:446-453); the dump above keeps the normal CollisionConstraints holds
+                if (dim2) nrm.z = 0.0f;
                 const double nx = (double)nrm.x, ny = (double)nrm.y, nz = (double)nrm.z;
                 const double centre = nx * S.s0[0][2] + ny * S.s0[1][2] + nz * S.s0[2][2];
                 const double (*rx)[28] = nx >= 0.0 ? S.reachL : S.reachU, (*ry)[28] = ny >= 0.0 ? S.reachL : S.reachU,
@@ -1226,6 +1236,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         if (type < 2) { valid = !(m == 0 && i < 3); h = type == 0 ? S.hi[k][m] : -S.lo[k][m]; }
         else if (type < 4) { valid = i <= 4 && !(m == 0 && i < 2); h = a.vmax[3 * qi + k] * md.hv_scale; }
         else { valid = i <= 3 && !(m == 0 && i == 0); h = a.amax[3 * qi + k] * md.ha_scale; }
+        if (dim2 && k == 2) valid = false;
         S.avalid[sl] = valid ? 1 : 0;
         if constexpr (TABLES_IN_LDS) S.ah[sl] = h;
         S.as_[sl] = 1.0; S.az[sl] = 0.0; S.at1[sl] = 0.0; S.at2[sl] = 0.0;
@@ -1246,7 +1257,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     __syncthreads();
     const bool overflow = S.flag != 0;
     const int nact = S.nact;
-    const double nrow = (double)(AXVALID + nact);
+    const double nrow = (double)(n_ax + nact);
 
     // x from y : x_t = sum coef * y_glob  (+ state constants for t < 3)
     auto compute_x = [&](const double *yv, double *xv, bool with_const) {
@@ -1658,7 +1669,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         __syncthreads();
         compute_x(S.y, S.x, true);
         __syncthreads();
-        for (int c = tid; c < AXVALID; c += NT) {
+        for (int c = tid; c < n_ax; c += NT) {
             const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
             S.at2[sl] = ax_row(S.x, type, ak, at) - AH(sl);
         }
@@ -1673,13 +1684,13 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         if (tid < NY) {
             const int g = tid, k = g < 36 ? (g % 9) / 3 : g - 36, va = g < 36 ? (g / 9) * 3 + (g % 3) : 12;
             const int t = va < 12 ? (va / 3) * NC + 3 + (va % 3) : (M - 1) * NC + 3;
-            S.y[g] = (double)S.pinit[k * SEGV + t];
+            S.y[g] = (dim2 && k == 2) ? md.z2d : (double)S.pinit[k * SEGV + t];
         }
         __syncthreads();
         compute_x(S.y, S.x, true);
         __syncthreads();
         const double smin = sqrt(mu0);
-        for (int c = tid; c < AXVALID; c += NT) {
+        for (int c = tid; c < n_ax; c += NT) {
             const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
             // velocity / acceleration rows are stored divided by n/dt and n(n-1)/dt^2: scale the floor with them so that
             // the start equals the one of the reference's row scaling
@@ -1730,7 +1741,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             else {
                 // P1 (fused with the previous step): s += alpha ds, z += alpha dz, then residuals, 1/s, v = w rp
                 double gp = 0.0, rpm = 0.0;
-                for (int c = tid; c < AXVALID; c += NT) {
+                for (int c = tid; c < n_ax; c += NT) {
                     const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
                     double sv = S.as_[sl] + alpha * S.at1[sl], zv = S.az[sl] + alpha * S.at2[sl];
                     double rp = ax_row(S.x, type, ak, at) + sv - AH(sl);
@@ -1753,7 +1764,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 }
                 // objective: sum x'(w_c Q)x + w_t sum |c - g|^2  (src/traj_optimizer.cpp:329-372)
                 double objp = 0.0;
-                if (tid < NV) {
+                if (tid < NV && !(dim2 && xk == 2)) {      // (planar world: the cost runs over `k < dim`, :330, 367)
                     objp = 0.5 * cost_grad() * S.x[tid];
                     if (xterm) { double e = S.x[tid] - S.goal[xk]; objp += md.w_t * e * e; }
                 }
@@ -1772,7 +1783,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             }
         } else if (phase == ST_CORR) {
             // P3: corrector right-hand side  v = w rp - (ds dz - sigma mu)/s
-            for (int c = tid; c < AXVALID; c += NT) {
+            for (int c = tid; c < n_ax; c += NT) {
                 const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
                 double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl];
                 double rp = ax_row(S.x, type, ak, at) + sv - AH(sl);
@@ -1824,7 +1835,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 compute_x(S.y, S.x, true);
                 __syncthreads();
                 double mins = 1e300, minz = 1e300;
-                for (int c = tid; c < AXVALID; c += NT) {
+                for (int c = tid; c < n_ax; c += NT) {
                     const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
                     double sv = AH(sl) - ax_row(S.x, type, ak, at);
                     S.as_[sl] = sv; S.az[sl] = -sv;
@@ -1841,7 +1852,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0;
                 const double shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
                 // the shift enters the loop as a "step" of length 1 (t1 = ds, t2 = dz) applied by the first fused pass
-                for (int c = tid; c < AXVALID; c += NT) { const int sl = S.amap[c] & 1023; S.at1[sl] = shs; S.at2[sl] = shz; }
+                for (int c = tid; c < n_ax; c += NT) { const int sl = S.amap[c] & 1023; S.at1[sl] = shs; S.at2[sl] = shz; }
                 for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt1[r] = shs; rt2[r] = shz; }
                 __syncthreads();
                 alpha = 1.0;
@@ -1850,7 +1861,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             } else if (phase == ST_PRED) {
                 // P2: affine step length and centring statistics (+ the Newton-step convergence test)
                 double amin = 1.0, s1 = 0.0, s2 = 0.0;
-                for (int c = tid; c < AXVALID; c += NT) {
+                for (int c = tid; c < n_ax; c += NT) {
                     const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, k = (am >> 13) & 3, t = am >> 15;
                     double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
                     double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
@@ -1894,7 +1905,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             } else {
                 // P4: step length; the step itself stays in t1 = ds, t2 = dz for the fused pass of the next round
                 double amin = 1e300;
-                for (int c = tid; c < AXVALID; c += NT) {
+                for (int c = tid; c < n_ax; c += NT) {
                     const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, k = (am >> 13) & 3, t = am >> 15;
                     double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
                     double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
@@ -1951,6 +1962,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     if (tid < NV) {
         if (status == LSC_STATUS_OK_K) {
             float v = (float)S.x[tid];
+            if (dim2 && tid >= 2 * SEGV) v = (float)md.z2d;        // octomap::point3d(x, y, param.world_z_2d), src/traj_optimizer.cpp:87-90
             out[tid] = v; stale[tid] = v;
         } else {
             out[tid] = stale[tid];
@@ -1964,6 +1976,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         float c0, c1, c2;
         if (status == LSC_STATUS_OK_K) {
             c0 = (float)S.x[k * SEGV + NC]; c1 = (float)S.x[k * SEGV + NC + 1]; c2 = (float)S.x[k * SEGV + NC + 2];
+            if (dim2 && k == 2) c0 = c1 = c2 = (float)md.z2d;
         } else {
             c0 = stale[k * SEGV + NC]; c1 = stale[k * SEGV + NC + 1]; c2 = stale[k * SEGV + NC + 2];
         }

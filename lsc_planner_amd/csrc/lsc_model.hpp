@@ -50,7 +50,15 @@ struct Model {
     double gap_tol;           // duality-gap tolerance, relative to 1 + |objective|
     double ws_mu0;            // warm start: initial complementarity target (0 = cold start only)
     int sigma_pow;            // Mehrotra centering exponent: sigma = (mu_aff / mu)^sigma_pow  (2, 3 or 4)
-    unsigned short amap[416]; // compact list of the valid axis-row slots (414)
+    unsigned short amap[416]; // compact list of the valid axis-row slots (414; 276 in a planar world)
+    int    n_ax;              // entries of amap
+    // world/dimension == 2 (src/traj_optimizer.cpp:8): the QP has the x and y variables only -- no z bounds, no z velocity /
+    // acceleration rows, collision and corridor rows without their z term (:264-266, 330, 367, 394, 411, 423, 450, 469, 529) --
+    // and every stored control point gets z = world/z_2d (:87-90).  The kernels keep their 39 unknowns: the z unknowns stay in
+    // the system without any row, decoupled from x / y (every n_z is zeroed), pinned at z_2d by the state constants, and are
+    // overwritten on output; the x / y iterates are those of the 26-unknown problem.
+    int    dim2;
+    double z2d;               // (double)(float)world/z_2d
 };
 
 // Dense variant of the same elimination for the alternate planner modes (lsc_general.hip): axis-major y, with

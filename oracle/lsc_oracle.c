@@ -521,128 +521,21 @@ int orc_terminal_segments(const float goal[3], const float pos[3], double v_nom,
 
 static inline int vidx(int k, int m, int i) { return k * ORC_SEGV + m * ORC_NC + i; }
 
+/* The default-mode assembly (LSC planner, no slack variables, every segment constrained) is the general routine of
+ * lsc_oracle_modes.c with its switches off: one restatement of populatebyrow, not two.  The number of variables is
+ * orc_qp_nvars(prm): dim * M * (n + 1) with dim = world/dimension (src/traj_optimizer.cpp:8, 264-266), i.e. 60 in a planar
+ * world; P has that leading dimension. */
+int orc_qp_nvars(const orc_params *prm) { return (prm->world_dimension == 2 ? 2 : 3) * ORC_SEGV; }
+
 int orc_qp_assemble(const orc_params *prm, const float state[9], const float goal[3], double v_nom,
                     const double vmax[3], const double amax[3], int n_obs, const float *obs_traj,
                     const float *normal, const double *d, const float *sfc, double *P, double *c, double *cst,
                     double *lo, double *hi, orc_row *rows)
 {
-    const double dt = prm->dt;
-    double Q[ORC_NC * ORC_NC], Aeq[(ORC_PHI * ORC_M) * ORC_SEGV];
-    orc_qbase(dt, Q);
-    orc_aeq_base(dt, Aeq);
-
-    /* bounds :274-303 */
-    for (int k = 0; k < 3; k++)
-        for (int m = 0; m < ORC_M; m++)
-            for (int i = 0; i < ORC_NC; i++) {
-                int r = vidx(k, m, i);
-                if (m == 0 && i < 3) { lo[r] = -INFINITY; hi[r] = INFINITY; }
-                else { lo[r] = (double)prm->world_min[k]; hi[r] = (double)prm->world_max[k]; }
-            }
-
-    /* cost :328-372 ; objective = x' (w_c Q) x + w_t sum |c - g|^2  =>  (1/2) x' P x with P = 2 w_c Q (+2 w_t) */
-    memset(P, 0, sizeof(double) * ORC_NV * ORC_NV);
-    memset(c, 0, sizeof(double) * ORC_NV);
-    *cst = 0;
-    for (int k = 0; k < 3; k++)
-        for (int m = 0; m < ORC_M; m++)
-            for (int i = 0; i < ORC_NC; i++)
-                for (int j = 0; j < ORC_NC; j++)
-                    if (Q[i * ORC_NC + j] != 0 && prm->w_control != 0)
-                        P[vidx(k, m, i) * ORC_NV + vidx(k, m, j)] += 2.0 * prm->w_control * Q[i * ORC_NC + j];
-    int T = orc_terminal_segments(goal, state, v_nom, dt);
-    for (int m = ORC_M - T; m < ORC_M; m++)
-        for (int k = 0; k < 3; k++) {
-            int r = vidx(k, m, ORC_N);
-            double g = (double)goal[k];
-            P[r * ORC_NV + r] += 2.0 * prm->w_terminal;
-            c[r] += -2.0 * prm->w_terminal * g;
-            *cst += prm->w_terminal * g * g;
-        }
-
-    int nr = 0;
-    /* equalities :394-405 */
-    for (int k = 0; k < 3; k++)
-        for (int r = 0; r < ORC_PHI * ORC_M; r++) {
-            orc_row *R = &rows[nr++];
-            R->nnz = 0; R->sense = 0;
-            for (int j = 0; j < ORC_SEGV; j++)
-                if (Aeq[r * ORC_SEGV + j] != 0) {
-                    R->idx[R->nnz] = k * ORC_SEGV + j;
-                    R->val[R->nnz] = Aeq[r * ORC_SEGV + j];
-                    R->nnz++;
-                }
-            R->rhs = (r < 3) ? (double)state[3 * r + k] : 0.0;
-        }
-    /* SFC :409-434 ; Box::convertToLSCs src/collision_constraints.cpp:37-59 */
-    if (prm->use_sfc && sfc) {
-        for (int m = 0; m < ORC_M; m++)
-            for (int f = 0; f < 6; f++) {
-                int ax = f / 2;
-                double sgn = (f & 1) ? -1.0 : 1.0;
-                double dd = (f & 1) ? -(double)sfc[m * 6 + 3 + ax] : (double)sfc[m * 6 + ax];
-                for (int j = 0; j < ORC_NC; j++) {
-                    if (m == 0 && j < ORC_PHI) continue;
-                    orc_row *R = &rows[nr++];
-                    R->nnz = 1; R->sense = 1;
-                    R->idx[0] = vidx(ax, m, j); R->val[0] = sgn; R->rhs = dd;
-                }
-            }
-    }
-    /* LSC :437-466 */
-    for (int oi = 0; oi < n_obs; oi++)
-        for (int m = 0; m < ORC_M; m++)
-            for (int i = 0; i < ORC_NC; i++) {
-                if (m == 0 && i < ORC_PHI) continue;
-                const float *nv = normal + (oi * ORC_M + m) * 3;
-                orc_row *R = &rows[nr++];
-                R->nnz = 3; R->sense = 1;
-                double rhs = d[(oi * ORC_M + m) * ORC_NC + i];
-                for (int k = 0; k < 3; k++) {
-                    double q = (double)obs_traj[(oi * 3 + k) * ORC_SEGV + m * ORC_NC + i];
-                    R->idx[k] = vidx(k, m, i);
-                    R->val[k] = (double)nv[k];
-                    rhs += (double)nv[k] * q;
-                }
-                R->rhs = rhs;
-            }
-    /* dynamic limits :468-525 */
-    for (int k = 0; k < 3; k++)
-        for (int m = 0; m < ORC_M; m++) {
-            for (int i = 0; i < ORC_N; i++) {
-                if (m == 0 && (i == 0 || i == 1)) continue;
-                for (int sg = 0; sg < 2; sg++) {
-                    double f = (sg ? -1.0 : 1.0) * pow(dt, -1) * ORC_N;
-                    orc_row *R = &rows[nr++];
-                    R->nnz = 2; R->sense = 2;
-                    R->idx[0] = vidx(k, m, i + 1); R->val[0] = f;
-                    R->idx[1] = vidx(k, m, i); R->val[1] = -f;
-                    R->rhs = vmax[k];
-                }
-            }
-            for (int i = 0; i < ORC_N - 1; i++) {
-                if (m == 0 && i == 0) continue;
-                for (int sg = 0; sg < 2; sg++) {
-                    double f = (sg ? -1.0 : 1.0) * pow(dt, -2) * ORC_N * (ORC_N - 1);
-                    orc_row *R = &rows[nr++];
-                    R->nnz = 3; R->sense = 2;
-                    R->idx[0] = vidx(k, m, i + 2); R->val[0] = f;
-                    R->idx[1] = vidx(k, m, i + 1); R->val[1] = -2 * f;
-                    R->idx[2] = vidx(k, m, i); R->val[2] = f;
-                    R->rhs = amax[k];
-                }
-            }
-        }
-    /* stop at horizon :527-536 */
-    for (int k = 0; k < 3; k++)
-        for (int i = 1; i < ORC_PHI; i++) {
-            orc_row *R = &rows[nr++];
-            R->nnz = 2; R->sense = 0;
-            R->idx[0] = vidx(k, ORC_M - 1, ORC_N); R->val[0] = 1.0;
-            R->idx[1] = vidx(k, ORC_M - 1, ORC_N - i); R->val[1] = -1.0;
-            R->rhs = 0.0;
-        }
-    return nr;
+    const orc_modes md = {0, 0, 0.0, -1, 0.0};
+    int nv = 0;
+    return orc_qp_assemble_ex(prm, &md, state, goal, v_nom, vmax, amax, n_obs, obs_traj, normal, d, sfc, NULL, &nv, P, c, cst, lo,
+                              hi, rows);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1163,8 +1056,13 @@ int orc_tick(const orc_params *prm, int N, const float *state, const float *goal
         double *P = (double *)malloc(sizeof(double) * ORC_NV * ORC_NV);
         double c[ORC_NV], lo[ORC_NV], hi[ORC_NV], x[ORC_NV], cst;
 
+        /* TrajPlanner::currentStateCallback (src/traj_planner.cpp:304-314): in a planar world the agent's OWN position is taken
+         * at z = world/z_2d whatever the message says (the other agents' messages are used as they come) */
+        float own[9];
+        memcpy(own, state + 9 * qi, sizeof own);
+        if (prm->world_dimension == 2) own[2] = (float)prm->world_z_2d;
         /* own initial trajectory :997-1016 (current-velocity model while planner_seq < 2) */
-        if (planner_seq < 2) orc_const_vel_traj(state + 9 * qi, state + 9 * qi + 3, prm->dt, init_traj);
+        if (planner_seq < 2) orc_const_vel_traj(own, own + 3, prm->dt, init_traj);
         else orc_shift_traj(prev_traj + (size_t)qi * ORC_NV, init_traj);
 
         int oi = 0;
@@ -1185,13 +1083,16 @@ int orc_tick(const orc_params *prm, int N, const float *state, const float *goal
         const float *sfc = (prm->use_sfc && sfc_io) ? sfc_io + (size_t)qi * ORC_M * 6 : NULL;
         int sfc_rc = 0;
         if (sfc && g_edt && g_sfc_init)   /* generateSFC, src/traj_planner.cpp:1242-1250 */
-            sfc_rc = orc_update_sfc(prm, g_edt, g_wres, state + 9 * qi, goal + 3 * qi, prev_traj + (size_t)qi * ORC_NV,
+            sfc_rc = orc_update_sfc(prm, g_edt, g_wres, own, goal + 3 * qi, prev_traj + (size_t)qi * ORC_NV,
                                     radius[qi], sfc_io + (size_t)qi * ORC_M * 6, &g_sfc_init[qi]);
-        int nr = orc_qp_assemble(prm, state + 9 * qi, goal + 3 * qi, vnom[qi], vmax + 3 * qi, amax + 3 * qi, n_obs,
+        int nr = orc_qp_assemble(prm, own, goal + 3 * qi, vnom[qi], vmax + 3 * qi, amax + 3 * qi, n_obs,
                                  obs_traj, nrm, dd, sfc, P, c, &cst, lo, hi, rows);
         double cost;
         int iters = 0;
-        int st = orc_qp_solve(P, c, cst, lo, hi, rows, nr, x, &cost, &iters, NULL);
+        const int nv = orc_qp_nvars(prm);
+        int st = orc_qp_solve_n(nv, P, c, cst, lo, hi, rows, nr, x, &cost, &iters, NULL);
+        /* planar world: only x and y are variables, the stored height is world/z_2d (src/traj_optimizer.cpp:87-90) */
+        for (int j = nv; j < ORC_NV; j++) x[j] = (double)(float)prm->world_z_2d;
         if (sfc_rc) st = 4;   /* seed box blocked: the reference throws out of plan(); reported, stale trajectory kept */
         float *o = out_traj + (size_t)qi * ORC_NV;
         float *stale = stale_traj + (size_t)qi * ORC_NV;

@@ -52,7 +52,9 @@ typedef struct {
     double reset_threshold;  /* multisim/reset_threshold (0.15)            */
     int    use_sfc;          /* world/use_octomap                          */
     int    obs_f32;          /* 1: obstacle radius/downwash pass through a float32 message field */
-    int    world_dimension;  /* world/dimension (src/param.cpp:12): 2 = planar goal grid at z = world_z_2d; anything else = 3 */
+    int    world_dimension;  /* world/dimension (src/param.cpp:12): 2 = planar world: goal grid at z = world_z_2d, QP in x and y only
+                                (src/traj_optimizer.cpp:8-90, 264-536), own position read at z = world_z_2d
+                                (src/traj_planner.cpp:304-314); anything else = 3 */
     double world_z_2d;       /* world/z_2d (src/param.cpp:15)                                                  */
 } orc_params;
 
@@ -88,7 +90,9 @@ void orc_lsc_pair(const float *init_traj /*[3][30]*/, const float *obs_traj /*[3
 /* ---- QP assembly in the reference's row order (src/traj_optimizer.cpp:261-548) ---- */
 int  orc_terminal_segments(const float goal[3], const float pos[3], double v_nom, double dt);
 /* rows must hold at least 51 + 27*n_obs + 252 (+162 with SFC) entries; returns #rows.
- * P is the dense 90x90 Hessian of (1/2)x'Px, c the linear term, cst the constant. */
+ * P is the dense nv x nv Hessian of (1/2)x'Px (nv = orc_qp_nvars(prm): 90, or 60 in a planar world -- dim = world/dimension,
+ * src/traj_optimizer.cpp:8, 264-266), c the linear term, cst the constant. */
+int  orc_qp_nvars(const orc_params *prm);
 int  orc_qp_assemble(const orc_params *prm, const float state[9], const float goal[3], double v_nom,
                      const double vmax[3], const double amax[3],
                      int n_obs, const float *obs_traj /*[n_obs][3][30]*/,

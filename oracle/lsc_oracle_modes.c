@@ -76,14 +76,17 @@ int orc_qp_assemble_ex(const orc_params *prm, const orc_modes *md, const float s
 {
     const double dt = prm->dt;
     const int nslack = orc_slack_count(md, n_obs, slack_flags);
-    const int nv = ORC_NV + nslack, off = ORC_NV;
+    /* dim = param.world_dimension (src/traj_optimizer.cpp:8): a planar world has no z variables, no z rows, and its
+     * collision / corridor rows drop their z term (:264-266, 330, 367, 394, 411, 423, 450, 469, 529) */
+    const int dim = prm->world_dimension == 2 ? 2 : 3;
+    const int nv = dim * ORC_SEGV + nslack, off = dim * ORC_SEGV;
     const int ncs = md->n_constraint_segments < 0 ? ORC_M : md->n_constraint_segments;
     double Q[ORC_NC * ORC_NC], Aeq[(ORC_PHI * ORC_M) * ORC_SEGV];
     orc_qbase(dt, Q);
     orc_aeq_base(dt, Aeq);
     *nv_out = nv;
 
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < dim; k++)
         for (int m = 0; m < ORC_M; m++)
             for (int i = 0; i < ORC_NC; i++) {
                 int r = vidx(k, m, i);
@@ -95,15 +98,15 @@ int orc_qp_assemble_ex(const orc_params *prm, const orc_modes *md, const float s
     memset(P, 0, sizeof(double) * (size_t)nv * nv);
     memset(c, 0, sizeof(double) * (size_t)nv);
     *cst = 0;
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < dim; k++)
         for (int m = 0; m < ORC_M; m++)
             for (int i = 0; i < ORC_NC; i++)
                 for (int j = 0; j < ORC_NC; j++)
                     if (Q[i * ORC_NC + j] != 0 && prm->w_control != 0)
                         P[(size_t)vidx(k, m, i) * nv + vidx(k, m, j)] += 2.0 * prm->w_control * Q[i * ORC_NC + j];
-    int T = orc_terminal_segments(goal, state, v_nom, dt);
+    int T = orc_terminal_segments(goal, state, v_nom, dt);       /* the 3-D norm in either case (:541-548) */
     for (int m = ORC_M - T; m < ORC_M; m++)
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < dim; k++) {
             int r = vidx(k, m, ORC_N);
             double g = (double)goal[k];
             P[(size_t)r * nv + r] += 2.0 * prm->w_terminal;
@@ -126,7 +129,7 @@ int orc_qp_assemble_ex(const orc_params *prm, const orc_modes *md, const float s
     }
 
     int nr = 0;
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < dim; k++)
         for (int r = 0; r < ORC_PHI * ORC_M; r++) {
             orc_row *R = &rows[nr++];
             R->nnz = 0; R->sense = 0;
@@ -140,7 +143,7 @@ int orc_qp_assemble_ex(const orc_params *prm, const orc_modes *md, const float s
         }
     if (prm->use_sfc && sfc) {
         for (int m = 0; m < ncs; m++)
-            for (int f = 0; f < 6; f++) {
+            for (int f = 0; f < 2 * dim; f++) {                   /* Box::convertToLSCs(world_dimension): 2 dim half-spaces */
                 int ax = f / 2;
                 double sgn = (f & 1) ? -1.0 : 1.0;
                 double dd = (f & 1) ? -(double)sfc[m * 6 + 3 + ax] : (double)sfc[m * 6 + ax];
@@ -159,9 +162,9 @@ int orc_qp_assemble_ex(const orc_params *prm, const orc_modes *md, const float s
                 if (m == 0 && i < ORC_PHI) continue;
                 const float *nv3 = normal + (oi * ORC_M + m) * 3;
                 orc_row *R = &rows[nr++];
-                R->nnz = 3; R->sense = 1;
+                R->nnz = dim; R->sense = 1;
                 double rhs = d[(oi * ORC_M + m) * ORC_NC + i];
-                for (int k = 0; k < 3; k++) {
+                for (int k = 0; k < dim; k++) {                   /* :446-453: the z term only `if (dim == 3)` */
                     double q = (double)obs_traj[(oi * 3 + k) * ORC_SEGV + m * ORC_NC + i];
                     R->idx[k] = vidx(k, m, i);
                     R->val[k] = (double)nv3[k];
@@ -169,11 +172,11 @@ int orc_qp_assemble_ex(const orc_params *prm, const orc_modes *md, const float s
                 }
                 if (md->slack_mode == 2 || (md->slack_mode != 1 && slack_flags && slack_flags[oi])) {
                     /* expr += -(d + eps) :455-457 */
-                    R->idx[3] = off + ORC_M * oi + m; R->val[3] = -1.0; R->nnz = 4;
+                    R->idx[dim] = off + ORC_M * oi + m; R->val[dim] = -1.0; R->nnz = dim + 1;
                 }
                 R->rhs = rhs;
             }
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < dim; k++)
         for (int m = 0; m < ORC_M; m++) {
             for (int i = 0; i < ORC_N; i++) {
                 if (m == 0 && (i == 0 || i == 1)) continue;
@@ -202,7 +205,7 @@ int orc_qp_assemble_ex(const orc_params *prm, const orc_modes *md, const float s
             }
         }
     if (md->planner_mode == 0) {                          /* stop at the horizon: LSC only :527-536 */
-        for (int k = 0; k < 3; k++)
+        for (int k = 0; k < dim; k++)
             for (int i = 1; i < ORC_PHI; i++) {
                 orc_row *R = &rows[nr++];
                 R->nnz = 2; R->sense = 0;
@@ -240,7 +243,11 @@ int orc_tick_ex(const orc_params *prm, const orc_modes *md, int N, const float *
         unsigned char *flags = (unsigned char *)calloc(no, 1);
         orc_row *rows = (orc_row *)malloc(sizeof(orc_row) * (size_t)(51 + 27 * n_obs + 252 + 162));
         unsigned char *myset = slack_set + (size_t)qi * N;
-        const float *pos = state + 9 * qi;
+        /* currentStateCallback (src/traj_planner.cpp:304-314): planar world -> the agent's own position sits at z = world/z_2d */
+        float own[9];
+        memcpy(own, state + 9 * qi, sizeof own);
+        if (prm->world_dimension == 2) own[2] = (float)prm->world_z_2d;
+        const float *pos = own;
 
         /* ---- obstaclePrediction (+Check): :610-637, 866-878 */
         int oi = 0;
@@ -302,7 +309,8 @@ int orc_tick_ex(const orc_params *prm, const orc_modes *md, int N, const float *
 
         /* ---- trajOptimization */
         const int nslack = orc_slack_count(md, n_obs, flags);
-        const int nv = ORC_NV + nslack;
+        const int nxy = (prm->world_dimension == 2 ? 2 : 3) * ORC_SEGV;
+        const int nv = nxy + nslack;
         double *P = (double *)malloc(sizeof(double) * (size_t)nv * nv);
         double *c = (double *)malloc(sizeof(double) * nv), *lo = (double *)malloc(sizeof(double) * nv);
         double *hi = (double *)malloc(sizeof(double) * nv), *x = (double *)malloc(sizeof(double) * nv);
@@ -315,7 +323,8 @@ int orc_tick_ex(const orc_params *prm, const orc_modes *md, int N, const float *
         float *o = out_traj + (size_t)qi * ORC_NV;
         float *stale = stale_traj + (size_t)qi * ORC_NV;
         if (st == 0) {
-            for (int j = 0; j < ORC_NV; j++) { o[j] = (float)x[j]; stale[j] = o[j]; }
+            /* planar world: the height of every control point is world/z_2d (src/traj_optimizer.cpp:87-90) */
+            for (int j = 0; j < ORC_NV; j++) { o[j] = j < nxy ? (float)x[j] : (float)prm->world_z_2d; stale[j] = o[j]; }
             out_cost[qi] = cost;
         } else {
             for (int j = 0; j < ORC_NV; j++) o[j] = stale[j];

