@@ -147,8 +147,13 @@ def cpu_baseline(ms, seconds_target=12.0, max_ticks=120, static_goal=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--start-tick", type=int, default=None,
+                    help="mission tick of the first TIMED step; the ticks before it run untimed (fast-forward, the last --warmup of "
+                         "them are the warm-up).  Default: 60 for the circle workload -- the 64 agents meet in ticks ~40-140 of the "
+                         "~226-tick mission, so any --steps starts in the crossing, where the ticks are longest -- and warmup + 1 for "
+                         "the strong-scaling workloads")
     ap.add_argument("--agents-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-leg", action="store_true")
@@ -301,7 +306,9 @@ def main():
         torch.cuda.synchronize()
 
     prev, nxt = traj_a, traj_b
-    for _ in range(args.warmup):
+    start_tick = args.start_tick if args.start_tick is not None else (60 if args.workload == "circle64" else args.warmup + 1)
+    start_tick = max(start_tick, args.warmup + 1)
+    for _ in range(start_tick - 1):          # untimed: fast-forward into the mission; its last --warmup ticks are the warm-up
         tick(prev, nxt)
         prev, nxt = nxt, prev
     sync()
@@ -320,16 +327,27 @@ def main():
     g_all = pl.kernel_times_ms(3) if bt_path is not None and goal_mode == "prior_based" else np.zeros(0)
     c_all = pl.kernel_times_ms(4) if bt_path is not None else np.zeros(0)
     iters_total = pl.iterations_total(reset=False)
+    rowit_total = pl.row_iterations_total()
     bad = int((status[first:first + count] != 0).sum().item())
     lrows = pl.row_counts()[first:first + count]
     pl.set_timing(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    it_t = torch.tensor([float(iters_total)], dtype=torch.float64, device=dev)
+    it_t = torch.tensor([float(iters_total), float(rowit_total)], dtype=torch.float64, device=dev)
     if G > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
-    iters_total = float(it_t.item())
+    iters_total, rowit_total = float(it_t[0].item()), float(it_t[1].item())
+    # how long the mission is (untimed, after the measurement): ticks until every agent is within plan/goal_threshold of its goal
+    mission_ticks = None
+    if args.workload == "circle64" and G == 1 and args.planner == "lsc":
+        gl = torch.from_numpy(ms.goal).to(dev)
+        n_done = seq
+        while n_done < 600 and float((states[0][:, :3] - gl).norm(dim=1).max().item()) >= 0.1:
+            tick(prev, nxt)
+            prev, nxt = nxt, prev
+            n_done += 1
+        mission_ticks = n_done if n_done < 600 else None
     # per-rank device times of the tick's launches (HIP events): where a sharded tick's time goes
     mine = torch.tensor([float(k_all.mean()) if len(k_all) else 0.0, float(np.percentile(k_all, 99)) if len(k_all) else 0.0,
                          float(g_all.mean()) if len(g_all) else 0.0, float(c_all.mean()) if len(c_all) else 0.0,
@@ -344,6 +362,9 @@ def main():
         value = n_agents * args.steps / elapsed
         flops = algorithmic_flops(n_agents, iters_total / G) / max(k_n, 1)   # per launch of this rank's kernel
         ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        # the same model charged with the rows the kernel really carried: (N-1) kflop per iteration = 27 (N-1) rows x ~37 flop
+        flops_exec = (rowit_total / G * (1.0e3 / 27.0) + iters_total / G * 0.3e6) / max(k_n, 1)
+        ach_exec = flops_exec / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         kname = "lsc_plan_kernel" if (args.reset_threshold <= 0 and args.planner == "lsc" and args.slack == "none") else "lsc_plan_alt_kernel"
         if count > torch.cuda.get_device_properties(dev).multi_processor_count:
             kname = kname.replace("_kernel", "_tp_kernel")       # more agents in the shard than CUs: the throughput build"
@@ -355,7 +376,8 @@ def main():
             "tick_solve_ms": {"p50": round(float(np.percentile(k_all, 50)), 4), "p99": round(float(np.percentile(k_all, 99)), 4),
                               "max": round(float(k_all.max()), 4),
                               "note": "device time of the per-tick launch (HIP events, rank 0) over the timed steps"},
-            "config": {"workload": f"{layout}, " + ("" if bt_path is not None else "empty map, ") + "LSC mode, "
+            "config": {"tick_window": [start_tick, start_tick + args.steps - 1], "mission_ticks": mission_ticks,
+                       "workload": f"{layout}, " + ("" if bt_path is not None else "empty map, ") + "LSC mode, "
                                    f"dt 0.2 s, M=5 n=5, mode/goal={goal_mode}, "
                                    + (f"one swarm sharded over {G} GPU(s), {-(-n_agents // G)} agents per rank, " if strong else f"{args.agents_per_gpu} agents per GPU, ")
                                    + "device-resident ticks ("
@@ -374,15 +396,18 @@ def main():
                    "reference_rows_per_agent": 27 * (n_agents - 1)},
             "roofline": {"kernel": kname, "bound": "valu_fp64", "achieved": round(ach, 5),
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_VALU_PEAK_TFLOPS, 7),
+                         "frac_executed": round(ach_exec / FP64_VALU_PEAK_TFLOPS, 7),
+                         "executed_rows_per_iteration_mean": round(rowit_total / max(iters_total, 1.0), 1),
                          "traffic": traffic,
                          "traffic_source": (f"not measured in this run: rocprofv3 --pmc passes of this command, {traffic_src}"
                                             if traffic is not None else None),
                          "avg_launch_ms": round(k_ms, 5), "launches": k_n,
                          "executed_rows_mean": float(np.mean(lrows)),
                          "note": "latency-bound: one 512-lane workgroup per agent; algorithmic flops = IP iterations x "
-                                 "((N-1) kflop + 0.3 Mflop) per SURVEY 8(d), which charges all 27(N-1) LSC rows although the "
-                                 "kernel executes only the non-redundant ones (executed_rows_mean, last tick); neither HBM nor "
-                                 "MFMA bounds this kernel"},
+                                 "((N-1) kflop + 0.3 Mflop) per SURVEY 8(d), which charges all 27(N-1) LSC rows; frac_executed "
+                                 "charges the rows the kernel carried after pruning the provably redundant ones (iterations x rows "
+                                 "accumulated on the device over the timed ticks, ~37 flop per row and iteration + 0.3 Mflop); "
+                                 "neither HBM nor MFMA bounds this kernel"},
         }
         result["per_rank"] = {"columns": ["plan_kernel_ms_mean", "plan_kernel_ms_p99", "goal_kernel_ms_mean", "corridor_kernel_ms_mean",
                                           "allgather_us_mean", "agents"], "ranks": per_rank,

@@ -285,6 +285,10 @@ int lsc_last_bucket_max(lsc_ctx *ctx, int *rows);
 
 /* Sum over agents of interior-point iterations since the last reset (bench flop accounting). Synchronises. */
 int lsc_iterations_total(lsc_ctx *ctx, long long *total, int reset);
+/* Sum over agents of iterations x LSC rows carried (the rows that survived the redundancy pruning), since the last reset of
+ * lsc_iterations_total: what the kernels executed, next to the 27 (N - 1) rows per iteration of the reference's model
+ * (bench.py: roofline.frac_executed). */
+int lsc_row_iterations_total(lsc_ctx *ctx, long long *total);
 
 /* Diagnostics.  lsc_phase_profile: enable=1 selects the instrumented plan kernel and clears its counters, 0 goes
  * back to the production kernel, -1 only reads; out (may be NULL) gets [N][16] counts (100 MHz wall clock)

@@ -560,12 +560,12 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMalloc(&c->d_order, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_obs_bound, sizeof(float) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (size_t)N));
+    HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * 2 * (size_t)N));       // [N] iterations, [N] iterations x LSC rows
     HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));          // [N] plan kernel, [N] general kernel
     HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_dbg, sizeof(double) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_dbg, 0, sizeof(double) * 4 * (size_t)N));
-    HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * 2 * (size_t)N));
     {
         const size_t n = (size_t)N;
         float *in = nullptr;
@@ -1642,7 +1642,21 @@ int lsc_iterations_total(lsc_ctx *c, long long *total, int reset)
     long long t = 0;
     for (long long v : h) t += v;
     *total = t;
-    if (reset) HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (size_t)c->N));
+    if (reset) HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * 2 * (size_t)c->N));
+    return LSC_OK;
+}
+
+// sum over agents of (interior-point iterations x LSC rows the agent's QP carried) since the last reset of lsc_iterations_total:
+// the row passes the kernels executed, against the 27 (N - 1) rows per iteration the reference's model holds
+int lsc_row_iterations_total(lsc_ctx *c, long long *total)
+{
+    if (!c || !total || c->N == 0) return LSC_EINVAL;
+    std::vector<long long> h(c->N);
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(h.data(), c->d_iters_acc + c->N, sizeof(long long) * (size_t)c->N, hipMemcpyDeviceToHost));
+    long long t = 0;
+    for (long long v : h) t += v;
+    *total = t;
     return LSC_OK;
 }
 

@@ -1081,7 +1081,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
         if (status == LSC_STATUS_OK_K) a.cost[qi] = obj;
         a.status[qi] = status;
         a.iters[qi] = iters;
-        if (a.iters_acc) a.iters_acc[qi] += iters;
+        if (a.iters_acc) { a.iters_acc[qi] += iters; a.iters_acc[a.N + qi] += (long long)iters * ((long long)nrow - md.n_ax - nu); }
         if (a.nrows) a.nrows[qi] = (int)nrow - md.n_ax - nu;  // collision rows + group sign rows
     }
     __syncthreads();

@@ -40,7 +40,8 @@ struct PlanArgs {
     double *cost;              // [N]
     int *status, *iters, *nrows;
     int *bucket_max;           // optional [N]: rows of the fullest control-point bucket (diagnostics)
-    long long *iters_acc;      // [N] running sum of interior-point iterations (bench accounting), may be null
+    long long *iters_acc;      // [N] running sum of interior-point iterations (bench accounting), may be null; entries [N, 2N) = running
+                               // sum of iterations x LSC rows the agent carried (the row passes the kernel really executed)
     float *stale;              // [N][90] optimiser's last good trajectory (persistent)
     const float *sfc;          // [N][M][6] or null
     const int *sfc_err;        // [N] or null: seed box blocked -> status 4

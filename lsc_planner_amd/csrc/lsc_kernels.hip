@@ -1992,7 +1992,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         if (status == LSC_STATUS_OK_K) a.cost[qi] = obj;
         a.status[qi] = status;
         a.iters[qi] = iters;
-        if (a.iters_acc) a.iters_acc[qi] += iters;
+        if (a.iters_acc) { a.iters_acc[qi] += iters; a.iters_acc[a.N + qi] += (long long)iters * S.nact; }
         if (a.nrows) a.nrows[qi] = S.nact;
         if (a.dbg) { a.dbg[4 * qi] = S.sc[5]; a.dbg[4 * qi + 1] = S.sc[6]; a.dbg[4 * qi + 2] = S.sc[3]; a.dbg[4 * qi + 3] = obj; }
         if constexpr (PROF) {

@@ -349,6 +349,12 @@ class SwarmPlanner:
         self._check(self.L.lsc_iterations_total(self.ctx, ctypes.byref(t), int(reset)))
         return t.value
 
+    def row_iterations_total(self):
+        """Sum over agents of iterations x LSC rows carried since the last iterations_total(reset=True)."""
+        t = ctypes.c_longlong()
+        self._check(self.L.lsc_row_iterations_total(self.ctx, ctypes.byref(t)))
+        return t.value
+
     def set_timing(self, on):
         self._check(self.L.lsc_set_timing(self.ctx, int(on)))
 
