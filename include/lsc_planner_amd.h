@@ -137,6 +137,9 @@ void lsc_default_config(lsc_config *cfg);
 lsc_ctx *lsc_create(const lsc_config *cfg);
 void     lsc_destroy(lsc_ctx *ctx);
 const char *lsc_last_error(const lsc_ctx *ctx);
+/* Informational remark of lsc_create, "" when there is none -- e.g. that a slack mode was configured with the LSC planner and
+ * fixed to none like TrajPlanner::checkPlannerMode does (src/traj_planner.cpp:445-448).  Never an error. */
+const char *lsc_last_note(const lsc_ctx *ctx);
 
 /* Mission::agents (src/mission.cpp:60-130): radius, downwash, max_vel[3], max_acc[3], nominal_velocity.
  * Doubles, as in struct Agent (include/sp_const.hpp:153-165); an agent seen as somebody else's
@@ -228,7 +231,9 @@ int lsc_propagate_device(lsc_ctx *ctx, const float *d_traj, float *d_state, void
 
 /* MultiSyncSimulator::savePlanningResult's agent-agent accounting (src/multi_sync_simulator.cpp:446-503) on the device, for
  * the plans of the last lsc_replan_tick / lsc_replan_tick_all.  times[n_times] (n_times <= 64): seconds into the plan at which
- * the swarm is sampled (the reference: 0, multisim_record_time_step, ... below multisim_time_step).  For every sample and
+ * the swarm is sampled (the reference: 0, multisim_record_time_step, ... below multisim_time_step).  The context must hold the new
+ * plans of ALL N agents: the last tick was lsc_replan_tick_all, or lsc_replan_tick of a context whose shard is the whole swarm
+ * (LSC_ESTATE otherwise -- the partners' rows would be stale).  For every sample and
  * every agent of this context's shard, the downwash-scaled distance to every other agent over the sum of the two radii
  * (distBetweenAgents, include/util.hpp:225-229): out_ratio[n_times][count] = the minimum over the partners,
  * out_partner[n_times][count] = the first partner attaining it (what the reference's collision message names); either may be

@@ -5,8 +5,10 @@ Only what the hot path needs lives here:
   _lib.py      ctypes binding of that ABI (fails loudly when the library or a GPU is missing)
   planner.py   host-side mirror of the reference's TrajPlanner / TrajOptimizer surface, batched per tick
   mission.py   mission JSON loader + the circle-swap / random-swarm generators of the BASELINE configs
-  simulator.py headless MultiSyncSimulator loop (update -> plan -> isFinished)
-  sharded.py   agent-sharded multi-GPU stepping (one process per GPU, torch.distributed all-gather)
+  csrc/host/   C++ host side above the ABI: Mission / Param / TrajPlanner-shaped facade, headless MultiSyncSimulator, result-CSV
+               writer and reader -> lsc_sim
+  sharded.py   partition arithmetic of the agent-sharded multi-GPU path + the torch.distributed fallback exchange (the native
+               exchange is the library's own RCCL all-gather, lsc_comm_init / lsc_tick_device_sharded)
 """
 from ._lib import LscError, load_library, lib_path  # noqa: F401
 from .mission import Mission, load_mission, circle_swap, random_swarm  # noqa: F401

@@ -55,7 +55,7 @@ class LscConfig(ctypes.Structure):
 
 # every symbol include/lsc_planner_amd.h declares
 EXPORTS = [
-    "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_set_agents", "lsc_set_shard",
+    "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_last_note", "lsc_set_agents", "lsc_set_shard",
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_safety_ratio", "lsc_sweep_device", "lsc_sweep_device_f32",
     "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_kernel_times_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_goal_profile", "lsc_goal_key_table", "lsc_general_profile", "lsc_dump_qp", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals", "lsc_set_goal_trace", "lsc_get_goal_trace",
     "lsc_last_bucket_max", "lsc_row_capacity", "lsc_comm_unique_id", "lsc_comm_init", "lsc_comm_info", "lsc_tick_device_sharded", "lsc_replan_tick_all",
@@ -94,6 +94,8 @@ def load_library():
     L.lsc_destroy.restype = None
     L.lsc_last_error.argtypes = [vp]
     L.lsc_last_error.restype = ctypes.c_char_p
+    L.lsc_last_note.argtypes = [vp]
+    L.lsc_last_note.restype = ctypes.c_char_p
     L.lsc_set_agents.argtypes = [vp, ctypes.c_int, dp, dp, dp, dp, dp]
     L.lsc_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.lsc_set_distmap.argtypes = [vp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ip, ctypes.c_double]
@@ -134,7 +136,7 @@ def load_library():
     L.lsc_row_iterations_total.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if fn.restype is ctypes.c_int or name not in ("lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_free_host"):
+        if fn.restype is ctypes.c_int or name not in ("lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_last_note", "lsc_free_host"):
             fn.restype = ctypes.c_int
     _LIB = L
     return L

@@ -296,4 +296,64 @@ class TrajPlanner {
     PlanningReport planning_report = PlanningReport::Initialized;
 };
 
+// MultiSyncReplayer::readCSVFile (src/multi_sync_replayer.cpp:53-114): the result CSV of a run -- 15 columns per agent
+// (id, t, position, velocity, acceleration, planning_time, qp_cost, planning_report, size), then 6 per obstacle (obs_id ...) --
+// back into per-agent state histories.  The counts come from the header row ("id" / "obs_id" cells), an agent's radius from
+// its `size` column, the make span from the last record's time, exactly as the reference's replayer takes them, so that a file
+// written by lsc_sim replays in the reference's tooling and the other way round.
+struct ReplayHistory {
+    int qn = 0, on = 0;
+    std::vector<std::vector<State>> agent_state_history;      // [qn][records]
+    std::vector<std::vector<point3d>> obstacle_position_history;
+    std::vector<double> agent_radius, obstacle_radius;
+    std::vector<double> record_time;
+    double makeSpan = 0;
+};
+inline ReplayHistory readResultCSV(const std::string &file_name) {
+    std::ifstream file(file_name);
+    if (file.fail()) throw std::invalid_argument("[MultiSyncReplayer] invalid csv file, current file name: " + file_name);
+    ReplayHistory h;
+    const int offset_agent = 15, offset_obs = 6;
+    std::string line;
+    int row_idx = 0;
+    while (std::getline(file, line)) {
+        std::vector<std::string> row;
+        std::string cell;
+        std::stringstream ss(line);
+        while (std::getline(ss, cell, ',')) row.push_back(cell);
+        if (row.size() < 2) break;
+        if (row_idx == 0) {
+            for (size_t i = 0; i + 2 < row.size(); i++) {      // (the reference scans row.size() - 2 cells)
+                if (row[i] == "id") h.qn++;
+                else if (row[i] == "obs_id") h.on++;
+            }
+            h.agent_state_history.assign(h.qn, {});
+            h.obstacle_position_history.assign(h.on, {});
+            h.agent_radius.assign(h.qn, 0.0);
+            h.obstacle_radius.assign(h.on, 0.0);
+        } else {
+            if ((int)row.size() < offset_agent * h.qn + offset_obs * h.on)
+                throw std::invalid_argument("[MultiSyncReplayer] row " + std::to_string(row_idx) + " of " + file_name + " is short");
+            for (int qi = 0; qi < h.qn; qi++) {
+                auto v = [&](int c) { return std::stod(row[offset_agent * qi + c]); };
+                State s;
+                s.position = point3d(v(2), v(3), v(4));
+                s.velocity = point3d(v(5), v(6), v(7));
+                s.acceleration = point3d(v(8), v(9), v(10));
+                h.agent_state_history[qi].push_back(s);
+                h.agent_radius[qi] = v(14);
+            }
+            for (int oi = 0; oi < h.on; oi++) {
+                auto v = [&](int c) { return std::stod(row[offset_agent * h.qn + offset_obs * oi + c]); };
+                h.obstacle_position_history[oi].push_back(point3d(v(2), v(3), v(4)));
+                h.obstacle_radius[oi] = v(5);
+            }
+            h.makeSpan = std::stod(row[1]);
+            h.record_time.push_back(h.makeSpan);
+        }
+        row_idx++;
+    }
+    return h;
+}
+
 }  // namespace DynamicPlanning

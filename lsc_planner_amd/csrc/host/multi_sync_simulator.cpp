@@ -165,9 +165,14 @@ class MultiSyncSimulator {
         total_ticks++; total_tick_ms += last_tick_ms;
         // TrajOptimizer::solve exports the model of a failed solve (log/QPmodel.lp, src/traj_optimizer.cpp:99-102); like there the
         // file is overwritten by every failure, so it holds the last one.  Best effort: a swarm with slack rows is not dumped.
-        if (!param.log_dir.empty() && param.rank == 0)
+        // The rank that OWNS the first failed agent writes it (only its context holds that agent's corridor and plan inputs; every
+        // rank sees all statuses, so they agree on who that is without talking).
+        if (!param.log_dir.empty())
             for (int qi = 0; qi < N; qi++)
                 if (h_status[qi] == LSC_STATUS_INFEASIBLE) {
+                    int ws = 1, rk = 0, shard = N;
+                    (void)lsc_comm_info(ctx, &ws, &rk, &shard, nullptr);
+                    if (qi / (shard > 0 ? shard : 1) != rk) break;
                     if (lsc_dump_qp(ctx, qi, (param.log_dir + "/QPmodel.lp").c_str()) == LSC_OK)
                         std::fprintf(stderr, "[TrajOptimizer] QP of agent %d failed at tick %d: model written to %s/QPmodel.lp\n", qi,
                                      total_ticks, param.log_dir.c_str());
@@ -345,12 +350,13 @@ int main(int argc, char **argv)
 {
     using namespace DynamicPlanning;
     Param param;
-    std::string mission_file, world_file;
+    std::string mission_file, world_file, replay_file;
     bool quiet = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
         if (a == "--mission") mission_file = next();
+        else if (a == "--replay") replay_file = next();
         else if (a == "--world") { world_file = next(); param.world_use_octomap = true; }
         else if (a == "--max-iter") param.multisim_max_planner_iteration = std::stoi(next());
         else if (a == "--csv") { param.log_dir = next(); param.multisim_save_result = true; }
@@ -369,7 +375,26 @@ int main(int argc, char **argv)
         else if (a == "--ranks") param.world = std::stoi(next());
         else if (a == "--rank") param.rank = std::stoi(next());
         else if (a == "--comm-file") param.comm_file = next();
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats] | lsc_sim --replay result.csv\n"); return 2; }
+    }
+    if (!replay_file.empty()) {
+        // MultiSyncReplayer (src/multi_sync_replayer.cpp): read a result CSV back -- needs no GPU -- and say what it holds
+        try {
+            const ReplayHistory h = readResultCSV(replay_file);
+            const size_t recs = h.qn ? h.agent_state_history[0].size() : 0;
+            double dist = 0;
+            for (int qi = 0; qi < h.qn; qi++)
+                for (size_t i = 0; i + 1 < recs; i++) dist += (h.agent_state_history[qi][i + 1].position - h.agent_state_history[qi][i].position).norm();
+            std::printf("replay: agents %d obstacles %d records %zu makeSpan %.9g total_distance %.9g\n", h.qn, h.on, recs, h.makeSpan, dist);
+            for (int qi = 0; qi < h.qn && recs; qi++) {
+                const point3d &p = h.agent_state_history[qi][recs - 1].position;
+                std::printf("agent %d radius %.9g final %.9g %.9g %.9g\n", qi, h.agent_radius[qi], (double)p.x(), (double)p.y(), (double)p.z());
+            }
+            return 0;
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "%s\n", e.what());
+            return 3;
+        }
     }
     if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
     // torchrun / mpirun style environment: one process per GPU

@@ -207,6 +207,7 @@ struct lsc_ctx {
     int N = 0, first = 0, count = 0, cap = 0, cap_tp = 0, n_cu = 256;
     size_t smem_tp = 0;
     std::string err;
+    std::string note;                    // informational remarks of lsc_create (not errors): lsc_last_note
     bool timing = false;
     // device
     Model *d_model = nullptr;
@@ -221,6 +222,7 @@ struct lsc_ctx {
     size_t gen_stride = 0;
     int gen_slots = 0;
     int last_host_seq = 0;               // planner_seq of the last host-buffer tick (lsc_dump_qp reads its inputs back)
+    bool next_has_all_rows = false;      // d_next holds the new plan of ALL N agents (whole-swarm shard, or lsc_replan_tick_all's gather)
     bool h_ever_stale = false;           // device-resident ticks ran since h_ever was last in step with d_ever
     std::vector<unsigned char> h_ever;   // host mirror for the host-buffer ticks (they decide on the host whether anybody is off plan)
     unsigned char *d_spill = nullptr;    // HBM row workspaces of the second pass (agents beyond the LDS row capacity)
@@ -241,7 +243,7 @@ struct lsc_ctx {
     uint32_t *d_fcode = nullptr;
     int fcode_rb = 0;
     unsigned char *d_safety = nullptr;           // lsc_safety_ratio's buffers
-    int safety_times = 0;
+    size_t safety_bytes = 0;
     long long *d_goal_prof = nullptr;
     bool goal_profiling = false;
     int grid_dims[3] = {0, 0, 0}, grid_row_cap = 0;
@@ -405,9 +407,8 @@ lsc_ctx *lsc_create(const lsc_config *cfg)
     if (c->cfg.planner_mode == 0 && c->cfg.slack_mode != 0) {
         // TrajPlanner::checkPlannerMode (src/traj_planner.cpp:445-448): "LSC does not need slack variables, fix to none".  The
         // slack rows of LSC mode are the ones a disturbance reset leaves behind (obs_slack_indices), nothing else.
-        std::fprintf(stderr, "lsc_create: LSC does not need slack variables, slack_mode fixed to none\n");
         c->cfg.slack_mode = 0;
-        c->err = "note: planner_mode lsc with a slack mode: slack_mode fixed to none (src/traj_planner.cpp:445-448)";
+        c->note = "planner_mode lsc with a slack mode: slack_mode fixed to none (src/traj_planner.cpp:445-448)";
     }
     {
         hipDeviceProp_t prop;
@@ -443,7 +444,7 @@ static void free_agents(lsc_ctx *c)
     void *gp[] = {c->d_edt, c->d_goal_planned, c->d_ray_stack, c->d_occ_static, c->d_goal_err, c->d_goal_flags, c->d_goal_exp,
                   c->d_goal_path, c->d_goal_plen, c->d_goal_prof, c->d_fcode, c->d_safety};
     for (void *p : gp) if (p) (void)hipFree(p);
-    c->d_goal_prof = nullptr; c->d_fcode = nullptr; c->d_safety = nullptr; c->safety_times = 0;
+    c->d_goal_prof = nullptr; c->d_fcode = nullptr; c->d_safety = nullptr; c->safety_bytes = 0;
     c->d_edt = c->d_goal_planned = c->d_ray_stack = nullptr; c->d_occ_static = nullptr;
     c->d_goal_err = c->d_goal_flags = c->d_goal_exp = c->d_goal_path = c->d_goal_plen = nullptr;
     c->d_radius = c->d_radius_obs = c->d_downwash = c->d_downwash_obs = c->d_vmax = c->d_amax = c->d_vnom = nullptr;
@@ -470,6 +471,7 @@ void lsc_destroy(lsc_ctx *c)
 }
 
 const char *lsc_last_error(const lsc_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *lsc_last_note(const lsc_ctx *c) { return c ? c->note.c_str() : ""; }
 
 int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwash, const double *max_vel,
                    const double *max_acc, const double *nominal_vel)
@@ -691,7 +693,9 @@ static int build_goal_grid(lsc_ctx *c, const std::vector<double> &radii)
             while (cap32 > 16 && goal_smem_bytes(H, W, A, cap32, words) > 158 * 1024) cap32--;
             if (goal_smem_bytes(H, W, A, cap32, words) > 158 * 1024 || cap32 < std::min(W * A, 192)) cap32 = 0;
         }
-        if (words > 0 && cap32 > 0 && c->cfg.goal_search != 2) {
+        int jb_unused = 0;
+        const bool fast = c->cfg.goal_search != 1 && goal_fast_slots(H, W, A, &jb_unused) != 0;     // else the table would be dead weight in LDS
+        if (words > 0 && cap32 > 0 && c->cfg.goal_search != 2 && fast) {
             int rb = 0;
             if (goal_key_table(words, c->h_fcode, rb)) { c->fcode_rb = rb; cap = cap32; }
         }
@@ -1054,6 +1058,7 @@ int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const flo
                 return LSC_ESTATE;
             }
     }
+    c->next_has_all_rows = c->count == c->N;
     if (c->timing)
         c->host_tick_ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count());
     return LSC_OK;
@@ -1182,6 +1187,7 @@ int lsc_replan_tick_all(lsc_ctx *c, const float *state, const float *goal, const
             c->err = "internal: an agent was handed to the alternate-mode kernel, which did not run";
             return LSC_ESTATE;
         }
+    c->next_has_all_rows = true;
     return LSC_OK;
 }
 
@@ -1193,6 +1199,11 @@ int lsc_safety_ratio(lsc_ctx *c, const double *times, int n_times, double *out_r
 {
     if (!c || !times || n_times < 1 || n_times > 64 || !out_min) return LSC_EINVAL;
     if (c->N < 1 || c->last_host_seq < 1) { if (c) c->err = "lsc_safety_ratio: no host-buffer tick was planned yet"; return LSC_ESTATE; }
+    if (!c->next_has_all_rows) {
+        // the partners of every pair are read from the context's own table: a sharded lsc_replan_tick leaves the other ranks' rows stale
+        c->err = "lsc_safety_ratio: the last tick planned a shard only (use lsc_replan_tick_all, or a context that owns the whole swarm)";
+        return LSC_ESTATE;
+    }
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int N = c->N, cnt = c->count;
     std::vector<double> w((size_t)n_times * NC);
@@ -1207,12 +1218,16 @@ int lsc_safety_ratio(lsc_ctx *c, const double *times, int n_times, double *out_r
         const double tl = t / c->cfg.dt - m;
         for (int i = 0; i < NC; i++) w[(size_t)ti * NC + i] = choose(DEG, i) * std::pow(tl, i) * std::pow(1 - tl, DEG - i);
     }
-    if (!c->d_safety || c->safety_times < n_times) {
-        if (c->d_safety) (void)hipFree(c->d_safety);
-        c->d_safety = nullptr;
+    {
+        // (sized for THIS call's shard and sample count: lsc_set_shard may have enlarged the shard since the last call, and the
+        // carve-up below depends on both)
         const size_t bytes = (size_t)n_times * (sizeof(double) * NC + sizeof(int) * 2 + sizeof(float) * 3 * (size_t)N + (sizeof(double) + sizeof(int)) * (size_t)cnt) + 64;
-        HIPCHK(c, hipMalloc(&c->d_safety, bytes));
-        c->safety_times = n_times;
+        if (!c->d_safety || c->safety_bytes < bytes) {
+            if (c->d_safety) (void)hipFree(c->d_safety);
+            c->d_safety = nullptr; c->safety_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->d_safety, bytes));
+            c->safety_bytes = bytes;
+        }
     }
     // carve-up: ratios, weights, global minimum | positions | partners, segments
     double *d_ratio = reinterpret_cast<double *>(c->d_safety);

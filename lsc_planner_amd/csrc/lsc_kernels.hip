@@ -874,8 +874,18 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         S.amap[i] = sl | (type << 10) | ((kt / SEGV) << 13) | ((kt % SEGV) << 15);
     }
     // per-lane solver constants -> LDS tables (see Smem)
-    const int vq = tid < NV ? tid : (tid >= NT - NV ? tid - (NT - NV) : -1);  // lanes 0..89 (x / objective) and the last 90 (row gather)
-    const int xk = vq >= 0 ? vq / SEGV : 0, xt = vq >= 0 ? vq % SEGV : 0;
+    // lanes 0..89 (x / objective) and the last 90 (row gather) work on variable (xk, xt).  Computed twice -- here for the tables
+    // of phase A and again behind phase B, from a copy of tid the compiler cannot see through -- so that the pair is not live
+    // across the GJK pass, where it was the value that went to scratch (0.4 MB of scratch writes per launch in the PMC pass).
+    int xk, xt;
+    auto lane_variable = [&]() {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        const int vq = tq < NV ? tq : (tq >= NT - NV ? tq - (NT - NV) : -1);
+        xk = vq >= 0 ? vq / SEGV : 0;
+        xt = vq >= 0 ? vq % SEGV : 0;
+    };
+    lane_variable();
     if (tid < NV) {
         const int xn = md.x_n[xt];
         S.xgp[tid] = (uint32_t)yglob(xk, md.x_i[xt][0]) | ((uint32_t)yglob(xk, md.x_i[xt][1]) << 8) |
@@ -902,7 +912,6 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                    ((uint32_t)(t3 * 3 + yk) << 24);
     }
     __syncthreads();
-    const bool xterm = (tid < NV) && (xt % NC == DEG) && (xt / NC >= M - S.tseg);
     // constant part of every Hessian entry: cost Hessian (same axis) + terminal weight on c_{m,5}
     auto kconst_of = [&](uint32_t id) -> double {
         const int gi = id >> 16, gj = id & 0xffff;
@@ -1227,6 +1236,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     }
     __syncthreads();
     stamp(PH_LSC);
+    lane_variable();
+    const bool xterm = (tid < NV) && (xt % NC == DEG) && (xt / NC >= M - S.tseg);
 
     // ------------------------------------------------------------------ phase C: interior point
     for (int sl = tid; sl < AXROWS; sl += NT) {
@@ -1241,7 +1252,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         if constexpr (TABLES_IN_LDS) S.ah[sl] = h;
         S.as_[sl] = 1.0; S.az[sl] = 0.0; S.at1[sl] = 0.0; S.at2[sl] = 0.0;
     }
-    if (tid < 3) { S.vlim[tid] = a.vmax[3 * qi + tid] * md.hv_scale; S.alim[tid] = a.amax[3 * qi + tid] * md.ha_scale; }
+    if (tid < 3) {
+        int tq = tid;                         // (opaque copy: the index 3 qi + tid of phase B's reach boxes is not kept alive for this)
+        asm volatile("" : "+v"(tq));
+        S.vlim[tq] = a.vmax[3 * qi + tq] * md.hv_scale; S.alim[tq] = a.amax[3 * qi + tq] * md.ha_scale;
+    }
     // right-hand side of axis row sl
     auto AH = [&](int sl) -> double {
         if constexpr (TABLES_IN_LDS) return S.ah[sl];
@@ -1262,6 +1277,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     // x from y : x_t = sum coef * y_glob  (+ state constants for t < 3)
     auto compute_x = [&](const double *yv, double *xv, bool with_const) {
         if (tid < NV) {
+            // (the control-point index is recomputed from a copy of tid the compiler cannot see through: sharing the value with the
+            // per-lane constants above kept it alive across the whole kernel, and it was what went to scratch)
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            const int xt = tq % SEGV;
             double v;
             if (xt < 3) v = with_const ? S.x0c[tid] : 0.0;
             else {

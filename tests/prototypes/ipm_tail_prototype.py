@@ -1,12 +1,12 @@
 """CPU prototype behind DESIGN 4.6's note on the linear tail of crowded ticks (not a test; it uses the oracle to produce the QPs of a
 64-agent mission, hence it lives under tests/): a dense numpy Mehrotra interior point on those QPs, standard against a variant that
 skips the predictor solve in the tail (sigma and the second-order term lagged from the previous iteration).
-    python tests/ipm_tail_prototype.py
+    python tests/prototypes/ipm_tail_prototype.py
 Round-3 outcome: the lagged iterations reduce the gap 7-12x with one solve instead of two, but block earlier (alpha ~0.95) and cost
 one more iteration: 13 iterations / 26 solves against 14 / 24 -- no gain in time; not built into the kernels."""
 import sys, numpy as np, scipy.linalg as sla
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from oracle import oracle as O
 import lsc_planner_amd as L

@@ -98,7 +98,7 @@ def test_lsc_mode_fixes_the_slack_mode_to_none(L):
     from lsc_planner_amd.planner import next_state_host
     ms = L.circle_swap(8, 1.2, world=(-5, -5, 0, 5, 5, 2.5))
     a = L.SwarmPlanner(ms, L.PlannerConfig(slack_mode="collision_constraint"))
-    assert b"slack_mode fixed to none" in a.L.lsc_last_error(a.ctx)
+    assert b"slack_mode fixed to none" in a.L.lsc_last_note(a.ctx) and a.L.lsc_last_error(a.ctx) == b""      # a remark, not an error
     b = L.SwarmPlanner(ms)
     state = np.zeros((8, 9), np.float32); state[:, :3] = ms.start
     traj = np.zeros((8, 3, 30), np.float32)

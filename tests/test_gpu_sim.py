@@ -45,6 +45,31 @@ def test_headless_simulator_runs_the_reference_mission(ticks, tmp_path):
     assert len(summ[0]) == 25 and summ[1][3] == "0"
 
 
+def test_result_csv_round_trip_through_the_reader(ticks, tmp_path):
+    """SURVEY 8(f)#3 writer AND reader: a run's result CSV read back by the restatement of MultiSyncReplayer::readCSVFile
+    (src/multi_sync_replayer.cpp:53-114, `lsc_sim --replay`) holds the run: agent count, two records per tick, the make span
+    and the flown distance the simulator printed, every agent's last record at its goal."""
+    ms = golden_mission(ticks, "multi_simple4")
+    mp = tmp_path / "multi_simple4.json"
+    _write_mission(str(mp), ms)
+    r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(tmp_path), "--quiet"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    flight = float(r.stdout.split("total flight time:")[1].split()[0])
+    dist = float(r.stdout.split("total distance:")[1].split()[0])
+    rp = subprocess.run([SIM, "--replay", str(tmp_path / "result_LSC_4agents.csv")], capture_output=True, text=True, timeout=60)
+    assert rp.returncode == 0, rp.stdout + rp.stderr
+    lines = rp.stdout.strip().splitlines()
+    head = lines[0].split()
+    n_rec = int(head[6])
+    assert head[2] == "4" and head[4] == "0" and n_rec % 2 == 0
+    assert abs(float(head[8]) - (flight - 0.1)) < 0.25           # last record: one record step before the time isFinished() saw
+    assert abs(float(head[10]) - dist) <= 1e-3 * dist              # same points, printed with 6 significant digits
+    for q in range(4):
+        w = lines[1 + q].split()
+        assert w[3] == "0.15"
+        assert np.linalg.norm(np.array(w[5:8], float) - ms.goal[q]) < 0.15, (q, w)
+
+
 def test_simulator_trajectory_equals_python_host_layer(ticks, tmp_path):
     """Same mission through the Python harness: the C++ and Python host layers feed the ABI identically."""
     import lsc_planner_amd as L

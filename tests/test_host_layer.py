@@ -234,3 +234,34 @@ def test_ctypes_config_struct_matches_the_header(tmp_path):
     assert int(out["sizeof"]) == ctypes.sizeof(LscConfig)
     for n in names:
         assert int(out[n]) == getattr(LscConfig, n).offset, n
+
+
+def test_result_csv_reader_reads_the_reference_s_layout(tmp_path):
+    """MultiSyncReplayer::readCSVFile (src/multi_sync_replayer.cpp:53-114): 15 columns per agent, 6 per obstacle, counts from the
+    header's "id" / "obs_id" cells, radius from the `size` column, make span = time of the last record.  `lsc_sim --replay` needs
+    no GPU."""
+    import subprocess
+    sim = os.path.join(ROOT, "lsc_planner_amd", "lsc_sim")
+    assert os.path.exists(sim), "lsc_sim not built"
+    hdr_a = "id,t,px,py,pz,vx,vy,vz,ax,ay,az,planning_time,qp_cost,planning_report,size"
+    hdr_o = "obs_id,t,px,py,pz,size"
+    rows = [",".join([hdr_a, hdr_a, hdr_o])]
+    for i in range(4):
+        t = 0.1 * i
+        a0 = [0, t, 1.0 + t, 2.0, 0.5, 1, 0, 0, 0, 0, 0, 0.001, 3.5, 0, 0.15]
+        a1 = [1, t, -1.0, 2.0 - 2 * t, 0.5, 0, -2, 0, 0, 0, 0, 0.001, 1.5, 0, 0.2]
+        ob = [0, t, 5.0, 5.0, 1.0, 0.3]
+        rows.append(",".join(repr(float(v)) if isinstance(v, float) else str(v) for v in a0 + a1 + ob))
+    f = tmp_path / "result_LSC_2agents.csv"
+    f.write_text("\n".join(rows) + "\n")
+    r = subprocess.run([sim, "--replay", str(f)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    head = lines[0].split()
+    assert head[:9] == ["replay:", "agents", "2", "obstacles", "1", "records", "4", "makeSpan", "0.3"], head
+    assert abs(float(head[10]) - (0.3 + 0.6)) < 1e-6                        # |dp| summed over both agents (float32 points)
+    a0, a1 = lines[1].split(), lines[2].split()
+    assert a0[:4] == ["agent", "0", "radius", "0.15"] and abs(float(a0[5]) - 1.3) < 1e-6
+    assert a1[:4] == ["agent", "1", "radius", "0.2"] and abs(float(a1[6]) - 1.4) < 1e-6
+    bad = subprocess.run([sim, "--replay", str(tmp_path / "missing.csv")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 3 and "invalid csv file" in bad.stderr
