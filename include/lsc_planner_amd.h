@@ -19,7 +19,7 @@
  * point that computes fails with LSC_ENODEV when no gfx950 device is usable.
  *
  * Layouts
- *   traj   float  [N][3][M*(n+1)]   axis-major control points, index k*30 + m*6 + i  (M=5, n=5)
+ *   traj   float  [N][3][M*(n+1)]   axis-major control points, index k*M*6 + m*6 + i  (n=5; M=5: k*30 + m*6 + i)
  *                                   == TrajOptimizer's variable order (src/traj_optimizer.cpp:277)
  *   state  float  [N][9]            position, velocity, acceleration (octomap::point3d = float32)
  *   goal   float  [N][3]            agent.current_goal_position (output of goal planning)
@@ -34,11 +34,19 @@
 extern "C" {
 #endif
 
-#define LSC_M 5          /* segments   : horizon / dt, launch/simulation.launch:60-61            */
+/* Segments of a plan: M = (int)((horizon + 1e-9) / dt), src/traj_optimizer.cpp:9.  A build parameter of the library: liblsc_hip.so
+ * plans M = 5 (dt 0.2, horizon 1.0: launch/simulation.launch:60-61 and every other shipped launch file), liblsc_hip_m4.so -- the same
+ * sources compiled with -DLSC_SEGMENTS=4 -- plans M = 4 (dt 0.5, horizon 2.0: the C++ defaults of src/param.cpp:66-67).  A caller
+ * built against the M = 4 library defines LSC_SEGMENTS=4 before this header; lsc_segments() says what a loaded library plans, and
+ * lsc_create refuses a configuration whose horizon / dt is another number. */
+#ifndef LSC_SEGMENTS
+#define LSC_SEGMENTS 5
+#endif
+#define LSC_M LSC_SEGMENTS
 #define LSC_DEG 5        /* Bernstein degree n (only n=5, phi=3 exist: traj_optimizer.cpp:190-207) */
 #define LSC_NC 6
-#define LSC_SEGV 30
-#define LSC_NV 90
+#define LSC_SEGV (LSC_M * LSC_NC)
+#define LSC_NV (3 * LSC_SEGV)
 
 #define LSC_OK 0
 #define LSC_EINVAL (-1)   /* bad argument                                              */
@@ -93,8 +101,9 @@ typedef struct {
                                   start as fallback; 0 = always cold start */
     double grid_resolution;    /* grid/resolution 0.3: cell of the goal planner's search grid (goal_mode 1 + use_octomap) */
     double grid_margin;        /* grid/margin     0.2: a cell is occupied when EDT(centre) < radius + grid_margin        */
-    double horizon;            /* traj/horizon 1.0: the kernels plan M = horizon/dt = 5 segments; anything else is refused
-                                  by lsc_create instead of silently planning a different horizon                          */
+    double horizon;            /* traj/horizon 1.0: M = (int)((horizon + 1e-9) / dt) must be the library's lsc_segments() (5, or 4
+                                  in liblsc_hip_m4.so); anything else is refused by lsc_create instead of silently planning
+                                  a different horizon                                                                       */
     int    goal_row_cap;       /* 0 = as large as LDS allows; > 0 lowers the goal search's OPEN-row capacity (tests)       */
     /* ---- alternate planner modes.  Any of them changes the shape of the QP; such agents are solved by a
      * general dense kernel (csrc/lsc_general.hip) instead of the banded fast path -- same results, several times slower. */
@@ -140,6 +149,8 @@ const char *lsc_last_error(const lsc_ctx *ctx);
 /* Informational remark of lsc_create, "" when there is none -- e.g. that a slack mode was configured with the LSC planner and
  * fixed to none like TrajPlanner::checkPlannerMode does (src/traj_planner.cpp:445-448).  Never an error. */
 const char *lsc_last_note(const lsc_ctx *ctx);
+/* Segments M this library was built for (see LSC_SEGMENTS above). */
+int lsc_segments(void);
 
 /* Mission::agents (src/mission.cpp:60-130): radius, downwash, max_vel[3], max_acc[3], nominal_velocity.
  * Doubles, as in struct Agent (include/sp_const.hpp:153-165); an agent seen as somebody else's

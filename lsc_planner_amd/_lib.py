@@ -7,9 +7,15 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
 
+# M = 5 (every shipped launch file) is the default build; load_library(4) loads the M = 4 build of the same sources
 M, DEG, NC, SEGV, NV = 5, 5, 6, 30, 90
+
+
+def segments_of(horizon, dt):
+    """M = static_cast<int>((horizon + SP_EPSILON) / dt), src/traj_optimizer.cpp:9."""
+    return int((horizon + 1e-9) / dt)
 
 STATUS_OK, STATUS_INFEASIBLE, STATUS_SFC_BLOCKED, STATUS_GOAL_CAPACITY = 0, 1, 4, 5
 COMM_ID_BYTES = 128
@@ -55,7 +61,7 @@ class LscConfig(ctypes.Structure):
 
 # every symbol include/lsc_planner_amd.h declares
 EXPORTS = [
-    "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_last_note", "lsc_set_agents", "lsc_set_shard",
+    "lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_last_note", "lsc_segments", "lsc_set_agents", "lsc_set_shard",
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_safety_ratio", "lsc_sweep_device", "lsc_sweep_device_f32",
     "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_kernel_times_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_goal_profile", "lsc_goal_key_table", "lsc_general_profile", "lsc_dump_qp", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals", "lsc_set_goal_trace", "lsc_get_goal_trace",
     "lsc_last_bucket_max", "lsc_row_capacity", "lsc_comm_unique_id", "lsc_comm_init", "lsc_comm_info", "lsc_tick_device_sharded", "lsc_replan_tick_all",
@@ -63,17 +69,19 @@ EXPORTS = [
 ]
 
 
-def lib_path():
-    """liblsc_hip.so next to this file; LSC_HIP_LIB overrides it (A/B runs of two builds on the same GPU box)."""
-    return os.environ.get("LSC_HIP_LIB") or os.path.join(_HERE, "liblsc_hip.so")
+def lib_path(segments=5):
+    """liblsc_hip.so (M = 5) / liblsc_hip_m4.so (M = 4) next to this file; LSC_HIP_LIB overrides the M = 5 one (A/B runs of two
+    builds on the same GPU box)."""
+    if segments == 5:
+        return os.environ.get("LSC_HIP_LIB") or os.path.join(_HERE, "liblsc_hip.so")
+    return os.path.join(_HERE, f"liblsc_hip_m{segments}.so")
 
 
-def load_library():
-    """Loads liblsc_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Raises if absent."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    p = lib_path()
+def load_library(segments=5):
+    """Loads the library built for `segments` = horizon / dt (__graft_entry__.build() / csrc/Makefile).  Raises if absent."""
+    if segments in _LIBS:
+        return _LIBS[segments]
+    p = lib_path(segments)
     if not os.path.exists(p):
         raise LscError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
@@ -138,5 +146,8 @@ def load_library():
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int or name not in ("lsc_default_config", "lsc_create", "lsc_destroy", "lsc_last_error", "lsc_last_note", "lsc_free_host"):
             fn.restype = ctypes.c_int
-    _LIB = L
+    L.lsc_segments.argtypes = []
+    if L.lsc_segments() != segments:
+        raise LscError(f"{p} plans M = {L.lsc_segments()} segments, not {segments}")
+    _LIBS[segments] = L
     return L

@@ -270,7 +270,7 @@ class TrajPlanner {
         planner_seq++;
         for (int m = 0; m < M; m++)
             for (int i = 0; i <= n; i++)
-                traj_curr[m][i] = point3d(traj90[m * (n + 1) + i], traj90[30 + m * (n + 1) + i], traj90[60 + m * (n + 1) + i]);
+                traj_curr[m][i] = point3d(traj90[m * (n + 1) + i], traj90[M * (n + 1) + m * (n + 1) + i], traj90[2 * M * (n + 1) + m * (n + 1) + i]);
         if (status == LSC_STATUS_OK) current_qp_cost = cost;
         // QP failures are swallowed: trajOptimization() returns true whatever the solver did, so planLSC reports SUCCESS
         // (src/traj_planner.cpp:1553-1584, :388-420).  A blocked corridor seed is different: expandBoxFromPoint throws

@@ -55,7 +55,7 @@ class MultiSyncSimulator {
         check(lsc_set_timing(ctx, 1));   // per-kernel device times -> the per-phase columns of the summary
         if (phase_stats_on) check(lsc_phase_profile(ctx, 1, nullptr));
         if (param.world_use_octomap) setOctomap(mission.world_file_name);
-        h_state.resize(9 * N); h_goal.resize(3 * N); h_prev.assign(90 * N, 0.f); h_next.resize(90 * N);
+        h_state.resize(9 * N); h_goal.resize(3 * N); h_prev.assign((size_t)LSC_NV * N, 0.f); h_next.resize((size_t)LSC_NV * N);
         h_cost.assign(N, 0.0); h_status.assign(N, 0); h_iters.assign(N, 0);
         points.resize(N);
         file_name_param = param.getPlannerModeStr() + "_" + std::to_string(N) + "agents";
@@ -128,7 +128,7 @@ class MultiSyncSimulator {
         // obstacle list of agent qi = every other agent's next state + previous trajectory: one shared table
         for (int qi = 0; qi < N; qi++) {
             const traj_t t = agents[qi]->getTraj();
-            for (int m = 0; m < 5; m++) for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) h_prev[90 * qi + 30 * k + 6 * m + i] = t[m][i](k);
+            for (int m = 0; m < LSC_M; m++) for (int i = 0; i < LSC_NC; i++) for (int k = 0; k < 3; k++) h_prev[LSC_NV * qi + LSC_SEGV * k + LSC_NC * m + i] = t[m][i](k);
             agents[qi]->setObsPrevTrajs({});
         }
         initial_update = false;
@@ -160,7 +160,7 @@ class MultiSyncSimulator {
         last_tick_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         for (int qi = 0; qi < N; qi++) {
             agents[qi]->agent.current_goal_position = point3d(goals[3 * qi], goals[3 * qi + 1], goals[3 * qi + 2]);
-            agents[qi]->acceptPlan(h_next.data() + 90 * qi, h_cost[qi], h_status[qi], last_tick_ms * 1e-3 / N);
+            agents[qi]->acceptPlan(h_next.data() + (size_t)LSC_NV * qi, h_cost[qi], h_status[qi], last_tick_ms * 1e-3 / N);
         }
         total_ticks++; total_tick_ms += last_tick_ms;
         // TrajOptimizer::solve exports the model of a failed solve (log/QPmodel.lp, src/traj_optimizer.cpp:99-102); like there the
@@ -371,11 +371,13 @@ int main(int argc, char **argv)
         else if (a == "--max-noise") param.multisim_max_noise = std::stod(next());
         else if (a == "--noise-seed") param.multisim_noise_seed = (unsigned)std::stoul(next());
         else if (a == "--dimension") param.world_dimension = std::stoi(next());
+        else if (a == "--dt") { param.dt = std::stod(next()); param.multisim_time_step = param.dt; }      // LSC: multisim_time_step must equal the segment time (src/traj_planner.cpp:434-436)
+        else if (a == "--horizon") param.horizon = std::stod(next());
         else if (a == "--z-2d") param.world_z_2d = std::stod(next());
         else if (a == "--ranks") param.world = std::stoi(next());
         else if (a == "--rank") param.rank = std::stoi(next());
         else if (a == "--comm-file") param.comm_file = next();
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats] | lsc_sim --replay result.csv\n"); return 2; }
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats] [--dt T --horizon H] | lsc_sim --replay result.csv\n"); return 2; }
     }
     if (!replay_file.empty()) {
         // MultiSyncReplayer (src/multi_sync_replayer.cpp): read a result CSV back -- needs no GPU -- and say what it holds
@@ -397,6 +399,11 @@ int main(int argc, char **argv)
         }
     }
     if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
+    if ((int)((param.horizon + 1e-9) / param.dt) != lsc_segments()) {
+        std::fprintf(stderr, "lsc_sim: horizon %g / dt %g = %d segments; this binary is linked with the M = %d library (lsc_sim: M = 5, lsc_sim_m4: M = 4)\n",
+                     param.horizon, param.dt, (int)((param.horizon + 1e-9) / param.dt), lsc_segments());
+        return 2;
+    }
     // torchrun / mpirun style environment: one process per GPU
     if (param.world == 1 && std::getenv("WORLD_SIZE")) {
         param.world = std::atoi(std::getenv("WORLD_SIZE"));

@@ -76,7 +76,7 @@ void build_model(const lsc_config &cfg, HostModel &H)
     for (int mm = 0; mm < M; mm++)
         for (int i = 0; i < NC; i++) {
             const int t = mm * NC + i;
-            if (mm == M - 1 && i >= 3) { Zm[t][12] = 1.0; continue; }        // stop at the horizon
+            if (mm == M - 1 && i >= 3) { Zm[t][NYL] = 1.0; continue; }       // stop at the horizon
             if (i >= 3) { Zm[t][3 * mm + (i - 3)] = 1.0; continue; }
             if (mm == 0) continue;                                         // fixed by the current state
             const int u3 = 3 * (mm - 1), u4 = u3 + 1, u5 = u3 + 2;          // c_{m-1,3..5}
@@ -108,8 +108,8 @@ void build_model(const lsc_config &cfg, HostModel &H)
 
     // Hessian assembly terms: K[(k,a),(k',b)] += Z[t][a] Z[t'][b] * Wx[(k,t),(k',t')]
     auto scomp = [](int k, int kk) { if (k > kk) std::swap(k, kk); return k == 0 ? kk : (k == 1 ? 2 + kk : 5); };  // xx xy xz yy yz zz
-    auto axis_of = [](int g) { return g < 36 ? (g % 9) / 3 : g - 36; };
-    auto var_of = [](int g) { return g < 36 ? (g / 9) * 3 + (g % 3) : 12; };
+    auto axis_of = [](int g) { return yaxis(g); };
+    auto var_of = [](int g) { return yvar(g); };
     H.terms.clear(); H.entries.clear();
     int n_entries = 0;
     for (int gi = 0; gi < NY; gi++)
@@ -166,7 +166,7 @@ void build_model(const lsc_config &cfg, HostModel &H)
         const bool valid = type < 2 ? !(mm == 0 && i < 3) : (type < 4 ? (i <= 4 && !(mm == 0 && i < 2)) : (i <= 3 && !(mm == 0 && i == 0)));
         if (valid && !(m.dim2 && k == 2)) m.amap[n++] = (unsigned short)sl;      // planar world: `for (k < dim)`, src/traj_optimizer.cpp:274, 469
     }
-    if (n != (m.dim2 ? 276 : 414)) { std::fprintf(stderr, "lsc: axis row count %d\n", n); std::abort(); }
+    if (n != (m.dim2 ? AXVALID_2D : AXVALID_3D)) { std::fprintf(stderr, "lsc: axis row count %d\n", n); std::abort(); }
     m.n_ax = n;
     m.sigma_pow = 3;
     // (no environment overrides: everything that changes the solve is an lsc_config field)
@@ -177,11 +177,11 @@ void build_gmodel(const lsc_config &cfg, const Model &m, GModel &g)
 {
     std::memset(&g, 0, sizeof(g));
     const bool stop = cfg.planner_mode == 0;
-    g.nya = stop ? 13 : 15;
+    g.nya = stop ? NYA : GNYA;
     for (int mm = 0; mm < M; mm++)
         for (int i = 0; i < NC; i++) {
             const int t = mm * NC + i;
-            if (mm == M - 1 && i >= 3) { g.Z[t][stop ? 12 : 12 + (i - 3)] = 1.0; continue; }
+            if (mm == M - 1 && i >= 3) { g.Z[t][stop ? NYL : NYL + (i - 3)] = 1.0; continue; }
             if (i >= 3) { g.Z[t][3 * mm + (i - 3)] = 1.0; continue; }
             if (mm == 0) continue;
             const int u3 = 3 * (mm - 1), u4 = u3 + 1, u5 = u3 + 2;
@@ -380,10 +380,12 @@ void lsc_default_config(lsc_config *cfg)
 lsc_ctx *lsc_create(const lsc_config *cfg)
 {
     if (!cfg || !(cfg->dt > 0)) return nullptr;
-    // M = horizon / dt (src/param.cpp, TrajPlanner ctor): the kernels are built for the M = 5 of every shipped launch file
+    // M = static_cast<int>((horizon + SP_EPSILON) / dt) (src/traj_optimizer.cpp:9, src/traj_planner.cpp:22).  The kernels are unrolled
+    // for their segment count: this library plans M segments (liblsc_hip.so: 5, every shipped launch file; liblsc_hip_m4.so: 4, the
+    // C++ defaults of src/param.cpp:66-67) and says so instead of silently planning another horizon.
     if ((int)((cfg->horizon + 1e-9) / cfg->dt) != M) {
-        std::fprintf(stderr, "lsc_create: horizon %g / dt %g = %d segments, this build plans M = %d\n", cfg->horizon, cfg->dt,
-                     (int)((cfg->horizon + 1e-9) / cfg->dt), M);
+        std::fprintf(stderr, "lsc_create: horizon %g / dt %g = %d segments, this library plans M = %d (lsc_segments(); the sibling build "
+                             "liblsc_hip%s.so plans %d)\n", cfg->horizon, cfg->dt, (int)((cfg->horizon + 1e-9) / cfg->dt), M, M == 5 ? "_m4" : "", M == 5 ? 4 : 5);
         return nullptr;
     }
     int ndev = 0;
@@ -472,6 +474,7 @@ void lsc_destroy(lsc_ctx *c)
 
 const char *lsc_last_error(const lsc_ctx *c) { return c ? c->err.c_str() : "null context"; }
 const char *lsc_last_note(const lsc_ctx *c) { return c ? c->note.c_str() : ""; }
+int lsc_segments(void) { return M; }
 
 int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwash, const double *max_vel,
                    const double *max_acc, const double *nominal_vel)
@@ -491,16 +494,17 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     int per_cp = c->cfg.max_rows_per_cp > 0 ? c->cfg.max_rows_per_cp : 64;
     if (per_cp > N - 1) per_cp = N - 1;
     if (per_cp < 1) per_cp = 1;
-    int cap = 27 * per_cp;
-    while (cap > 27 && plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, cap) > 160 * 1024) cap -= 27;
+    constexpr int NBR = NCP - 3;              // control points that carry rows: 27 for M = 5
+    int cap = NBR * per_cp;
+    while (cap > NBR && plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, cap) > 160 * 1024) cap -= NBR;
     c->cap = cap;
     c->hm.m.cap = cap;
     // Throughput build (256 lanes, two workgroups per CU): used when the shard has more agents than the GPU has CUs; its
     // capacity is what fits half a CU's LDS.  (Pointless -- and slower per agent -- for a shard that fits the chip.)
     c->cap_tp = 0; c->smem_tp = 0;
     if (c->cfg.max_rows_per_cp == 0) {
-        int ct = 27;
-        while (plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, ct + 27, false) <= 80 * 1024 - 512) ct += 27;
+        int ct = NBR;
+        while (plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, ct + NBR, false) <= 80 * 1024 - 512) ct += NBR;
         if (ct < cap && plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, ct, false) <= 80 * 1024 - 512) {
             c->cap_tp = ct;
             c->smem_tp = plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, ct, false);
@@ -535,7 +539,7 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         HIPCHK(c, hipMemcpy(c->d_sfc_init, ones.data(), sizeof(int) * (size_t)N, hipMemcpyHostToDevice));
     }
     c->h_radius.assign(radius, radius + N);
-    if (cap < 27 * (N - 1)) {
+    if (cap < NBR * (N - 1)) {
         // An agent can carry more rows than the LDS capacity holds: those agents are re-planned by a second pass with
         // their rows in HBM (the reference never drops a row, src/traj_optimizer.cpp:437-466).  One workspace per
         // persistent workgroup; 256 = one per CU.
@@ -1631,9 +1635,9 @@ int lsc_solver_trace(lsc_ctx *c, int agent, double *out)
 {
     if (!c || c->N == 0) return LSC_EINVAL;
     HIPCHK(c, hipDeviceSynchronize());
-    if (!c->d_trace) { HIPCHK(c, hipMalloc(&c->d_trace, sizeof(double) * (64 * 8 + 39 * 41 + 450 + 512))); }
-    if (out) HIPCHK(c, hipMemcpy(out, c->d_trace, sizeof(double) * (64 * 8 + 39 * 41 + 450 + 512), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemset(c->d_trace, 0, sizeof(double) * (64 * 8 + 39 * 41 + 450 + 512)));
+    if (!c->d_trace) { HIPCHK(c, hipMalloc(&c->d_trace, sizeof(double) * (64 * 8 + NY * KLD + W_SIZE + 512))); }
+    if (out) HIPCHK(c, hipMemcpy(out, c->d_trace, sizeof(double) * (64 * 8 + NY * KLD + W_SIZE + 512), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->d_trace, 0, sizeof(double) * (64 * 8 + NY * KLD + W_SIZE + 512)));
     c->trace_agent = agent;
     return LSC_OK;
 }

@@ -42,9 +42,10 @@ typedef const PlanArgs KArgs;
 
 constexpr int GT = 512;            // lanes per agent
 constexpr int GW = GT / 64;
-constexpr int PMAX = 3 * GNYA + 2 * M;      // 45 + 10
+constexpr int PMAX = 3 * GNYA + 2 * M;      // 45 + 10 for M = 5
+constexpr int P_STOP = 3 * NYA, P_FREE = 3 * GNYA;   // unknowns with / without the stop-at-horizon rows (39 / 45 for M = 5)
 constexpr int KL = PMAX + 2;       // leading dimension of the dense matrices in LDS (57 doubles: rows of one column fall in different banks)
-constexpr int NBK = 27;            // control points that carry collision rows
+constexpr int NBK = NCP - 3;       // control points that carry collision rows (27 for M = 5)
 constexpr int SEG_E = 171;
 // sections of lsc_general_profile
 enum { GP_SETUP = 0, GP_START, GP_RESID, GP_REDUCE, GP_ASSEMBLE, GP_FACTOR, GP_SOLVE, GP_AFFINE, GP_CORR_RHS, GP_REDUCE2, GP_ASSEMBLE2, GP_STEP, GP_ITERS, GP_AGENTS };         // symmetric 18 x 18 block of one segment (6 control points x 3 axes)
@@ -527,7 +528,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     }
     for (int c = tid; c < NCL; c += GT) {
         const int oe = c / NBK, cpi = c % NBK;
-        const bool there = oe < n_obs;                                                   // (NCL is 27 even with nobody kept)
+        const bool there = oe < n_obs;                                                   // (NCL is NBK even with nobody kept)
         const int src = there ? omap[oe] * NBK + cpi : 0;
         crhs[c] = there ? t_crhs[src] : 0.0;
         cact[c] = there ? t_act[src] : 0;
@@ -815,8 +816,8 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     // dense K = L D L^T, then L D L^T dy = rhs: wave 0, out of line (dense_factor_w0 / dense_solve_w0 above)
     auto factor = [&]() -> bool {
         if (wave == 0) {
-            if (P <= 39) dense_factor_w0<39>();
-            else if (P <= 45) dense_factor_w0<45>();
+            if (P <= P_STOP) dense_factor_w0<P_STOP>();
+            else if (P <= P_FREE) dense_factor_w0<P_FREE>();
             else dense_factor_w0<PMAX>();
         }
         __syncthreads();
@@ -826,8 +827,8 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
         if (wave == 0) {
             long long t0 = 0;
             if (gp) t0 = (long long)__builtin_readcyclecounter();
-            if (P <= 39) dense_solve_w0<39>(P);
-            else if (P <= 45) dense_solve_w0<45>(P);
+            if (P <= P_STOP) dense_solve_w0<P_STOP>(P);
+            else if (P <= P_FREE) dense_solve_w0<P_FREE>(P);
             else dense_solve_w0<PMAX>(P);
             if (gp && tid == 0) gp[14] += (long long)__builtin_readcyclecounter() - t0;
         }
@@ -890,7 +891,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
             const double mu0 = md.ws_mu0, smin = sqrt(mu0);
             if (tid < P0) {
                 const int k = tid / nya, aa = tid % nya;
-                const int t = aa < 12 ? (aa / 3) * NC + 3 + aa % 3 : (M - 1) * NC + 3 + (aa - 12);
+                const int t = aa < NYL ? (aa / 3) * NC + 3 + aa % 3 : (M - 1) * NC + 3 + (aa - NYL);
                 const int m = t / NC, i = t % NC;
                 const float *tp = a.traj_prev + (size_t)qi * NV + k * SEGV;
                 S.y[tid] = (dim2 && k == 2) ? md.z2d : (double)((m < M - 1) ? tp[(m + 1) * NC + i] : tp[(M - 1) * NC + DEG]);

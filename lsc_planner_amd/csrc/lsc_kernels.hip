@@ -380,13 +380,13 @@ __global__ __launch_bounds__(64) void lsc_sfc_kernel(SfcArgs a)
 // ---------------------------------------------------------------------------------------------------
 // The per-agent planning kernel
 // ---------------------------------------------------------------------------------------------------
-constexpr int NB = 27;        // control points that carry LSC rows: all but (m=0, i<3)
+constexpr int NB = NCP - 3;   // control points that carry LSC rows: all but (m=0, i<3)   (27 for M = 5)
 // Row reduction (reduce_rows): a lane sums all components over a few consecutive rows of one control point's bucket, a second
 // step adds the parts of a bucket in order.  Slots = lanes of the first step; their partial sums are staged in LDS that is dead
 // at that point: K (NY x KLD doubles, 12 components per slot) before a factorisation, the factorisation's scratch (colbuf, mid2,
 // xch: 388 doubles, 3 components per slot: a corrector pass only needs sum v n) in a corrector pass.
 constexpr int RSLOT_P = (NY * KLD) / 12, RSLOT_C = 128;
-constexpr int AXVALID = 414;  // 162 bound + 138 velocity + 114 acceleration rows (src/traj_optimizer.cpp:274-303, 468-525)
+constexpr int AXVALID = AXVALID_3D;  // M = 5: 162 bound + 138 velocity + 114 acceleration rows (src/traj_optimizer.cpp:274-303, 468-525)
 
 // SMALL = the throughput build's variant: what can be recomputed or read from L2 (right-hand sides of the axis rows, the
 // constant part of the Hessian entries, the assembly tables) is not kept, the LDS goes to row capacity instead
@@ -571,8 +571,9 @@ __device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, dou
 // [14, 25) which wave 0 then factorises.  K = T D T^T with T unit lower triangular in its first 25 columns and unit
 // upper triangular in its last 14; the dependent chain is 14 + 11 pivots instead of 39.  The substitutions use the
 // same split: 14 steps from both ends in parallel, 11 + 10 in the middle, 13 steps back out in parallel.
-constexpr int TW_A = 14;                 // pivots taken from each end
-constexpr int TW_M1 = NY - TW_A;         // middle block = [TW_A, TW_M1)
+constexpr int TW_A = (NY - BAND + 1) / 2; // pivots taken from the top ...            (14 for NY = 39, 10 for NY = 30)
+constexpr int TW_B = NY - BAND - TW_A;    // ... and from the bottom (the same, or one less)  (14,             9)
+constexpr int TW_M1 = NY - TW_B;          // middle block = [TW_A, TW_M1)
 static_assert(TW_M1 - TW_A == BAND, "the middle block must absorb exactly one bandwidth");
 
 template <int J, int JEND>
@@ -595,6 +596,14 @@ __device__ __forceinline__ void bwd_steps(const double (&c)[CNT], double &b)
 // load of a "condition ? loaded value : 0" into a branch of its own -- exec mask, load, wait, restore -- and the loads of one
 // group, which are independent, are served one LDS latency after the other.)
 #define LSC_P(a, i) "+v"(a[i])
+__device__ __forceinline__ void pin_values(double (&a)[8])
+{
+    asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7));
+}
+__device__ __forceinline__ void pin_values(double (&a)[9])
+{
+    asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7), LSC_P(a, 8));
+}
 __device__ __forceinline__ void pin_values(double (&a)[10])
 {
     asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7), LSC_P(a, 8), LSC_P(a, 9));
@@ -899,8 +908,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         S.Qh6[tid - 128] = md.Qh[tid - 128];
     } else if (tid >= 192 && tid < 192 + NY) {
         const int g = tid - 192;
-        const int yk = g < 36 ? (g % 9) / 3 : g - 36;
-        const int va = g < 36 ? (g / 9) * 3 + (g % 3) : 12;
+        const int yk = yaxis(g);
+        const int va = yvar(g);
         const int n = md.t_n[va];
         S.ytc[g][0] = n > 0 ? md.t_c[va][0] : 0.0; S.ytc[g][1] = n > 1 ? md.t_c[va][1] : 0.0;
         S.ytc[g][2] = n > 2 ? md.t_c[va][2] : 0.0; S.ytc[g][3] = n > 3 ? md.t_c[va][3] : 0.0;
@@ -915,13 +924,13 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     // constant part of every Hessian entry: cost Hessian (same axis) + terminal weight on c_{m,5}
     auto kconst_of = [&](uint32_t id) -> double {
         const int gi = id >> 16, gj = id & 0xffff;
-        const int ki = gi < 36 ? (gi % 9) / 3 : gi - 36, kj = gj < 36 ? (gj % 9) / 3 : gj - 36;
-        const int va = gi < 36 ? (gi / 9) * 3 + (gi % 3) : 12, vb = gj < 36 ? (gj / 9) * 3 + (gj % 3) : 12;
+        const int ki = yaxis(gi), kj = yaxis(gj);
+        const int va = yvar(gi), vb = yvar(gj);
         double v = 0.0;
         if (ki == kj) {
             v = md.Hc[va * NYA + vb];
             if (va == vb) {
-                const int mterm = va == 12 ? 4 : ((va % 3) == 2 ? va / 3 : -1);
+                const int mterm = va == NYL ? M - 1 : ((va % 3) == 2 ? va / 3 : -1);
                 if (mterm >= M - S.tseg) v += 2.0 * md.w_t;
             }
         }
@@ -1533,14 +1542,17 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 // the Schur updates of this sweep
 #pragma unroll
                 for (int j = 0; j < NY; j++)
-                    lrow[j] = (act && j <= lane && lane - j <= BAND && j < TW_A) ? S.K[(RV - j) * KLD + (RV - lane)] : 0.0;
+                    lrow[j] = (act && j <= lane && lane - j <= BAND && j < TW_B) ? S.K[(RV - j) * KLD + (RV - lane)] : 0.0;
             }
             dinv_own = 0.0;
-            chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
+            // (wave 0 takes TW_A pivots from the top, wave 1 TW_B from the bottom: the same number, or one less when NY - BAND is odd)
+            if (wave == 0) chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
+            else chol_step<0, TW_B>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
             if (wave == 1) {
-                if (lane >= TW_A && lane < TW_M1) {
+                // the middle block in the reversed numbering is [TW_B, TW_B + BAND); reversed (r, c) is original (RV - r, RV - c)
+                if (lane >= TW_B && lane < TW_B + BAND) {
 #pragma unroll
-                    for (int c = TW_A; c < TW_M1; c++)
+                    for (int c = TW_B; c < TW_B + BAND; c++)
                         if (c <= lane) S.mid2[(RV - c - TW_A) * BAND + (RV - lane - TW_A)] = lrow[c];
                 }
                 if (lane == 0) S.ok2 = ok ? 1.0 : 0.0;
@@ -1564,11 +1576,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             if (lane < TW_M1) S.dinv[lane] = dinv_own;
             if (lane == 0) S.sc[7] = ok ? 1.0 : 0.0;
         } else if (wave == 1) {
-            if (lane < TW_A) S.dinv[RV - lane] = dinv_own;
+            if (lane < TW_B) S.dinv[RV - lane] = dinv_own;
             // multipliers of the bottom-up sweep, reversed (r, c) -> original (RV-r, RV-c), kept at the mirrored band position
 #pragma unroll
-            for (int c = 0; c < TW_A; c++)
-                if (lane < TW_M1 && c < lane && lane - c <= BAND) S.K[(RV - c) * KLD + (RV - lane)] = lrow[c];
+            for (int c = 0; c < TW_B; c++)
+                if (lane < TW_B + BAND && c < lane && lane - c <= BAND) S.K[(RV - c) * KLD + (RV - lane)] = lrow[c];
         }
         __syncthreads();
         return S.sc[7] != 0.0 && S.ok2 != 0.0;
@@ -1592,20 +1604,21 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             double bt = l < TW_M1 ? rhs : 0.0;              // top-down sweep: unknowns 0..13, what it takes off the middle rows
             double bb = l >= TW_M1 ? rhs : 0.0;             // bottom-up sweep: unknowns 38..25, what it takes off the middle rows
             {
-                double ct[TW_A], cb[TW_A];
+                double ct[TW_A], cb[TW_B];
 #pragma unroll
-                for (int q = 0; q < TW_A; q++) { ct[q] = Krow[q]; cb[q] = Kcol[(RV - q) * KLD]; }
+                for (int q = 0; q < TW_A; q++) ct[q] = Krow[q];
+#pragma unroll
+                for (int q = 0; q < TW_B; q++) cb[q] = Kcol[(RV - q) * KLD];
                 pin_values(ct);
                 pin_values(cb);
 #pragma unroll
-                for (int q = 0; q < TW_A; q++) {
-                    ct[q] = (l > q && l <= q + BAND) ? ct[q] : 0.0;                      // T[l][q], l in (q, q + BAND] (<= 24: the top sweep ends in the middle block)
-                    cb[q] = (l < RV - q && l >= RV - q - BAND) ? cb[q] : 0.0;            // pivot RV - q: rows above it, stored at the mirrored place
-                }
+                for (int q = 0; q < TW_A; q++) ct[q] = (l > q && l <= q + BAND) ? ct[q] : 0.0;                  // T[l][q], l in (q, q + BAND]: the top sweep ends in the middle block
+#pragma unroll
+                for (int q = 0; q < TW_B; q++) cb[q] = (l < RV - q && l >= RV - q - BAND) ? cb[q] : 0.0;        // pivot RV - q: rows above it, stored at the mirrored place
 #pragma unroll
                 for (int q = 0; q < TW_A; q++) {
                     bt = fma(-ct[q], lane_value(bt, q), bt);
-                    bb = fma(-cb[q], lane_value(bb, RV - q), bb);
+                    if (q < TW_B) bb = fma(-cb[q < TW_B ? q : 0], lane_value(bb, RV - q), bb);
                 }
             }
             double b = bt + bb;
@@ -1637,21 +1650,21 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             }
             bt = b; bb = b;
             {
-                double co[TW_A - 1], ci[TW_A - 1];
+                double co[TW_A - 1], ci[TW_B - 1];
 #pragma unroll
-                for (int q = 0; q < TW_A - 1; q++) { co[q] = Kcol[(TW_A - 1 - q) * KLD]; ci[q] = Krow[TW_M1 + q]; }
+                for (int q = 0; q < TW_A - 1; q++) co[q] = Kcol[(TW_A - 1 - q) * KLD];
+#pragma unroll
+                for (int q = 0; q < TW_B - 1; q++) ci[q] = Krow[TW_M1 + q];
                 pin_values(co);
                 pin_values(ci);
 #pragma unroll
-                for (int q = 0; q < TW_A - 1; q++) {
-                    const int It = TW_A - 1 - q, Ib = TW_M1 + q;
-                    co[q] = (l < It && l >= It - BAND) ? co[q] : 0.0;
-                    ci[q] = (l > Ib && l < NY && l - Ib <= BAND) ? ci[q] : 0.0;
-                }
+                for (int q = 0; q < TW_A - 1; q++) { const int It = TW_A - 1 - q; co[q] = (l < It && l >= It - BAND) ? co[q] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < TW_B - 1; q++) { const int Ib = TW_M1 + q; ci[q] = (l > Ib && l < NY && l - Ib <= BAND) ? ci[q] : 0.0; }
 #pragma unroll
                 for (int q = 0; q < TW_A - 1; q++) {
                     bt = fma(-co[q], lane_value(bt, TW_A - 1 - q), bt);
-                    bb = fma(-ci[q], lane_value(bb, TW_M1 + q), bb);
+                    if (q < TW_B - 1) bb = fma(-ci[q < TW_B - 1 ? q : 0], lane_value(bb, TW_M1 + q), bb);
                 }
             }
             if (l < NY) S.dy[l] = l < TW_M1 ? bt : bb;
@@ -1702,8 +1715,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     };
     auto prepare_warm = [&](double mu0) {
         if (tid < NY) {
-            const int g = tid, k = g < 36 ? (g % 9) / 3 : g - 36, va = g < 36 ? (g / 9) * 3 + (g % 3) : 12;
-            const int t = va < 12 ? (va / 3) * NC + 3 + (va % 3) : (M - 1) * NC + 3;
+            const int g = tid, k = yaxis(g), va = yvar(g);
+            const int t = va < NYL ? (va / 3) * NC + 3 + (va % 3) : (M - 1) * NC + 3;
             S.y[g] = (dim2 && k == 2) ? md.z2d : (double)S.pinit[k * SEGV + t];
         }
         __syncthreads();

@@ -15,16 +15,34 @@
 
 namespace lsc {
 
-constexpr int M = 5, DEG = 5, NC = 6, SEGV = 30, NV = 90;
-constexpr int NYA = 13;        // free variables per axis
-constexpr int NY = 39;         // free variables per agent
-constexpr int NCP = 30;        // control points per agent (27 carry constraints)
-constexpr int KLD = 41;        // leading dimension of the 39x39 matrices in LDS (bank spread)
-constexpr int BAND = 11;       // half bandwidth of the reduced Hessian in cluster-major order
-constexpr int AXROWS = 6 * NV; // bound(2) / velocity(2) / acceleration(2) row slots per variable
+// Segments of a plan: M = horizon / dt is a run-time number in the reference (src/traj_optimizer.cpp:9, src/traj_planner.cpp:22);
+// here it is a build parameter -- every array below is sized by it and the factorisation is unrolled for it.  Two instantiations
+// are built: M = 5 (every shipped launch file: dt 0.2, horizon 1.0) -> liblsc_hip.so, and M = 4 (the C++ defaults of
+// src/param.cpp:66-67: dt 0.5, horizon 2.0) -> liblsc_hip_m4.so, from the same sources with -DLSC_SEGMENTS=4.
+#ifndef LSC_SEGMENTS
+#define LSC_SEGMENTS 5
+#endif
+constexpr int M = LSC_SEGMENTS, DEG = 5, NC = 6, SEGV = M * NC, NV = 3 * SEGV;
+static_assert(M >= 3 && M <= 5, "built and tested for 3 <= M <= 5 (the LDS tables and the twisted factorisation are sized for it)");
+constexpr int NYL = 3 * (M - 1);   // free variables of an axis inside the clusters: c_{m,3..5} for m < M - 1
+constexpr int NYA = NYL + 1;       // + c_{M-1,3} (= c_{M-1,4} = c_{M-1,5}: stop at the horizon)
+constexpr int NYC = 9 * (M - 1);   // cluster part of the global order: (M - 1) clusters of 3 axes x 3 locals, then the 3 last unknowns
+constexpr int NY = 3 * NYA;        // free variables per agent (39 for M = 5)
+constexpr int NCP = SEGV;          // control points per agent (all but 3 carry constraints)
+constexpr int KLD = NY + 2 - (NY % 2 == 0);   // leading dimension of the NY x NY matrices in LDS, odd (bank spread): 41 for NY = 39
+constexpr int BAND = 11;           // half bandwidth of the reduced Hessian in cluster-major order (9 + 2, whatever M is)
+constexpr int AXROWS = 6 * NV;     // bound(2) / velocity(2) / acceleration(2) row slots per variable
+// rows that exist (src/traj_optimizer.cpp:274-303, 468-525): bounds on all but c_{0,0..2}; 5 M - 2 velocity and 4 M - 1 acceleration
+// differences per axis, two signs each
+constexpr int AXVALID_3D = 2 * 3 * (SEGV - 3) + 2 * 3 * (5 * M - 2) + 2 * 3 * (4 * M - 1);
+constexpr int AXVALID_2D = AXVALID_3D / 3 * 2;
+static_assert(M != 5 || (NY == 39 && KLD == 41 && AXVALID_3D == 414 && AXVALID_2D == 276), "the M = 5 layout of rounds 1-3");
 
 // global (cluster-major) index of free variable a of axis k: clusters of 3 axes x 3 locals
-__host__ __device__ inline int yglob(int k, int a) { return a < 12 ? (a / 3) * 9 + k * 3 + (a % 3) : 36 + k; }
+__host__ __device__ inline int yglob(int k, int a) { return a < NYL ? (a / 3) * 9 + k * 3 + (a % 3) : NYC + k; }
+// ... and back: axis and per-axis index of global unknown g
+__host__ __device__ inline int yaxis(int g) { return g < NYC ? (g % 9) / 3 : g - NYC; }
+__host__ __device__ inline int yvar(int g) { return g < NYC ? (g / 9) * 3 + (g % 3) : NYL; }
 
 struct Model {
     double dt, w_c, w_t;
@@ -50,7 +68,7 @@ struct Model {
     double gap_tol;           // duality-gap tolerance, relative to 1 + |objective|
     double ws_mu0;            // warm start: initial complementarity target (0 = cold start only)
     int sigma_pow;            // Mehrotra centering exponent: sigma = (mu_aff / mu)^sigma_pow  (2, 3 or 4)
-    unsigned short amap[416]; // compact list of the valid axis-row slots (414; 276 in a planar world)
+    unsigned short amap[AXVALID_3D + 2]; // compact list of the valid axis-row slots (414 for M = 5; 276 in a planar world)
     int    n_ax;              // entries of amap
     // world/dimension == 2 (src/traj_optimizer.cpp:8): the QP has the x and y variables only -- no z bounds, no z velocity /
     // acceleration rows, collision and corridor rows without their z term (:264-266, 330, 367, 394, 411, 423, 450, 469, 529) --
@@ -63,7 +81,7 @@ struct Model {
 
 // Dense variant of the same elimination for the alternate planner modes (lsc_general.hip): axis-major y, with
 // (nya = 13) or without (nya = 15, BVC: c_{4,3..5} stay free) the stop-at-horizon rows.
-constexpr int GNYA = 15;
+constexpr int GNYA = NYL + 3;      // 15 for M = 5
 struct GModel {
     int    nya;
     double Z[SEGV][GNYA];     // x_t = (state constants for t < 3) + sum_a Z[t][a] y[a]
@@ -71,10 +89,11 @@ struct GModel {
 };
 
 // offsets inside the x-space weight array W that the assembly terms read from
-constexpr int W_D = 0;          // [3][30] diagonal        (bounds + velocity + acceleration stencils)
-constexpr int W_1 = 90;         // [3][30] (t, t+1) coupling
-constexpr int W_2 = 180;        // [3][30] (t, t+2) coupling
-constexpr int W_S = 270;        // [30][6]  LSC blocks  sum w n n^T : xx, xy, xz, yy, yz, zz
-constexpr int W_SIZE = 450;
+constexpr int W_D = 0;          // [3][SEGV] diagonal        (bounds + velocity + acceleration stencils)
+constexpr int W_1 = NV;         // [3][SEGV] (t, t+1) coupling
+constexpr int W_2 = 2 * NV;     // [3][SEGV] (t, t+2) coupling
+constexpr int W_S = 3 * NV;     // [NCP][6]  LSC blocks  sum w n n^T : xx, xy, xz, yy, yz, zz
+constexpr int W_SIZE = 3 * NV + 6 * NCP;
+static_assert(W_SIZE < 1024, "an assembly term addresses W with 10 bits");
 
 }  // namespace lsc

@@ -32,7 +32,7 @@ class PlannerConfig:
     goal_radius: float = 2.0
     grid_resolution: float = 0.3    # grid/resolution (goal planner's search grid; goal_mode prior_based + use_octomap)
     grid_margin: float = 0.2        # grid/margin
-    horizon: float = 1.0            # traj/horizon (M = horizon / dt must be 5)
+    horizon: float = 1.0            # traj/horizon; M = horizon / dt: 5 (liblsc_hip.so) or 4 (liblsc_hip_m4.so)
     goal_row_cap: int = 0           # > 0: smaller OPEN-row capacity of the goal search (tests of the overflow path)
     planner_mode: str = "lsc"       # mode/planner: "lsc" or "bvc"
     slack_mode: str = "none"        # SlackMode: "none", "dynamical_limit", "collision_constraint"
@@ -62,8 +62,11 @@ class SwarmPlanner:
     """All agents' TrajPlanner + TrajOptimizer state behind one context of liblsc_hip.so."""
 
     def __init__(self, mission, config=None):
-        self.L = _lib.load_library()
         self.cfg = config or PlannerConfig()
+        # M = horizon / dt picks the library (the kernels are unrolled for their segment count): 5 -> liblsc_hip.so, 4 -> liblsc_hip_m4.so
+        self.M = _lib.segments_of(self.cfg.horizon, self.cfg.dt)
+        self.SEGV, self.NV = NC * self.M, 3 * NC * self.M
+        self.L = _lib.load_library(self.M if self.M in (4,) else 5)
         self.mission = mission
         c = LscConfig()
         self.L.lsc_default_config(ctypes.byref(c))
@@ -111,7 +114,7 @@ class SwarmPlanner:
         self.count = min(self.shard_rows, self.N - self.first)
         # TrajPlanner state (src/traj_planner.cpp:41-48)
         self.planner_seq = 0
-        self.traj_curr = np.zeros((self.N, 3, SEGV), np.float32)
+        self.traj_curr = np.zeros((self.N, 3, self.SEGV), np.float32)
         self.qp_cost = np.zeros(self.N)
         self.planning_report = np.zeros(self.N, np.int32)
         self.iters = np.zeros(self.N, np.int32)
@@ -155,15 +158,15 @@ class SwarmPlanner:
         N, cnt = self.N, self.count
         state = np.ascontiguousarray(state, np.float32).reshape(N, 9)
         goal = np.ascontiguousarray(current_goal, np.float32).reshape(N, 3)
-        prev = np.ascontiguousarray(obs_prev_trajs, np.float32).reshape(N, 3, SEGV)
+        prev = np.ascontiguousarray(obs_prev_trajs, np.float32).reshape(N, 3, self.SEGV)
         self.planner_seq += 1                                   # src/traj_planner.cpp:127
-        out = np.zeros((cnt, 3, SEGV), np.float32)
+        out = np.zeros((cnt, 3, self.SEGV), np.float32)
         cost = self.qp_cost[self.first:self.first + cnt].copy()
         status = np.zeros(cnt, np.int32)
         iters = np.zeros(cnt, np.int32)
-        nrm = np.zeros((cnt, max(N - 1, 1), M, 3), np.float32) if want_constraints else None
-        dd = np.zeros((cnt, max(N - 1, 1), M, NC), np.float64) if want_constraints else None
-        sfc = np.zeros((cnt, M, 6), np.float32) if self.cfg.use_octomap else None
+        nrm = np.zeros((cnt, max(N - 1, 1), self.M, 3), np.float32) if want_constraints else None
+        dd = np.zeros((cnt, max(N - 1, 1), self.M, NC), np.float64) if want_constraints else None
+        sfc = np.zeros((cnt, self.M, 6), np.float32) if self.cfg.use_octomap else None
         self._check(self.L.lsc_replan_tick(self.ctx, _fp(state), _fp(goal), _fp(prev), self.planner_seq, _fp(out), _dp(cost),
                                            _ip(status), _ip(iters), _fp(nrm) if want_constraints else None,
                                            _dp(dd) if want_constraints else None, _fp(sfc) if sfc is not None else None))
@@ -185,9 +188,9 @@ class SwarmPlanner:
         N = self.N
         state = np.ascontiguousarray(state, np.float32).reshape(N, 9)
         goal = np.ascontiguousarray(current_goal, np.float32).reshape(N, 3)
-        prev = np.ascontiguousarray(obs_prev_trajs, np.float32).reshape(N, 3, SEGV)
+        prev = np.ascontiguousarray(obs_prev_trajs, np.float32).reshape(N, 3, self.SEGV)
         self.planner_seq += 1
-        out = np.zeros((N, 3, SEGV), np.float32)
+        out = np.zeros((N, 3, self.SEGV), np.float32)
         cost = self.qp_cost.copy()
         status = np.zeros(N, np.int32)
         iters = np.zeros(N, np.int32)
@@ -337,11 +340,14 @@ class SwarmPlanner:
         return out
 
     def solver_trace(self, agent, read=False):
-        out = np.zeros(64 * 8 + 39 * 41 + 450 + 512)
+        ny = 3 * (3 * (self.M - 1) + 1)
+        kld = ny + 2 - (ny % 2 == 0)
+        wsz = 3 * self.NV + 6 * self.SEGV
+        out = np.zeros(64 * 8 + ny * kld + wsz + 512)
         self._check(self.L.lsc_solver_trace(self.ctx, agent, _dp(out) if read else None))
-        self.trace_K = out[512:512 + 39 * 41].reshape(39, 41)[:, :39]
-        self.trace_W = out[512 + 39 * 41:512 + 39 * 41 + 450]
-        self.trace_kconst = out[512 + 39 * 41 + 450:]
+        self.trace_K = out[512:512 + ny * kld].reshape(ny, kld)[:, :ny]
+        self.trace_W = out[512 + ny * kld:512 + ny * kld + wsz]
+        self.trace_kconst = out[512 + ny * kld + wsz:]
         return out[:512].reshape(64, 8)
 
     def iterations_total(self, reset=False):
@@ -404,7 +410,8 @@ def edt_from_bt(bt_path, world_min, world_max, maxdist=1.0):
 
 def next_state_host(traj, dt=0.2):
     """getStateFromControlPoints at t = dt in float32 (include/polynomial.hpp:63-97), numpy, all agents."""
-    t = np.asarray(traj, np.float32).reshape(-1, 3, SEGV)
+    t = np.asarray(traj, np.float32)
+    t = t if t.ndim == 3 else t.reshape(len(t), 3, -1)          # [N][3][M (n + 1)] for any M (or the same rows flattened)
     c1 = t[:, :, NC:NC + 3]
     fn, fn1, finv = np.float32(5), np.float32(4), np.float32(dt ** -1)
     v0 = ((c1[:, :, 1] - c1[:, :, 0]) * fn) * finv

@@ -18,6 +18,8 @@
  * Constants
  * ---------------------------------------------------------------------------------------- */
 
+int orc_segments(void) { return ORC_M; }
+
 static int binom(int n, int k)
 {
     if (k < 0 || k > n) return 0;

@@ -35,7 +35,12 @@
 extern "C" {
 #endif
 
+/* Segments M = (int)((horizon + 1e-9) / dt), src/traj_optimizer.cpp:9: a build parameter here as in the product.  liblsc_oracle.so
+ * is built for M = 5 (every shipped launch file), liblsc_oracle_m4.so from the same files with -DORC_M=4 (the C++ defaults of
+ * src/param.cpp:66-67: dt 0.5, horizon 2.0). */
+#ifndef ORC_M
 #define ORC_M 5
+#endif
 #define ORC_N 5
 #define ORC_PHI 3
 #define ORC_NC (ORC_N + 1)            /* control points per segment   */
@@ -66,6 +71,8 @@ typedef struct {
     double rhs;
     int    sense;
 } orc_row;
+
+int orc_segments(void);   /* ORC_M of this build */
 
 /* ---- constants (src/traj_optimizer.cpp:169-236, include/polynomial.hpp:415-428) ---- */
 void orc_bernstein_basis(double B[ORC_NC * ORC_NC]);

@@ -9,8 +9,23 @@ import subprocess
 
 import numpy as np
 
+import contextlib
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 M, NDEG, NC, SEGV, NV = 5, 5, 6, 30, 90
+
+
+@contextlib.contextmanager
+def segments(m):
+    """Everything inside the block uses the oracle built for M = m segments (liblsc_oracle.so: 5, liblsc_oracle_m4.so: 4) --
+    array shapes included.  Objects made inside (Swarm, QP) belong to that M."""
+    global M, SEGV, NV
+    old = M
+    M, SEGV, NV = m, NC * m, 3 * NC * m
+    try:
+        yield
+    finally:
+        M, SEGV, NV = old, NC * old, 3 * NC * old
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _fp = ctypes.POINTER(ctypes.c_float)
@@ -71,24 +86,26 @@ class OrcEdt(ctypes.Structure):
     ]
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "liblsc_oracle.so")
+def build(force=False, m=5):
+    name = "liblsc_oracle.so" if m == 5 else f"liblsc_oracle_m{m}.so"
+    so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in ("lsc_oracle.c", "lsc_oracle_sfc.c", "lsc_oracle_modes.c", "lsc_oracle_goal.cpp", "lsc_oracle.h")]
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "liblsc_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, name], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference") and (force or not os.path.exists(os.path.join(_HERE, "_ref", "libref_opengjk.so"))):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
 
-_lib = None
+_libs = {}
 
 
 def lib():
-    global _lib
-    if _lib is None:
-        L = ctypes.CDLL(build())
+    if M not in _libs:
+        L = ctypes.CDLL(build(m=M))
+        L.orc_segments.restype = ctypes.c_int
+        assert L.orc_segments() == M
         L.orc_gjk_origin.restype = ctypes.c_double
         L.orc_gjk_origin.argtypes = [_dp, ctypes.c_int, _dp, _ip, _ip]
         L.orc_qbase.argtypes = [ctypes.c_double, _dp]
@@ -148,8 +165,8 @@ def lib():
         L.orc_tick_ex.restype = ctypes.c_int
         L.orc_tick_ex.argtypes = [pp, pm, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _fp, _ubp,
                                   ctypes.POINTER(OrcEdt), ctypes.c_double, _fp, _ip, _fp, _dp, _ip, _ip, _fp, _dp, ctypes.c_int]
-        _lib = L
-    return _lib
+        _libs[M] = L
+    return _libs[M]
 
 
 def _f(a):
@@ -193,7 +210,7 @@ def qbase(dt=0.2):
 
 
 def aeq_base(dt=0.2):
-    a = np.zeros((15, SEGV))
+    a = np.zeros((3 * M, SEGV))
     lib().orc_aeq_base(dt, _d(a))
     return a
 

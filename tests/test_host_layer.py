@@ -236,6 +236,15 @@ def test_ctypes_config_struct_matches_the_header(tmp_path):
         assert int(out[n]) == getattr(LscConfig, n).offset, n
 
 
+def test_the_four_segment_library_exports_the_same_abi():
+    """liblsc_hip_m4.so (same sources, -DLSC_SEGMENTS=4: dt 0.5 / horizon 2.0 of src/param.cpp:66-67) loads and says so."""
+    from lsc_planner_amd import _lib
+    L4 = _lib.load_library(4)
+    assert L4.lsc_segments() == 4 and _lib.load_library(5).lsc_segments() == 5
+    for name in _lib.EXPORTS:
+        assert hasattr(L4, name), name
+
+
 def test_result_csv_reader_reads_the_reference_s_layout(tmp_path):
     """MultiSyncReplayer::readCSVFile (src/multi_sync_replayer.cpp:53-114): 15 columns per agent, 6 per obstacle, counts from the
     header's "id" / "obs_id" cells, radius from the `size` column, make span = time of the last record.  `lsc_sim --replay` needs

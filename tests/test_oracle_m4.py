@@ -1,0 +1,63 @@
+"""M = horizon / dt other than 5: the reference computes the segment count at run time (src/traj_optimizer.cpp:9,
+src/traj_planner.cpp:22) and its C++ defaults are dt 0.5 / horizon 2.0, i.e. M = 4 (src/param.cpp:66-67).  The oracle built with
+-DORC_M=4 (oracle/liblsc_oracle_m4.so): structure of the QP, optimum against HiGHS."""
+import numpy as np
+import pytest
+
+import highs_qp as H
+
+DT, HORIZON = 0.5, 2.0
+
+
+def _fly(O, n=8, ticks=8):
+    import lsc_planner_amd as L
+    ms = L.circle_swap(n, circle_radius=2.5, z=1.0, world=(-6, -6, 0, 6, 6, 2.5))
+    prm = O.make_params(dt=DT, world_min=ms.world_min, world_max=ms.world_max, obs_f32=True)
+    sw = O.Swarm(prm, ms.radius, ms.downwash, ms.max_vel, ms.max_acc, ms.nominal_velocity)
+    state = np.zeros((n, 9), np.float32)
+    state[:, :3] = ms.start
+    traj = np.zeros((n, 3, O.SEGV), np.float32)
+    hist = []
+    for tick in range(1, ticks + 1):
+        goals = O.goal_prior_based(state, ms.goal, traj, tick, dt=DT)
+        o = sw.tick(state, goals, traj, tick, want_lsc=True)
+        hist.append((state.copy(), goals.copy(), traj.copy(), o))
+        traj = o["traj"]
+        state = np.array([O.next_state(traj[q], DT) for q in range(n)], np.float32)
+    return ms, prm, hist
+
+
+def test_four_segment_qp_structure_and_optimum(oracle):
+    O = oracle
+    with O.segments(4):
+        assert O.lib().orc_segments() == 4 and (O.SEGV, O.NV) == (24, 72)
+        A = O.aeq_base(DT)
+        assert A.shape == (12, 24) and np.linalg.matrix_rank(A) == 12          # phi + (M - 1) phi equalities per axis (:186-236)
+        assert np.allclose(A[1, :2], [-10, 10]) and np.allclose(A[2, :3], [80, -160, 80])      # n / dt, n (n - 1) / dt^2
+        ms, prm, hist = _fly(O)
+        n = ms.qn
+        moved = np.linalg.norm(hist[-1][0][:, :3] - ms.start, axis=1)
+        assert (moved > 1.0).all()                                              # 3.5 s of flight at up to 1 m/s
+        state, goals, prev, o = hist[-1]
+        assert (o["status"] == 0).all()
+        for a in range(n):
+            others = [j for j in range(n) if j != a]
+            obs = np.array([O.shift_traj(prev[j]) for j in others])
+            qp = O.qp_assemble(prm, state[a], goals[a], ms.nominal_velocity[a], ms.max_vel[a], ms.max_acc[a], obs, o["normal"][a], o["d"][a])
+            assert qp.nv == 72
+            # 12 equalities, 18 + 15 velocity / acceleration differences x 2 signs, 2 stop rows per axis; 21 rows per obstacle
+            assert qp.nrows == 3 * 12 + 21 * (n - 1) + 3 * 2 * (18 + 15) + 3 * 2
+            st, x, cost, it, kkt = qp.solve()
+            assert st == 0 and abs(cost - o["cost"][a]) <= 1e-12 * abs(cost) + 1e-14
+            assert np.abs(x.astype(np.float32).reshape(3, 24) - o["traj"][a]).max() == 0
+            hs, hx, hcost, viol = H.solve_oracle_qp(qp)
+            assert hs == "Optimal" and abs(hcost - cost) <= 1e-7 * abs(cost) + 1e-9, (a, hs, hcost, cost)
+    assert (O.M, O.SEGV, O.NV) == (5, 30, 90) and O.lib().orc_segments() == 5     # the default oracle is untouched
+
+
+def test_terminal_segments_follow_the_horizon(oracle):
+    """getTerminalSegments (src/traj_optimizer.cpp:541-548): T = max((int)((M dt - |goal - pos| / v_nom + 1e-9) / dt), 1)."""
+    O = oracle
+    with O.segments(4):
+        f = lambda d: O.lib().orc_terminal_segments(O._f(np.array([d, 0, 0], np.float32)), O._f(np.zeros(3, np.float32)), 1.0, DT)
+        assert [f(d) for d in (0.0, 0.4, 0.6, 1.1, 1.6, 5.0)] == [4, 3, 2, 1, 1, 1]
