@@ -148,6 +148,13 @@ __device__ __forceinline__ double ax_x(const double *x, int type, int k, int t)
 // rows and columns P..PU-1 are the identity (written once at set-up).  K is stored as a full symmetric matrix.
 extern __shared__ __align__(16) unsigned char gsm_general[];
 __device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uni_u64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <typename T>
+__device__ __forceinline__ T *uni_p(T *p) { return (T *)uni_u64((unsigned long long)p); }
 template <int PU>
 __device__ __attribute__((noinline)) void dense_factor_w0()
 {
@@ -244,20 +251,34 @@ __host__ __device__ inline size_t ws_lds_bytes(int N)
 #else
 #define LSC_LDS_PTR(T) T *
 #endif
+// (inlined into the kernel: as a function of its own it saved the ~110 callee-saved vector registers of the calling convention at
+// entry -- a third of the scratch writes; with the spills gone there is no frame left whose set-up the early exit would have to dodge)
 template <bool LDSP>
-__device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, unsigned char *smem_raw, unsigned char *wsb,
-                                                         unsigned char *lds_ws, size_t lds_ws_bytes)
+static __device__ __forceinline__ bool general_agent(KArgs &a_in, const int al_in, unsigned char *smem_raw_in, unsigned char *wsb_in,
+                                                         unsigned char *lds_ws_in, size_t lds_ws_bytes_in)
 {
+    // The arguments of an out-of-line device function arrive in VECTOR registers, and everything derived from them -- every row-array
+    // pointer, every offset -- stays there: ~230 loop-invariant values were spilled once per agent (the 40 MB of scratch writes per
+    // launch in round 3's PMC pass) and reloaded ~600 times per iteration.  They are uniform by construction: back to scalars.
+    KArgs &a = *(KArgs *)uni_u64((unsigned long long)&a_in);
+    const int al = uni_i(al_in);
+    unsigned char *smem_raw = uni_p(smem_raw_in), *wsb = uni_p(wsb_in), *lds_ws = uni_p(lds_ws_in);
+    size_t lds_ws_bytes = (size_t)uni_u64((unsigned long long)lds_ws_bytes_in);
     using FP = typename std::conditional<LDSP, LSC_LDS_PTR(float), float *>::type;
     using BP = typename std::conditional<LDSP, LSC_LDS_PTR(unsigned char), unsigned char *>::type;
     using DP = typename std::conditional<LDSP, LSC_LDS_PTR(double), double *>::type;
     GS &S = *reinterpret_cast<GS *>(smem_raw);
     const GModel &gm = *a.gmodel;
     const Model &md = *a.model;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // `tid` is re-read through an opaque copy at the start of every phase (fresh()): the compiler otherwise hoists the per-lane address
+    // arithmetic of ALL phases to the top of the function -- ~120 values per lane that do not fit the register file and went to
+    // scratch once per agent, to be reloaded ~600 times per iteration (the rest of round 3's 40 MB of scratch writes per launch).
+    int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    auto fresh = [&]() { int t = threadIdx.x; asm volatile("" : "+v"(t)); tid = t; };
     const int qi = a.first + al;
     const int N = a.N, n_all = N - 1, nob_all = n_all > 0 ? n_all : 1;
-    const int nya = gm.nya, P0 = 3 * nya;
+    const int nya = uni_i(gm.nya), P0 = 3 * nya;
     const int nu = a.slack_mode == 1 ? 2 * M : 0;
     const int P = P0 + nu;
     const int ncs = a.ncs < 0 ? M : (a.ncs > M ? M : a.ncs);
@@ -367,6 +388,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
         S.avalid[sl] = valid ? 1 : 0;
         S.ah[sl] = h;
     }
+    fresh();
     // ---- collision rows of every obstacle: LSC via GJK, or the BVC half-space.  Rows that cannot be active inside the
     // reachable box of their control point are redundant (the test of lsc_plan_kernel's phase B; it rests on the velocity and
     // acceleration rows being hard, so not with DYNAMICALLIMIT's slack on them; a slack variable on the row only relaxes it
@@ -454,6 +476,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     }
     __threadfence_block();
     __syncthreads();
+    fresh();
     // kept obstacles, in order: ballot ranks per wave, wave offsets through LDS
     {
         int base = 0;
@@ -480,7 +503,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     }
     __threadfence_block();
     __syncthreads();
-    const int n_obs = S.nk, nob = n_obs > 0 ? n_obs : 1;
+    const int n_obs = uni_i(S.nk), nob = n_obs > 0 ? n_obs : 1;
     // ---- workspace carve-up: per-row state of the interior point, collision rows of the kept obstacles
     const int NCL = NBK * nob, NGR = M * nob;
     const int US0 = AXROWS, CL0 = AXROWS + 2 * M, GS0 = CL0 + NCL, RT = GS0 + NGR;
@@ -510,6 +533,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     DP rs = (DP)take(sizeof(double) * RT);
     if (LDSP && !fits) return false;                                                     // (uniform: sizes only)
 
+    fresh();
     for (int oe = tid; oe < n_obs; oe += GT) {
         const int oi = omap[oe];
         slk[oe] = in_set_of(oi < qi ? oi : oi + 1) ? 1 : 0;
@@ -545,8 +569,9 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     for (int g = tid; g < NGR; g += GT) { ev[g] = 0.0; dev[g] = 0.0; Dg[g] = 1.0; iDg[g] = 0.0; qg[g] = 0.0; if (g >= n_obs * M) gact[g] = 0; }   // (groups without an active row stay like this)
     __syncthreads();
 
-    const int tseg = S.tseg;
+    const int tseg = uni_i(S.tseg);
     auto compute_x = [&](const double *yv, double *xv, bool with_const) {
+        fresh();
         const int xk = tid < NV ? tid / SEGV : 0, xt = tid < NV ? tid % SEGV : 0;
         if (tid < NV) {
             double v = (xt < 3 && with_const) ? S.s0[xk][xt] : 0.0;
@@ -600,6 +625,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     // x-space sums of a per-row coefficient (rt2 = vv, rz = z) and, with_w, of the weights rt1 = w: the only place where
     // the rows meet the unknowns.  Fixed summation orders: results do not depend on scheduling.
     auto reduce_rows = [&](bool with_w, bool unit_w) {
+        fresh();
         const int xk = tid < NV ? tid / SEGV : 0, xt = tid < NV ? tid % SEGV : 0;
         if (tid < NV) {
             const int k = xk, t = xt, i = t % NC, b = tid;
@@ -754,6 +780,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     };
     // dense reduced system: K (lower triangle) and rhs = q_y - sum_g m_g q_g / D_g ; stationarity residual in dy
     auto assemble = [&](bool with_k) {
+        fresh();
         if (with_k && tid >= P && tid < PMAX) S.K[tid * KL + tid] = 1.0;     // identity beyond P (the factor left its L there: zero)
         if (with_k)
             for (int e = tid; e < P * (P + 1) / 2; e += GT) {       // lower triangle, row-major: e = r (r + 1) / 2 + c
@@ -824,6 +851,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
         return S.ok != 0;
     };
     auto solve = [&]() {
+        fresh();
         if (wave == 0) {
             long long t0 = 0;
             if (gp) t0 = (long long)__builtin_readcyclecounter();
@@ -853,6 +881,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     };
     // generic sweep over all valid rows: f(row index r, value a_r.v at (xv, uv, gv), value at the step, rhs h)
     auto for_rows = [&](auto &&f) {
+        fresh();
         for (int sl = tid; sl < AXROWS; sl += GT)
             if (S.avalid[sl]) f(sl, val_axis(sl, S.x, S.y + P0), val_axis(sl, S.dx, S.dy + P0), S.ah[sl]);
         if (tid < nu) f(US0 + tid, S.y[P0 + tid], S.dy[P0 + tid], 0.0);
@@ -862,6 +891,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
             if (g / M < n_obs && grp_valid(g)) f(GS0 + g, ev[g], dev[g], 0.0);
     };
     auto objective = [&]() -> double {
+        fresh();
         const int xk = tid < NV ? tid / SEGV : 0, xt = tid < NV ? tid % SEGV : 0;
         double o = 0.0;
         if (tid < NV && !(dim2 && xk == 2)) {
@@ -885,6 +915,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     else if (a.sfc_err && a.sfc_err[qi] != 0) { status = LSC_STATUS_SFC_K; can = false; }
     const bool try_warm = md.ws_mu0 > 0.0 && a.planner_seq >= 2;
     for (int attempt = try_warm ? 0 : 1; can && attempt < 2; attempt++) {
+        fresh();
         bool run = true;
         iters = 0;
         if (attempt == 0) {
@@ -1054,6 +1085,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
     iters += spent;
 
     // ------------------------------------------------------------------ output (same conventions as lsc_plan_kernel)
+    fresh();
     float *out = a.traj_next + (size_t)qi * NV;
     float *stale = a.stale + (size_t)qi * NV;
     __syncthreads();
@@ -1091,7 +1123,7 @@ __device__ __attribute__((noinline)) bool general_agent(KArgs &a, const int al, 
 
 // The agents of one workgroup, out of line.  (Round 2 copied the argument block into private memory here: 2.2 KB of scratch per
 // lane, 50 MB of writes per launch in the PMC counters.)
-__device__ __attribute__((noinline)) void general_entry(KArgs *ka, unsigned char *smem_raw)
+static __device__ __forceinline__ void general_entry(KArgs *ka, unsigned char *smem_raw)
 {
     KArgs &a = *ka;
 #ifdef LSC_POISON_LDS
