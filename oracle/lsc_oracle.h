@@ -169,6 +169,9 @@ typedef struct {
 int  orc_bt_read(const char *path, double *res, int **leaves /*[n][4] min key + cube edge*/, int *n);
 int  orc_edt_build(const int *leaves, int n, double res, const float world_min[3], const float world_max[3],
                    double maxdist, orc_edt *edt);
+/* the same field by dynamicEDT3D's published propagation (26-neighbour "lower" wavefront): see lsc_oracle_sfc.c */
+int  orc_edt_brushfire(const int *leaves, int n, double res, const float world_min[3], const float world_max[3],
+                       double maxdist, orc_edt *edt, int *sq_out);
 int  orc_expand_box(const orc_params *prm, const orc_edt *edt, double world_res,
                     const float point[3], const float goal[3], double radius, double box[6]);
 int  orc_update_sfc(const orc_params *prm, const orc_edt *edt, double world_res, const float pos[3], const float goal[3],

@@ -138,6 +138,79 @@ int orc_edt_build(const int *leaves, int n, double res, const float world_min[3]
     return 0;
 }
 
+/* The same field by the propagation dynamicEDT3D itself runs (Lau, Sprunk, Burgard, "Efficient grid-based spatial representations
+ * for robot navigation in dynamic environments", RAS 2013, algorithm "lower"; dynamicEDT3D is an apt package absent from this image,
+ * so this is a restatement of the PUBLISHED algorithm, not of its source): every occupied cell enters a queue ordered by squared
+ * distance with itself as closest obstacle; a popped cell offers its closest obstacle to its 26 neighbours, a neighbour takes it when
+ * the squared distance to THAT obstacle is smaller than what it holds (and within the truncation radius) and is queued in turn.
+ * This is a vector propagation, not an exact Euclidean transform: a cell whose true nearest obstacle is not the nearest obstacle of any
+ * of its 26 neighbours keeps a slightly larger value.  tests/test_map_assumptions.py runs it next to orc_edt_build on the reference's
+ * three maps to see whether -- and from which distance on -- the two differ.  sq_out (optional): the squared distances in cells. */
+int orc_edt_brushfire(const int *leaves, int n, double res, const float world_min[3], const float world_max[3],
+                      double maxdist, orc_edt *edt, int *sq_out)
+{
+    int kmin[3], dims[3];
+    for (int a = 0; a < 3; a++) {
+        kmin[a] = coord_to_key((double)world_min[a], res);
+        dims[a] = coord_to_key((double)world_max[a], res) - kmin[a] + 1;
+        if (dims[a] < 1) return -1;
+    }
+    const int nx = dims[0], ny = dims[1], nz = dims[2];
+    const size_t C = (size_t)nx * ny * nz;
+    const int md = (int)(maxdist / res + 1), md2 = md * md;
+    int *sq = (int *)malloc(sizeof(int) * C);
+    int *ob = (int *)malloc(sizeof(int) * C);              /* closest obstacle: its cell index, -1 none */
+    for (size_t i = 0; i < C; i++) { sq[i] = md2; ob[i] = -1; }
+    /* bucket queue by squared distance: bucket d holds cell indices, appended as they are (re)inserted */
+    int **bk = (int **)calloc((size_t)md2 + 1, sizeof(int *));
+    int *bn = (int *)calloc((size_t)md2 + 1, sizeof(int)), *bc = (int *)calloc((size_t)md2 + 1, sizeof(int));
+#define ORC_PUSH(d, idx) do { if (bn[d] == bc[d]) { bc[d] = bc[d] ? 2 * bc[d] : 256; bk[d] = (int *)realloc(bk[d], sizeof(int) * (size_t)bc[d]); } bk[d][bn[d]++] = (idx); } while (0)
+    for (int l = 0; l < n; l++) {
+        const int *k = leaves + 4 * l;
+        for (int dx = 0; dx < k[3]; dx++)
+            for (int dy = 0; dy < k[3]; dy++)
+                for (int dz = 0; dz < k[3]; dz++) {
+                    int x = k[0] + dx - kmin[0], y = k[1] + dy - kmin[1], z = k[2] + dz - kmin[2];
+                    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
+                    const int idx = (x * ny + y) * nz + z;
+                    if (sq[idx] == 0) continue;
+                    sq[idx] = 0; ob[idx] = idx;
+                    ORC_PUSH(0, idx);
+                }
+    }
+    for (int d = 0; d < md2; d++)
+        for (int q = 0; q < bn[d]; q++) {                   /* (a bucket may grow while it is walked: entries of the same distance) */
+            const int s = bk[d][q];
+            if (sq[s] != d) continue;                       /* superseded by a smaller distance since it was queued */
+            const int sx = s / (ny * nz), sy = (s / nz) % ny, sz = s % nz;
+            const int o = ob[s], ox = o / (ny * nz), oy = (o / nz) % ny, oz = o % nz;
+            for (int ax = -1; ax <= 1; ax++)
+                for (int ay = -1; ay <= 1; ay++)
+                    for (int az = -1; az <= 1; az++) {
+                        if (!ax && !ay && !az) continue;
+                        const int x = sx + ax, y = sy + ay, z = sz + az;
+                        if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
+                        const int nd = (x - ox) * (x - ox) + (y - oy) * (y - oy) + (z - oz) * (z - oz);
+                        const int ni = (x * ny + y) * nz + z;
+                        if (nd < sq[ni] && nd < md2) { sq[ni] = nd; ob[ni] = o; ORC_PUSH(nd, ni); }
+                    }
+        }
+#undef ORC_PUSH
+    float *dist = (float *)malloc(sizeof(float) * C);
+    for (size_t i = 0; i < C; i++) {
+        float cells = (float)sqrt((double)sq[i]);
+        dist[i] = (float)((double)cells * res);
+    }
+    if (sq_out) memcpy(sq_out, sq, sizeof(int) * C);
+    for (int d = 0; d <= md2; d++) free(bk[d]);
+    free(bk); free(bn); free(bc); free(sq); free(ob);
+    edt->dist = dist;
+    edt->nx = nx; edt->ny = ny; edt->nz = nz;
+    edt->key_min[0] = kmin[0]; edt->key_min[1] = kmin[1]; edt->key_min[2] = kmin[2];
+    edt->res = res;
+    return 0;
+}
+
 /* DynamicEDTOctomap::getDistance(point3d): -1 outside the grid */
 static float edt_lookup(const orc_edt *e, const float p[3])
 {

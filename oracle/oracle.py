@@ -132,6 +132,8 @@ def lib():
         L.orc_bt_read.argtypes = [ctypes.c_char_p, _dp, ctypes.POINTER(_ip), _ip]
         L.orc_edt_build.restype = ctypes.c_int
         L.orc_edt_build.argtypes = [_ip, ctypes.c_int, ctypes.c_double, _fp, _fp, ctypes.c_double, ctypes.POINTER(OrcEdt)]
+        L.orc_edt_brushfire.restype = ctypes.c_int
+        L.orc_edt_brushfire.argtypes = [_ip, ctypes.c_int, ctypes.c_double, _fp, _fp, ctypes.c_double, ctypes.POINTER(OrcEdt), _ip]
         L.orc_goal_prior_based.restype = None
         L.orc_goal_prior_based.argtypes = [ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                            ctypes.c_double, ctypes.c_double, _fp]
@@ -552,6 +554,24 @@ class DistMap:
         e.dist = _f(self.dist)
         self.key_min = np.array([e.key_min[0], e.key_min[1], e.key_min[2]], np.int32)
         self.res = res
+
+    @classmethod
+    def brushfire(cls, leaves, res, world_min, world_max, maxdist=1.0):
+        """The field by dynamicEDT3D's published 26-neighbour propagation instead of the exact transform (map assumption tests)."""
+        self = cls.__new__(cls)
+        self.edt = OrcEdt()
+        wmin = np.ascontiguousarray(world_min, np.float32)
+        wmax = np.ascontiguousarray(world_max, np.float32)
+        leaves = np.ascontiguousarray(leaves, np.int32)
+        if lib().orc_edt_brushfire(_i(leaves), len(leaves), res, _f(wmin), _f(wmax), maxdist, ctypes.byref(self.edt), None):
+            raise ValueError("orc_edt_brushfire failed")
+        e = self.edt
+        self.dist = np.ctypeslib.as_array(e.dist, shape=(e.nx, e.ny, e.nz)).copy()
+        ctypes.CDLL(None).free(e.dist)
+        e.dist = _f(self.dist)
+        self.key_min = np.array([e.key_min[0], e.key_min[1], e.key_min[2]], np.int32)
+        self.res = res
+        return self
 
     @classmethod
     def from_array(cls, dist, key_min, res):

@@ -92,3 +92,19 @@ def test_simple_forest_is_the_map_survey_describes():
     assert res == 0.1 and len(centres) == 4384
     lo, hi = centres.min(0) - res / 2, centres.max(0) + res / 2
     assert np.allclose(lo, [-2.9, -2.5, 0.0], atol=1e-9) and np.allclose(hi, [2.6, 3.2, 2.5], atol=1e-9)
+
+
+def test_reference_maps_exact_transform_equals_the_published_propagation():
+    """On every map the reference ships (world/*.bt and world/forest/*.bt) the exact lattice transform of the oracle / product and
+    dynamicEDT3D's published 26-neighbour propagation (orc_edt_brushfire) give the same field, cell for cell, within the 1 m
+    truncation -- so every threshold the path reads (corridor 0.2 m, grid 0.35 m, castRay up to 1 m) sees the same numbers."""
+    import glob
+    from oracle import oracle as O
+    maps = sorted(glob.glob(os.path.join(REF, "world", "*.bt")) + glob.glob(os.path.join(REF, "world", "forest", "*.bt")))
+    assert len(maps) >= 3
+    for path in maps:
+        res, leaves = O.bt_read(path)
+        world = (-6, -6, 0, 6, 6, 2.5) if "forest" in path else (-10, -10, 0, 10, 10, 2.5)
+        a = O.DistMap(leaves, res, world[:3], world[3:])
+        b = O.DistMap.brushfire(leaves, res, world[:3], world[3:])
+        assert np.array_equal(a.dist, b.dist), (path, int((a.dist != b.dist).sum()))
