@@ -100,7 +100,7 @@ def test_reference_maps_exact_transform_equals_the_published_propagation():
     truncation -- so every threshold the path reads (corridor 0.2 m, grid 0.35 m, castRay up to 1 m) sees the same numbers."""
     import glob
     from oracle import oracle as O
-    maps = sorted(glob.glob(os.path.join(REF, "world", "*.bt")) + glob.glob(os.path.join(REF, "world", "forest", "*.bt")))
+    maps = sorted(glob.glob(os.path.join(REF, "*.bt")) + glob.glob(os.path.join(REF, "forest", "*.bt")))
     assert len(maps) >= 3
     for path in maps:
         res, leaves = O.bt_read(path)
