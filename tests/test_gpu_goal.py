@@ -61,7 +61,7 @@ def test_forest_goal_planning_bitwise_over_a_mission(L, oracle):
 def test_planar_world_goal_planning(L, oracle):
     """world/dimension = 2 (src/grid_based_planner.cpp:82-85, 127-133, 199-215; src/mission.cpp:88-112): the planning grid is
     the single layer z = world/z_2d, starts, goals and the stamped higher-priority agents sit in it whatever their height is,
-    and the search has no vertical moves.  Paths, flags and goals against the oracle, bit for bit; the QP stays 3-D."""
+    and the search has no vertical moves.  Paths, flags and goals against the oracle, bit for bit.  (The QP of a planar world has 60 variables: tests/test_gpu_round4.py.)"""
     from maputil import forest_leaves
     from lsc_planner_amd.planner import next_state_host
     leaves, res = forest_leaves()
