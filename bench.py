@@ -8,6 +8,10 @@ A "step" is one synchronous replan tick of the whole swarm: prediction shift -> 
 every agent (the reference's MultiSyncSimulator::plan loop), followed by the ideal-state propagation that feeds the
 next tick.  Everything stays resident in HBM during the timed region (no host round trip inside a tick).
 
+The timed window (config.tick_window): the mission is fast-forwarded untimed to --start-tick (default 60) so that any --steps
+starts inside the crossing of the swarm (ticks ~40-140 of ~216), where the ticks are longest; config.mission_ticks is the tick at
+which the last agent arrives (found by flying on, untimed, after the measurement).
+
 Workload (config.workload): BASELINE.json configs[2], the 64-agent circle swap on the empty map
 (matlab/mission_generator.m geometry, R = 8 m, z = 1 m, testall_empty.launch parameters incl. mode/goal =
 prior_based: goalPlanningWithPriority runs on the device; on maps without a distance field the reference's grid A*
@@ -421,6 +425,32 @@ def main():
                               "exchange_us_per_tick": {"mean": round(1e3 * float(x_all.mean()), 2) if len(x_all) else None,
                                                        "p99": round(1e3 * float(np.percentile(x_all, 99)), 2) if len(x_all) else None},
                               "note": "HIP events around the all-gather on rank 0 (includes waiting for the slowest rank's plan kernel)"}
+
+    # ---- the goal planner's grid search in the octomap workload: what bounds it, measured over a few more (untimed) ticks.  A launch
+    # lasts as long as its longest search (one wave per agent), so shader cycles per expanded node = launch time x clock / the
+    # largest expansion count of the tick.
+    if rank == 0 and bt_path is not None and goal_mode == "prior_based":
+        pl.set_timing(True)
+        exp_max, exp_sum = [], []
+        for _ in range(10):
+            tick(prev, nxt)
+            prev, nxt = nxt, prev
+            torch.cuda.synchronize()
+            e = pl.goal_trace()["expansions"]
+            exp_max.append(int(e.max())); exp_sum.append(int(e.sum()))
+        gk = pl.kernel_times_ms(3)
+        pl.set_timing(False)
+        if len(gk) == len(exp_max) and len(gk):
+            clock_mhz = 2400.0
+            cyc = [1e3 * t * clock_mhz / max(m, 1) for t, m in zip(gk, exp_max)]
+            result["roofline_goal"] = {
+                "kernel": "lsc_goal_kernel", "bound": "latency (instruction issue of one wave per search; neither HBM nor MFMA: the search state is in LDS and registers)",
+                "avg_launch_ms": round(float(np.mean(gk)), 4), "share_of_tick": round(float(np.mean(g_all) / (1e3 * elapsed / args.steps)), 3) if len(g_all) else None,
+                "longest_search_nodes_mean": round(float(np.mean(exp_max)), 1), "nodes_per_tick_all_agents_mean": round(float(np.mean(exp_sum)), 1),
+                "achieved": round(float(np.mean(exp_max) / (np.mean(gk) * 1e-3)), 1), "unit": "expanded nodes/s of the longest search", "peak": None, "frac": None,
+                "shader_cycles_per_node": round(float(np.mean(cyc)), 1),
+                "note": "one wave per agent alone on its SIMD issues one instruction per 5.7-8.5 cycles (profiles/r03_microbench.log): the cost of a node is its "
+                        "instruction count; ticks measured after the timed region, " + str(len(gk)) + " launches"}
 
     # ---- dense LSC sweep kernel (the HBM-class stage of SURVEY 8(d)): N(N-1)*180 B written per launch
     nobs = n_agents - 1

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Turn rocprofv3's rocpd sqlite output into the small text summaries kept under profiles/.
 
-    python profiles/summarize_rocpd.py stats  <results.db>            -> CSV on stdout (per-kernel calls/total/avg)
+    python profiles/summarize_rocpd.py stats  <results.db> [kernel first count]   -> CSV on stdout (per-kernel calls/total/avg;
+                                                   with a window: also the average over dispatches first .. first+count-1 of that
+                                                   kernel, in launch order -- the launches bench.py times after its fast-forward)
     python profiles/summarize_rocpd.py pmc    <results.db> [...]      -> JSON on stdout (per kernel x grid: mean counter values)
 
 rocprofv3 in this image writes a database (views `top_kernels`, `kernels`, `counters_collection`) rather than the CSV
@@ -12,7 +14,7 @@ import sqlite3
 import sys
 
 
-def stats(path):
+def stats(path, window=None):
     con = sqlite3.connect(path)
     print("name,calls,total_us,average_us,min_us,max_us,percent")
     rows = con.execute(
@@ -21,6 +23,13 @@ def stats(path):
     tot = sum(r[2] for r in rows) or 1
     for name, calls, total, avg, mn, mx in rows:
         print(f"\"{name}\",{calls},{total / 1e3:.3f},{avg / 1e3:.3f},{mn / 1e3:.3f},{mx / 1e3:.3f},{100.0 * total / tot:.2f}")
+    if window:
+        name, first, count = window[0], int(window[1]), int(window[2])
+        d = [r[0] for r in con.execute("select duration from kernels where name like ? order by start", (f"%{name}%",))]
+        w = d[first:first + count]
+        if w:
+            print(f"# window: kernel *{name}*, dispatches {first}..{first + len(w) - 1} of {len(d)} in launch order (0-based): "
+                  f"average_us {sum(w) / len(w) / 1e3:.3f}, min_us {min(w) / 1e3:.3f}, max_us {max(w) / 1e3:.3f}")
     # per-grid breakdown (the dense sweep runs at two swarm sizes in the default bench)
     print("# per (kernel, grid) breakdown: name,grid,workgroup,calls,average_us,lds_bytes,scratch_bytes,vgpr,sgpr")
     try:
@@ -51,6 +60,6 @@ if __name__ == "__main__":
     if len(sys.argv) < 3 or sys.argv[1] not in ("stats", "pmc"):
         sys.exit(__doc__)
     if sys.argv[1] == "stats":
-        stats(sys.argv[2])
+        stats(sys.argv[2], sys.argv[3:6] if len(sys.argv) >= 6 else None)
     else:
         pmc(sys.argv[2:])

@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
-BENCH="python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-latency-leg"
+BENCH="python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-latency-leg"      # default --start-tick 60: timed launches = dispatches 59 .. 158 of the plan kernel
 FOREST="python $ROOT/tools/config_runs.py --only forest256p,forest256,forest256x4p,forest256x4 --ticks 30 --warmup 5"
 LARGE="python $ROOT/tools/config_runs.py --only random1024 --ticks 30 --warmup 5"
 GENERAL="python $ROOT/tools/general_profile.py --modes bvc,collision_constraint,gust"      # lsc_general_kernel under load
@@ -29,7 +29,8 @@ done
 cd $ROOT
 for d in stats_bench stats_forest stats_large stats_general; do
   db=$(find $OUT/$d -name "*.db" | head -1)
-  [ -n "$db" ] && python profiles/summarize_rocpd.py stats $db > $OUT/$d.csv
+  if [ "$d" = stats_bench ]; then win="lsc_plan_alt_kernel 59 100"; else win=""; fi
+  [ -n "$db" ] && python profiles/summarize_rocpd.py stats $db $win > $OUT/$d.csv
 done
 python profiles/summarize_rocpd.py pmc $(find $OUT/pmc_bench_* -name "*.db") > $OUT/pmc_bench.json
 python profiles/summarize_rocpd.py pmc $(find $OUT/pmc_forest_* -name "*.db") > $OUT/pmc_forest.json

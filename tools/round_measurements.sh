@@ -7,6 +7,8 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 B="python bench.py"
 timeout 900 $B > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 300 $B --steps 20 --warmup 5 --no-latency-leg --sweep-agents 0 > $OUT/bench_driver_style_20steps.json 2>> $OUT/bench_default.err      # what the driver runs
+timeout 300 $B --start-tick 21 --steps 190 --no-cpu-baseline --no-latency-leg --sweep-agents 0 > $OUT/bench_whole_mission_window.json 2>> $OUT/bench_default.err
 timeout 300 $B --reset-threshold 0 --no-cpu-baseline --no-latency-leg --sweep-agents 0 > $OUT/bench_no_checks.json 2>> $OUT/bench_default.err
 timeout 300 $B --unfused --no-cpu-baseline --no-latency-leg --sweep-agents 0 > $OUT/bench_unfused.json 2>> $OUT/bench_default.err
 for mode in "--planner bvc" "--planner bvc --slack collision_constraint" "--planner bvc --slack dynamical_limit"; do
