@@ -379,7 +379,9 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "tick_solve_ms": {"p50": round(float(np.percentile(k_all, 50)), 4), "p99": round(float(np.percentile(k_all, 99)), 4),
                               "max": round(float(k_all.max()), 4),
-                              "note": "device time of the per-tick launch (HIP events, rank 0) over the timed steps"},
+                              "mean_by_20_ticks": [round(float(k_all[i:i + 20].mean()), 4) for i in range(0, len(k_all), 20)],
+                              "note": "device time of the per-tick launch (HIP events, rank 0) over the timed steps; mean_by_20_ticks: "
+                                      "consecutive blocks of the timed window (how much the answer depends on where 20 steps land)"},
             "config": {"tick_window": [start_tick, start_tick + args.steps - 1], "mission_ticks": mission_ticks,
                        "workload": f"{layout}, " + ("" if bt_path is not None else "empty map, ") + "LSC mode, "
                                    f"dt 0.2 s, M=5 n=5, mode/goal={goal_mode}, "

@@ -886,6 +886,7 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     if (c->N == 0) return LSC_ESTATE;
     a.model = c->d_model; a.terms = c->d_terms; a.entries = c->d_entries;
     a.N = c->N; a.first = c->first; a.count = c->count; a.planner_seq = seq; a.cap = c->cap;
+    a.dim2 = c->cfg.world_dimension == 2 ? 1 : 0;
     a.cap_tp = (c->count > c->n_cu) ? c->cap_tp : 0; a.smem_tp = c->smem_tp;
     a.order = (c->count > 2 * c->n_cu) ? c->d_order : nullptr;   // more than one round of throughput workgroups
     a.obs_bound = a.cap_tp > 0 ? c->d_obs_bound : nullptr;       // obstacle-level pre-cull of the throughput build
@@ -1379,6 +1380,7 @@ int lsc_phase_profile(lsc_ctx *c, int enable, long long *out)
     if (!c || c->N == 0) return LSC_EINVAL;
     HIPCHK(c, hipDeviceSynchronize());
     if (out) HIPCHK(c, hipMemcpy(out, c->d_prof, sizeof(long long) * PROF_PHASES * (size_t)c->N, hipMemcpyDeviceToHost));
+    if (enable > 0 && c->cfg.world_dimension == 2) { c->err = "lsc_phase_profile: the instrumented plan kernel exists for 3-D worlds only"; return LSC_EINVAL; }
     if (enable >= 0) {
         c->profiling = enable != 0;
         HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * 2 * PROF_PHASES * (size_t)c->N));

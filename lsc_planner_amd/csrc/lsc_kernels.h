@@ -20,6 +20,7 @@ struct PlanArgs {
     const uint32_t *terms;     // packed Hessian assembly terms
     const uint32_t *entries;   // [n_entries+1][2] : (gi<<16|gj, first term)
     int N, first, count, planner_seq;
+    int dim2;                  // world/dimension == 2: the launch takes the planar instantiation of the plan kernels (a compile-time switch)
     int cap;                   // LSC rows the LDS pass holds (total over the 27 control points; compact layout)
     int *order;                // throughput build: launch order of the shard's agents (longest first), or null
     float *obs_bound;          // throughput build: [N][4] bounding sphere of every agent's predicted control points, or null

@@ -641,7 +641,9 @@ static_assert(PH_COUNT == PROF_PHASES, "lsc_phase_profile copies PROF_PHASES cou
 //                   out of the default instantiation so that the fast path's register allocation is untouched by them
 //   NTT           : lanes of the workgroup -- 512 (8 waves, one workgroup per CU: the latency build) or 256 (4 waves, two
 //                   workgroups per CU when the LDS request allows it: the throughput build for swarms larger than the chip)
-template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512>
+//   DIM2          : planar world (world/dimension == 2): a compile-time switch, because as a run-time flag it cost the non-planar
+//                   kernel 1.5 % (measured: six missions 184.2 -> 186.9 ms of kernel time with the flag, 184.x without)
+template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512, bool DIM2 = false>
 __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *ws)
 {
     constexpr int WS_FEW_ROWS = 200;
@@ -676,9 +678,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     const int R = SPILL ? NB * (n_obs > 1 ? n_obs : 1) : a.cap;
     const int n_terms = md.n_terms, n_entries = md.n_entries;
     // axis rows that exist: 414, or 276 in a planar world (no z rows: `for (k < dim)`, src/traj_optimizer.cpp:274, 469)
-    const int n_ax = md.n_ax;
-    __builtin_assume(n_ax >= 0 && n_ax <= AXVALID);
-    const bool dim2 = md.dim2 != 0;
+    constexpr int n_ax = DIM2 ? AXVALID_2D : AXVALID_3D;
+    constexpr bool dim2 = DIM2;
 
     // dynamic LDS carve-up.  The throughput build leaves the (agent-independent, 9 KB) assembly tables in HBM/L2 -- its two
     // workgroups per CU hide that latency -- and spends the LDS on row capacity instead.
@@ -1286,11 +1287,6 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     // x from y : x_t = sum coef * y_glob  (+ state constants for t < 3)
     auto compute_x = [&](const double *yv, double *xv, bool with_const) {
         if (tid < NV) {
-            // (the control-point index is recomputed from a copy of tid the compiler cannot see through: sharing the value with the
-            // per-lane constants above kept it alive across the whole kernel, and it was what went to scratch)
-            int tq = tid;
-            asm volatile("" : "+v"(tq));
-            const int xt = tq % SEGV;
             double v;
             if (xt < 3) v = with_const ? S.x0c[tid] : 0.0;
             else {
@@ -1546,7 +1542,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             }
             dinv_own = 0.0;
             // (wave 0 takes TW_A pivots from the top, wave 1 TW_B from the bottom: the same number, or one less when NY - BAND is odd)
-            if (wave == 0) chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
+            if constexpr (TW_A == TW_B) chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);      // (one body for both waves)
+            else if (wave == 0) chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
             else chol_step<0, TW_B>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
             if (wave == 1) {
                 // the middle block in the reversed numbering is [TW_B, TW_B + BAND); reversed (r, c) is original (RV - r, RV - c)
@@ -2037,34 +2034,37 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     if constexpr (PROF) { if (tid == NT - 1 && a.prof) a.prof[(size_t)qi * PH_COUNT + PH_RED_GATHER] += t_acc[PH_RED_GATHER]; }
 }
 
-template <bool PROF>
+template <bool PROF, bool DIM2>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<PROF, false>(a, blockIdx.x, smem_raw, nullptr);
+    plan_agent<PROF, false, false, NT, DIM2>(a, blockIdx.x, smem_raw, nullptr);
 }
 
 // the same kernel with the alternate-mode hooks (contexts with reset_threshold > 0, BVC or a slack mode)
+template <bool DIM2>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_alt_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<false, false, true>(a, blockIdx.x, smem_raw, nullptr);
+    plan_agent<false, false, true, NT, DIM2>(a, blockIdx.x, smem_raw, nullptr);
 }
 
 // Throughput build for swarms larger than the chip (more agents in the shard than CUs): 256 lanes = one wave per SIMD, and
 // an LDS request of at most half a CU's 160 KB, so that two agents share a CU and one hides the other's latencies (the
 // solver is a chain of dependent LDS / cross-lane operations: VALU active 13 % of wave-cycles in the latency build).
+template <bool DIM2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_tp_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<false, false, false, 256>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
+    plan_agent<false, false, false, 256, DIM2>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
 }
 
 // ... and the throughput build with the alternate-mode hooks
+template <bool DIM2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_alt_tp_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<false, false, true, 256>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
+    plan_agent<false, false, true, 256, DIM2>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
 }
 
 // Preparation pass of the throughput build:
@@ -2127,6 +2127,7 @@ __global__ __launch_bounds__(256) void lsc_prep_kernel(PlanArgs a)
 
 // Second pass: agents whose rows did not fit the LDS capacity of the first pass are solved again with their rows in
 // HBM.  Persistent workgroups (one workspace each) walk the shard; everybody else's result is left untouched.
+template <bool DIM2>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_spill_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -2141,7 +2142,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int al = blockIdx.x; al < a.count; al += gridDim.x) {
         if (a.status[a.first + al] != LSC_STATUS_CAPACITY_K) continue;   // uniform over the workgroup
         __syncthreads();
-        plan_agent<false, true, false, NT>(a, al, smem_raw, ws);
+        plan_agent<false, true, false, NT, DIM2>(a, al, smem_raw, ws);
         __syncthreads();
     }
 }
@@ -2177,10 +2178,13 @@ size_t plan_spill_bytes(int N)
 // (several contexts on several GPUs of one process each get it on their own device).
 hipError_t init_device_kernels()
 {
-    const void *fns[] = {reinterpret_cast<const void *>(&lsc_plan_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_kernel<true>),
-                         reinterpret_cast<const void *>(&lsc_plan_alt_kernel), reinterpret_cast<const void *>(&lsc_plan_tp_kernel),
-                         reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel),
-                         reinterpret_cast<const void *>(&lsc_plan_spill_kernel), reinterpret_cast<const void *>(&lsc_sfc_kernel)};
+    const void *fns[] = {reinterpret_cast<const void *>(&lsc_plan_kernel<false, false>), reinterpret_cast<const void *>(&lsc_plan_kernel<true, false>),
+                         reinterpret_cast<const void *>(&lsc_plan_kernel<false, true>),
+                         reinterpret_cast<const void *>(&lsc_plan_alt_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_alt_kernel<true>),
+                         reinterpret_cast<const void *>(&lsc_plan_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_tp_kernel<true>),
+                         reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<true>),
+                         reinterpret_cast<const void *>(&lsc_plan_spill_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_spill_kernel<true>),
+                         reinterpret_cast<const void *>(&lsc_sfc_kernel)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -2197,19 +2201,22 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;          // empty shard (more ranks than agents): nothing to plan
     const bool alt = a.general_all || (a.reset_thr > 0.0 && a.ever);
+    const bool d2 = a.dim2 != 0;                  // planar world: the 60-variable instantiations
+    if (d2 && a.prof) return hipErrorInvalidValue;   // (the instrumented build exists for 3-D worlds only)
     PlanArgs t = a;
     if (uses_throughput_build(a)) {
         // throughput build: smaller capacity (an agent beyond it takes the second pass), two workgroups per CU
         t.cap = a.cap_tp;
         if (t.order || t.obs_bound) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
-        if (alt) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
-        else hipLaunchKernelGGL(lsc_plan_tp_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
+        if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
+        else { if (d2) hipLaunchKernelGGL(lsc_plan_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
         return hipGetLastError();
     }
     t.order = nullptr; t.obs_bound = nullptr;     // filled by lsc_prep_kernel only
-    if (alt) hipLaunchKernelGGL(lsc_plan_alt_kernel, dim3(a.count), dim3(NT), smem, st, t);
-    else if (a.prof) hipLaunchKernelGGL(lsc_plan_kernel<true>, dim3(a.count), dim3(NT), smem, st, t);
-    else hipLaunchKernelGGL(lsc_plan_kernel<false>, dim3(a.count), dim3(NT), smem, st, t);
+    if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_kernel<true>, dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL(lsc_plan_alt_kernel<false>, dim3(a.count), dim3(NT), smem, st, t); }
+    else if (a.prof) hipLaunchKernelGGL((lsc_plan_kernel<true, false>), dim3(a.count), dim3(NT), smem, st, t);
+    else if (d2) hipLaunchKernelGGL((lsc_plan_kernel<false, true>), dim3(a.count), dim3(NT), smem, st, t);
+    else hipLaunchKernelGGL((lsc_plan_kernel<false, false>), dim3(a.count), dim3(NT), smem, st, t);
     return hipGetLastError();
 }
 
@@ -2219,7 +2226,8 @@ hipError_t launch_plan_spill(const PlanArgs &a, int slots, size_t smem, hipStrea
     const int grid = a.count < slots ? a.count : slots;
     PlanArgs t = a;
     if (!uses_throughput_build(a)) t.obs_bound = nullptr;      // (bounds of this tick exist only behind the throughput launch)
-    hipLaunchKernelGGL(lsc_plan_spill_kernel, dim3(grid), dim3(NT), smem, st, t);
+    if (a.dim2) hipLaunchKernelGGL(lsc_plan_spill_kernel<true>, dim3(grid), dim3(NT), smem, st, t);
+    else hipLaunchKernelGGL(lsc_plan_spill_kernel<false>, dim3(grid), dim3(NT), smem, st, t);
     return hipGetLastError();
 }
 
