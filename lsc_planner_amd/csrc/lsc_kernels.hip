@@ -401,7 +401,7 @@ struct SmemT {
     double Tv[NCP * 3];         // per control point: -sum v n over its LSC rows
     double Tz[NCP * 3];         // per control point: -sum z n
     double K[NY * KLD];         // reduced Hessian (lower band); rows of its Cholesky factor after factor()
-    double red[6][NWAVE];
+    double red[2][5][NWAVE];    // per-wave partials of the block reductions, two banks used in turn (one barrier per reduction)
     double colbuf[2][2 * 64];   // column broadcast buffers of the two factorising waves (double-buffered by column parity)
     double mid2[BAND * BAND + 7];   // Schur contribution of the bottom-up sweep to the middle block (original indices); + room for the corrector-pass staging
     double dinv[NY + 1];            // 1 / d of every pivot of K = T D T^T (published by both sweeps of the factorisation)
@@ -813,12 +813,12 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         }
         // block argmin with the sequential loop's tie rule (lowest obstacle index among equal distances)
         const double wmin = wave_min(best);
-        if (lane == 0) S.red[0][wave] = wmin;
+        if (lane == 0) S.red[0][0][wave] = wmin;
         if (tid == 0) S.itmp = 0x7fffffff;
         __syncthreads();
-        double dmin = S.red[0][0];
+        double dmin = S.red[0][0][0];
 #pragma unroll
-        for (int w = 1; w < NWAVE; w++) dmin = fmin(dmin, S.red[0][w]);
+        for (int w = 1; w < NWAVE; w++) dmin = fmin(dmin, S.red[0][0][w]);
         if (bq != 0x7fffffff && best == dmin) atomicMin(&S.itmp, bq);
         __syncthreads();
         if (tid == 0) {
@@ -1297,6 +1297,27 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             xv[tid] = v;
         }
     };
+    // the same for ONE variable v, and for all variables on wave 0 alone (lane l: v = l and l + 64).  Used right behind a value
+    // that wave 0 has just written itself (dy after the substitutions, y after the step): LDS operations of a wave complete in
+    // order, so a wave-level fence replaces the workgroup barrier that used to sit between the two.
+    auto x_of = [&](const double *yv, double *xv, bool with_const, int v) {
+        const int t = v % SEGV;
+        double val;
+        if (t < 3) val = with_const ? S.x0c[v] : 0.0;
+        else {
+            const uint32_t gp = S.xgp[v];
+            const double *c = S.xtc[t];
+            val = c[0] * yv[gp & 0xff] + c[1] * yv[(gp >> 8) & 0xff] + c[2] * yv[gp >> 16];
+        }
+        xv[v] = val;
+    };
+    auto compute_x_wave0 = [&](const double *yv, double *xv, bool with_const) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        x_of(yv, xv, with_const, lane);
+        if (lane + 64 < NV) x_of(yv, xv, with_const, lane + 64);
+    };
     // cost gradient in x-space for this lane's variable: 2 w_c Q x within the segment (terminal term added by caller)
     auto cost_grad = [&]() -> double {
         const double *xs = S.x + xk * SEGV + (xt / NC) * NC;
@@ -1305,29 +1326,40 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         for (int j = 0; j < NC; j++) g += S.Qh6[(xt % NC) * NC + j] * xs[j];
         return g;
     };
-    // block reduction of up to 5 values: op 0 sum, 1 max, 2 min ; results in S.sc[0..4] (one barrier pair; the
-    // per-wave partials are combined by five lanes)
+    // block reduction of up to 5 values: op 0 sum, 1 max, 2 min; results in rv[0..4] (uniform registers).  One barrier: lane 0 of
+    // every wave publishes the wave's partials, then EVERY wave combines them itself -- lane k walks slot k in wave order (the
+    // summation order of rounds 1-3, so the results are the same bits) and the five results travel by v_readlane.  Round 3 had five
+    // lanes of the workgroup combine, write S.sc and a second barrier in front of the read.  Two banks of partials, used in turn:
+    // the next reduction may publish while a slow wave still reads this one's.
     // (op < 0: slot unused -- its wave reduction, ~45 instructions on every wave, is not emitted)
+    double rv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int red_bank = 0;
     auto block_reduce = [&](double v0, double v1, double v2, double v3, double v4, int op0, int op1, int op2, int op3, int op4) {
         auto wr = [&](double v, int op) { return op < 0 ? 0.0 : (op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v))); };
         double r0 = wr(v0, op0), r1 = wr(v1, op1), r2 = wr(v2, op2), r3 = wr(v3, op3), r4 = wr(v4, op4);
+        auto &bank = S.red[red_bank];         // [5][waves of the largest build]
         if (lane == 0) {
-            S.red[0][wave] = r0;
-            if (op1 >= 0) S.red[1][wave] = r1;
-            if (op2 >= 0) S.red[2][wave] = r2;
-            if (op3 >= 0) S.red[3][wave] = r3;
-            if (op4 >= 0) S.red[4][wave] = r4;
+            bank[0][wave] = r0;
+            if (op1 >= 0) bank[1][wave] = r1;
+            if (op2 >= 0) bank[2][wave] = r2;
+            if (op3 >= 0) bank[3][wave] = r3;
+            if (op4 >= 0) bank[4][wave] = r4;
         }
         __syncthreads();
         const int nused = op4 >= 0 ? 5 : (op3 >= 0 ? 4 : (op2 >= 0 ? 3 : (op1 >= 0 ? 2 : 1)));
-        if (tid < nused) {
-            const int op = tid == 0 ? op0 : (tid == 1 ? op1 : (tid == 2 ? op2 : (tid == 3 ? op3 : op4)));
-            double t = S.red[tid][0];
+        double t = 0.0;
+        if (lane < nused) {
+            const int op = lane == 0 ? op0 : (lane == 1 ? op1 : (lane == 2 ? op2 : (lane == 3 ? op3 : op4)));
+            t = bank[lane][0];
 #pragma unroll
-            for (int w = 1; w < NWAVE; w++) t = op == 0 ? t + S.red[tid][w] : (op == 1 ? fmax(t, S.red[tid][w]) : fmin(t, S.red[tid][w]));
-            S.sc[tid] = t;
+            for (int w = 1; w < NWAVE; w++) t = op == 0 ? t + bank[lane][w] : (op == 1 ? fmax(t, bank[lane][w]) : fmin(t, bank[lane][w]));
         }
-        __syncthreads();
+        rv[0] = lane_value(t, 0);
+        if (op1 >= 0) rv[1] = lane_value(t, 1);
+        if (op2 >= 0) rv[2] = lane_value(t, 2);
+        if (op3 >= 0) rv[3] = lane_value(t, 3);
+        if (op4 >= 0) rv[4] = lane_value(t, 4);
+        red_bank ^= 1;
     };
 
     // Reduction of the per-row values (w = z*t1 or 1, v = t2) into x-space weights and gradients.
@@ -1516,7 +1548,9 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             S.dy[tid] = yc0 * (S.gz[yo0] + S.Tz[yp0]) + yc1 * (S.gz[yo1] + S.Tz[yp1]) + yc2 * (S.gz[yo2] + S.Tz[yp2]) +
                         yc3 * (S.gz[yo3] + S.Tz[yp3]);
         }
-        __syncthreads();
+        // (no barrier here: rhs and the parked residual are written by lanes of wave 0 and next read by wave 0 -- the stationarity
+        // reduction, the substitutions --; K, written by everybody, is read behind the barrier of that reduction, or behind the
+        // explicit one of the cold start)
     };
 
     double dinv_own = 0.0;      // wave 0: 1 / d_lane of the current factor K = M D M^T
@@ -1591,6 +1625,9 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         constexpr int RV = NY - 1;
         if (wave == 0) {
             const int l = lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // rhs was written by this wave (assemble): wave-level order is enough
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // The loads are unconditional (what a lane outside the range reads lies inside this struct and is discarded) and pinned
             // group by group (pin_values), so that a group is ONE batch of loads ahead of its chain.
             const int lr = l < NY ? l : NY - 1;
@@ -1666,9 +1703,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             }
             if (l < NY) S.dy[l] = l < TW_M1 ? bt : bb;
             if constexpr (PROF) { if (tid == 0) t_acc[PH_SPARE0] += wall_clock64() - t_last; }
+            compute_x_wave0(S.dy, S.dx, false);      // dx right here, on the wave that holds dy (one workgroup barrier less per solve)
         }
-        __syncthreads();
-        compute_x(S.dy, S.dx, false);
         __syncthreads();
     };
     // LSC row helpers (row r: -n.x <= -rhs)
@@ -1799,7 +1835,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     if (xterm) { double e = S.x[tid] - S.goal[xk]; objp += md.w_t * e * e; }
                 }
                 block_reduce(gp, rpm, objp, 0.0, 0.0, 0, 1, 0, -1, -1);
-                gap = S.sc[0]; rpmax = S.sc[1]; obj = S.sc[2];
+                gap = rv[0]; rpmax = rv[1]; obj = rv[2];
                 mu = gap / nrow;
                 gap_ok = gap <= md.gap_tol * (1.0 + fabs(obj));
                 if (tid == 0) { S.sc[5] = gap; S.sc[6] = rpmax; }
@@ -1834,12 +1870,13 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             reduce_rows(with_w, phase == ST_COLD);
             stamp(PH_REDUCE);
             assemble(with_w);
+            if (phase == ST_COLD) __syncthreads();
             stamp(PH_ASSEMBLE);
             if (phase == ST_PRED) {
                 // cheap exit before the factorisation: primal residual, gap and stationarity all at tolerance
                 const double rda = (tid < NY) ? fabs(S.dy[tid]) : 0.0;
                 block_reduce(rda, 0.0, 0.0, 0.0, 0.0, 1, -1, -1, -1, -1);
-                if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
+                if (rpmax <= 1e-9 * hmax && gap_ok && rv[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
             }
             if (with_w) {
                 const bool fok = factor();
@@ -1847,10 +1884,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 if (!fok) {
                     if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) { double *tr = a.trace + iters * 8; tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = -1; tr[5] = -1; tr[7] = mu; }
                     // K lost definiteness to round-off: accept only a point that is already optimal to slightly relaxed
-                    // tolerances -- primal residual, gap AND the projected stationarity residual (S.sc[0], reduced just
+                    // tolerances -- primal residual, gap AND the projected stationarity residual (rv[0], reduced just
                     // above for the cheap exit); otherwise this start has failed
                     if (phase == ST_PRED && rpmax <= 1e-8 * hmax && gap <= 1e-7 * (1.0 + fabs(obj)) &&
-                        S.sc[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
+                        rv[0] <= 1e-5 * (1.0 + fabs(obj))) { status = LSC_STATUS_OK_K; break; }
                     failed = true;
                 }
             }
@@ -1879,8 +1916,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     mins = fmin(mins, sv); minz = fmin(minz, -sv);
                 }
                 block_reduce(mins, minz, 0.0, 0.0, 0.0, 2, 2, -1, -1, -1);
-                const double shs = S.sc[0] <= 0.0 ? 1.0 - S.sc[0] : 0.0;
-                const double shz = S.sc[1] <= 0.0 ? 1.0 - S.sc[1] : 0.0;
+                const double shs = rv[0] <= 0.0 ? 1.0 - rv[0] : 0.0;
+                const double shz = rv[1] <= 0.0 ? 1.0 - rv[1] : 0.0;
                 // the shift enters the loop as a "step" of length 1 (t1 = ds, t2 = dz) applied by the first fused pass
                 for (int c = tid; c < n_ax; c += NT) { const int sl = S.amap[c] & 1023; S.at1[sl] = shs; S.at2[sl] = shz; }
                 for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt1[r] = shs; rt2[r] = shz; }
@@ -1919,16 +1956,16 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 // Newton-step test: with gap and primal residual at tolerance, the affine (pure Newton) step measures
                 // the distance to the optimum (the stationarity residual itself can stall at the round-off level of
                 // the ill-conditioned normal equations when z/s is huge).
-                if (rpmax <= 1e-9 * hmax && gap_ok && S.sc[3] <= md.dx_tol * fmax(1.0, S.sc[4])) { status = LSC_STATUS_OK_K; break; }
-                const double aaff = S.sc[0];
-                const double mu_aff = (gap + aaff * S.sc[1] + aaff * aaff * S.sc[2]) / nrow;
+                if (rpmax <= 1e-9 * hmax && gap_ok && rv[3] <= md.dx_tol * fmax(1.0, rv[4])) { status = LSC_STATUS_OK_K; break; }
+                const double aaff = rv[0];
+                const double mu_aff = (gap + aaff * rv[1] + aaff * aaff * rv[2]) / nrow;
                 double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
                 sigma = md.sigma_pow == 2 ? sigma * sigma : (md.sigma_pow == 4 ? (sigma * sigma) * (sigma * sigma) : sigma * sigma * sigma);
                 smu = sigma * mu;
                 tau = fmin(1.0 - 1e-5, fmax(0.99, aaff));
                 if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) {
                     double *tr = a.trace + iters * 8;
-                    tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = aaff; tr[4] = sigma; tr[6] = S.sc[3]; tr[7] = mu;
+                    tr[0] = gap; tr[1] = rpmax; tr[2] = obj; tr[3] = aaff; tr[4] = sigma; tr[6] = rv[3]; tr[7] = mu;
                 }
                 phase = ST_CORR;
                 stamp(PH_P2);
@@ -1957,11 +1994,12 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     rt1[r] = ds; rt2[r] = dz;
                 }
                 block_reduce(amin, 0.0, 0.0, 0.0, 0.0, 2, -1, -1, -1, -1);
-                alpha = fmin(1.0, tau * S.sc[0]);
+                alpha = fmin(1.0, tau * rv[0]);
                 if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) a.trace[iters * 8 + 5] = alpha;
-                if (tid < NY) S.y[tid] += alpha * S.dy[tid];
-                __syncthreads();
-                compute_x(S.y, S.x, true);
+                if (wave == 0) {
+                    if (lane < NY) S.y[lane] += alpha * S.dy[lane];
+                    compute_x_wave0(S.y, S.x, true);
+                }
                 __syncthreads();
                 iters++;
                 phase = ST_PRED;
@@ -1973,7 +2011,6 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 // warm start did not converge: fall back to the cold start
                 attempt = 1;
                 spent += iters;
-                if (tid == 0) S.sc[3] = 1000.0 + (double)spent;   // diagnostics
                 iters = 0;
                 prepare_cold();
                 phase = ST_COLD;
@@ -2024,7 +2061,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         a.iters[qi] = iters;
         if (a.iters_acc) { a.iters_acc[qi] += iters; a.iters_acc[a.N + qi] += (long long)iters * S.nact; }
         if (a.nrows) a.nrows[qi] = S.nact;
-        if (a.dbg) { a.dbg[4 * qi] = S.sc[5]; a.dbg[4 * qi + 1] = S.sc[6]; a.dbg[4 * qi + 2] = S.sc[3]; a.dbg[4 * qi + 3] = obj; }
+        if (a.dbg) { a.dbg[4 * qi] = S.sc[5]; a.dbg[4 * qi + 1] = S.sc[6]; a.dbg[4 * qi + 2] = spent > 0 ? 1000.0 + (double)spent : rv[3]; a.dbg[4 * qi + 3] = obj; }
         if constexpr (PROF) {
             stamp(PH_OUT);
             if (a.prof)
