@@ -63,7 +63,7 @@ def _single_gpu_reference(N, ticks_dev=12, ticks_host=5):
     return {k: np.array(v) for k, v in out.items()}
 
 
-@pytest.mark.parametrize("world,N", [(2, 64), (4, 64), (4, 5), (2, 5)])
+@pytest.mark.parametrize("world,N", [(1, 64), (2, 64), (4, 64), (4, 5), (2, 5)])      # (world 1: the worker itself, on any box)
 def test_native_rccl_with_more_than_one_rank(world, N, tmp_path):
     if _n_gpus() < world:
         pytest.skip(f"needs {world} GPUs on this box (has {_n_gpus()})")
