@@ -30,7 +30,8 @@ def _new(time_limit=5.0):
     h = _hc._Highs()
     h.setOptionValue("output_flag", False)
     h.setOptionValue("time_limit", float(time_limit))
-    h.setOptionValue("threads", 1)
+    # (no "threads" option: HiGHS sizes ONE process-wide task scheduler at the first run; an instance that later asks for another
+    # thread count -- ours next to scipy.optimize.linprog's default -- refuses to run and reports "Not Set")
     h.setOptionValue("primal_feasibility_tolerance", 1e-9)
     h.setOptionValue("dual_feasibility_tolerance", 1e-9)
     return h
