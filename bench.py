@@ -48,14 +48,14 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (guide: half the 157.3 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-PMC_FILE = "profiles/r03_pmc_summary.json"
+PMC_FILE = "profiles/r04_pmc_summary.json"
 
 
 def pmc_traffic(key):
     """HBM-side traffic per launch (bytes).  NOT measured by this run: hardware counters need rocprofv3, so the
     value is read from the committed PMC passes of this same command (PMC_FILE, made by profiles/summarize_rocpd.py;
     FETCH_SIZE + WRITE_SIZE, raw counter values in KB); the bench line says so in `traffic_source`.  None when absent."""
-    for f in (PMC_FILE, "profiles/r01_pmc_summary_v8.json"):
+    for f in (PMC_FILE, "profiles/r03_pmc_summary.json"):
         try:
             d = json.load(open(os.path.join(ROOT, f)))["kernels"][key]
             return int((d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024), f
@@ -151,7 +151,7 @@ def cpu_baseline(ms, seconds_target=12.0, max_ticks=120, static_goal=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--start-tick", type=int, default=None,
                     help="mission tick of the first TIMED step; the ticks before it run untimed (fast-forward, the last --warmup of "
