@@ -294,3 +294,15 @@ def test_fuzz_device_resident_chain_equals_host_buffer_chain():
         host.close()
         devp.close()
     assert agent_ticks > 5000
+
+
+@pytest.mark.parametrize("variant,seed0", [("planar", 81000), ("m4", 82000), ("planar_m4", 83000)])
+def test_fuzz_planar_worlds_and_four_segments(oracle, variant, seed0):
+    """The round-4 builds under the same generator (tests/fuzz_variants.py): the planar 60-variable QP (world_dimension 2), the M = 4
+    library against the M = 4 oracle, and both at once; statuses, goals, cost and plans as in the LSC-mode fuzz above."""
+    import lsc_planner_amd as L
+    from fuzz_variants import run_variant
+    agent_ticks, failures, bad = run_variant(L, oracle, seed0, 50, variant)
+    assert not bad, bad[:3]
+    # (a planar trial ends when an agent whose first QP failed is left out of the plane -- see the generator)
+    assert agent_ticks > (12 if "planar" in variant else 45) * 50 and failures > 40, (agent_ticks, failures)

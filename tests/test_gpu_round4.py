@@ -11,6 +11,7 @@ import os
 import numpy as np
 import pytest
 
+from conftest import GOLDEN
 from tolerances import COST_ATOL, COST_RTOL, NEAR_GOAL_COST_ATOL, TRAJ_ATOL
 
 pytestmark = pytest.mark.gpu
@@ -238,3 +239,20 @@ def test_a_library_refuses_another_segment_count(L):
         lib.lsc_default_config(ctypes.byref(c))
         c.dt, c.horizon = dt, hz
         assert not lib.lsc_create(ctypes.byref(c))            # NULL: horizon / dt is not this library's M
+
+
+def test_fuzz_found_m4_instance_through_the_kernel_against_highs(L):
+    """tests/golden/fuzz_found_m4_4602619.npz: the M = 4 QP on which kernel and oracle were 8.2e-5 m apart at 3.9e-9 relative cost
+    (tests/test_oracle_m4.py re-derives the optimum with HiGHS and shows the oracle's plan is the distant one).  The current
+    kernel on the recorded inputs -- from a fresh context, i.e. another warm start than in the fuzz run -- against HiGHS's cost and
+    the plan recorded then."""
+    Z = np.load(os.path.join(GOLDEN, "fuzz_found_m4_4602619.npz"))
+    a, hc = int(Z["agent"]), float(Z["highs_cost"])
+    ms = L.Mission(Z["state"][:, :3].copy(), Z["goal"], Z["wmin"], Z["wmax"], Z["radius"], Z["dw"], Z["vmax"], Z["amax"], Z["vnom"])
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(dt=0.5, horizon=2.0))
+    assert pl.M == 4
+    pl.planner_seq = int(Z["tick"]) - 1
+    r = pl.plan(Z["state"], Z["goal"], Z["traj"])
+    pl.close()
+    assert r["status"][a] == 0 and abs(r["cost"][a] - hc) <= 1e-9 * hc
+    assert np.abs(r["traj"][a] - Z["gtraj"][a]).max() <= 5e-6

@@ -1,10 +1,14 @@
 """M = horizon / dt other than 5: the reference computes the segment count at run time (src/traj_optimizer.cpp:9,
 src/traj_planner.cpp:22) and its C++ defaults are dt 0.5 / horizon 2.0, i.e. M = 4 (src/param.cpp:66-67).  The oracle built with
 -DORC_M=4 (oracle/liblsc_oracle_m4.so): structure of the QP, optimum against HiGHS."""
+import os
+
 import numpy as np
 import pytest
 
 import highs_qp as H
+from conftest import GOLDEN
+from tolerances import FUZZ_TRAJ_ATOL_HALF_SECOND
 
 DT, HORIZON = 0.5, 2.0
 
@@ -61,3 +65,31 @@ def test_terminal_segments_follow_the_horizon(oracle):
     with O.segments(4):
         f = lambda d: O.lib().orc_terminal_segments(O._f(np.array([d, 0, 0], np.float32)), O._f(np.zeros(3, np.float32)), 1.0, DT)
         assert [f(d) for d in (0.0, 0.4, 0.6, 1.1, 1.6, 5.0)] == [4, 3, 2, 1, 1, 1]
+
+
+def test_fuzz_found_flat_optimum_of_the_half_second_segments(oracle):
+    """tests/golden/fuzz_found_m4_4602619.npz (tests/fuzz_variants.py, variant m4, tick 6, agent 4): kernel and oracle 3.9e-9 apart
+    in cost but 8.2e-5 m apart in the plan.  HiGHS decides whose plan is the optimum's: the kernel's (recorded on an MI355X:
+    3e-7 m from HiGHS, cost 1e-11 relative), while the oracle's interior point stopped 4e-9 above it, inside its own stopping rule.
+    With dt = 0.5 the jerk weights are (0.2 / 0.5)^5 = 1/100 of the M = 5 ones, so the same cost slack moves the plan ten times
+    as far -- the reason for tolerances.FUZZ_TRAJ_ATOL_HALF_SECOND."""
+    O = oracle
+    Z = np.load(os.path.join(GOLDEN, "fuzz_found_m4_4602619.npz"))
+    a, tick, hc = int(Z["agent"]), int(Z["tick"]), float(Z["highs_cost"])
+    with O.segments(4):
+        n = len(Z["state"])
+        prm = O.make_params(world_min=Z["wmin"], world_max=Z["wmax"], obs_f32=True, dt=float(Z["dt"]))
+        sw = O.SwarmEx(prm, O.make_modes(), Z["radius"], Z["dw"], Z["vmax"], Z["amax"], Z["vnom"])
+        sw.stale[:] = Z["stale"]
+        o = sw.tick(Z["state"], Z["goal"], Z["traj"], tick, want_lsc=True, nthreads=2)
+        assert o["status"][a] == 0
+        assert 0 <= o["cost"][a] - hc <= 1e-8 * hc and abs(Z["gcost"][a] - hc) <= 1e-10 * hc
+        assert 5e-5 < np.abs(o["traj"][a] - Z["gtraj"][a]).max() <= FUZZ_TRAJ_ATOL_HALF_SECOND
+        if H.available():
+            others = [j for j in range(n) if j != a]
+            obs = np.array([O.shift_traj(Z["traj"][j]) for j in others])
+            qp = O.qp_assemble(prm, Z["state"][a], Z["goal"][a], Z["vnom"][a], Z["vmax"][a], Z["amax"][a], obs, o["normal"][a], o["d"][a])
+            verdict, xh, cost = H.solve_oracle_qp(qp)[:3]
+            assert verdict == "Optimal" and abs(cost - hc) <= 1e-9 * hc
+            xh = np.asarray(xh).reshape(3, 24)
+            assert np.abs(xh - Z["gtraj"][a]).max() <= 2e-6 < 5e-5 < np.abs(xh - o["traj"][a]).max()
