@@ -394,10 +394,6 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t k, uint32_t nb, uint32_t 
     return min(r, r - nb);
 }
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ double readlane_d(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
 
 __device__ int f_row_find(int lane, const uint32_t *row, int cnt, uint32_t jz)
 {
@@ -1165,8 +1161,8 @@ __global__ __launch_bounds__(64) void lsc_goal_kernel(GoalArgs a)
                     todo &= todo - 1;
                     const uint32_t nkey = (uint32_t)__builtin_amdgcn_readlane(nkey_l, d);
                     const uint32_t sv = (uint32_t)__builtin_amdgcn_readlane((int)sv_l, d);
-                    const int di = d == 0 ? -1 : (d == 5 ? 1 : 0), dj = d == 1 ? -1 : (d == 4 ? 1 : 0), dz = d == 2 ? -1 : (d == 3 ? 1 : 0);
-                    const int ni = ci + di, nj = cj + dj, nz = cz + dz;
+                    const int di = d == 0 ? -1 : (d == 5 ? 1 : 0);
+                    const int ni = ci + di;
                     const uint32_t ne = nkey | ((uint32_t)ng << KEY_BITS);
                     uint32_t *row = c.rows + (size_t)ni * c.cap;
                     const RowInfo ri = row_info(c, ni);            // everything the insertion and the bookkeeping need, one round trip
