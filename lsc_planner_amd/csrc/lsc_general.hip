@@ -155,6 +155,36 @@ __device__ __forceinline__ unsigned long long uni_u64(unsigned long long v)
 }
 template <typename T>
 __device__ __forceinline__ T *uni_p(T *p) { return (T *)uni_u64((unsigned long long)p); }
+// column J of the right-looking factor: the entries l_k d_J of the later columns reach every lane as broadcasts (v_readlane -> scalar pair), in
+// batches of eight -- eight broadcasts, then their eight updates: a broadcast directly in front of its update costs a wait state each, and
+// left to itself the scheduler either does exactly that or hoists whole columns of broadcasts and keeps ~100 more registers alive
+template <int PU, int J, int K0>
+__device__ __forceinline__ void dense_factor_batch(double (&av)[PU], const double l)
+{
+    constexpr int NB8 = (PU - K0) < 8 ? (PU - K0) : 8;
+    double sk[NB8];
+#pragma unroll
+    for (int q = 0; q < NB8; q++) sk[q] = lane_value(av[J], K0 + q);
+#pragma unroll
+    for (int q = 0; q < NB8; q++) av[K0 + q] = fma(-l, sk[q], av[K0 + q]);
+    if constexpr (K0 + 8 < PU) dense_factor_batch<PU, J, K0 + 8>(av, l);
+}
+template <int PU, int J>
+__device__ __forceinline__ void dense_factor_step(double (&av)[PU], double *invd, int &npos)
+{
+    const double d = lane_value(av[J], J);
+    npos += d > 0.0 ? 1 : 0;                               // (a count, not a flag: the chain of ANDs was kept in 2 PU scalar registers to the end)
+    const double dd = d > 0.0 ? d : 1.0;
+    double inv = __builtin_amdgcn_rcp(dd);                 // 1 / d: hardware estimate + two Newton steps (full division is twice the chain)
+    inv = fma(fma(-dd, inv, 1.0), inv, inv);
+    inv = fma(fma(-dd, inv, 1.0), inv, inv);
+    const double l = av[J] * inv;                          // column J of L
+    invd[J] = inv;                                         // uniform over the wave: every lane stores the same word (selecting lane J's copy at the
+                                                           // end kept all PU reciprocals alive: 2 PU registers, the callee-saved ones among them)
+    if constexpr (J + 1 < PU) dense_factor_batch<PU, J, J + 1>(av, l);
+    av[J] = l;
+    if constexpr (J + 1 < PU) dense_factor_step<PU, J + 1>(av, invd, npos);
+}
 template <int PU>
 __device__ __attribute__((noinline)) void dense_factor_w0()
 {
@@ -164,28 +194,15 @@ __device__ __attribute__((noinline)) void dense_factor_w0()
     double av[PU];
 #pragma unroll
     for (int c = 0; c < PU; c++) av[c] = S.K[lr * KL + c];
-    bool ok = true;
-    double myinv = 1.0;
-#pragma unroll
-    for (int j = 0; j < PU; j++) {
-        const double d = lane_value(av[j], j);
-        if (!(d > 0.0)) ok = false;
-        const double dd = d > 0.0 ? d : 1.0;
-        double inv = __builtin_amdgcn_rcp(dd);               // 1 / d: hardware estimate + two Newton steps (full division is twice the chain)
-        inv = fma(fma(-dd, inv, 1.0), inv, inv);
-        inv = fma(fma(-dd, inv, 1.0), inv, inv);
-        const double l = av[j] * inv;                      // column j of L
-        if (lane == j) myinv = inv;
-#pragma unroll
-        for (int k = j + 1; k < PU; k++) av[k] = fma(-l, lane_value(av[j], k), av[k]);
-        av[j] = l;
-    }
+    int npos = 0;
+    dense_factor_step<PU, 0>(av, S.invd, npos);
     if (lane < PU) {
+        int lw = lr;                                         // (an opaque copy: the ~PU / 2 addresses of the loads above are not kept for these stores)
+        asm volatile("" : "+v"(lw));
 #pragma unroll
-        for (int c = 0; c < PU; c++) S.K[lr * KL + c] = c < lane ? av[c] : 0.0;
-        S.invd[lane] = myinv;
+        for (int c = 0; c < PU; c++) S.K[lw * KL + c] = c < lane ? av[c] : 0.0;
     }
-    if (lane == 0) S.ok = ok ? 1 : 0;
+    if (lane == 0) S.ok = npos == PU ? 1 : 0;
 }
 template <int PU>
 __device__ __attribute__((noinline)) void dense_solve_w0(int P_in)
@@ -274,6 +291,7 @@ static __device__ __forceinline__ bool general_agent(KArgs &a_in, const int al_i
     // arithmetic of ALL phases to the top of the function -- ~120 values per lane that do not fit the register file and went to
     // scratch once per agent, to be reloaded ~600 times per iteration (the rest of round 3's 40 MB of scratch writes per launch).
     int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));       // (opaque from the first use on: what the set-up derives from it is not hoisted out of the kernel's loop over agents)
     const int lane = tid & 63, wave = tid >> 6;
     auto fresh = [&]() { int t = threadIdx.x; asm volatile("" : "+v"(t)); tid = t; };
     const int qi = a.first + al;

@@ -8,7 +8,7 @@ from lsc_planner_amd.planner import PlannerConfig, next_state_host
 from lsc_planner_amd.mission import Mission
 from oracle import oracle as O
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from tolerances import COST_ATOL, COST_RTOL, FUZZ_TRAJ_ATOL as TRAJ_ATOL
+from tolerances import COST_ATOL, COST_RTOL, FUZZ_PLAN_COMPARED_BELOW_COST, FUZZ_TRAJ_ATOL as TRAJ_ATOL
 seed0=int(sys.argv[1]); ntr=int(sys.argv[2])
 bad=0; tot=0; fails=0
 MODES=[(dict(planner_mode="bvc"), dict(planner="bvc")),
@@ -49,8 +49,8 @@ for trial in range(ntr):
         if not np.array_equal(g["status"],o["status"]): msg="status %s vs %s"%(g["status"],o["status"])
         elif not np.isfinite(g["traj"]).all(): msg="non-finite"
         elif not (np.abs(g["cost"]-o["cost"])[ok] <= COST_RTOL*np.abs(o["cost"])[ok]+COST_ATOL).all(): msg="cost rel %.2e"%(np.abs(g["cost"]-o["cost"])[ok]/np.maximum(1e-30,np.abs(o["cost"])[ok])).max()
-        elif np.abs(g["traj"]-o["traj"])[(~ok) | (np.abs(o["cost"])<1e4)].max(initial=0.0)>TRAJ_ATOL: msg="traj %.2e"%np.abs(g["traj"]-o["traj"]).max()   # (plans compared below |f| = 1e4 only, see tests/test_gpu_fuzz.py)
-        elif (np.abs(o["cost"])>=1e4).any(): big=locals().get("big",0)+1
+        elif np.abs(g["traj"]-o["traj"])[(~ok) | (np.abs(o["cost"])<FUZZ_PLAN_COMPARED_BELOW_COST)].max(initial=0.0)>TRAJ_ATOL: msg="traj %.2e"%np.abs(g["traj"]-o["traj"]).max()   # (plans compared below |f| = 1e4 only, see tests/test_gpu_fuzz.py)
+        elif (np.abs(o["cost"])>=FUZZ_PLAN_COMPARED_BELOW_COST).any(): big=locals().get("big",0)+1
         if msg:
             bad+=1; print("MISMATCH seed",seed0+trial,"n",n,"mode",ck,"tick",tick,msg,flush=True)
             import os; os.makedirs("gpurun_out/fuzz",exist_ok=True)

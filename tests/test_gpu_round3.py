@@ -102,19 +102,25 @@ def test_kernel_statuses_and_costs_against_highs_verdicts(L):
     assert n_inf >= 140 and n_opt >= 300, (n_inf, n_opt)
 
 
-def test_fuzz_found_instance_through_the_kernel_against_highs(L):
+@pytest.mark.parametrize("seed,which,cfg,agent,highs_cost",
+                         [(5023, 3, dict(planner_mode="bvc", n_constraint_segments=2), 2, 1.3618641918561454),
+                          (4800332, 2, dict(planner_mode="bvc", slack_mode="dynamical_limit"), 2, 1860.235625116953)])
+def test_fuzz_found_instance_through_the_kernel_against_highs(L, seed, which, cfg, agent, highs_cost):
     """tests/golden/fuzz_found_5023.npz: the alternate-mode QP (BVC, two constraint segments) on which the oracle used to give
-    up and HiGHS found the optimum 1.3618641918561454 (tests/test_oracle_pins.py re-derives it when HiGHS is importable).  The
-    current kernel on the recorded inputs, against that number directly."""
-    Z = np.load(os.path.join(GOLDEN, "fuzz_found_5023.npz"))
-    assert int(Z["which"]) == 3
+    up and HiGHS found the optimum 1.3618641918561454; fuzz_found_4800332.npz (round 4): BVC with the dynamical-limit slack at
+    |f| = 1860, where the oracle's plan is the one 6.7e-5 m from HiGHS's (tests/test_oracle_pins.py re-derives both optima when
+    HiGHS is importable).  The current kernel on the recorded inputs, against those numbers directly."""
+    Z = np.load(os.path.join(GOLDEN, "fuzz_found_%d.npz" % seed))
+    assert int(Z["which"]) == which
     ms = L.Mission(Z["state"][:, :3].copy(), Z["goal"], Z["wmin"], Z["wmax"], Z["radius"], Z["dw"], Z["vmax"], Z["amax"], Z["vnom"])
-    pl = L.SwarmPlanner(ms, L.PlannerConfig(planner_mode="bvc", n_constraint_segments=2))
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(**cfg))
     pl.planner_seq = int(Z["tick"]) - 1
     r = pl.plan(Z["state"], Z["goal"], Z["traj"])
     pl.close()
     assert (r["status"] == 0).all() and np.array_equal(r["status"], Z["gstatus"])
-    assert abs(r["cost"][2] - 1.3618641918561454) <= 1e-8 * 1.3618641918561454
+    assert abs(r["cost"][agent] - highs_cost) <= 1e-8 * highs_cost
+    if seed == 4800332:
+        assert np.abs(r["traj"][agent] - Z["gtraj"][agent]).max() <= 5e-6      # (the recorded plan is 1.2e-7 m from HiGHS's)
 
 
 def _safety_reference(traj, times, dt, radius, downwash):

@@ -204,8 +204,10 @@ def test_alternate_mode_qps_vs_highs(oracle, mode):
 # (3400814: found by round 3's large-count run, tools/fuzz_round.sh -- a gust case where the ORACLE stops 7.7e-9 relative above the
 #  optimum with its plan 1.7e-4 m from HiGHS's, while the kernel's recorded plan is within 1.2e-5 m of it: the fuzzer compares plans
 #  against the oracle and flagged the kernel)
+# (4800332: round 4's run of tests/fuzz_modes.py -- BVC with the dynamical-limit slack, |f| = 1860: the oracle stops 1.2e-8 relative above the optimum
+#  with its plan 6.7e-5 m from HiGHS's, the kernel's recorded plan is 1.2e-7 m from it; same answer from round 3's kernel)
 @pytest.mark.parametrize("seed,agent,highs_cost", [(5023, 2, 1.3618641918561454), (5059, 6, 106.74117597754659),
-                                                   (3400814, 2, 837.1755490814921)])
+                                                   (3400814, 2, 837.1755490814921), (4800332, 2, 1860.235625116953)])
 def test_instances_on_which_the_oracle_used_to_give_up(oracle, seed, agent, highs_cost):
     """Found by tests/test_gpu_fuzz.py: alternate-mode QPs close to a degenerate optimum, where the oracle's normal equations
     lose definiteness.  It used to answer "infeasible"; HiGHS (cost recorded here, re-derived when HiGHS is importable) and the
@@ -213,7 +215,7 @@ def test_instances_on_which_the_oracle_used_to_give_up(oracle, seed, agent, high
     (the tick's states, previous plans, persistent slack set and the seeded agents of the fuzzer)."""
     O = oracle
     Z = np.load(os.path.join(GOLDEN, "fuzz_found_%d.npz" % seed))
-    modes = [dict(planner="bvc"), dict(slack="collision_constraint"), dict(slack="dynamical_limit"),
+    modes = [dict(planner="bvc"), dict(planner="bvc", slack="collision_constraint"), dict(planner="bvc", slack="dynamical_limit"),      # (MODES of tests/fuzz_modes.py)
              dict(planner="bvc", n_constraint_segments=2), dict(reset_threshold=0.15)]
     mk = modes[int(Z["which"])]
     md = O.make_modes(**mk)
@@ -240,6 +242,6 @@ def test_instances_on_which_the_oracle_used_to_give_up(oracle, seed, agent, high
                               np.array(obs, np.float32), o["normal"][agent], o["d"][agent], slack_flags=sw.slack_set[agent, others])
         verdict, xh, cost = H.solve_oracle_qp(qp)[:3]
         assert verdict == "Optimal" and abs(cost - highs_cost) <= 1e-8 * highs_cost
-        if seed == 3400814:                     # whose plan is the optimum's: the kernel's (recorded on an MI355X), not the oracle's
+        if seed in (3400814, 4800332):          # whose plan is the optimum's: the kernel's (recorded on an MI355X), not the oracle's
             xh = np.asarray(xh)[:90].reshape(3, 30)
             assert np.abs(xh - Z["gtraj"][agent]).max() <= 2e-5 < np.abs(xh - o["traj"][agent]).max()

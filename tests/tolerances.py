@@ -20,7 +20,9 @@ FUZZ_TRAJ_ATOL = 5e-5
 FUZZ_TRAJ_ATOL_HALF_SECOND = 2e-4
 # ... and with the 1e5 slack penalty a grossly violated limit makes |f| ~ 1e7; both solvers stop on criteria relative to |f|
 # and their plans may then differ by centimetres at 4e-8 relative cost: plans are compared below this objective only.
-FUZZ_PLAN_COMPARED_BELOW_COST = 1e4
+# (1e4 until round 4, when a BVC + dynamical-limit-slack QP at |f| = 1860 came out 6.7e-5 m apart at 1.2e-8 relative cost -- the oracle's slack again,
+#  HiGHS 1.2e-7 m from the kernel: tests/golden/fuzz_found_4800332.npz.  The cost comparison still pins the optimum above the limit.)
+FUZZ_PLAN_COMPARED_BELOW_COST = 1e3
 # 1024-agent swarms near their goals: costs approach 0 (1e-6..1e-5), so the absolute floor is what binds.
 LARGE_SWARM_COST_ATOL = 1e-7
 # The same at the end of a mission flown to completion (tick 193 of the 64-agent bench mission: cost 2.4e-5, kernel and oracle
