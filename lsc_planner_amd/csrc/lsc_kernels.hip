@@ -1563,16 +1563,20 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         bool ok = true;
         const double pend0[BAND] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (wave < 2) {
-            const bool act = lane < NY;
+            // No lane-dependent masks on these loads (nor on the stores and the substitutions' loads below): S.K holds zeros wherever it
+            // does not hold a band entry -- set once at entry, kept by the row reduction's staging (which clears what it parks there) and by
+            // assemble() (band entries only) --, so "outside the band" and "above the diagonal" read as 0.0 by themselves.  The ~200
+            // predicates of the masked version were loop invariants the compiler kept in scalar pairs, spilled into vector lanes and
+            // restored with two v_readlane each: a fifth of the substitutions' instructions (round 4, read off the ISA).
+            const int lk = lane < NY ? lane : NY - 1;      // (lanes beyond the matrix repeat the last row; nothing of theirs is kept)
             if (wave == 0) {
 #pragma unroll
-                for (int j = 0; j < NY; j++) lrow[j] = (act && j <= lane && lane - j <= BAND) ? S.K[lane * KLD + j] : 0.0;
+                for (int j = 0; j < NY; j++) lrow[j] = S.K[lk * KLD + j];
             } else {
                 // K'[r][c] = K[RV-c][RV-r]; the middle block (and what lies beyond it) starts at zero: it only collects
                 // the Schur updates of this sweep
 #pragma unroll
-                for (int j = 0; j < NY; j++)
-                    lrow[j] = (act && j <= lane && lane - j <= BAND && j < TW_B) ? S.K[(RV - j) * KLD + (RV - lane)] : 0.0;
+                for (int j = 0; j < NY; j++) lrow[j] = j < TW_B ? S.K[(RV - j) * KLD + (RV - lk)] : 0.0;
             }
             dinv_own = 0.0;
             // (wave 0 takes TW_A pivots from the top, wave 1 TW_B from the bottom: the same number, or one less when NY - BAND is odd)
@@ -1604,10 +1608,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
 #pragma unroll
             for (int j = 0; j < TW_M1; j++)
                 if (lane < TW_M1 && j < lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
-            if (lane < TW_M1) S.dinv[lane] = dinv_own;
+            if (lane < TW_M1) { S.dinv[lane] = dinv_own; S.K[lane * KLD + lane] = 0.0; }      // (the diagonal of K: the substitutions read rows and columns of T unmasked)
             if (lane == 0) S.sc[7] = ok ? 1.0 : 0.0;
         } else if (wave == 1) {
-            if (lane < TW_B) S.dinv[RV - lane] = dinv_own;
+            if (lane < TW_B) { S.dinv[RV - lane] = dinv_own; S.K[(RV - lane) * KLD + (RV - lane)] = 0.0; }
             // multipliers of the bottom-up sweep, reversed (r, c) -> original (RV-r, RV-c), kept at the mirrored band position
 #pragma unroll
             for (int c = 0; c < TW_B; c++)
@@ -1645,10 +1649,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int q = 0; q < TW_B; q++) cb[q] = Kcol[(RV - q) * KLD];
                 pin_values(ct);
                 pin_values(cb);
-#pragma unroll
-                for (int q = 0; q < TW_A; q++) ct[q] = (l > q && l <= q + BAND) ? ct[q] : 0.0;                  // T[l][q], l in (q, q + BAND]: the top sweep ends in the middle block
-#pragma unroll
-                for (int q = 0; q < TW_B; q++) cb[q] = (l < RV - q && l >= RV - q - BAND) ? cb[q] : 0.0;        // pivot RV - q: rows above it, stored at the mirrored place
+                // (no masks: T[l][q] for l outside (q, q + BAND] and T[RV - q][l] for l outside [RV - q - BAND, RV - q) are zeros of S.K --
+                //  above the diagonal, the zeroed diagonal, outside the band; see factor())
 #pragma unroll
                 for (int q = 0; q < TW_A; q++) {
                     bt = fma(-ct[q], lane_value(bt, q), bt);
@@ -1661,10 +1663,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
 #pragma unroll
                 for (int q = 0; q < BAND - 1; q++) cm[q] = Krow[TW_A + q];
                 pin_values(cm);
+                // (rows below the middle block hold the other sweep's multipliers in these columns: they sit this block out)
+                double bm = b;
 #pragma unroll
-                for (int q = 0; q < BAND - 1; q++) cm[q] = (l > TW_A + q && l < TW_M1) ? cm[q] : 0.0;
-#pragma unroll
-                for (int q = 0; q < BAND - 1; q++) b = fma(-cm[q], lane_value(b, TW_A + q), b);
+                for (int q = 0; q < BAND - 1; q++) bm = fma(-cm[q], lane_value(bm, TW_A + q), bm);
+                b = l < TW_M1 ? bm : b;
             }
             b *= dinv;
             {   // back: the middle block first (its solution goes to the rows above AND below it), then outwards
@@ -1673,12 +1676,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int q = 0; q < BAND; q++) { const int I = TW_M1 - 1 - q; cu[q] = Kcol[I * KLD]; cd[q] = Krow[I]; }
                 pin_values(cu);
                 pin_values(cd);
+                const bool below = l >= TW_M1;
 #pragma unroll
-                for (int q = 0; q < BAND; q++) {
-                    const int I = TW_M1 - 1 - q;
-                    const double up = (l < I && l >= I - BAND) ? cu[q] : 0.0;                     // T[I][l]: rows above I (middle and top)
-                    cu[q] = (l >= TW_M1 && l < NY && l - I <= BAND) ? cd[q] : up;                 // T[I][l] of a bottom row l, at the mirrored place
-                }
+                for (int q = 0; q < BAND; q++) cu[q] = below ? cd[q] : cu[q];      // T[I][l]: rows above I (middle and top: the column, zero from the
+                                                                                   // diagonal on) | a bottom row l: its entry at the mirrored place, T[l][I]
 #pragma unroll
                 for (int q = 0; q < BAND; q++) b = fma(-cu[q], lane_value(b, TW_M1 - 1 - q), b);
             }
@@ -1691,10 +1692,6 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int q = 0; q < TW_B - 1; q++) ci[q] = Krow[TW_M1 + q];
                 pin_values(co);
                 pin_values(ci);
-#pragma unroll
-                for (int q = 0; q < TW_A - 1; q++) { const int It = TW_A - 1 - q; co[q] = (l < It && l >= It - BAND) ? co[q] : 0.0; }
-#pragma unroll
-                for (int q = 0; q < TW_B - 1; q++) { const int Ib = TW_M1 + q; ci[q] = (l > Ib && l < NY && l - Ib <= BAND) ? ci[q] : 0.0; }
 #pragma unroll
                 for (int q = 0; q < TW_A - 1; q++) {
                     bt = fma(-co[q], lane_value(bt, TW_A - 1 - q), bt);
