@@ -404,7 +404,8 @@ struct SmemT {
     double red[2][5][NWAVE];    // per-wave partials of the block reductions, two banks used in turn (one barrier per reduction)
     double colbuf[2][2 * 64];   // column broadcast buffers of the two factorising waves (double-buffered by column parity)
     double mid2[BAND * BAND + 7];   // Schur contribution of the bottom-up sweep to the middle block (original indices); + room for the corrector-pass staging
-    double dinv[NY + 1];            // 1 / d of every pivot of K = T D T^T (published by both sweeps of the factorisation)
+    double dinv[NY + 1];            // 1 / d of the pivots of K = T D T^T taken top-down (unknown = index), stored by every lane as each is formed
+    double dinvb[(NY - BAND) / 2 + 1];   // ... of the pivots of the bottom-up sweep, in ITS order (index q = unknown NY - 1 - q)
     double ok2;                 // pivots of the bottom-up sweep all positive
     double sc[8];               // broadcast scalars
     double gap0;                // complementarity gap at the first iteration of the current start (divergence test)
@@ -503,7 +504,7 @@ __device__ __forceinline__ double rcp_nr(double d)
     return y;
 }
 template <int J, int JEND>
-__device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, double &dinv_own, int lane, bool &ok,
+__device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, double *dinv_out, int lane, int &npos,
                                           double u_p1, const double (&pend_p1)[BAND], double u_p2, const double (&pend_p2)[BAND])
 {
     constexpr int K1 = (J + BAND) < (NY - 1) ? (J + BAND) : (NY - 1);
@@ -528,9 +529,9 @@ __device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, dou
     const double s1 = bcast_lane<(J + 1 < NY ? J + 1 : 0)>(cj);
     const double s2 = bcast_lane<(J + 2 < NY ? J + 2 : 0)>(cj);
     const double s3 = bcast_lane<(J + 3 < NY ? J + 3 : 0)>(cj);
-    if (!(dj > 0.0)) ok = false;
-    const double r = rcp_nr(dj);          // 1 / d_J, uniform over the wave
-    if (lane == J) dinv_own = r;
+    npos += dj > 0.0 ? 1 : 0;             // (a count, not a flag: the chain of ANDs behind a flag is kept in scalar pairs to the end of the sweep)
+    const double r = rcp_nr(dj);          // 1 / d_J, uniform over the wave: every lane stores the same word (selecting lane J's copy at the end
+    dinv_out[J] = r;                      // of the sweep costs two restored predicate words and two selects per pivot)
     const double u = cj * r;              // M[i][J] = A[i][J] / d_J  (unit-diagonal factor entry)
     if constexpr (J + 1 <= K1) row[J + 1] = fma(-u, s1, row[J + 1]);
     if constexpr (J + 2 <= K1) row[J + 2] = fma(-u, s2, row[J + 2]);
@@ -546,7 +547,7 @@ __device__ __forceinline__ void chol_step(double (&row)[NY], double *colbuf, dou
         }
     }
     row[J] = u;
-    if constexpr (J + 1 < JEND) chol_step<J + 1, JEND>(row, colbuf, dinv_own, lane, ok, u, nxt, u_p1, pend_p1);
+    if constexpr (J + 1 < JEND) chol_step<J + 1, JEND>(row, colbuf, dinv_out, lane, npos, u, nxt, u_p1, pend_p1);
     else {
         // end of this range of pivots: apply the far-column updates of the last two columns that are still deferred
         if constexpr (J >= 1) {
@@ -1553,21 +1554,24 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         // explicit one of the cold start)
     };
 
-    double dinv_own = 0.0;      // wave 0: 1 / d_lane of the current factor K = M D M^T
-
     // The factor lives in LDS (S.K, unit-diagonal M = L D^-1, lower band) between phases; registers hold it only inside
     // factor() and solve(), so the row passes and reductions in between keep the whole register budget.
     auto factor = [&]() -> bool {
         constexpr int RV = NY - 1;
         double lrow[NY];          // lane = row, register = column (wave 1: of the index-reversed matrix)
-        bool ok = true;
+        int npos = 0;             // positive pivots of this wave's sweeps
         const double pend0[BAND] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // Lane-dependent predicates are what this function avoids (round 4, read off the ISA: ~300 of them -- load masks, store masks, "lane == J"
+        // selects -- were loop invariants of the solver loop, kept in scalar pairs, spilled into vector lanes and restored with two v_readlane
+        // each, a fifth of the instructions of the factorisation's tail and of the substitutions):
+        //  * loads: S.K holds zeros wherever it does not hold a band entry -- set once at entry, kept by the row reduction's staging (which
+        //    clears what it parks there) and by assemble() (band entries only) --, so "outside the band" and "above the diagonal" read as 0.0;
+        //  * the registers ABOVE a lane's diagonal collect meaningless updates (the symmetric half, started from zero); they feed nothing that
+        //    is kept, so the hand-over of the middle block adds and stores whole rows, and only the write-back of T is masked -- by one compare
+        //    per entry on an opaque copy of the lane index (so that it is not hoisted), instead of three spilled conditions.
+        int rel = lane - 1;       // (lane - 1) - j in [0, BAND)  <=>  j < lane <= j + BAND
+        asm volatile("" : "+v"(rel));
         if (wave < 2) {
-            // No lane-dependent masks on these loads (nor on the stores and the substitutions' loads below): S.K holds zeros wherever it
-            // does not hold a band entry -- set once at entry, kept by the row reduction's staging (which clears what it parks there) and by
-            // assemble() (band entries only) --, so "outside the band" and "above the diagonal" read as 0.0 by themselves.  The ~200
-            // predicates of the masked version were loop invariants the compiler kept in scalar pairs, spilled into vector lanes and
-            // restored with two v_readlane each: a fifth of the substitutions' instructions (round 4, read off the ISA).
             const int lk = lane < NY ? lane : NY - 1;      // (lanes beyond the matrix repeat the last row; nothing of theirs is kept)
             if (wave == 0) {
 #pragma unroll
@@ -1578,44 +1582,44 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
 #pragma unroll
                 for (int j = 0; j < NY; j++) lrow[j] = j < TW_B ? S.K[(RV - j) * KLD + (RV - lk)] : 0.0;
             }
-            dinv_own = 0.0;
+            double *const dinv_w = wave == 0 ? S.dinv : S.dinvb;
             // (wave 0 takes TW_A pivots from the top, wave 1 TW_B from the bottom: the same number, or one less when NY - BAND is odd)
-            if constexpr (TW_A == TW_B) chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);      // (one body for both waves)
-            else if (wave == 0) chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
-            else chol_step<0, TW_B>(lrow, S.colbuf[wave], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
+            if constexpr (TW_A == TW_B) chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_w, lane, npos, 0.0, pend0, 0.0, pend0);      // (one body for both waves)
+            else if (wave == 0) chol_step<0, TW_A>(lrow, S.colbuf[wave], dinv_w, lane, npos, 0.0, pend0, 0.0, pend0);
+            else chol_step<0, TW_B>(lrow, S.colbuf[wave], dinv_w, lane, npos, 0.0, pend0, 0.0, pend0);
             if (wave == 1) {
                 // the middle block in the reversed numbering is [TW_B, TW_B + BAND); reversed (r, c) is original (RV - r, RV - c)
                 if (lane >= TW_B && lane < TW_B + BAND) {
 #pragma unroll
-                    for (int c = TW_B; c < TW_B + BAND; c++)
-                        if (c <= lane) S.mid2[(RV - c - TW_A) * BAND + (RV - lane - TW_A)] = lrow[c];
+                    for (int c = TW_B; c < TW_B + BAND; c++) S.mid2[(RV - c - TW_A) * BAND + (RV - lane - TW_A)] = lrow[c];
                 }
-                if (lane == 0) S.ok2 = ok ? 1.0 : 0.0;
+                if (lane == 0) S.ok2 = npos == TW_B ? 1.0 : 0.0;
             }
         }
         __syncthreads();
         if (wave == 0) {
             if (lane >= TW_A && lane < TW_M1) {
 #pragma unroll
-                for (int k = TW_A; k < TW_M1; k++)
-                    if (k <= lane) lrow[k] += S.mid2[(lane - TW_A) * BAND + (k - TW_A)];
+                for (int k = TW_A; k < TW_M1; k++) lrow[k] += S.mid2[(lane - TW_A) * BAND + (k - TW_A)];
             }
             if (lane >= TW_M1) {
 #pragma unroll
                 for (int k = TW_A; k < TW_M1; k++) lrow[k] = 0.0;      // rows below the middle block belong to the other sweep
             }
-            chol_step<TW_A, TW_M1>(lrow, S.colbuf[0], dinv_own, lane, ok, 0.0, pend0, 0.0, pend0);
+            chol_step<TW_A, TW_M1>(lrow, S.colbuf[0], S.dinv, lane, npos, 0.0, pend0, 0.0, pend0);
+            if (lane < TW_M1) {
 #pragma unroll
-            for (int j = 0; j < TW_M1; j++)
-                if (lane < TW_M1 && j < lane && lane - j <= BAND) S.K[lane * KLD + j] = lrow[j];
-            if (lane < TW_M1) { S.dinv[lane] = dinv_own; S.K[lane * KLD + lane] = 0.0; }      // (the diagonal of K: the substitutions read rows and columns of T unmasked)
-            if (lane == 0) S.sc[7] = ok ? 1.0 : 0.0;
+                for (int j = 0; j < TW_M1; j++)
+                    if ((unsigned)(rel - j) < (unsigned)BAND) S.K[lane * KLD + j] = lrow[j];
+                S.K[lane * KLD + lane] = 0.0;      // (the diagonal of K: the substitutions read rows and columns of T unmasked)
+            }
+            if (lane == 0) S.sc[7] = npos == TW_M1 ? 1.0 : 0.0;
         } else if (wave == 1) {
-            if (lane < TW_B) { S.dinv[RV - lane] = dinv_own; S.K[(RV - lane) * KLD + (RV - lane)] = 0.0; }
             // multipliers of the bottom-up sweep, reversed (r, c) -> original (RV-r, RV-c), kept at the mirrored band position
 #pragma unroll
             for (int c = 0; c < TW_B; c++)
-                if (lane < TW_B + BAND && c < lane && lane - c <= BAND) S.K[(RV - c) * KLD + (RV - lane)] = lrow[c];
+                if ((unsigned)(rel - c) < (unsigned)BAND) S.K[(RV - c) * KLD + (RV - lane)] = lrow[c];
+            if (lane < TW_B) S.K[(RV - lane) * KLD + (RV - lane)] = 0.0;
         }
         __syncthreads();
         return S.sc[7] != 0.0 && S.ok2 != 0.0;
@@ -1638,7 +1642,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             const double *Krow = S.K + lr * KLD;            // T[l][.]
             const double *Kcol = S.K + lr;                  // T[.][l]
             const double rhs = l < NY ? S.rhs[l] : 0.0;
-            const double dinv = l < NY ? S.dinv[l] : 0.0;
+            const double dinv = l < TW_M1 ? S.dinv[l] : S.dinvb[l < NY ? RV - l : 0];
             double bt = l < TW_M1 ? rhs : 0.0;              // top-down sweep: unknowns 0..13, what it takes off the middle rows
             double bb = l >= TW_M1 ? rhs : 0.0;             // bottom-up sweep: unknowns 38..25, what it takes off the middle rows
             {
