@@ -12,8 +12,10 @@ __device__ __forceinline__ double dpp_move(double v, double identity)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
     const int ilo = __double2loint(identity), ihi = __double2hiint(identity);
-    lo = __builtin_amdgcn_update_dpp(ilo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(ihi, hi, CTRL, 0xf, 0xf, false);
+    // (identity 0.0 = bound_ctrl: a lane without a source reads zero, and the destination needs no initialising move)
+    const bool zero_id = ilo == 0 && ihi == 0;
+    lo = zero_id ? __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(ilo, lo, CTRL, 0xf, 0xf, false);
+    hi = zero_id ? __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(ihi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_value(double v, int lane_const)
