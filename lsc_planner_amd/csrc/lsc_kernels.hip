@@ -1213,16 +1213,25 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     __syncthreads();
     if constexpr (!SPILL) {
         // slot tables of the row reduction: bucket b is cut into parts of rpl rows; rpl is the smallest that fits the staging
-        if (tid < 2) {
-            const int cap_slots = tid == 0 ? RSLOT_P : RSLOT_C, min_rpl = 4;
+        // (one lane per bucket and table, the offsets by a 32-lane prefix sum: two lanes walking the 27 buckets with a division each were
+        //  ~670 instructions on a wave everybody waited for, 1.7 us per tick)
+        static_assert(NB < 32, "one half-wave per slot table");
+        if (tid < 64) {
+            const int which = tid >> 5, b = tid & 31;
+            const int cap_slots = which == 0 ? RSLOT_P : RSLOT_C, min_rpl = 4;
             const int na_ = S.nact;
             int rpl = (na_ + (cap_slots - NB) - 1) / (cap_slots - NB);
             rpl = rpl < min_rpl ? min_rpl : rpl;
-            unsigned short *so = tid == 0 ? S.soffP : S.soffC;
-            int o = 0;
-            for (int b = 0; b < NB; b++) { so[b] = (unsigned short)o; o += (S.cnt[b + 3] + rpl - 1) / rpl; }
-            so[NB] = (unsigned short)o;
-            S.rpl[tid] = rpl;
+            const int parts = b < NB ? (S.cnt[b + 3] + rpl - 1) / rpl : 0;
+            int incl = parts;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const int up = __shfl_up(incl, d, 32);
+                if (b >= d) incl += up;
+            }
+            unsigned short *so = which == 0 ? S.soffP : S.soffC;
+            if (b <= NB) so[b] = (unsigned short)(incl - parts);
+            if (b == 0) S.rpl[which] = rpl;
         }
         __syncthreads();
         for (int q = tid; q < 2 * NB; q += NT) {
