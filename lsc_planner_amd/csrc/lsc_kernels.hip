@@ -1345,8 +1345,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
     double rv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int red_bank = 0;
     auto block_reduce = [&](double v0, double v1, double v2, double v3, double v4, int op0, int op1, int op2, int op3, int op4) {
-        auto wr = [&](double v, int op) { return op < 0 ? 0.0 : (op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v))); };
-        double r0 = wr(v0, op0), r1 = wr(v1, op1), r2 = wr(v2, op2), r3 = wr(v3, op3), r4 = wr(v4, op4);
+        double wv[5] = {v0, v1, v2, v3, v4};
+        const int wop[5] = {op0, op1, op2, op3, op4};
+        wave_reduce5(wv, wop);                // (stage by stage over the values: lsc_wave.hpp)
+        const double r0 = wv[0], r1 = wv[1], r2 = wv[2], r3 = wv[3], r4 = wv[4];
         auto &bank = S.red[red_bank];         // [5][waves of the largest build]
         if (lane == 0) {
             bank[0][wave] = r0;
@@ -1666,8 +1668,12 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 //  above the diagonal, the zeroed diagonal, outside the band; see factor())
 #pragma unroll
                 for (int q = 0; q < TW_A; q++) {
-                    bt = fma(-ct[q], lane_value(bt, q), bt);
-                    if (q < TW_B) bb = fma(-cb[q < TW_B ? q : 0], lane_value(bb, RV - q), bb);
+                    // both broadcasts first, in scalar pairs of their own, then both updates: with one pair reused for the two chains every
+                    // update sat one wait state behind its v_readlane (VALU-writes-SGPR hazard), 27 s_nop per solve on the wave that issues alone
+                    double xt = lane_value(bt, q), xb = q < TW_B ? lane_value(bb, RV - (q < TW_B ? q : 0)) : 0.0;
+                    asm volatile("" : "+s"(xt), "+s"(xb));
+                    bt = fma(-ct[q], xt, bt);
+                    if (q < TW_B) bb = fma(-cb[q < TW_B ? q : 0], xb, bb);
                 }
             }
             double b = bt + bb;
@@ -1707,8 +1713,10 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 pin_values(ci);
 #pragma unroll
                 for (int q = 0; q < TW_A - 1; q++) {
-                    bt = fma(-co[q], lane_value(bt, TW_A - 1 - q), bt);
-                    if (q < TW_B - 1) bb = fma(-ci[q < TW_B - 1 ? q : 0], lane_value(bb, TW_M1 + q), bb);
+                    double xt = lane_value(bt, TW_A - 1 - q), xb = q < TW_B - 1 ? lane_value(bb, TW_M1 + (q < TW_B - 1 ? q : 0)) : 0.0;
+                    asm volatile("" : "+s"(xt), "+s"(xb));
+                    bt = fma(-co[q], xt, bt);
+                    if (q < TW_B - 1) bb = fma(-ci[q < TW_B - 1 ? q : 0], xb, bb);
                 }
             }
             if (l < NY) S.dy[l] = l < TW_M1 ? bt : bb;
@@ -1936,38 +1944,41 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 phase = ST_PRED;
                 stamp(PH_INIT);
             } else if (phase == ST_PRED) {
-                // P2: affine step length and centring statistics (+ the Newton-step convergence test)
-                double amin = 1.0, s1 = 0.0, s2 = 0.0;
+                // P2: affine step length and centring statistics (+ the Newton-step convergence test).
+                // Ratio test without a division: along the affine direction s dz + z ds = -s z, so with r = ds / s (= ds * t1, t1 = 1 / s from
+                // P1) the two ratios of a row are -ds / s = -r and -dz / z = 1 + r; the step is 1 / max(1, max over rows of both).  (Two
+                // predicated fp64 divisions per row stood here: ~15 instructions each.)
+                double rmax = 0.0, s1 = 0.0, s2 = 0.0;
                 for (int c = tid; c < n_ax; c += NT) {
                     const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, k = (am >> 13) & 3, t = am >> 15;
-                    double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
+                    double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl], w = zv * is;
                     double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
                     double adx = ax_row(S.dx, type, k, t);
                     double ds = -rp - adx, dz = -zv - w * ds;
-                    if (ds < 0.0) amin = fmin(amin, -sv / ds);
-                    if (dz < 0.0) amin = fmin(amin, -zv / dz);
+                    const double r = ds * is;
+                    rmax = fmax(rmax, fmax(-r, 1.0 + r));
                     s1 += sv * dz + zv * ds; s2 += ds * dz;
                     S.at2[sl] = ds * dz;
                 }
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
-                    const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
-                    double sv = rs[r], zv = rz[r], w = zv * rt1[r];
-                    double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
-                    double adx = lsc_ax(S.dx, r, cp);
+                    const int r_ = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
+                    double sv = rs[r_], zv = rz[r_], is = rt1[r_], w = zv * is;
+                    double rp = lsc_ax(S.x, r_, cp) + sv + rrhs[r_];
+                    double adx = lsc_ax(S.dx, r_, cp);
                     double ds = -rp - adx, dz = -zv - w * ds;
-                    if (ds < 0.0) amin = fmin(amin, -sv / ds);
-                    if (dz < 0.0) amin = fmin(amin, -zv / dz);
+                    const double r = ds * is;
+                    rmax = fmax(rmax, fmax(-r, 1.0 + r));
                     s1 += sv * dz + zv * ds; s2 += ds * dz;
-                    rt2[r] = ds * dz;
+                    rt2[r_] = ds * dz;
                 }
                 const double dxa = (tid < NV) ? fabs(S.dx[tid]) : 0.0, xa = (tid < NV) ? fabs(S.x[tid]) : 0.0;
-                block_reduce(amin, s1, s2, dxa, xa, 2, 0, 0, 1, 1);
+                block_reduce(rmax, s1, s2, dxa, xa, 1, 0, 0, 1, 1);
                 // Newton-step test: with gap and primal residual at tolerance, the affine (pure Newton) step measures
                 // the distance to the optimum (the stationarity residual itself can stall at the round-off level of
                 // the ill-conditioned normal equations when z/s is huge).
                 if (rpmax <= 1e-9 * hmax && gap_ok && rv[3] <= md.dx_tol * fmax(1.0, rv[4])) { status = LSC_STATUS_OK_K; break; }
-                const double aaff = rv[0];
+                const double aaff = 1.0 / fmax(rv[0], 1.0);
                 const double mu_aff = (gap + aaff * rv[1] + aaff * aaff * rv[2]) / nrow;
                 double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
                 sigma = md.sigma_pow == 2 ? sigma * sigma : (md.sigma_pow == 4 ? (sigma * sigma) * (sigma * sigma) : sigma * sigma * sigma);
@@ -1980,31 +1991,31 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 phase = ST_CORR;
                 stamp(PH_P2);
             } else {
-                // P4: step length; the step itself stays in t1 = ds, t2 = dz for the fused pass of the next round
-                double amin = 1e300;
+                // P4: step length; the step itself stays in t1 = ds, t2 = dz for the fused pass of the next round.
+                // (ratio test as max of -ds / s = -ds * t1 and -dz / z = -dz * (1 / z), reciprocal by v_rcp_f64 + one Newton step; one division
+                //  per workgroup behind the reduction instead of two predicated ones per row)
+                double rmax = 0.0;
                 for (int c = tid; c < n_ax; c += NT) {
                     const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, k = (am >> 13) & 3, t = am >> 15;
-                    double sv = S.as_[sl], zv = S.az[sl], w = zv * S.at1[sl];
+                    double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl], w = zv * is;
                     double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
                     double adx = ax_row(S.dx, type, k, t);
                     double ds = -rp - adx, dz = -zv + S.at2[sl] + w * adx;
-                    if (ds < 0.0) amin = fmin(amin, -sv / ds);
-                    if (dz < 0.0) amin = fmin(amin, -zv / dz);
+                    rmax = fmax(rmax, fmax(-ds * is, -dz * rcp_nr(zv)));
                     S.at1[sl] = ds; S.at2[sl] = dz;
                 }
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
                     const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
-                    double sv = rs[r], zv = rz[r], w = zv * rt1[r];
+                    double sv = rs[r], zv = rz[r], is = rt1[r], w = zv * is;
                     double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
                     double adx = lsc_ax(S.dx, r, cp);
                     double ds = -rp - adx, dz = -zv + rt2[r] + w * adx;
-                    if (ds < 0.0) amin = fmin(amin, -sv / ds);
-                    if (dz < 0.0) amin = fmin(amin, -zv / dz);
+                    rmax = fmax(rmax, fmax(-ds * is, -dz * rcp_nr(zv)));
                     rt1[r] = ds; rt2[r] = dz;
                 }
-                block_reduce(amin, 0.0, 0.0, 0.0, 0.0, 2, -1, -1, -1, -1);
-                alpha = fmin(1.0, tau * rv[0]);
+                block_reduce(rmax, 0.0, 0.0, 0.0, 0.0, 1, -1, -1, -1, -1);
+                alpha = rv[0] > tau ? tau / rv[0] : 1.0;      // min(1, tau / max ratio); no row limits the step: 1
                 if (a.trace && qi == a.trace_agent && tid == 0 && iters < 64) a.trace[iters * 8 + 5] = alpha;
                 if (wave == 0) {
                     if (lane < NY) S.y[lane] += alpha * S.dy[lane];

@@ -62,6 +62,45 @@ __device__ __forceinline__ double wave_reduce(double v)
     v = red_op<OP>(v, dpp_move<0x118>(v, id));   // row_shr:8  -> lane 15 of every row holds the row result
     return red_op<OP>(red_op<OP>(lane_value(v, 15), lane_value(v, 31)), red_op<OP>(lane_value(v, 47), lane_value(v, 63)));
 }
+// Up to five values at once, stage by stage: the moves of one value fill the wait states behind another's (a DPP move may not follow the
+// instruction that wrote its source by less than two wait states; value by value, a five-value reduction carried ~40 s_nop).
+// op[i]: 0 sum, 1 max, 2 min, < 0 unused (compile-time constants at every call site: the selects fold).
+template <int CTRL>
+__device__ __forceinline__ void red5_stage(double (&v)[5], int (&tlo)[5], int (&thi)[5], const int (&op)[5])
+{
+    double m[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        if (op[i] < 0) continue;
+        if (op[i] == 0) m[i] = dpp_move<CTRL>(v[i], 0.0);
+        else {
+            tlo[i] = __builtin_amdgcn_update_dpp(tlo[i], __double2loint(v[i]), CTRL, 0xf, 0xf, false);
+            thi[i] = __builtin_amdgcn_update_dpp(thi[i], __double2hiint(v[i]), CTRL, 0xf, 0xf, false);
+            m[i] = __hiloint2double(thi[i], tlo[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        if (op[i] < 0) continue;
+        v[i] = op[i] == 0 ? v[i] + m[i] : (op[i] == 1 ? hw_extreme<1>(v[i], m[i]) : hw_extreme<2>(v[i], m[i]));
+    }
+}
+__device__ __forceinline__ void wave_reduce5(double (&v)[5], const int (&op)[5])
+{
+    int tlo[5], thi[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { tlo[i] = __double2loint(v[i]); thi[i] = __double2hiint(v[i]); }
+    red5_stage<0x111>(v, tlo, thi, op);
+    red5_stage<0x112>(v, tlo, thi, op);
+    red5_stage<0x114>(v, tlo, thi, op);
+    red5_stage<0x118>(v, tlo, thi, op);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        if (op[i] < 0) { v[i] = 0.0; continue; }
+        const double a = lane_value(v[i], 15), b = lane_value(v[i], 31), c = lane_value(v[i], 47), d = lane_value(v[i], 63);
+        v[i] = op[i] == 0 ? (a + b) + (c + d) : (op[i] == 1 ? hw_extreme<1>(hw_extreme<1>(a, b), hw_extreme<1>(c, d)) : hw_extreme<2>(hw_extreme<2>(a, b), hw_extreme<2>(c, d)));
+    }
+}
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce<0>(v); }
 __device__ __forceinline__ double wave_max(double v) { return wave_reduce<1>(v); }
 __device__ __forceinline__ double wave_min(double v) { return wave_reduce<2>(v); }
