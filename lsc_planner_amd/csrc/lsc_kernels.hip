@@ -1441,18 +1441,36 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 const uint32_t e = with_w ? S.slotP[tid] : S.slotC[tid];
                 const int r0 = (int)(e & 0xffffu), n = (int)((e >> 16) & 0xffu);
                 double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, t0 = 0, t1 = 0, t2 = 0, u0 = 0, u1 = 0, u2 = 0;
-                for (int q = 0; q < n; q++) {
-                    const int r = r0 + q;
-                    const double nx = (double)rn[r], ny = (double)rn[R + r], nz = (double)rn[2 * R + r];
-                    const double vv = rt2[r];
-                    t0 = fma(vv, nx, t0); t1 = fma(vv, ny, t1); t2 = fma(vv, nz, t2);
-                    if (with_w) {
-                        const double zv = rz[r];
-                        u0 = fma(zv, nx, u0); u1 = fma(zv, ny, u1); u2 = fma(zv, nz, u2);
-                        const double w = unit_w ? 1.0 : zv * rt1[r];
-                        const double wx = w * nx, wy = w * ny, wz = w * nz;
-                        s0 = fma(wx, nx, s0); s1 = fma(wx, ny, s1); s2 = fma(wx, nz, s2);
-                        s3 = fma(wy, ny, s3); s4 = fma(wy, nz, s4); s5 = fma(wz, nz, s5);
+                // Two rows per trip, all twelve loads of the pair issued before anything waits (they used to sit behind the uniform
+                // branches of the pass kind, one LDS round trip each: four per row).  An odd last row is read twice and its second copy
+                // carries weight zero; the rows of a slot are still added in their order.
+                for (int q = 0; q < n; q += 2) {
+                    const int ra = r0 + q, rb = q + 1 < n ? ra + 1 : ra;
+                    const bool two = q + 1 < n;
+                    const float fax = rn[ra], fay = rn[R + ra], faz = rn[2 * R + ra], fbx = rn[rb], fby = rn[R + rb], fbz = rn[2 * R + rb];
+                    const double va = rt2[ra], vb_ = rt2[rb], za_ = rz[ra], zb_ = rz[rb], ia = rt1[ra], ib = rt1[rb];
+                    const double vb = two ? vb_ : 0.0, zb = two ? zb_ : 0.0;
+                    {
+                        const double nx = (double)fax, ny = (double)fay, nz = (double)faz;
+                        t0 = fma(va, nx, t0); t1 = fma(va, ny, t1); t2 = fma(va, nz, t2);
+                        if (with_w) {
+                            u0 = fma(za_, nx, u0); u1 = fma(za_, ny, u1); u2 = fma(za_, nz, u2);
+                            const double w = unit_w ? 1.0 : za_ * ia;
+                            const double wx = w * nx, wy = w * ny, wz = w * nz;
+                            s0 = fma(wx, nx, s0); s1 = fma(wx, ny, s1); s2 = fma(wx, nz, s2);
+                            s3 = fma(wy, ny, s3); s4 = fma(wy, nz, s4); s5 = fma(wz, nz, s5);
+                        }
+                    }
+                    {
+                        const double nx = (double)fbx, ny = (double)fby, nz = (double)fbz;
+                        t0 = fma(vb, nx, t0); t1 = fma(vb, ny, t1); t2 = fma(vb, nz, t2);
+                        if (with_w) {
+                            u0 = fma(zb, nx, u0); u1 = fma(zb, ny, u1); u2 = fma(zb, nz, u2);
+                            const double w = two ? (unit_w ? 1.0 : zb * ib) : 0.0;
+                            const double wx = w * nx, wy = w * ny, wz = w * nz;
+                            s0 = fma(wx, nx, s0); s1 = fma(wx, ny, s1); s2 = fma(wx, nz, s2);
+                            s3 = fma(wy, ny, s3); s4 = fma(wy, nz, s4); s5 = fma(wz, nz, s5);
+                        }
                     }
                 }
                 double *o = stage + tid * ncomp;
@@ -1468,8 +1486,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     double *e = stage + sl * ncomp + c;
                     sum += *e;
                     *e = 0.0;                                      // (K must not keep anything assemble() does not overwrite)
-                }
-                const int j = with_w ? c : c + 6;
+                }                const int j = with_w ? c : c + 6;
                 if (j < 6) S.W[W_S + cp * 6 + j] = sum;
                 else if (j < 9) S.Tv[cp * 3 + (j - 6)] = -sum;
                 else S.Tz[cp * 3 + (j - 9)] = -sum;
