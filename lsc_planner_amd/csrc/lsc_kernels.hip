@@ -464,6 +464,19 @@ __device__ __forceinline__ double ax_row(const double *x, int type, int k, int t
     return (type & 1) ? -v : v;
 }
 
+// the same from three loaded values (the row passes load everything a row needs in one batch, see LSC_PIN)
+__device__ __forceinline__ double ax_row3(double x0, double x1, double x2, int type)
+{
+    const int kind = type >> 1;
+    const double a0 = kind == 1 ? -1.0 : 1.0, a1 = kind == 0 ? 0.0 : (kind == 1 ? 1.0 : -2.0), a2 = kind == 2 ? 1.0 : 0.0;
+    const double v = fma(a2, x2, fma(a1, x1, a0 * x0));
+    return (type & 1) ? -v : v;
+}
+// All operands in registers HERE: the loads that produce them are issued together ahead of this point and waited for once.  Left to
+// itself the scheduler puts every load directly in front of its first use -- four to five LDS round trips per row in the row passes.
+#define LSC_PIN(...) asm volatile("" : __VA_ARGS__)
+#define PV(x) "+v"(x)
+
 // value of lane L (compile-time) broadcast to the wave: two v_readlane_b32, no LDS round trip
 template <int L>
 __device__ __forceinline__ double bcast_lane(double v)
@@ -1844,8 +1857,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 double gp = 0.0, rpm = 0.0;
                 for (int c = tid; c < n_ax; c += NT) {
                     const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
-                    double sv = S.as_[sl] + alpha * S.at1[sl], zv = S.az[sl] + alpha * S.at2[sl];
-                    double rp = ax_row(S.x, type, ak, at) + sv - AH(sl);
+                    const double *xq = S.x + ak * SEGV + at;
+                    double l_s = S.as_[sl], l_ds = S.at1[sl], l_z = S.az[sl], l_dz = S.at2[sl], x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl);
+                    LSC_PIN(PV(l_s), PV(l_ds), PV(l_z), PV(l_dz), PV(x0), PV(x1), PV(x2), PV(hh));
+                    double sv = l_s + alpha * l_ds, zv = l_z + alpha * l_dz;
+                    double rp = ax_row3(x0, x1, x2, type) + sv - hh;
                     double is = 1.0 / sv;
                     S.as_[sl] = sv; S.az[sl] = zv;
                     S.at1[sl] = is;
@@ -1855,8 +1871,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
                     const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
-                    double sv = rs[r] + alpha * rt1[r], zv = rz[r] + alpha * rt2[r];
-                    double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
+                    double l_s = rs[r], l_ds = rt1[r], l_z = rz[r], l_dz = rt2[r], x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r];
+                    float n0 = rn[r], n1 = rn[R + r], n2 = rn[2 * R + r];
+                    LSC_PIN(PV(l_s), PV(l_ds), PV(l_z), PV(l_dz), PV(x0), PV(x1), PV(x2), PV(hh), PV(n0), PV(n1), PV(n2));
+                    double sv = l_s + alpha * l_ds, zv = l_z + alpha * l_dz;
+                    double rp = -((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2) + sv + hh;
                     double is = 1.0 / sv;
                     rs[r] = sv; rz[r] = zv;
                     rt1[r] = is;
@@ -1886,16 +1905,20 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             // P3: corrector right-hand side  v = w rp - (ds dz - sigma mu)/s
             for (int c = tid; c < n_ax; c += NT) {
                 const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
-                double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl];
-                double rp = ax_row(S.x, type, ak, at) + sv - AH(sl);
-                S.at2[sl] = zv * is * rp - (S.at2[sl] - smu) * is;
+                const double *xq = S.x + ak * SEGV + at;
+                double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl], cc = S.at2[sl], x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl);
+                LSC_PIN(PV(sv), PV(zv), PV(is), PV(cc), PV(x0), PV(x1), PV(x2), PV(hh));
+                double rp = ax_row3(x0, x1, x2, type) + sv - hh;
+                S.at2[sl] = zv * is * rp - (cc - smu) * is;
             }
             for (int c = tid; c < nact; c += NT) {
                 const uint32_t e = cmap[c];
                 const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
-                double sv = rs[r], zv = rz[r], is = rt1[r];
-                double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
-                rt2[r] = zv * is * rp - (rt2[r] - smu) * is;
+                double sv = rs[r], zv = rz[r], is = rt1[r], cc = rt2[r], x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r];
+                float n0 = rn[r], n1 = rn[R + r], n2 = rn[2 * R + r];
+                LSC_PIN(PV(sv), PV(zv), PV(is), PV(cc), PV(x0), PV(x1), PV(x2), PV(hh), PV(n0), PV(n1), PV(n2));
+                double rp = -((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2) + sv + hh;
+                rt2[r] = zv * is * rp - (cc - smu) * is;
             }
             __syncthreads();
             stamp(PH_P3);
@@ -1968,9 +1991,12 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 double rmax = 0.0, s1 = 0.0, s2 = 0.0;
                 for (int c = tid; c < n_ax; c += NT) {
                     const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, k = (am >> 13) & 3, t = am >> 15;
-                    double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl], w = zv * is;
-                    double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
-                    double adx = ax_row(S.dx, type, k, t);
+                    const double *xq = S.x + k * SEGV + t, *dq = S.dx + k * SEGV + t;
+                    double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl], x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl), d0 = dq[0], d1 = dq[1], d2 = dq[2];
+                    LSC_PIN(PV(sv), PV(zv), PV(is), PV(x0), PV(x1), PV(x2), PV(hh), PV(d0), PV(d1), PV(d2));
+                    double w = zv * is;
+                    double rp = ax_row3(x0, x1, x2, type) + sv - hh;
+                    double adx = ax_row3(d0, d1, d2, type);
                     double ds = -rp - adx, dz = -zv - w * ds;
                     const double r = ds * is;
                     rmax = fmax(rmax, fmax(-r, 1.0 + r));
@@ -1980,9 +2006,13 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
                     const int r_ = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
-                    double sv = rs[r_], zv = rz[r_], is = rt1[r_], w = zv * is;
-                    double rp = lsc_ax(S.x, r_, cp) + sv + rrhs[r_];
-                    double adx = lsc_ax(S.dx, r_, cp);
+                    double sv = rs[r_], zv = rz[r_], is = rt1[r_], x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r_];
+                    double d0 = S.dx[cp], d1 = S.dx[SEGV + cp], d2 = S.dx[2 * SEGV + cp];
+                    float n0 = rn[r_], n1 = rn[R + r_], n2 = rn[2 * R + r_];
+                    LSC_PIN(PV(sv), PV(zv), PV(is), PV(x0), PV(x1), PV(x2), PV(hh), PV(d0), PV(d1), PV(d2), PV(n0), PV(n1), PV(n2));
+                    double w = zv * is;
+                    double rp = -((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2) + sv + hh;
+                    double adx = -((double)n0 * d0 + (double)n1 * d1 + (double)n2 * d2);
                     double ds = -rp - adx, dz = -zv - w * ds;
                     const double r = ds * is;
                     rmax = fmax(rmax, fmax(-r, 1.0 + r));
@@ -2014,20 +2044,27 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 double rmax = 0.0;
                 for (int c = tid; c < n_ax; c += NT) {
                     const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, k = (am >> 13) & 3, t = am >> 15;
-                    double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl], w = zv * is;
-                    double rp = ax_row(S.x, type, k, t) + sv - AH(sl);
-                    double adx = ax_row(S.dx, type, k, t);
-                    double ds = -rp - adx, dz = -zv + S.at2[sl] + w * adx;
+                    const double *xq = S.x + k * SEGV + t, *dq = S.dx + k * SEGV + t;
+                    double sv = S.as_[sl], zv = S.az[sl], is = S.at1[sl], cc = S.at2[sl], x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl), d0 = dq[0], d1 = dq[1], d2 = dq[2];
+                    LSC_PIN(PV(sv), PV(zv), PV(is), PV(cc), PV(x0), PV(x1), PV(x2), PV(hh), PV(d0), PV(d1), PV(d2));
+                    double w = zv * is;
+                    double rp = ax_row3(x0, x1, x2, type) + sv - hh;
+                    double adx = ax_row3(d0, d1, d2, type);
+                    double ds = -rp - adx, dz = -zv + cc + w * adx;
                     rmax = fmax(rmax, fmax(-ds * is, -dz * rcp_nr(zv)));
                     S.at1[sl] = ds; S.at2[sl] = dz;
                 }
                 for (int c = tid; c < nact; c += NT) {
                     const uint32_t e = cmap[c];
                     const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
-                    double sv = rs[r], zv = rz[r], is = rt1[r], w = zv * is;
-                    double rp = lsc_ax(S.x, r, cp) + sv + rrhs[r];
-                    double adx = lsc_ax(S.dx, r, cp);
-                    double ds = -rp - adx, dz = -zv + rt2[r] + w * adx;
+                    double sv = rs[r], zv = rz[r], is = rt1[r], cc = rt2[r], x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r];
+                    double d0 = S.dx[cp], d1 = S.dx[SEGV + cp], d2 = S.dx[2 * SEGV + cp];
+                    float n0 = rn[r], n1 = rn[R + r], n2 = rn[2 * R + r];
+                    LSC_PIN(PV(sv), PV(zv), PV(is), PV(cc), PV(x0), PV(x1), PV(x2), PV(hh), PV(d0), PV(d1), PV(d2), PV(n0), PV(n1), PV(n2));
+                    double w = zv * is;
+                    double rp = -((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2) + sv + hh;
+                    double adx = -((double)n0 * d0 + (double)n1 * d1 + (double)n2 * d2);
+                    double ds = -rp - adx, dz = -zv + cc + w * adx;
                     rmax = fmax(rmax, fmax(-ds * is, -dz * rcp_nr(zv)));
                     rt1[r] = ds; rt2[r] = dz;
                 }
