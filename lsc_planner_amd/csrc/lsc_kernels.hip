@@ -969,17 +969,21 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
         // A = amax dt^2/(n(n-1)) (acceleration rows :494-523; C1/C2 continuity carries both across segment ends), and the
         // first difference d0 = c_{0,2} - c_{0,1} is fixed by the current state.  Hence after K steps, per axis,
         //   sum_{j<=K} max(-V, d0 - jA)  <=  c - c_{0,2}  <=  sum_{j<=K} min(V, d0 + jA).
-        if (tid < 3) {
-            const int k = tid;
+        // (one lane per step and axis, the sums by a 32-lane prefix scan: three lanes walking the 27 steps were 1.2 us per tick on a wave
+        //  everybody waited for.  The scan adds in another order than the walk -- a few ulp, against a 1e-9 pad per step.)
+        if (tid < 96) {
+            const int k = tid >> 5, j = tid & 31;
             const double V = a.vmax[3 * qi + k] * md.hv_scale, A = a.amax[3 * qi + k] * md.ha_scale;
             const double d0 = S.s0[k][2] - S.s0[k][1];
-            double lo = 0.0, hi = 0.0;
-            S.reachL[k][0] = 0.0; S.reachU[k][0] = 0.0;
-            for (int j = 1; j < 28; j++) {
-                lo += fmax(-V, d0 - (double)j * A) - 1e-9;
-                hi += fmin(V, d0 + (double)j * A) + 1e-9;
-                S.reachL[k][j] = lo; S.reachU[k][j] = hi;
+            const bool in = j >= 1 && j < 28;
+            double lo = in ? fmax(-V, d0 - (double)j * A) - 1e-9 : 0.0;
+            double hi = in ? fmin(V, d0 + (double)j * A) + 1e-9 : 0.0;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const double ul = __shfl_up(lo, d, 32), uh = __shfl_up(hi, d, 32);
+                if (j >= d) { lo += ul; hi += uh; }
             }
+            if (j < 28) { S.reachL[k][j] = lo; S.reachU[k][j] = hi; }
         }
         __syncthreads();
         // ---- spatial pre-cull (large swarms): most obstacles are so far away that every row against them is redundant,
@@ -1191,62 +1195,84 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 kslot = __builtin_amdgcn_readfirstlane(base) + pre;
             }
             __syncthreads();
+            // first position of every wave's rows in every bucket: the bucket's count so far + the rows of the waves in front.  One lane per
+            // (wave, control point), its loads in one batch; every row then needs ONE word.  (Each row used to walk the counts of the waves in
+            // front of it, an LDS round trip per wave: up to 42 dependent trips per lane, 5 us per tick at 64 agents -- more than the GJK.)
+            int *const wpre = reinterpret_cast<int *>(&S.colbuf[0][0]);      // [NWAVE + 1][32]; the factorisation's buffers are idle in phase B
+            static_assert(sizeof(S.colbuf) >= sizeof(int) * (NWAVE + 1) * 32, "scratch of the bucket positions");
+            if (tid < NWAVE * 32) {
+                const int w = tid >> 5, cp = tid & 31;
+                int c[NWAVE];
+#pragma unroll
+                for (int v = 0; v < NWAVE; v++) c[v] = S.wcnt[v][cp];
+                int sum = S.cnt[cp];
+#pragma unroll
+                for (int v = 0; v < NWAVE; v++) sum += v < w ? c[v] : 0;
+                wpre[w * 32 + cp] = sum;
+                if (w == NWAVE - 1) wpre[NWAVE * 32 + cp] = sum + c[NWAVE - 1];      // the bucket's new count
+            }
+            __syncthreads();
             if (live) {
+                int base[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) base[i] = wpre[wave * 32 + m * NC + i];
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     if (!actv[i]) continue;
                     const int cp = m * NC + i;
-                    int pos = S.cnt[cp] + rank[i];          // position inside the bucket: obstacle order, deterministic
-                    for (int w = 0; w < wave; w++) pos += S.wcnt[w][cp];
+                    const int pos = base[i] + rank[i];      // position inside the bucket: obstacle order, deterministic
                     const int k = kslot++;
                     if (k < R) tmp_rows[k] = TmpRow{rhs[i], nrm.x, nrm.y, nrm.z, (uint32_t)cp | ((uint32_t)pos << 8)};
                 }
             }
-            __syncthreads();
-            if (tid < NCP) {
-                int c = S.cnt[tid];
-                for (int w = 0; w < NWAVE; w++) c += S.wcnt[w][tid];
-                S.cnt[tid] = c;
-            }
-            __syncthreads();
+            if (tid < NCP) S.cnt[tid] = wpre[NWAVE * 32 + tid];      // (next read behind the next barrier: the next pass's, or the one below)
         }
+        __syncthreads();
     }
-    if (tid == 0) {
-        int o = 0, mx = 0;
-        for (int b = 0; b < NB; b++) { S.offs[b] = o; o += S.cnt[b + 3]; mx = S.cnt[b + 3] > mx ? S.cnt[b + 3] : mx; }
-        if (a.bucket_max) a.bucket_max[qi] = mx;     // diagnostics: the fullest control-point bucket
-        if (o > R) {                                 // more rows than this pass holds: left to the pass with the rows in HBM
-            S.flag = 1;
-            o = 0;
-            for (int b = 0; b < 32; b++) S.cnt[b] = 0;
+    // bucket offsets, and (rows in LDS) the slot tables of the row reduction -- bucket b is cut into parts of rpl rows; rpl is the smallest
+    // that fits the staging --: one lane per bucket (and table), offsets by 32-lane prefix sums.  (One lane walking the 27 buckets for
+    // the offsets and two walking them with a division each for the tables were ~900 instructions on a wave everybody waited for.)
+    static_assert(NB < 32, "one half-wave per bucket table");
+    if (tid < 64) {
+        const int which = tid >> 5, b = tid & 31;
+        int c = b < NB ? S.cnt[b + 3] : 0;
+        int incl = c, mx = c;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const int up = __shfl_up(incl, d, 32);
+            if (b >= d) incl += up;
+            mx = max(mx, __shfl_xor(mx, d, 32));
         }
-        for (int b = 0; b < NB; b++) S.offcnt[b] = (uint32_t)S.offs[b] | ((uint32_t)S.cnt[b + 3] << 16);
-        S.nact = o;
+        int total = __shfl(incl, 31, 32);
+        const bool over = total > R;                 // more rows than this pass holds: left to the pass with the rows in HBM
+        if (over) { c = 0; incl = 0; total = 0; }
+        if (which == 0) {
+            if (b < NB) { S.offs[b] = incl - c; S.offcnt[b] = (uint32_t)(incl - c) | ((uint32_t)c << 16); }
+            if (over) S.cnt[b] = 0;
+            if (b == 0) {
+                if (a.bucket_max) a.bucket_max[qi] = mx;     // diagnostics: the fullest control-point bucket
+                if (over) S.flag = 1;
+                S.nact = total;
+            }
+        }
+        if constexpr (!SPILL) {
+            const int cap_slots = which == 0 ? RSLOT_P : RSLOT_C, min_rpl = 4;
+            int rpl = (total + (cap_slots - NB) - 1) / (cap_slots - NB);
+            rpl = rpl < min_rpl ? min_rpl : rpl;
+            const int parts = b < NB ? (c + rpl - 1) / rpl : 0;
+            int pin = parts;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const int up = __shfl_up(pin, d, 32);
+                if (b >= d) pin += up;
+            }
+            unsigned short *so = which == 0 ? S.soffP : S.soffC;
+            if (b <= NB) so[b] = (unsigned short)(pin - parts);
+            if (b == 0) S.rpl[which] = rpl;
+        }
     }
     __syncthreads();
     if constexpr (!SPILL) {
-        // slot tables of the row reduction: bucket b is cut into parts of rpl rows; rpl is the smallest that fits the staging
-        // (one lane per bucket and table, the offsets by a 32-lane prefix sum: two lanes walking the 27 buckets with a division each were
-        //  ~670 instructions on a wave everybody waited for, 1.7 us per tick)
-        static_assert(NB < 32, "one half-wave per slot table");
-        if (tid < 64) {
-            const int which = tid >> 5, b = tid & 31;
-            const int cap_slots = which == 0 ? RSLOT_P : RSLOT_C, min_rpl = 4;
-            const int na_ = S.nact;
-            int rpl = (na_ + (cap_slots - NB) - 1) / (cap_slots - NB);
-            rpl = rpl < min_rpl ? min_rpl : rpl;
-            const int parts = b < NB ? (S.cnt[b + 3] + rpl - 1) / rpl : 0;
-            int incl = parts;
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
-                const int up = __shfl_up(incl, d, 32);
-                if (b >= d) incl += up;
-            }
-            unsigned short *so = which == 0 ? S.soffP : S.soffC;
-            if (b <= NB) so[b] = (unsigned short)(incl - parts);
-            if (b == 0) S.rpl[which] = rpl;
-        }
-        __syncthreads();
         for (int q = tid; q < 2 * NB; q += NT) {
             const int which = q >= NB, b = which ? q - NB : q;
             const unsigned short *so = which ? S.soffC : S.soffP;
