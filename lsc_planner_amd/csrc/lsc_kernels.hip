@@ -1595,9 +1595,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     uint32_t tm[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) tm[u] = terms[q + u < t1 ? q + u : t0];
+                    LSC_PIN(PV(tm[0]), PV(tm[1]), PV(tm[2]), PV(tm[3]));      // (the four words in one batch, then the four weights in one)
                     double w[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) w[u] = S.W[(tm[u] >> 8) & 0x3ff];
+                    LSC_PIN(PV(w[0]), PV(w[1]), PV(w[2]), PV(w[3]));
 #pragma unroll
                     for (int u = 0; u < 4; u++) v += (q + u < t1 ? (double)((int)(tm[u] & 0xff) - 128) : 0.0) * w[u];
                 }

@@ -1,6 +1,10 @@
 """Seeded fuzzing of the alternate planner modes against the oracle (large-count version of test_fuzz_alternate_modes).
     python tests/fuzz_modes.py SEED0 TRIALS
-Mismatching ticks are dumped to gpurun_out/fuzz/ for a HiGHS check on the CPU."""
+A tick on which kernel and oracle differ in cost or plan (statuses equal) goes to a third solver when HiGHS is importable: the agents'
+QPs are solved by HiGHS (tests/highs_qp.py), and the tick counts as ARBITRATED -- the oracle's miss, not a mismatch -- when the kernel
+is inside the tolerance table against HiGHS.  (The oracle's normal equations lose the optimum of near-degenerate slack-mode QPs now and
+then: 3.6e-6 relative in tests/golden/fuzz_found_6800157.npz, where HiGHS and the kernel agree to 2e-8.)  Every such tick, and every
+mismatch, is dumped to gpurun_out/fuzz/."""
 import os, sys, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import lsc_planner_amd as L
@@ -10,7 +14,39 @@ from oracle import oracle as O
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from tolerances import COST_ATOL, COST_RTOL, FUZZ_PLAN_COMPARED_BELOW_COST, FUZZ_TRAJ_ATOL as TRAJ_ATOL
 seed0=int(sys.argv[1]); ntr=int(sys.argv[2])
-bad=0; tot=0; fails=0
+bad=0; tot=0; fails=0; arbitrated=0
+try:
+    import highs_qp as H
+    HAVE_H = H.available()
+except Exception:
+    HAVE_H = False
+
+
+def highs_verdict(sw, prm, md_kw, state, goal, traj, tick, g, o2, vnom, vmax, amax):
+    """True when, for every agent on which kernel and oracle differ, the kernel is inside the table against HiGHS."""
+    n = len(state)
+    bvc = md_kw.get("planner") == "bvc"
+    okh = True
+    for a in range(n):
+        dc = abs(g["cost"][a] - o2["cost"][a]); dp = np.abs(g["traj"][a] - o2["traj"][a]).max()
+        if dc <= COST_RTOL * abs(o2["cost"][a]) + COST_ATOL and dp <= TRAJ_ATOL:
+            continue
+        others = [j for j in range(n) if j != a]
+        obs = []
+        for j in others:
+            pred = O.shift_traj(traj[j]) if tick >= 2 else O.const_vel_traj(state[j, :3], state[j, 3:6])
+            moved = sw.slack_set[a, j] and np.linalg.norm(pred[:, 0] - state[j, :3]) > 0.15
+            obs.append(np.repeat(state[j, :3, None], 30, axis=1) if (bvc or moved) else pred)
+        qp = O.qp_assemble_ex(prm, O.make_modes(**md_kw), state[a], goal[a], float(vnom[a]), vmax[a], amax[a], np.array(obs, np.float32),
+                              o2["normal"][a], o2["d"][a], slack_flags=sw.slack_set[a, others])
+        verdict, xh, hc = H.solve_oracle_qp(qp)[:3]
+        if verdict != "Optimal":
+            return False
+        xh = np.asarray(xh)[:90].reshape(3, 30)
+        good = abs(g["cost"][a] - hc) <= COST_RTOL * abs(hc) + COST_ATOL and (abs(hc) >= FUZZ_PLAN_COMPARED_BELOW_COST or np.abs(xh - g["traj"][a]).max() <= TRAJ_ATOL)
+        print("   HiGHS agent", a, "cost", hc, "kernel", g["cost"][a], "oracle", o2["cost"][a], "|plan - HiGHS| kernel %.2e oracle %.2e" % (np.abs(xh - g["traj"][a]).max(), np.abs(xh - o2["traj"][a]).max()), flush=True)
+        okh = okh and good
+    return okh
 MODES=[(dict(planner_mode="bvc"), dict(planner="bvc")),
        (dict(planner_mode="bvc", slack_mode="collision_constraint"), dict(planner="bvc", slack="collision_constraint")),
        (dict(planner_mode="bvc", slack_mode="dynamical_limit"), dict(planner="bvc", slack="dynamical_limit")),
@@ -51,6 +87,13 @@ for trial in range(ntr):
         elif not (np.abs(g["cost"]-o["cost"])[ok] <= COST_RTOL*np.abs(o["cost"])[ok]+COST_ATOL).all(): msg="cost rel %.2e"%(np.abs(g["cost"]-o["cost"])[ok]/np.maximum(1e-30,np.abs(o["cost"])[ok])).max()
         elif np.abs(g["traj"]-o["traj"])[(~ok) | (np.abs(o["cost"])<FUZZ_PLAN_COMPARED_BELOW_COST)].max(initial=0.0)>TRAJ_ATOL: msg="traj %.2e"%np.abs(g["traj"]-o["traj"]).max()   # (plans compared below |f| = 1e4 only, see tests/test_gpu_fuzz.py)
         elif (np.abs(o["cost"])>=FUZZ_PLAN_COMPARED_BELOW_COST).any(): big=locals().get("big",0)+1
+        if msg and HAVE_H and not msg.startswith("status") and msg != "non-finite":
+            o2=sw.tick(state, goal, traj, tick, want_lsc=True, nthreads=8)
+            if highs_verdict(sw, prm, mk, state, goal, traj, tick, g, o2, vnom, vmax, amax):
+                arbitrated+=1; print("ARBITRATED seed",seed0+trial,"n",n,"mode",ck,"tick",tick,msg,"(the kernel is inside the table against HiGHS)",flush=True)
+                import os; os.makedirs("gpurun_out/fuzz",exist_ok=True)
+                np.savez("gpurun_out/fuzz/arbitrated_%d.npz"%(seed0+trial), state=state, traj=traj, stale=stale, goal=goal, tick=tick, gstatus=g["status"], ostatus=o["status"], gtraj=g["traj"], gcost=g["cost"], ocost=o["cost"], slack=sw.slack_set, which=trial%len(MODES), start=start, radius=radius, dw=dw, vmax=vmax, amax=amax, vnom=vnom, wmin=wmin, wmax=wmax, giters=g["iters"])
+                msg=None
         if msg:
             bad+=1; print("MISMATCH seed",seed0+trial,"n",n,"mode",ck,"tick",tick,msg,flush=True)
             import os; os.makedirs("gpurun_out/fuzz",exist_ok=True)
@@ -58,4 +101,4 @@ for trial in range(ntr):
             break
         stale=np.where(ok[:,None,None], g["traj"], stale).astype(np.float32); traj=g["traj"]; state=next_state_host(traj)
     pl.close()
-print("modes fuzz done: trials",ntr,"agent-ticks",tot,"oracle failures",fails,"mismatching trials",bad)
+print("modes fuzz done: trials",ntr,"agent-ticks",tot,"oracle failures",fails,"mismatching trials",bad,"arbitrated by HiGHS (oracle off)",arbitrated)

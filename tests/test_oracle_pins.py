@@ -245,3 +245,38 @@ def test_instances_on_which_the_oracle_used_to_give_up(oracle, seed, agent, high
         if seed in (3400814, 4800332):          # whose plan is the optimum's: the kernel's (recorded on an MI355X), not the oracle's
             xh = np.asarray(xh)[:90].reshape(3, 30)
             assert np.abs(xh - Z["gtraj"][agent]).max() <= 2e-5 < np.abs(xh - o["traj"][agent]).max()
+
+
+@pytest.mark.parametrize("seed,agent,highs_cost,oracle_rel", [(6800157, 0, 4258.793418172383, 3.7e-6), (6800522, 0, 16.849414817360, 6e-7)])
+def test_instances_on_which_the_oracle_itself_is_off(oracle, seed, agent, highs_cost, oracle_rel):
+    """Round 4, tests/fuzz_modes.py: BVC with the dynamical-limit slack (penalty 1e5).  On 6800157 the ORACLE ends 3.6e-6 relative above
+    the optimum -- outside the 1e-6 of the tolerance table it is the yardstick of -- and on 6800522 5.8e-7 above with its plan 1.2e-4 m
+    away: its normal equations lose definiteness close to these optima, the shifted factorisation damps the Newton steps, and the
+    Newton-step test ends the run with the multipliers still moving (a retry with shorter steps and a centring floor jams at the same
+    place; tried, not kept).  HiGHS and the kernel (recorded on an MI355X) agree with each other to 2e-8 in cost.  The fuzzer therefore
+    takes differing ticks to HiGHS before it calls them mismatches; this test keeps the two instances and the size of the oracle's miss."""
+    O = oracle
+    Z = np.load(os.path.join(GOLDEN, "fuzz_found_%d.npz" % seed))
+    assert int(Z["which"]) == 2
+    mk = dict(planner="bvc", slack="dynamical_limit")
+    md = O.make_modes(**mk)
+    state, traj, goal, tick = Z["state"], Z["traj"], Z["goal"], int(Z["tick"])
+    n = len(state)
+    prm = O.make_params(world_min=Z["wmin"], world_max=Z["wmax"], obs_f32=True)
+    sw = O.SwarmEx(prm, md, Z["radius"], Z["dw"], Z["vmax"], Z["amax"], Z["vnom"])
+    sw.slack_set[:] = Z["slack"]
+    sw.stale[:] = Z["stale"]
+    o = sw.tick(state, goal, traj, tick, want_lsc=True, nthreads=2)
+    assert (o["status"] == 0).all() and np.array_equal(o["status"], Z["gstatus"])
+    assert abs(Z["gcost"][agent] - highs_cost) <= 5e-8 * highs_cost                       # the kernel's answer on the same inputs
+    assert 0 < o["cost"][agent] - highs_cost <= oracle_rel * highs_cost                   # the oracle: above the optimum, by this much
+    others = [j for j in range(n) if j != agent]
+    assert (np.abs(o["cost"] - Z["gcost"])[others] <= 1e-6 * np.abs(Z["gcost"])[others]).all()      # every other agent of the tick: as usual
+    if H.available():
+        obs = [np.repeat(state[j, :3, None], 30, axis=1) for j in others]                 # BVC: obstacles at their current positions
+        qp = O.qp_assemble_ex(prm, md, state[agent], goal[agent], float(Z["vnom"][agent]), Z["vmax"][agent], Z["amax"][agent],
+                              np.array(obs, np.float32), o["normal"][agent], o["d"][agent], slack_flags=sw.slack_set[agent, others])
+        verdict, xh, cost = H.solve_oracle_qp(qp)[:3]
+        assert verdict == "Optimal" and abs(cost - highs_cost) <= 1e-8 * highs_cost
+        xh = np.asarray(xh)[:90].reshape(3, 30)
+        assert np.abs(xh - Z["gtraj"][agent]).max() < np.abs(xh - o["traj"][agent]).max()       # whose plan is nearer the optimum's
