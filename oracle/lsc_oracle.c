@@ -577,6 +577,66 @@ static void chol_solve(const double *L, int n, double *b)
     }
 }
 
+/* Quadruple-precision fallback of the Newton system (round 4).  Close to a near-degenerate optimum the weights z/s of the rows span
+ * twenty decades and K = Hy + Z'G' diag(z/s) G Z, assembled in double, is no longer numerically positive definite: the Cholesky
+ * factorisation fails, and a diagonal shift -- the previous answer -- damps the Newton steps in exactly the directions that matter
+ * (the solver then stalled up to 3.6e-6 relative above the optimum of slack-mode QPs: tests/golden/fuzz_found_6800157.npz, HiGHS and
+ * the kernel agreeing with each other).  Assembled and factored (LDL', no square roots) in __float128 the matrix keeps its definiteness;
+ * only the iterations that need it pay for it.  Returns 0 and the factor in Kq (unit lower L below the diagonal, D on it). */
+typedef __float128 orc_q;
+static int quad_build_factor(int NV, int ny, int R, const orc_row *G, const double *w, const double *Z, const double *Hy, orc_q *Kq,
+                             orc_q *Kxq, orc_q *KxZq)
+{
+    for (size_t i = 0; i < (size_t)NV * NV; i++) Kxq[i] = 0;
+    for (int r = 0; r < R; r++) {
+        const orc_q wr = w[r];
+        for (int a = 0; a < G[r].nnz; a++)
+            for (int b = 0; b < G[r].nnz; b++) Kxq[G[r].idx[a] * NV + G[r].idx[b]] += wr * (orc_q)G[r].val[a] * (orc_q)G[r].val[b];
+    }
+    for (size_t i = 0; i < (size_t)NV * ny; i++) KxZq[i] = 0;
+    for (int i = 0; i < NV; i++)
+        for (int l = 0; l < NV; l++) {
+            const orc_q p = Kxq[i * NV + l];
+            if (p == 0) continue;
+            for (int j = 0; j < ny; j++) KxZq[i * ny + j] += p * (orc_q)Z[l * ny + j];
+        }
+    for (int i = 0; i < ny * ny; i++) Kq[i] = Hy[i];
+    for (int i = 0; i < NV; i++)
+        for (int a = 0; a < ny; a++) {
+            const double z = Z[i * ny + a];
+            if (z == 0) continue;
+            for (int b = 0; b < ny; b++) Kq[a * ny + b] += (orc_q)z * KxZq[i * ny + b];
+        }
+    /* LDL' in place (lower part) */
+    for (int j = 0; j < ny; j++) {
+        orc_q d = Kq[j * ny + j];
+        for (int k = 0; k < j; k++) d -= Kq[j * ny + k] * Kq[j * ny + k] * Kq[k * ny + k];
+        if (!(d > 0)) return -1;
+        Kq[j * ny + j] = d;
+        for (int i = j + 1; i < ny; i++) {
+            orc_q t = Kq[i * ny + j];
+            for (int k = 0; k < j; k++) t -= Kq[i * ny + k] * Kq[j * ny + k] * Kq[k * ny + k];
+            Kq[i * ny + j] = t / d;
+        }
+    }
+    return 0;
+}
+static void quad_solve(const orc_q *Kq, int n, double *b, orc_q *w)
+{
+    for (int i = 0; i < n; i++) {
+        orc_q t = b[i];
+        for (int k = 0; k < i; k++) t -= Kq[i * n + k] * w[k];
+        w[i] = t;
+    }
+    for (int i = 0; i < n; i++) w[i] /= Kq[i * n + i];
+    for (int i = n - 1; i >= 0; i--) {
+        orc_q t = w[i];
+        for (int k = i + 1; k < n; k++) t -= Kq[k * n + i] * w[k];
+        w[i] = t;
+    }
+    for (int i = 0; i < n; i++) b[i] = (double)w[i];
+}
+
 int orc_qp_solve(const double *P, const double *c, double cst, const double *lo, const double *hi,
                  const orc_row *rows, int nrows, double *x, double *cost, int *iters, double *kkt)
 {
@@ -713,9 +773,13 @@ int orc_qp_solve_n(const int NV, const double *P, const double *c, double cst, c
     double *rp = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
     double *u = (double *)calloc((size_t)(R > 0 ? R : 1), sizeof(double));
     double *K = (double *)calloc((size_t)ny * ny, sizeof(double));
+    orc_q *Kq = NULL, *Kxq = NULL, *KxZq = NULL, *wq = NULL, *txq = NULL;      /* quadruple-precision fallback: allocated when first needed */
+    int everq = 0, stall = 0;
+    double obj_prev = INFINITY;
     double *Kx = (double *)calloc((size_t)NV * NV, sizeof(double));
     double xx[NV], dx[NV], tx[NV];
     double *rd = (double *)calloc(ny, sizeof(double));
+    double *g0 = (double *)calloc(ny, sizeof(double));
     double *dy = (double *)calloc(ny, sizeof(double));
     double *KxZ = (double *)calloc((size_t)NV * ny, sizeof(double));
 
@@ -801,9 +865,22 @@ int orc_qp_solve_n(const int NV, const double *P, const double *c, double cst, c
         for (int a = 0; a < ny; a++) {
             double t = gy[a];
             for (int b = 0; b < ny; b++) t += Hy[a * ny + b] * y[b];
+            g0[a] = t;                                    /* cost gradient alone (right-hand sides below) */
             rd[a] += t;
-            if (fabs(rd[a]) > rdn) rdn = fabs(rd[a]);
         }
+        if (everq) {
+            /* once K has needed quadruple precision the multipliers of the degenerate rows are of any size (the complementarity products
+             * stay tiny): Z'G'z in double is then round-off only, and with it the stationarity test.  The same sum in quadruple precision. */
+            for (int i = 0; i < NV; i++) txq[i] = 0;
+            for (int r = 0; r < R; r++)
+                for (int j = 0; j < G[r].nnz; j++) txq[G[r].idx[j]] += (orc_q)G[r].val[j] * (orc_q)z[r];
+            for (int a = 0; a < ny; a++) {
+                orc_q t = g0[a];
+                for (int i = 0; i < NV; i++) t += (orc_q)Z[i * ny + a] * txq[i];
+                rd[a] = (double)t;
+            }
+        }
+        for (int a = 0; a < ny; a++) if (fabs(rd[a]) > rdn) rdn = fabs(rd[a]);
         for (int r = 0; r < R; r++) {
             rp[r] = ROWDOT(r, xx) + s[r] - G[r].rhs;
             if (fabs(rp[r]) > rpn) rpn = fabs(rp[r]);
@@ -819,20 +896,42 @@ int orc_qp_solve_n(const int NV, const double *P, const double *c, double cst, c
         /* optimal: primal residual at round-off, duality gap 1e-9 relative, stationarity small.
          * (the normal-equation solve loses digits as z/s grows, so rd is held to a looser bound) */
         int gap_ok = gap <= 1e-9 * (1.0 + fabs(obj));
-        if (rpn <= 1e-9 * hmax && rdn <= 1e-5 * (1.0 + fabs(obj)) && gap_ok) {
+        if (rpn <= 1e-9 * hmax && rdn <= 1e-8 * (1.0 + fabs(obj)) && gap_ok) {
             status = 0;
             break;
         }
+        /* last resort (round 4): feasible, complementary to 1e-7 (the bound of the other fallback below) and the objective unchanged to
+         * 1e-9 for three iterations in a row -- a run that has converged but passes neither test above.  Two ways there, both found by
+         * fuzzing after the right-hand sides were corrected: a slack-mode QP whose optima form a FACE (the iterates drift along it, the
+         * Newton step never gets small, the multipliers of the degenerate rows have no limit: tests/golden/fuzz_found_7301082.npz), and a
+         * run whose steps are blocked with the gap a few per cent above 1e-9 (1 + |f|) (tick 12 of the forest parity test).  Left
+         * running, either loses its multipliers to round-off within a few iterations and ends "infeasible" at the iteration cap.  A run
+         * that converges normally goes from 1e-7 to 1e-9 in one or two iterations and never gets here. */
+        if (rpn <= 1e-9 * hmax && gap <= 1e-7 * (1.0 + fabs(obj)) && fabs(obj - obj_prev) <= 1e-9 * (1.0 + fabs(obj))) stall++; else stall = 0;
+        obj_prev = obj;
+        if (stall >= 3) { status = 0; break; }
         if (getenv("ORC_DEBUG")) fprintf(stderr, "it %d rp %.3e rd %.3e gap %.3e obj %.9g\n", it, rpn, rdn, gap, obj);
         if (!isfinite(rdn) || !isfinite(rpn) || !isfinite(mu)) break;
 
         for (int r = 0; r < R; r++) u[r] = z[r] / s[r];
         BUILD_K(u);
-        if (chol_factor(K, ny) != 0) {
-            /* K lost definiteness to round-off (z/s spans ~20 decades close to a degenerate optimum).  A solver that stands
-             * where CPLEX stood must not call that "infeasible": shift the diagonal by the smallest amount that factors
-             * (1e-13 .. 1e-7 of the largest diagonal entry; an inexact Newton step, the residuals stay exact) and go on.
-             * Found by fuzzing the alternate modes: two such instances in 7.9 k agent-ticks, optimum confirmed by HiGHS. */
+        int useq = 0;
+        const int cfail = chol_factor(K, ny) != 0;
+        if (cfail) {
+            if (!Kq) {
+                Kq = (orc_q *)malloc(sizeof(orc_q) * (size_t)ny * ny); Kxq = (orc_q *)malloc(sizeof(orc_q) * (size_t)NV * NV);
+                KxZq = (orc_q *)malloc(sizeof(orc_q) * (size_t)NV * ny); wq = (orc_q *)malloc(sizeof(orc_q) * (size_t)ny);
+                txq = (orc_q *)malloc(sizeof(orc_q) * (size_t)NV);
+            }
+            useq = quad_build_factor(NV, ny, R, G, u, Z, Hy, Kq, Kxq, KxZq) == 0;
+            everq = 1;
+            if (getenv("ORC_DEBUG")) fprintf(stderr, "chol failed, quadruple precision: %d\n", useq);
+        }
+        if (cfail && !useq) {
+            /* (not positive definite in quadruple precision either.)  K lost definiteness to round-off (z/s spans ~20 decades close
+             * to a degenerate optimum).  A solver that stands where CPLEX stood must not call that "infeasible": shift the diagonal by
+             * the smallest amount that factors (1e-13 .. 1e-7 of the largest diagonal entry; an inexact Newton step, the residuals stay
+             * exact) and go on.  Found by fuzzing the alternate modes (round 2): two such instances in 7.9 k agent-ticks. */
             int fixed = 0;
             double dmax = 0.0;
             for (double shift = 1e-13; shift <= 1e-7 && !fixed; shift *= 100.0) {
@@ -848,12 +947,14 @@ int orc_qp_solve_n(const int NV, const double *P, const double *c, double cst, c
             }
         }
 
-        /* predictor (sigma = 0): rc = s.z */
+        /* predictor (sigma = 0): rc = s.z.  The right-hand side is -rd - Z'G'((z rp - s z)/s); the multipliers themselves cancel between
+         * the two terms, so it is formed as -(Hy y + gy) - Z'G'(z rp / s) -- with z in the 1e10s close to a degenerate optimum the
+         * difference of the two sums had no digits left (round 4; the kernel has always formed it this way). */
         double *rhs = dy;
-        for (int r = 0; r < R; r++) u[r] = (z[r] * rp[r] - s[r] * z[r]) / s[r];
+        for (int r = 0; r < R; r++) u[r] = z[r] * rp[r] / s[r];
         GT_APPLY(u, rhs);
-        for (int a = 0; a < ny; a++) rhs[a] = -rd[a] - rhs[a];
-        chol_solve(K, ny, rhs);
+        for (int a = 0; a < ny; a++) rhs[a] = -g0[a] - rhs[a];
+        if (useq) quad_solve(Kq, ny, rhs, wq); else chol_solve(K, ny, rhs);
         X_FROM_Y(dy, dx, 0);
         {
             /* Newton-step test: with the gap and the primal residual at tolerance, the affine (pure Newton)
@@ -861,6 +962,7 @@ int orc_qp_solve_n(const int NV, const double *P, const double *c, double cst, c
              * round-off level of the ill-conditioned normal equations when z/s is huge. */
             double dxn = 0, xn = 1.0;
             for (int i = 0; i < NV; i++) { if (fabs(dx[i]) > dxn) dxn = fabs(dx[i]); if (fabs(xx[i]) > xn) xn = fabs(xx[i]); }
+            if (getenv("ORC_DEBUG")) fprintf(stderr, "      newton step %.3e (x %.3e) useq %d\n", dxn, xn, useq);
             if (rpn <= 1e-9 * hmax && gap_ok && dxn <= 1e-9 * xn) { status = 0; break; }
         }
         double alpha = 1.0;
@@ -879,12 +981,12 @@ int orc_qp_solve_n(const int NV, const double *P, const double *c, double cst, c
         /* corrector: rc = s.z + ds_aff.dz_aff - sigma mu */
         for (int r = 0; r < R; r++) {
             double rc = s[r] * z[r] + ds[r] * dz[r] - sigma * mu;
-            u[r] = (z[r] * rp[r] - rc) / s[r];
+            u[r] = (z[r] * rp[r] - (ds[r] * dz[r] - sigma * mu)) / s[r];      /* (z rp - rc)/s + z: see the predictor */
             ds[r] = rc; /* stash rc */
         }
         GT_APPLY(u, rhs);
-        for (int a = 0; a < ny; a++) rhs[a] = -rd[a] - rhs[a];
-        chol_solve(K, ny, rhs);
+        for (int a = 0; a < ny; a++) rhs[a] = -g0[a] - rhs[a];
+        if (useq) quad_solve(Kq, ny, rhs, wq); else chol_solve(K, ny, rhs);
         X_FROM_Y(dy, dx, 0);
         alpha = 1.0;
         double amax_ = INFINITY;
@@ -939,7 +1041,7 @@ done:
         kkt[0] = st; kkt[1] = pf; kkt[2] = df; kkt[3] = cp;
     }
     free(G); free(W); free(beq); free(HV); free(Z); free(xp); free(PZ); free(Hy); free(gy);
-    free(y); free(s); free(z); free(ds); free(dz); free(rp); free(u); free(K); free(rd); free(dy); free(KxZ); free(Kx);
+    free(y); free(s); free(z); free(ds); free(dz); free(rp); free(u); free(K); free(Kq); free(Kxq); free(KxZq); free(wq); free(txq); free(rd); free(g0); free(dy); free(KxZ); free(Kx);
     return status;
 }
 

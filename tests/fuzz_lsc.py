@@ -10,7 +10,7 @@ from oracle import oracle
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from tolerances import COST_ATOL, COST_RTOL, FUZZ_TRAJ_ATOL as TRAJ_ATOL
 seed0=int(sys.argv[1]); ntr=int(sys.argv[2])
-bad=0; tot=0; fails=0
+bad=0; tot=0; fails=0; maxd=0.0; maxc=0.0
 for trial in range(ntr):
     rng=np.random.default_rng(seed0+trial)
     n=int(rng.integers(1,int(sys.argv[3]) if len(sys.argv)>3 else 14))
@@ -48,8 +48,10 @@ for trial in range(ntr):
         elif not np.isfinite(g["traj"]).all(): msg="non-finite traj"
         elif not (np.abs(g["cost"]-o["cost"])[ok] <= COST_RTOL*np.abs(o["cost"])[ok]+COST_ATOL).all(): msg="cost %s"%(np.abs(g["cost"]-o["cost"])[ok]/np.maximum(1e-30,np.abs(o["cost"])[ok])).max()
         elif np.abs(g["traj"]-o["traj"]).max()>TRAJ_ATOL: msg="traj %.2e"%np.abs(g["traj"]-o["traj"]).max()
+        if msg is None:
+            maxd=max(maxd, float(np.abs(g["traj"]-o["traj"]).max())); maxc=max(maxc, float((np.abs(g["cost"]-o["cost"])[ok]/np.maximum(1e-3,np.abs(o["cost"])[ok])).max(initial=0.0)))
         if msg:
             bad+=1; print("MISMATCH seed",seed0+trial,"n",n,"kind",kind,"mode",mode,"tick",tick,msg, flush=True); break
         stale=np.where(ok[:,None,None], g["traj"], stale).astype(np.float32); traj=g["traj"]; state=next_state_host(traj)
     pl.close()
-print("fuzz done: trials",ntr,"agent-ticks",tot,"oracle failures",fails,"mismatching trials",bad)
+print("fuzz done: trials",ntr,"agent-ticks",tot,"oracle failures",fails,"mismatching trials",bad,"| largest plan difference %.2e m, cost difference %.2e relative (|f| > 1e-3)"%(maxd,maxc))

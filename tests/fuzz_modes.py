@@ -14,7 +14,7 @@ from oracle import oracle as O
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from tolerances import COST_ATOL, COST_RTOL, FUZZ_PLAN_COMPARED_BELOW_COST, FUZZ_TRAJ_ATOL as TRAJ_ATOL
 seed0=int(sys.argv[1]); ntr=int(sys.argv[2])
-bad=0; tot=0; fails=0; arbitrated=0
+bad=0; tot=0; fails=0; arbitrated=0; maxd=0.0; maxc=0.0
 try:
     import highs_qp as H
     HAVE_H = H.available()
@@ -87,6 +87,9 @@ for trial in range(ntr):
         elif not (np.abs(g["cost"]-o["cost"])[ok] <= COST_RTOL*np.abs(o["cost"])[ok]+COST_ATOL).all(): msg="cost rel %.2e"%(np.abs(g["cost"]-o["cost"])[ok]/np.maximum(1e-30,np.abs(o["cost"])[ok])).max()
         elif np.abs(g["traj"]-o["traj"])[(~ok) | (np.abs(o["cost"])<FUZZ_PLAN_COMPARED_BELOW_COST)].max(initial=0.0)>TRAJ_ATOL: msg="traj %.2e"%np.abs(g["traj"]-o["traj"]).max()   # (plans compared below |f| = 1e4 only, see tests/test_gpu_fuzz.py)
         elif (np.abs(o["cost"])>=FUZZ_PLAN_COMPARED_BELOW_COST).any(): big=locals().get("big",0)+1
+        if msg is None:
+            sel=(~ok) | (np.abs(o["cost"])<FUZZ_PLAN_COMPARED_BELOW_COST)
+            maxd=max(maxd, float(np.abs(g["traj"]-o["traj"])[sel].max(initial=0.0))); maxc=max(maxc, float((np.abs(g["cost"]-o["cost"])[ok]/np.maximum(1e-3,np.abs(o["cost"])[ok])).max(initial=0.0)))
         if msg and HAVE_H and not msg.startswith("status") and msg != "non-finite":
             o2=sw.tick(state, goal, traj, tick, want_lsc=True, nthreads=8)
             if highs_verdict(sw, prm, mk, state, goal, traj, tick, g, o2, vnom, vmax, amax):
@@ -101,4 +104,4 @@ for trial in range(ntr):
             break
         stale=np.where(ok[:,None,None], g["traj"], stale).astype(np.float32); traj=g["traj"]; state=next_state_host(traj)
     pl.close()
-print("modes fuzz done: trials",ntr,"agent-ticks",tot,"oracle failures",fails,"mismatching trials",bad,"arbitrated by HiGHS (oracle off)",arbitrated)
+print("modes fuzz done: trials",ntr,"agent-ticks",tot,"oracle failures",fails,"mismatching trials",bad,"arbitrated by HiGHS (oracle off)",arbitrated,"| largest plan difference %.2e m, cost difference %.2e relative"%(maxd,maxc))

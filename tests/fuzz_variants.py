@@ -32,6 +32,7 @@ def run_variant(L, O, seed0, trials, variant, max_agents=14, verbose=False):
         pkw.update(world_dimension=2, world_z_2d=Z2D)
     agent_ticks = failures = 0
     bad = []
+    run_variant.maxd = 0.0
     with O.segments(M):
         for trial in range(trials):
             rng = np.random.default_rng(seed0 + trial)
@@ -93,7 +94,13 @@ def run_variant(L, O, seed0, trials, variant, max_agents=14, verbose=False):
                     msg = "plan %.2e" % np.abs(g["traj"] - o["traj"])[tame].max()
                 elif planar and not (g["traj"][ok][:, 2, :] == np.float32(Z2D)).all():
                     msg = "a planar plan left z_2d"
+                if msg is None:
+                    run_variant.maxd = max(run_variant.maxd, float(np.abs(g["traj"] - o["traj"])[tame].max(initial=0.0)))
                 if msg:
+                    os.makedirs("gpurun_out/fuzz", exist_ok=True)
+                    np.savez("gpurun_out/fuzz/variant_%s_%d.npz" % (variant, seed0 + trial), state=state, goal=goals, traj=traj, stale=stale, tick=tick, dt=dt,
+                             gtraj=g["traj"], gcost=g["cost"], gstatus=g["status"], otraj=o["traj"], ocost=o["cost"], ostatus=o["status"],
+                             radius=radius, dw=dw, vmax=vmax, amax=amax, vnom=vnom, wmin=wmin, wmax=wmax)
                     bad.append("seed %d n %d kind %d mode %s tick %d: %s" % (seed0 + trial, n, kind, mode, tick, msg))
                     if verbose:
                         print("MISMATCH", variant, bad[-1], flush=True)
@@ -116,4 +123,4 @@ if __name__ == "__main__":
     cap = int(sys.argv[4]) if len(sys.argv) > 4 else 14
     for v in (["planar", "m4", "planar_m4"] if which == "all" else [which]):
         at, fl, bad = run_variant(L, O, seed0, trials, v, cap, verbose=True)
-        print("fuzz %s done: trials %d agent-ticks %d oracle failures %d mismatching trials %d" % (v, trials, at, fl, len(bad)), flush=True)
+        print("fuzz %s done: trials %d agent-ticks %d oracle failures %d mismatching trials %d | largest plan difference %.2e m" % (v, trials, at, fl, len(bad), run_variant.maxd), flush=True)

@@ -105,8 +105,9 @@ def test_kernel_statuses_and_costs_against_highs_verdicts(L):
 @pytest.mark.parametrize("seed,which,cfg,agent,highs_cost",
                          [(5023, 3, dict(planner_mode="bvc", n_constraint_segments=2), 2, 1.3618641918561454),
                           (4800332, 2, dict(planner_mode="bvc", slack_mode="dynamical_limit"), 2, 1860.235625116953),
-                          (6800157, 2, dict(planner_mode="bvc", slack_mode="dynamical_limit"), 0, 4258.793418172383),      # (the oracle is 3.6e-6 off here)
-                          (6800522, 2, dict(planner_mode="bvc", slack_mode="dynamical_limit"), 0, 16.849414817360)])
+                          (6800157, 2, dict(planner_mode="bvc", slack_mode="dynamical_limit"), 0, 4258.793418172383),      # (the oracle was 3.6e-6 off here until round 4)
+                          (6800522, 2, dict(planner_mode="bvc", slack_mode="dynamical_limit"), 0, 16.849414817360),
+                          (7301082, 2, dict(planner_mode="bvc", slack_mode="dynamical_limit"), 3, 3523.9260890555174)])      # (a face of optima: the value decides)
 def test_fuzz_found_instance_through_the_kernel_against_highs(L, seed, which, cfg, agent, highs_cost):
     """tests/golden/fuzz_found_5023.npz: the alternate-mode QP (BVC, two constraint segments) on which the oracle used to give
     up and HiGHS found the optimum 1.3618641918561454; fuzz_found_4800332.npz (round 4): BVC with the dynamical-limit slack at

@@ -242,19 +242,27 @@ def test_instances_on_which_the_oracle_used_to_give_up(oracle, seed, agent, high
                               np.array(obs, np.float32), o["normal"][agent], o["d"][agent], slack_flags=sw.slack_set[agent, others])
         verdict, xh, cost = H.solve_oracle_qp(qp)[:3]
         assert verdict == "Optimal" and abs(cost - highs_cost) <= 1e-8 * highs_cost
-        if seed in (3400814, 4800332):          # whose plan is the optimum's: the kernel's (recorded on an MI355X), not the oracle's
+        if seed in (3400814, 4800332):          # both plans at the optimum (until round 4 only the kernel's was: see the test below)
             xh = np.asarray(xh)[:90].reshape(3, 30)
-            assert np.abs(xh - Z["gtraj"][agent]).max() <= 2e-5 < np.abs(xh - o["traj"][agent]).max()
+            assert np.abs(xh - Z["gtraj"][agent]).max() <= 2e-5 and np.abs(xh - o["traj"][agent]).max() <= 2e-5
 
 
-@pytest.mark.parametrize("seed,agent,highs_cost,oracle_rel", [(6800157, 0, 4258.793418172383, 3.7e-6), (6800522, 0, 16.849414817360, 6e-7)])
-def test_instances_on_which_the_oracle_itself_is_off(oracle, seed, agent, highs_cost, oracle_rel):
-    """Round 4, tests/fuzz_modes.py: BVC with the dynamical-limit slack (penalty 1e5).  On 6800157 the ORACLE ends 3.6e-6 relative above
-    the optimum -- outside the 1e-6 of the tolerance table it is the yardstick of -- and on 6800522 5.8e-7 above with its plan 1.2e-4 m
-    away: its normal equations lose definiteness close to these optima, the shifted factorisation damps the Newton steps, and the
-    Newton-step test ends the run with the multipliers still moving (a retry with shorter steps and a centring floor jams at the same
-    place; tried, not kept).  HiGHS and the kernel (recorded on an MI355X) agree with each other to 2e-8 in cost.  The fuzzer therefore
-    takes differing ticks to HiGHS before it calls them mismatches; this test keeps the two instances and the size of the oracle's miss."""
+@pytest.mark.parametrize("seed,agent,highs_cost", [(6800157, 0, 4258.793418172383), (6800522, 0, 16.849414817360), (7301082, 3, 3523.9260890555174)])
+def test_instances_that_found_the_cancellation_in_the_oracle(oracle, seed, agent, highs_cost):
+    """Round 4, tests/fuzz_modes.py: BVC with the dynamical-limit slack (penalty 1e5).  On 6800157 the oracle used to end 3.6e-6 relative
+    above the optimum -- outside the 1e-6 of the tolerance table it is the yardstick of --, on 6800522 5.8e-7 above with its plan
+    1.2e-4 m away, while HiGHS and the kernel (recorded on an MI355X) agreed to 2e-8.  Cause, found with these two: the oracle formed
+    the Newton right-hand side as  -rd - Z'G'((z rp - s z) / s),  two sums that each carry the multipliers z and cancel them between
+    each other; with z in the 1e10s close to a degenerate optimum the difference had no digits left, the multipliers wandered, and the
+    Newton-step test ended the run on damped steps.  Formed as  -(Hy y + gy) - Z'G'(z rp / s)  (what the kernel has always done) and
+    with a quadruple-precision assembly / LDL' of K for the iterations whose double-precision K is no longer positive definite (instead
+    of a diagonal shift), the oracle reaches the same optimum as HiGHS and the kernel -- here and on every earlier "the oracle's plan is
+    the distant one" fixture (3400814, 4800332, m4_4602619), which were this defect, not flat optima.
+    7301082 is what the corrected solver then met: a slack-mode QP whose optima form a face.  The value is final after eleven iterations
+    (HiGHS, kernel and this solver: 3523.9260890), but the iterates drift along the face, the Newton step never gets small and the
+    multipliers of the degenerate rows have no limit, so neither convergence test fires -- the run ended "infeasible" at the iteration
+    cap.  The solver now also stops when it is feasible, complementary to 1e-7 and the objective has not moved by 1e-9 for three
+    iterations in a row; the plans of such a QP are not comparable (and are not compared above |f| = 1e3)."""
     O = oracle
     Z = np.load(os.path.join(GOLDEN, "fuzz_found_%d.npz" % seed))
     assert int(Z["which"]) == 2
@@ -269,14 +277,14 @@ def test_instances_on_which_the_oracle_itself_is_off(oracle, seed, agent, highs_
     o = sw.tick(state, goal, traj, tick, want_lsc=True, nthreads=2)
     assert (o["status"] == 0).all() and np.array_equal(o["status"], Z["gstatus"])
     assert abs(Z["gcost"][agent] - highs_cost) <= 5e-8 * highs_cost                       # the kernel's answer on the same inputs
-    assert 0 < o["cost"][agent] - highs_cost <= oracle_rel * highs_cost                   # the oracle: above the optimum, by this much
+    assert abs(o["cost"][agent] - highs_cost) <= 5e-8 * highs_cost                        # ... and now the oracle's
+    assert abs(o["cost"][agent] - Z["gcost"][agent]) <= 1e-9 * highs_cost                 # (HiGHS is the loosest of the three)
+    assert (np.abs(o["cost"] - Z["gcost"]) <= 1e-6 * np.abs(Z["gcost"])).all()
     others = [j for j in range(n) if j != agent]
-    assert (np.abs(o["cost"] - Z["gcost"])[others] <= 1e-6 * np.abs(Z["gcost"])[others]).all()      # every other agent of the tick: as usual
+    assert np.abs(o["traj"] - Z["gtraj"])[others if seed == 7301082 else slice(None)].max() <= 5e-6
     if H.available():
         obs = [np.repeat(state[j, :3, None], 30, axis=1) for j in others]                 # BVC: obstacles at their current positions
         qp = O.qp_assemble_ex(prm, md, state[agent], goal[agent], float(Z["vnom"][agent]), Z["vmax"][agent], Z["amax"][agent],
                               np.array(obs, np.float32), o["normal"][agent], o["d"][agent], slack_flags=sw.slack_set[agent, others])
         verdict, xh, cost = H.solve_oracle_qp(qp)[:3]
         assert verdict == "Optimal" and abs(cost - highs_cost) <= 1e-8 * highs_cost
-        xh = np.asarray(xh)[:90].reshape(3, 30)
-        assert np.abs(xh - Z["gtraj"][agent]).max() < np.abs(xh - o["traj"][agent]).max()       # whose plan is nearer the optimum's

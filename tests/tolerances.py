@@ -14,14 +14,16 @@ TRAJ_ATOL = 2e-5
 # Seeded fuzzing of tiny swarms with extreme parameters (vmax 0.2..3, amax 0.5..6, radii 0.05..0.4, goals outside the world,
 # coincident agents): optima with nearly flat directions -- the plan may move 3-4e-5 m at 1e-9 relative cost.
 FUZZ_TRAJ_ATOL = 5e-5
-# The same with dt = 0.5 (the M = 4 build): the jerk weights are (0.2 / 0.5)^5 = 1/100 of the dt = 0.2 ones, so the same cost slack
-# moves a plan ten times as far.  Found: 8.2e-5 m at 3.9e-9 relative cost in 165 k agent-ticks (tests/golden/fuzz_found_m4_4602619.npz,
-# where HiGHS puts the optimum 3e-7 m from the kernel's plan: the slack is the oracle's).
+# The same with dt = 0.5 (the M = 4 build): the jerk weights are (0.2 / 0.5)^5 = 1/100 of the dt = 0.2 ones, so the same cost slack moves a
+# plan ten times as far.  What is left after the oracle's right-hand sides were corrected in round 4 (tests/test_oracle_pins.py; the
+# 8.2e-5 m of tests/golden/fuzz_found_m4_4602619.npz was that defect): one seed in 320 k fuzzed agent-ticks (7500378, variants m4 and
+# planar_m4) with kernel and oracle 2.5e-10 and 3.3e-10 relative above HiGHS's cost and 4.0e-5 / 8.2e-5 m from its plan, on opposite
+# sides: 1.2e-4 m apart.  Everything else: <= 4.3e-5 m.
 FUZZ_TRAJ_ATOL_HALF_SECOND = 2e-4
 # ... and with the 1e5 slack penalty a grossly violated limit makes |f| ~ 1e7; both solvers stop on criteria relative to |f|
 # and their plans may then differ by centimetres at 4e-8 relative cost: plans are compared below this objective only.
-# (1e4 until round 4, when a BVC + dynamical-limit-slack QP at |f| = 1860 came out 6.7e-5 m apart at 1.2e-8 relative cost -- the oracle's slack again,
-#  HiGHS 1.2e-7 m from the kernel: tests/golden/fuzz_found_4800332.npz.  The cost comparison still pins the optimum above the limit.)
+# (1e4 until round 4.  Slack-mode QPs can have a face of optima -- tests/golden/fuzz_found_7301082.npz: one value, no one plan -- and they
+#  are the ones with a violated limit at penalty 1e5, i.e. with a large objective.  The cost comparison pins the optimum above the limit.)
 FUZZ_PLAN_COMPARED_BELOW_COST = 1e3
 # 1024-agent swarms near their goals: costs approach 0 (1e-6..1e-5), so the absolute floor is what binds.
 LARGE_SWARM_COST_ATOL = 1e-7
