@@ -1056,10 +1056,13 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     const unsigned long long mask = __ballot(keep);
                     if (lane == 0) S.cullc[wave] = __popcll(mask);
                     __syncthreads();
+                    int cw[NWAVE];                     // (all counts in one batch of loads, not one LDS round trip per wave in front)
+#pragma unroll
+                    for (int w = 0; w < NWAVE; w++) cw[w] = S.cullc[w];
                     int off = tot0;
-                    for (int w = 0; w < wave; w++) off += S.cullc[w];
+#pragma unroll
+                    for (int w = 0; w < NWAVE; w++) { off += w < wave ? cw[w] : 0; tot0 += cw[w]; }
                     if (keep) olist[off + __popcll(mask & lt_mask)] = (uint16_t)oi;
-                    for (int w = 0; w < NWAVE; w++) tot0 += S.cullc[w];
                     __syncthreads();
                 }
                 n_o = tot0;
@@ -1100,14 +1103,17 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                 const unsigned long long mask = __ballot(keep);
                 if (lane == 0) S.cullc[wave] = __popcll(mask);
                 __syncthreads();
+                int cw[NWAVE];
+#pragma unroll
+                for (int w = 0; w < NWAVE; w++) cw[w] = S.cullc[w];
                 int off = total;
-                for (int w = 0; w < wave; w++) off += S.cullc[w];
+#pragma unroll
+                for (int w = 0; w < NWAVE; w++) { off += w < wave ? cw[w] : 0; total += cw[w]; }
                 if (keep) {
                     const int at = off + __popcll(mask & lt_mask);
                     if (at < list_cap) ulist[at] = (uint16_t)u;
                     else S.listfull = 1;
                 }
-                for (int w = 0; w < NWAVE; w++) total += S.cullc[w];
                 __syncthreads();
             }
             if (S.listfull) cull = false;          // more survivors than the list holds: every unit takes the GJK
