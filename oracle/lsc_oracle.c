@@ -775,6 +775,7 @@ int orc_qp_solve_n(const int NV, const double *P, const double *c, double cst, c
     double *K = (double *)calloc((size_t)ny * ny, sizeof(double));
     orc_q *Kq = NULL, *Kxq = NULL, *KxZq = NULL, *wq = NULL, *txq = NULL;      /* quadruple-precision fallback: allocated when first needed */
     int everq = 0, stall = 0;
+    double gap0 = 0.0;
     double obj_prev = INFINITY;
     double *Kx = (double *)calloc((size_t)NV * NV, sizeof(double));
     double xx[NV], dx[NV], tx[NV];
@@ -912,6 +913,11 @@ int orc_qp_solve_n(const int NV, const double *P, const double *c, double cst, c
         if (stall >= 3) { status = 0; break; }
         if (getenv("ORC_DEBUG")) fprintf(stderr, "it %d rp %.3e rd %.3e gap %.3e obj %.9g\n", it, rpn, rdn, gap, obj);
         if (!isfinite(rdn) || !isfinite(rpn) || !isfinite(mu)) break;
+        /* divergence: on an infeasible QP the multipliers run away and the gap grows without bound; a convergent run never exceeds its
+         * starting gap by orders of magnitude (the kernel's test, lsc_kernels.hip).  Without it an infeasible QP burns the iteration cap
+         * -- since round 4 with a quadruple-precision factorisation in most of those iterations. */
+        if (it == 0) gap0 = gap;
+        else if (gap > 1e8 * gap0) break;
 
         for (int r = 0; r < R; r++) u[r] = z[r] / s[r];
         BUILD_K(u);
