@@ -17,7 +17,7 @@ FUZZ_TRAJ_ATOL = 5e-5
 # The same with dt = 0.5 (the M = 4 build): the jerk weights are (0.2 / 0.5)^5 = 1/100 of the dt = 0.2 ones, so the same cost slack moves a
 # plan ten times as far.  What is left after the oracle's right-hand sides were corrected in round 4 (tests/test_oracle_pins.py; the
 # 8.2e-5 m of tests/golden/fuzz_found_m4_4602619.npz was that defect): one seed in 320 k fuzzed agent-ticks (7500378, variants m4 and
-# planar_m4) with kernel and oracle 2.5e-10 and 3.3e-10 relative above HiGHS's cost and 4.0e-5 / 8.2e-5 m from its plan, on opposite
+# planar_m4; tests/golden/fuzz_found_planar_m4_7500378.npz) with kernel and oracle 2.5e-10 and 3.3e-10 relative above HiGHS's cost and 4.0e-5 / 8.2e-5 m from its plan, on opposite
 # sides: 1.2e-4 m apart.  Everything else: <= 4.3e-5 m.
 FUZZ_TRAJ_ATOL_HALF_SECOND = 2e-4
 # ... and with the 1e5 slack penalty a grossly violated limit makes |f| ~ 1e7; both solvers stop on criteria relative to |f|
