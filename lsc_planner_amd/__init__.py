@@ -5,6 +5,7 @@ Only what the hot path needs lives here:
   _lib.py      ctypes binding of that ABI (fails loudly when the library or a GPU is missing)
   planner.py   host-side mirror of the reference's TrajPlanner / TrajOptimizer surface, batched per tick
   mission.py   mission JSON loader + the circle-swap / random-swarm generators of the BASELINE configs
+  maps.py      octomap .bt writer + the committed occupancy of the reference's simple_forest map (data/)
   csrc/host/   C++ host side above the ABI: Mission / Param / TrajPlanner-shaped facade, headless MultiSyncSimulator, result-CSV
                writer and reader -> lsc_sim
   sharded.py   partition arithmetic of the agent-sharded multi-GPU path + the torch.distributed fallback exchange (the native

@@ -69,11 +69,16 @@ EXPORTS = [
 ]
 
 
+BUILT_SEGMENTS = (5, 4)      # csrc/Makefile builds these two; other M = recompile with -DLSC_SEGMENTS=k (3 <= k <= 5)
+
+
 def lib_path(segments=5):
-    """liblsc_hip.so (M = 5) / liblsc_hip_m4.so (M = 4) next to this file; LSC_HIP_LIB overrides the M = 5 one (A/B runs of two
-    builds on the same GPU box)."""
+    """liblsc_hip.so (M = 5) / liblsc_hip_m4.so (M = 4) next to this file.  LSC_HIP_LIB overrides the M = 5 path and
+    LSC_HIP_LIB_M4 the M = 4 one (A/B runs of two builds on the same GPU box; the LDS-poison builds of `make poison poison_m4`)."""
     if segments == 5:
         return os.environ.get("LSC_HIP_LIB") or os.path.join(_HERE, "liblsc_hip.so")
+    if segments == 4:
+        return os.environ.get("LSC_HIP_LIB_M4") or os.path.join(_HERE, "liblsc_hip_m4.so")
     return os.path.join(_HERE, f"liblsc_hip_m{segments}.so")
 
 

@@ -527,6 +527,18 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, up(&c->d_vnom, nominal_vel, N));
     HIPCHK(c, hipMalloc(&c->d_stale, sizeof(float) * NV * (size_t)N));
     HIPCHK(c, hipMemset(c->d_stale, 0, sizeof(float) * NV * (size_t)N));   // TrajOptimizer::trajectory starts at (0,0,0)
+    if (c->cfg.world_dimension == 2) {
+        // Planar world: an agent whose FIRST solve fails keeps this trajectory (src/traj_planner.cpp:1553-1584).  The reference
+        // leaves its z at 0 and overrides the agent's own z with world/z_2d on the next state callback (src/traj_planner.cpp:304-314);
+        // here the z block starts at z_2d, so that the stale plan -- and the state propagated from it -- stay in the plane the
+        // kernels and the host-buffer ticks' input check rely on (an out-of-plane stale plan used to make every later
+        // host-buffer tick of the whole swarm return LSC_EINVAL).
+        std::vector<float> init((size_t)NV * N, 0.0f);
+        const float z = (float)c->cfg.world_z_2d;
+        for (int q = 0; q < N; q++)
+            for (int j = 0; j < SEGV; j++) init[(size_t)q * NV + 2 * SEGV + j] = z;
+        HIPCHK(c, hipMemcpy(c->d_stale, init.data(), sizeof(float) * init.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipMalloc(&c->d_sfc, sizeof(float) * M * 6 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_sfc, 0, sizeof(float) * M * 6 * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_goal_cur, sizeof(float) * 3 * Np));
@@ -1378,9 +1390,10 @@ int lsc_kernel_times_ms(lsc_ctx *c, int which, double *out_ms, long capacity, lo
 int lsc_phase_profile(lsc_ctx *c, int enable, long long *out)
 {
     if (!c || c->N == 0) return LSC_EINVAL;
+    // (checked before anything is copied: a refused call leaves `out` untouched)
+    if (enable > 0 && c->cfg.world_dimension == 2) { c->err = "lsc_phase_profile: the instrumented plan kernel exists for 3-D worlds only"; return LSC_EINVAL; }
     HIPCHK(c, hipDeviceSynchronize());
     if (out) HIPCHK(c, hipMemcpy(out, c->d_prof, sizeof(long long) * PROF_PHASES * (size_t)c->N, hipMemcpyDeviceToHost));
-    if (enable > 0 && c->cfg.world_dimension == 2) { c->err = "lsc_phase_profile: the instrumented plan kernel exists for 3-D worlds only"; return LSC_EINVAL; }
     if (enable >= 0) {
         c->profiling = enable != 0;
         HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * 2 * PROF_PHASES * (size_t)c->N));

@@ -1531,7 +1531,8 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
                     double *e = stage + sl * ncomp + c;
                     sum += *e;
                     *e = 0.0;                                      // (K must not keep anything assemble() does not overwrite)
-                }                const int j = with_w ? c : c + 6;
+                }
+                const int j = with_w ? c : c + 6;
                 if (j < 6) S.W[W_S + cp * 6 + j] = sum;
                 else if (j < 9) S.Tv[cp * 3 + (j - 6)] = -sum;
                 else S.Tz[cp * 3 + (j - 9)] = -sum;
@@ -2141,7 +2142,11 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             if (dim2 && tid >= 2 * SEGV) v = (float)md.z2d;        // octomap::point3d(x, y, param.world_z_2d), src/traj_optimizer.cpp:87-90
             out[tid] = v; stale[tid] = v;
         } else {
-            out[tid] = stale[tid];
+            float v = stale[tid];
+            // planar world: a plan is in the plane whatever the optimiser's stale trajectory holds (lsc_set_agents starts its z block
+            // at z_2d; this covers a stale plan that came from anywhere else)
+            if (dim2 && tid >= 2 * SEGV) { v = (float)md.z2d; stale[tid] = v; }
+            out[tid] = v;
         }
     }
     if (a.state_next && tid < 3) {
@@ -2155,6 +2160,7 @@ __device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsi
             if (dim2 && k == 2) c0 = c1 = c2 = (float)md.z2d;
         } else {
             c0 = stale[k * SEGV + NC]; c1 = stale[k * SEGV + NC + 1]; c2 = stale[k * SEGV + NC + 2];
+            if (dim2 && k == 2) c0 = c1 = c2 = (float)md.z2d;
         }
         const float fn = (float)DEG, fn1 = (float)(DEG - 1), finv = a.finv;
         const float v0 = ((c1 - c0) * fn) * finv;

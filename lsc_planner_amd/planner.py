@@ -66,7 +66,11 @@ class SwarmPlanner:
         # M = horizon / dt picks the library (the kernels are unrolled for their segment count): 5 -> liblsc_hip.so, 4 -> liblsc_hip_m4.so
         self.M = _lib.segments_of(self.cfg.horizon, self.cfg.dt)
         self.SEGV, self.NV = NC * self.M, 3 * NC * self.M
-        self.L = _lib.load_library(self.M if self.M in (4,) else 5)
+        if self.M not in _lib.BUILT_SEGMENTS:
+            raise LscError(f"horizon / dt = {self.cfg.horizon} / {self.cfg.dt} gives M = {self.M} segments; libraries are built for M in "
+                           f"{_lib.BUILT_SEGMENTS} (the segment count is a build parameter: make LSC_SEGMENTS=k, src/traj_optimizer.cpp:9 "
+                           "computes it at run time)")
+        self.L = _lib.load_library(self.M)
         self.mission = mission
         c = LscConfig()
         self.L.lsc_default_config(ctypes.byref(c))

@@ -14,6 +14,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def swarm_and_config(L, N):
+    """The swarm and the planner configuration of an N-agent case -- shared with the single-GPU reference of the test.
+    N > 256: a whole-swarm context would take the 256-lane throughput build (more agents than CUs) while a rank's shard takes the 512-lane
+    latency build; an explicit row capacity selects the latency build on both sides (lsc_row_capacity: throughput_rows = 0), so that
+    the sharded ticks can be held to the single-GPU ones bit for bit."""
+    R = 8.0 * N / 64.0 if N >= 16 else 1.2
+    ms = L.circle_swap(N, circle_radius=R, z=1.0, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
+    cfg = dict(goal_mode="prior_based", reset_threshold=0.15)
+    if N > 256:
+        cfg["max_rows_per_cp"] = 48
+    return ms, cfg
+
+
 def main():
     rank, world, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     out_dir, token_file = sys.argv[4], sys.argv[5]
@@ -35,9 +48,8 @@ def main():
                 raise SystemExit("no rendezvous token")
             time.sleep(0.05)
         tok = open(token_file, "rb").read()
-    R = 8.0 * N / 64.0 if N >= 16 else 1.2
-    ms = L.circle_swap(N, circle_radius=R, z=1.0, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
-    cfg = dict(device=rank, goal_mode="prior_based", reset_threshold=0.15)
+    ms, cfg = swarm_and_config(L, N)
+    cfg["device"] = rank
     pl = L.SwarmPlanner(ms, L.PlannerConfig(comm=(world, rank, tok), **cfg))
     rows = pl.table_rows
     info = np.array([pl.world, pl.rank, pl.shard_rows, pl.table_rows, pl.first, pl.count])

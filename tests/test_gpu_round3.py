@@ -215,6 +215,13 @@ def test_plans_do_not_depend_on_what_the_lds_held_before():
         pytest.skip("liblsc_hip_poison.so not built (make -C lsc_planner_amd/csrc poison)")
     env = dict(os.environ, LSC_HIP_LIB=lib)
     files = [os.path.join(root, "tests", f) for f in ("test_gpu_parity.py", "test_gpu_edges.py", "test_gpu_goal.py", "test_gpu_modes.py")]
+    # ... and the M = 4 instantiation through ITS poison build (round 5: `make poison_m4`, LSC_HIP_LIB_M4): its twisted factorisation has
+    # sweeps of different lengths and its unmasked loads rest on the same "S.K is zero outside the band" invariant
+    lib4 = os.path.join(root, "lsc_planner_amd", "liblsc_hip_m4_poison.so")
+    if os.path.exists(lib4):
+        env["LSC_HIP_LIB_M4"] = lib4
+        files.append(os.path.join(root, "tests", "test_gpu_round4.py") + "::test_four_segments_the_reference_s_cpp_defaults")
+        files.append(os.path.join(root, "tests", "test_gpu_round4.py") + "::test_four_segments_in_the_forest_and_in_the_alternate_modes")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu"] + files, env=env, cwd=root, capture_output=True, text=True,
                        timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:]

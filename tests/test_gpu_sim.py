@@ -200,6 +200,44 @@ def test_simulator_over_the_native_communicator_writes_the_same_run(ticks, tmp_p
         assert [v for i, v in enumerate(x) if i not in skip] == [v for i, v in enumerate(y) if i not in skip]
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_simulator_on_several_ranks_writes_the_single_gpu_run(world, ticks, tmp_path):
+    """lsc_sim --ranks W, one process per GPU (rendezvous file, lsc_comm_init, lsc_replan_tick_all's RCCL group, the safety accounting's
+    all-reduce): rank 0's result CSV must be the plain single-GPU run's.  8 = the target node; the 4-agent mission then leaves ranks
+    4-7 without agents.  Skips on a box with fewer GPUs (exchange point: MultiSyncSimulator::update, src/multi_sync_simulator.cpp:249-304)."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs on this box (has {torch.cuda.device_count()})")
+    ms = golden_mission(ticks, "multi_simple4")
+    mp = tmp_path / "m.json"
+    _write_mission(str(mp), ms)
+    a, b = tmp_path / "plain", tmp_path / "ranks"
+    a.mkdir(); b.mkdir()
+    r1 = subprocess.run([SIM, "--mission", str(mp), "--csv", str(a), "--quiet", "--max-iter", "40"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [subprocess.Popen([SIM, "--mission", str(mp), "--csv", str(b), "--quiet", "--max-iter", "40", "--ranks", str(world), "--rank", str(r),
+                               "--device", str(r), "--comm-file", str(tmp_path / "token")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    ra = list(csv.reader(open(a / "result_LSC_4agents.csv")))
+    rb = list(csv.reader(open(b / "result_LSC_4agents.csv")))
+    assert len(ra) == len(rb) > 40
+    skip = {15 * q + 11 for q in range(4)}                          # planning_time column (wall clock)
+    for x, y in zip(ra, rb):
+        assert [v for i, v in enumerate(x) if i not in skip] == [v for i, v in enumerate(y) if i not in skip]
+
+
 def test_blocked_corridor_seed_stops_the_run_like_the_reference(tmp_path):
     """An agent that starts inside an obstacle's margin: the reference's expandBoxFromPoint throws std::invalid_argument
     out of plan() (include/corridor_constructor.hpp:35-38) and the simulator dies; lsc_sim must fail as loudly instead

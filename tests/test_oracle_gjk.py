@@ -15,7 +15,7 @@ def test_oracle_gjk_matches_reference_golden_bitwise(oracle, gjk_golden):
 
 
 def test_oracle_gjk_live_against_reference_build(oracle):
-    """Only where oracle/_ref was built (build container, and it travels to the GPU box)."""
+    """Only where oracle/_ref was built: the build container (it is git- AND gpurun-ignored: the reference's GPLv3 openGJK does not travel)."""
     ref = oracle.ref_gjk_lib()
     if ref is None:
         import pytest

@@ -13,7 +13,7 @@ bench lines): device-resident tick loop, one JSON line per configuration.
               tiled 2 x 2 (20 x 20 x 2.5 m; 67 x 67 x 9 search grid: the goal planner's long-search stress case)
   random1024  1024-agent random swarm, empty 40 x 40 x 5 m world               (configs[4] on one GPU)
 Needs a GPU; nothing here touches oracle/ or /root/reference.  The forest occupancy comes from the committed leaf
-fixture (tests/golden/simple_forest_leaves.npz) written out as a .bt file and read back by the product's own reader.
+fixture (lsc_planner_amd/data/simple_forest_leaves.npz) written out as a .bt file and read back by the product's own reader.
 """
 import argparse
 import json
@@ -26,11 +26,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def forest_tiles(tiles):
-    from maputil import forest_leaves, write_bt
+    from lsc_planner_amd.maps import forest_leaves, write_bt
     leaves, res = forest_leaves()
     per = int(round(10.0 / res))           # the fixture covers [-5, 5]^2
     out = []

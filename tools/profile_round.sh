@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
-BENCH="python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-latency-leg"      # default --start-tick 60: timed launches = dispatches 59 .. 158 of the plan kernel
+BENCH="python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-latency-leg --missions 0"      # default --start-tick 60: timed launches = dispatches 59 .. 158 of the plan kernel
 FOREST="python $ROOT/tools/config_runs.py --only forest256p,forest256,forest256x4p,forest256x4 --ticks 30 --warmup 5"
 LARGE="python $ROOT/tools/config_runs.py --only random1024 --ticks 30 --warmup 5"
 GENERAL="python $ROOT/tools/general_profile.py --modes bvc,collision_constraint,gust"      # lsc_general_kernel under load
@@ -19,7 +19,9 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats_forest -o forest -- $FOREST > $OU
 rocprofv3 --kernel-trace --stats -d $OUT/stats_large -o large -- $LARGE > $OUT/large_under_rocprof.jsonl 2> $OUT/stats_large.err
 rocprofv3 --kernel-trace --stats -d $OUT/stats_general -o general -- $GENERAL --ticks 30 > $OUT/general_under_rocprof.jsonl 2> $OUT/stats_general.err
 # 2. counters, each group in its own pass, kernel trace only
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
+# (fourth pass, round 5: the LDS side north_star asks for -- SQ_LDS_IDX_ACTIVE = all LDS-array cycles, SQ_LDS_BANK_CONFLICT = the extra
+#  cycles of bank conflicts, SQ_ACTIVE_INST_LDS / SQ_WAIT_INST_LDS = wave-cycles on / waiting for LDS instructions; MI355X_MICROARCH.md, LDS section)
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_bench_$tag -o bench -- $BENCH --steps 30 > /dev/null 2> $OUT/pmc_bench_$tag.err
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_forest_$tag -o forest -- $FOREST --ticks 10 > /dev/null 2> $OUT/pmc_forest_$tag.err
