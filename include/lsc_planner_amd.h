@@ -132,7 +132,10 @@ typedef struct {
                                   planned control point gets z = world_z_2d (:87-90).  The whole swarm must sit in that plane
                                   (states and previous plans at z = (float)world_z_2d, which is what the reference's simulator
                                   produces: src/mission.cpp:88-112, src/traj_planner.cpp:304-314); the host-buffer ticks return
-                                  LSC_EINVAL otherwise.  0 is read as 3                                                      */
+                                  LSC_EINVAL otherwise.  An agent whose solve fails keeps the optimiser's previous trajectory, which
+                                  starts as zeros in the reference (src/traj_optimizer.cpp:16-19) and has its own z overridden on the
+                                  next state callback; here that stale plan's z block starts at world_z_2d, so a failed first solve
+                                  leaves the swarm in the plane.  0 is read as 3                                              */
     double world_z_2d;         /* world/z_2d (src/param.cpp:15; 1.0)                                                        */
     int    goal_search;        /* goal planner's grid search: 0 (default) the register-resident search whenever the grid admits it
                                   (at most 128 rows, (j, z) of a cell in 17 bits), with 32-bit search keys when their table fits
@@ -203,6 +206,20 @@ int lsc_tick_device(lsc_ctx *ctx, const float *d_state, const float *d_goal, con
 int lsc_tick_device_fused(lsc_ctx *ctx, const float *d_state, const float *d_goal, const float *d_traj_prev,
                           int planner_seq, float *d_traj_next, float *d_state_next, double *d_cost, int *d_status,
                           int *d_iters, void *hip_stream);
+
+/* ---- several independent swarms on one GPU: the mission list as a batch axis ------------------------------
+ * The reference's node flies a directory of missions back to back (src/multi_sync_simulator_node.cpp:43-70, src/param.cpp:106-122;
+ * launch/testall_*.launch: 30 missions per swarm size).  A 64-agent swarm is 64 workgroups on a 256-CU chip, so up to LSC_BATCH_MAX
+ * swarms -- one context each, all on one device -- are planned by ONE launch: lsc_tick_device_fused for every ctx[i] with its own
+ * buffers and its own planner_seq[i], bit-identical results.  Every array argument has n entries (arrays of device pointers, held on
+ * the host).  The contexts must be of one kind: empty maps (no distance field), not sharded, at most one agent per CU each, all with or
+ * all without the alternate-mode hooks (reset_threshold > 0 / BVC / slack), all planar or all 3-D; LSC_EINVAL otherwise, with the
+ * reason in lsc_last_error(ctx[0]).  With lsc_set_timing the launch is timed on ctx[0]. */
+#define LSC_BATCH_MAX 8
+int lsc_tick_device_fused_batch(lsc_ctx *const *ctx, int n, const float *const *d_state, const float *const *d_goal,
+                                const float *const *d_traj_prev, const int *planner_seq, float *const *d_traj_next,
+                                float *const *d_state_next, double *const *d_cost, int *const *d_status, int *const *d_iters,
+                                void *hip_stream);
 
 /* ---- agent-sharded multi-GPU: one context (= one process, one GPU) per rank ---------------------
  * The reference's exchange point is MultiSyncSimulator::update (src/multi_sync_simulator.cpp:297-303), where every

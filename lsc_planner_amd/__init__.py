@@ -13,7 +13,7 @@ Only what the hot path needs lives here:
 """
 from ._lib import LscError, load_library, lib_path  # noqa: F401
 from .mission import Mission, load_mission, circle_swap, random_swarm  # noqa: F401
-from .planner import SwarmPlanner, PlannerConfig, edt_from_bt, comm_unique_id  # noqa: F401
+from .planner import SwarmPlanner, PlannerConfig, edt_from_bt, comm_unique_id, tick_device_fused_batch  # noqa: F401
 
 __all__ = ["LscError", "load_library", "lib_path", "Mission", "load_mission", "circle_swap", "random_swarm",
-           "SwarmPlanner", "PlannerConfig", "edt_from_bt", "comm_unique_id"]
+           "SwarmPlanner", "PlannerConfig", "edt_from_bt", "comm_unique_id", "tick_device_fused_batch"]

@@ -65,7 +65,7 @@ EXPORTS = [
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_safety_ratio", "lsc_sweep_device", "lsc_sweep_device_f32",
     "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_kernel_times_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_goal_profile", "lsc_goal_key_table", "lsc_general_profile", "lsc_dump_qp", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals", "lsc_set_goal_trace", "lsc_get_goal_trace",
     "lsc_last_bucket_max", "lsc_row_capacity", "lsc_comm_unique_id", "lsc_comm_init", "lsc_comm_info", "lsc_tick_device_sharded", "lsc_replan_tick_all",
-    "lsc_row_iterations_total",
+    "lsc_row_iterations_total", "lsc_tick_device_fused_batch",
 ]
 
 
@@ -115,6 +115,8 @@ def load_library(segments=5):
     L.lsc_replan_tick.argtypes = [vp, fp, fp, fp, ctypes.c_int, fp, dp, ip, ip, fp, dp, fp]
     L.lsc_tick_device.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp]
     L.lsc_tick_device_fused.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp, vp, vp]
+    vpp = ctypes.POINTER(vp)
+    L.lsc_tick_device_fused_batch.argtypes = [vpp, ctypes.c_int, vpp, vpp, vpp, ip, vpp, vpp, vpp, vpp, vpp, vp]
     L.lsc_propagate_device.argtypes = [vp, vp, vp, vp]
     L.lsc_safety_ratio.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]
     ubp = ctypes.POINTER(ctypes.c_ubyte)

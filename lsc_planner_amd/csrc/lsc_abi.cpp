@@ -1022,6 +1022,57 @@ int lsc_tick_device_fused(lsc_ctx *c, const float *d_state, const float *d_goal,
     return rc;
 }
 
+// One tick of several independent swarms in ONE launch (lsc_plan_batch_kernel, blockIdx.y = swarm): the reference's mission list
+// (src/multi_sync_simulator_node.cpp:43-70, src/param.cpp:106-122) as a batch axis.  Every context plans exactly what
+// lsc_tick_device_fused would plan for it -- the same instantiation of the planning code reads the context's own argument block --
+// so the results are the same bits; what changes is that a 64-agent swarm no longer has a 256-CU chip to itself.
+int lsc_tick_device_fused_batch(lsc_ctx *const *ctx, int n, const float *const *d_state, const float *const *d_goal,
+                                const float *const *d_traj_prev, const int *planner_seq, float *const *d_traj_next,
+                                float *const *d_state_next, double *const *d_cost, int *const *d_status, int *const *d_iters,
+                                void *hip_stream)
+{
+    if (!ctx || n < 1 || !ctx[0]) return LSC_EINVAL;
+    lsc_ctx *c0 = ctx[0];
+    if (n > PLAN_BATCH_MAX) { c0->err = "lsc_tick_device_fused_batch: at most " + std::to_string(PLAN_BATCH_MAX) + " swarms per launch"; return LSC_EINVAL; }
+    if (!d_state || !d_goal || !d_traj_prev || !planner_seq || !d_traj_next || !d_state_next || !d_cost || !d_status || !d_iters) return LSC_EINVAL;
+    PlanArgs a[PLAN_BATCH_MAX];
+    size_t smem = 0;
+    int slots = 0x7fffffff;
+    bool general = false;
+    for (int i = 0; i < n; i++) {
+        lsc_ctx *c = ctx[i];
+        if (!c || !d_state[i] || !d_goal[i] || !d_traj_prev[i] || !d_traj_next[i] || !d_state_next[i] || !d_cost[i] || !d_status[i] || !d_iters[i]) return LSC_EINVAL;
+        if (c->N == 0) { c0->err = "lsc_tick_device_fused_batch: context " + std::to_string(i) + " has no agents"; return LSC_ESTATE; }
+        // what one launch can hold: swarms on this device that take the latency build with their rows in LDS and nothing between
+        // their launches (maps with a distance field run the goal search and the corridor kernel first; sharded swarms exchange)
+        const char *why = nullptr;
+        if (c->cfg.device != c0->cfg.device) why = "is on another device";
+        else if (c->cfg.use_octomap) why = "has a distance field (goal search and corridor launches precede its plan kernel)";
+        else if (c->comm || c->world != 1) why = "is a rank of a sharded swarm";
+        else if (c->count > c->n_cu) why = "has more agents than the GPU has CUs (the throughput build is not batched)";
+        else if (c->d_spill) why = "needs the second pass (row capacity below 27 (N - 1))";
+        else if (c->profiling || c->trace_agent >= 0) why = "is being profiled / traced";
+        if (why) { c0->err = "lsc_tick_device_fused_batch: context " + std::to_string(i) + " " + why; return LSC_EINVAL; }
+        const int rc = fill_plan_args(c, a[i], d_state[i], d_goal[i], d_traj_prev[i], planner_seq[i], d_traj_next[i], d_cost[i], d_status[i], d_iters[i]);
+        if (rc) return rc;
+        a[i].state_next = d_state_next[i];
+        const size_t sm = plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, c->cap);
+        smem = sm > smem ? sm : smem;
+        if (c->cfg.reset_threshold > 0.0) c->h_ever_stale = true;
+        if (want_general(c, -1)) { general = true; slots = c->gen_slots < slots ? c->gen_slots : slots; }
+    }
+    // (all or none: the alternate-mode hooks are one instantiation per launch, and the hand-over launch covers every swarm of the batch)
+    for (int i = 0; i < n; i++)
+        if (want_general(ctx[i], -1) != general) { c0->err = "lsc_tick_device_fused_batch: contexts with and without alternate-mode hooks in one batch"; return LSC_EINVAL; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipEvent_t e1 = nullptr;
+    if (c0->timing && timing_begin(c0, 0, st, &e1) != LSC_OK) return LSC_EHIP;      // (one launch: timed on the first context)
+    if (launch_plan_batch(a, n, smem, st) != hipSuccess) { c0->err = "lsc_tick_device_fused_batch: launch failed (contexts of different planar / alternate-mode classes?)"; return LSC_EHIP; }
+    if (general) HIPCHK(c0, launch_general_batch(a, n, slots, st));
+    if (c0->timing) HIPCHK(c0, hipEventRecord(e1, st));
+    return LSC_OK;
+}
+
 int lsc_replan_tick(lsc_ctx *c, const float *state, const float *goal, const float *prev_traj, int planner_seq,
                     float *out_traj, double *out_cost, int *out_status, int *out_iters, float *out_lsc_normal,
                     double *out_lsc_d, float *out_sfc)

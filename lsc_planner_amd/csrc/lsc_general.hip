@@ -33,12 +33,7 @@ namespace lsc {
 
 namespace {
 
-// the kernel's argument block, read where it lies: in the kernarg segment (constant address space => scalar loads, no private copy)
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef const __attribute__((address_space(4))) PlanArgs KArgs;
-#else
-typedef const PlanArgs KArgs;
-#endif
+// (KArgs -- the kernel's argument block, read where it lies in the kernarg segment -- is declared in lsc_kernels.h)
 
 constexpr int GT = 512;            // lanes per agent
 constexpr int GW = GT / 64;
@@ -1179,13 +1174,30 @@ __global__ __launch_bounds__(GT) void lsc_general_kernel(PlanArgs)
     general_entry(ka, smem_raw);
 }
 
+// The same for a batch of independent swarms (blockIdx.y = swarm; lsc_kernels.h: PlanBatch).
+__global__ __launch_bounds__(GT) void lsc_general_batch_kernel(PlanBatch)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+#if defined(__HIP_DEVICE_COMPILE__)
+    KArgs *ka = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.y;
+#else
+    KArgs *ka = nullptr;
+#endif
+    bool work = false;
+    for (int al = blockIdx.x; al < ka->count; al += gridDim.x) work |= ka->status[ka->first + al] == LSC_STATUS_GENERAL_K;
+    if (!work) return;
+    general_entry(ka, smem_raw);
+}
+
 size_t general_ws_bytes(int N) { return ws_bytes_of(N); }
 
 size_t general_smem_bytes() { return gs_bytes(); }
 
 hipError_t init_device_general_kernel()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_general_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&lsc_general_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 hipError_t launch_general(const PlanArgs &a, int slots, hipStream_t st)
@@ -1194,6 +1206,27 @@ hipError_t launch_general(const PlanArgs &a, int slots, hipStream_t st)
     const int grid = a.count < slots ? a.count : slots;
     const size_t smem = gs_bytes() + ws_lds_bytes(a.N);
     hipLaunchKernelGGL(lsc_general_kernel, dim3(grid), dim3(GT), smem, st, a);
+    return hipGetLastError();
+}
+
+// n swarms of the same size class in one launch; every swarm's workgroups use ITS workspace (gen_ws of its own block), so `slots`
+// is the smallest slot count among them
+hipError_t launch_general_batch(const PlanArgs *a, int n, int slots, hipStream_t st)
+{
+    if (n < 1 || n > PLAN_BATCH_MAX || slots < 1) return hipErrorInvalidValue;
+    PlanBatch b;
+    int grid = 0, Nmax = 0;
+    for (int i = 0; i < n; i++) {
+        if (!a[i].gen_ws) return hipErrorInvalidValue;
+        b.a[i] = a[i];
+        const int g = a[i].count < slots ? a[i].count : slots;
+        grid = g > grid ? g : grid;
+        Nmax = a[i].N > Nmax ? a[i].N : Nmax;
+    }
+    for (int i = n; i < PLAN_BATCH_MAX; i++) { b.a[i] = a[0]; b.a[i].count = 0; }
+    if (grid == 0) return hipSuccess;
+    const size_t smem = gs_bytes() + ws_lds_bytes(Nmax);
+    hipLaunchKernelGGL(lsc_general_batch_kernel, dim3(grid, n), dim3(GT), smem, st, b);
     return hipGetLastError();
 }
 

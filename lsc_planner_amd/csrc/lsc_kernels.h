@@ -15,6 +15,14 @@
 
 namespace lsc {
 
+struct PlanArgs;
+// an argument block read where it lies, in the kernarg segment: constant address space => scalar loads, no private copy
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) PlanArgs KArgs;
+#else
+typedef const PlanArgs KArgs;
+#endif
+
 struct PlanArgs {
     const Model *model;
     const uint32_t *terms;     // packed Hessian assembly terms
@@ -68,6 +76,15 @@ struct PlanArgs {
     size_t gen_stride;
 };
 constexpr int PROF_PHASES = 16;
+
+// Several independent swarms -- one argument block each -- planned by ONE launch (blockIdx.y = swarm): the reference flies a list of
+// missions back to back (src/multi_sync_simulator_node.cpp:43-70, src/param.cpp:106-122), and a 64-agent swarm is 64 workgroups on a
+// 256-CU chip.  The blocks travel in the kernarg segment itself (no copy to the device; kernarg segments hold 4 KB).
+constexpr int PLAN_BATCH_MAX = 8;
+struct PlanBatch {
+    PlanArgs a[PLAN_BATCH_MAX];
+};
+static_assert(sizeof(PlanBatch) <= 4096, "a batch of argument blocks must fit the kernarg segment");
 
 struct SweepArgs {
     int N, first, count, planner_seq;
@@ -150,6 +167,8 @@ size_t plan_spill_bytes(int N);
 hipError_t init_device_kernels();
 hipError_t init_device_goal_kernel();
 hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st);
+hipError_t launch_plan_batch(const PlanArgs *a, int n, size_t smem, hipStream_t st);
+hipError_t launch_general_batch(const PlanArgs *a, int n, int slots, hipStream_t st);
 hipError_t launch_plan_spill(const PlanArgs &a, int slots, size_t smem, hipStream_t st);
 hipError_t launch_sweep(const SweepArgs &a, hipStream_t st);
 hipError_t launch_propagate(const float *traj, float *state, int N, double dt, hipStream_t st);

@@ -657,8 +657,10 @@ static_assert(PH_COUNT == PROF_PHASES, "lsc_phase_profile copies PROF_PHASES cou
 //                   workgroups per CU when the LDS request allows it: the throughput build for swarms larger than the chip)
 //   DIM2          : planar world (world/dimension == 2): a compile-time switch, because as a run-time flag it cost the non-planar
 //                   kernel 1.5 % (measured: six missions 184.2 -> 186.9 ms of kernel time with the flag, 184.x without)
-template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512, bool DIM2 = false>
-__device__ __forceinline__ void plan_agent(const PlanArgs &a, const int al, unsigned char *smem_raw, unsigned char *ws)
+//   ArgsT         : the argument block as the caller holds it -- `const PlanArgs` (the kernel's by-value parameter) or KArgs (a block
+//                   of a batch launch, read where it lies in the kernarg segment)
+template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512, bool DIM2 = false, class ArgsT = const PlanArgs>
+__device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char *smem_raw, unsigned char *ws)
 {
     constexpr int WS_FEW_ROWS = 200;
     constexpr int NT = NTT;             // shadow the namespace-level constants (those size the LDS arrays: maxima)
@@ -2219,6 +2221,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     plan_agent<false, false, true, 256, DIM2>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
 }
 
+// Several independent swarms in one launch (blockIdx.y = swarm, PlanBatch in lsc_kernels.h): the mission-list outer loop of the reference
+// (src/multi_sync_simulator_node.cpp:43-70) as a batch axis.  A 64-agent swarm is 64 workgroups on a 256-CU chip; four of them in ONE
+// dispatch are placed one per CU (four launches on four streams are not: measured 2.1-2.8x against 3.4-3.9x).
+// The swarm's argument block is read where it lies in the kernarg segment; the planning code is the same instantiation otherwise.
+template <bool ALT, bool DIM2>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_batch_kernel(PlanBatch)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+#if defined(__HIP_DEVICE_COMPILE__)
+    KArgs *ka = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.y;
+#else
+    KArgs *ka = nullptr;                                                             // (host pass of the single-source build)
+#endif
+    if ((int)blockIdx.x >= ka->count) return;                                        // (swarms of a batch may differ in size)
+    plan_agent<false, false, ALT, NT, DIM2, KArgs>(*ka, blockIdx.x, smem_raw, nullptr);
+}
+
 // Preparation pass of the throughput build:
 //  * bounding sphere (centre, radius; float32, radius rounded up) of the agent's predicted control points of all segments
 //    (32 lanes per agent) --
@@ -2336,6 +2355,8 @@ hipError_t init_device_kernels()
                          reinterpret_cast<const void *>(&lsc_plan_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_tp_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_spill_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_spill_kernel<true>),
+                         reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, true>),
+                         reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, true>),
                          reinterpret_cast<const void *>(&lsc_sfc_kernel)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2369,6 +2390,28 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     else if (a.prof) hipLaunchKernelGGL((lsc_plan_kernel<true, false>), dim3(a.count), dim3(NT), smem, st, t);
     else if (d2) hipLaunchKernelGGL((lsc_plan_kernel<false, true>), dim3(a.count), dim3(NT), smem, st, t);
     else hipLaunchKernelGGL((lsc_plan_kernel<false, false>), dim3(a.count), dim3(NT), smem, st, t);
+    return hipGetLastError();
+}
+
+// n independent swarms (same planar / alternate-mode class, latency build, rows in LDS) in one launch
+hipError_t launch_plan_batch(const PlanArgs *a, int n, size_t smem, hipStream_t st)
+{
+    if (n < 1 || n > PLAN_BATCH_MAX) return hipErrorInvalidValue;
+    PlanBatch b;
+    int grid = 0;
+    const bool alt = a[0].general_all || (a[0].reset_thr > 0.0 && a[0].ever);
+    const bool d2 = a[0].dim2 != 0;
+    for (int i = 0; i < n; i++) {
+        const bool alt_i = a[i].general_all || (a[i].reset_thr > 0.0 && a[i].ever);
+        if (alt_i != alt || (a[i].dim2 != 0) != d2 || a[i].prof || a[i].out_normal || a[i].trace) return hipErrorInvalidValue;
+        b.a[i] = a[i];
+        b.a[i].order = nullptr; b.a[i].obs_bound = nullptr;      // (filled by lsc_prep_kernel only: the throughput build is not batched)
+        grid = a[i].count > grid ? a[i].count : grid;
+    }
+    for (int i = n; i < PLAN_BATCH_MAX; i++) { b.a[i] = a[0]; b.a[i].count = 0; }
+    if (grid == 0) return hipSuccess;
+    if (alt) { if (d2) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, true>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<true, false>), dim3(grid, n), dim3(NT), smem, st, b); }
+    else { if (d2) hipLaunchKernelGGL((lsc_plan_batch_kernel<false, true>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<false, false>), dim3(grid, n), dim3(NT), smem, st, b); }
     return hipGetLastError();
 }
 

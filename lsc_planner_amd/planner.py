@@ -384,6 +384,23 @@ class SwarmPlanner:
         return out[:n.value]
 
 
+def tick_device_fused_batch(planners, states, goals, trajs_prev, trajs_next, states_next, costs, statuses, iters, planner_seqs, stream=0):
+    """One tick of several independent swarms -- one SwarmPlanner (context) each, all on one device -- in ONE launch
+    (lsc_tick_device_fused_batch): every argument is a list with one entry per swarm; results are those of tick_device_fused."""
+    n = len(planners)
+    L = planners[0].L
+    vp = ctypes.c_void_p
+
+    def ptrs(ts):
+        return (vp * n)(*[t.data_ptr() for t in ts])
+    ctxs = (vp * n)(*[p.ctx for p in planners])
+    seqs = (ctypes.c_int * n)(*[int(q) for q in planner_seqs])
+    rc = L.lsc_tick_device_fused_batch(ctxs, n, ptrs(states), ptrs(goals), ptrs(trajs_prev), seqs, ptrs(trajs_next), ptrs(states_next),
+                                       ptrs(costs), ptrs(statuses), ptrs(iters), stream)
+    if rc != 0:
+        raise LscError(f"lsc error {rc}: {L.lsc_last_error(planners[0].ctx).decode()}")
+
+
 def comm_unique_id():
     """Rendezvous token of the RCCL communicator (ncclGetUniqueId): rank 0 makes it, every rank passes it to PlannerConfig.comm."""
     L = _lib.load_library()

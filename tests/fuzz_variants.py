@@ -68,6 +68,10 @@ def run_variant(L, O, seed0, trials, variant, max_agents=14, verbose=False):
                     state[:, 5] = 0
             traj = np.zeros((n, 3, 6 * M), np.float32)
             stale = np.zeros_like(traj)
+            if planar:
+                # the optimiser's trajectory starts at zero (src/traj_optimizer.cpp:16-19); in a planar world the product starts its z block
+                # at z_2d, so that an agent whose FIRST QP fails keeps a plan in the plane (round 5; lsc_set_agents) -- the oracle is told the same
+                stale[:, 2, :] = np.float32(Z2D)
             for tick in range(1, 9):
                 g = pl.plan(state, goal, traj)
                 goals = goal
@@ -109,8 +113,8 @@ def run_variant(L, O, seed0, trials, variant, max_agents=14, verbose=False):
                 traj = g["traj"]
                 state = next_state_host(traj, dt=dt)
                 if planar and not (traj[:, 2, :] == np.float32(Z2D)).all():
-                    break         # an agent whose FIRST QP failed keeps the optimiser's zero-initialised trajectory (src/traj_optimizer.cpp:16-19): it is out
-                                  # of the plane, and the next planar tick is refused with LSC_EINVAL (include/lsc_planner_amd.h, world_dimension)
+                    bad.append("seed %d tick %d: a plan of a planar world left the plane (failed solves keep a stale plan whose z block is z_2d)" % (seed0 + trial, tick))
+                    break
             pl.close()
     return agent_ticks, failures, bad
 

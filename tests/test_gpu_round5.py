@@ -51,11 +51,29 @@ def test_four_concurrent_missions_plan_the_same_bits_as_four_sequential_ones(L):
                 con_out[m].append(snapshot(r))
     for r in runs:
         r.close()
+    # ... and through ONE launch per tick (lsc_tick_device_fused_batch: blockIdx.y = mission)
+    runs = [MissionRun(L, torch, ms, cfg(), dev, torch.cuda.current_stream()) for ms in missions]
+    bat_out = [[] for _ in missions]
+    for t in range(ticks):
+        for r in runs:
+            r.seq += 1
+        L.tick_device_fused_batch([r.pl for r in runs], [r.states[0] for r in runs], [r.goal for r in runs], [r.prev for r in runs],
+                                  [r.nxt for r in runs], [r.states[1] for r in runs], [r.cost for r in runs], [r.status for r in runs],
+                                  [r.iters for r in runs], [r.seq for r in runs], runs[0].stream)
+        for r in runs:
+            r.states.reverse()
+            r.prev, r.nxt = r.nxt, r.prev
+        if t % 10 == 9 or t == ticks - 1:
+            for m, r in enumerate(runs):
+                bat_out[m].append(snapshot(r))
+    for r in runs:
+        r.close()
     for m in range(len(missions)):
-        assert len(seq_out[m]) == len(con_out[m])
-        for a, b in zip(seq_out[m], con_out[m]):
-            for x, y in zip(a, b):
-                assert np.array_equal(x, y), f"mission {m}"
+        assert len(seq_out[m]) == len(con_out[m]) == len(bat_out[m])
+        for a, b, c in zip(seq_out[m], con_out[m], bat_out[m]):
+            for x, y, z in zip(a, b, c):
+                assert np.array_equal(x, y), f"mission {m} (streams)"
+                assert np.array_equal(x, z), f"mission {m} (batch launch)"
         assert (seq_out[m][-1][3] == 0).all()
     # the missions are not copies of each other
     assert not np.array_equal(seq_out[0][-1][0], seq_out[1][-1][0])
@@ -84,3 +102,56 @@ def test_planar_world_keeps_planning_after_a_first_solve_that_fails(L):
         assert np.all(state[:, 2] == np.float32(0.7))
     pl.close()
     assert failed_first, "the scene is meant to make the first solve of an agent fail"
+
+
+def test_batch_launch_with_ragged_swarms_modes_and_refusals(L):
+    """lsc_tick_device_fused_batch beyond the bench's four equal swarms: swarms of different sizes in one launch (workgroups beyond a
+    swarm's size leave at once), a planar batch, a batch after a gust (the hand-over launch of the alternate-mode kernel is batched too),
+    and the combinations it refuses (mixed alternate-mode classes, an octomap context) with the reason in lsc_last_error."""
+    import torch
+    from bench import MissionRun
+    dev = torch.device("cuda", 0)
+
+    def fly(missions, cfgs, ticks, batch, gust_at=None):
+        runs = [MissionRun(L, torch, ms, cfg, dev, torch.cuda.current_stream()) for ms, cfg in zip(missions, cfgs)]
+        for t in range(ticks):
+            if gust_at is not None and t == gust_at:
+                for r in runs:                       # push agent 0 of every swarm 0.3 m off its plan (> reset_threshold)
+                    r.states[0][0, 0] += 0.3
+            if batch:
+                for r in runs:
+                    r.seq += 1
+                L.tick_device_fused_batch([r.pl for r in runs], [r.states[0] for r in runs], [r.goal for r in runs], [r.prev for r in runs],
+                                          [r.nxt for r in runs], [r.states[1] for r in runs], [r.cost for r in runs], [r.status for r in runs],
+                                          [r.iters for r in runs], [r.seq for r in runs], runs[0].stream)
+                for r in runs:
+                    r.states.reverse()
+                    r.prev, r.nxt = r.nxt, r.prev
+            else:
+                for r in runs:
+                    r.tick()
+        torch.cuda.synchronize()
+        out = [[x.cpu().numpy().copy() for x in (r.prev, r.states[0], r.cost, r.status, r.iters)] for r in runs]
+        for r in runs:
+            r.close()
+        return out
+
+    def same(a, b):
+        return all(np.array_equal(x, y) for ra, rb in zip(a, b) for x, y in zip(ra, rb))
+
+    # ragged: 5, 20 and 64 agents in one launch
+    ms = [L.circle_swap(n, circle_radius=max(1.2, 8.0 * n / 64.0), z=1.0, world=(-10, -10, 0, 10, 10, 2.5)) for n in (5, 20, 64)]
+    cfgs = lambda **kw: [L.PlannerConfig(goal_mode="prior_based", **kw) for _ in ms]
+    assert same(fly(ms, cfgs(), 25, False), fly(ms, cfgs(), 25, True))
+    # disturbance checks on, a gust at tick 6: every swarm hands agents to the alternate-mode kernel, batched
+    a, b = fly(ms, cfgs(reset_threshold=0.15), 12, False, gust_at=6), fly(ms, cfgs(reset_threshold=0.15), 12, True, gust_at=6)
+    assert same(a, b)
+    # planar worlds
+    mp = [L.circle_swap(n, circle_radius=max(1.2, 8.0 * n / 64.0), z=0.8, world=(-10, -10, 0, 10, 10, 2.5)) for n in (8, 16)]
+    pc = lambda: [L.PlannerConfig(world_dimension=2, world_z_2d=0.8) for _ in mp]
+    assert same(fly(mp, pc(), 15, False), fly(mp, pc(), 15, True))
+    # refusals: mixed classes
+    with pytest.raises(L.LscError, match="alternate-mode"):
+        fly(ms[:2], [L.PlannerConfig(reset_threshold=0.15), L.PlannerConfig()], 1, True)
+    with pytest.raises(L.LscError, match="planar|classes|launch failed"):
+        fly(mp, [L.PlannerConfig(world_dimension=2, world_z_2d=0.8), L.PlannerConfig()], 1, True)
