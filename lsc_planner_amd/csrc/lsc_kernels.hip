@@ -2213,6 +2213,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     plan_agent<false, false, false, 256, DIM2>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
 }
 
+// ... its instrumented variant (lsc_phase_profile on a shard larger than the chip: where the throughput build's time goes)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_tp_prof_kernel(PlanArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    plan_agent<true, false, false, 256, false>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
+}
+
 // ... and the throughput build with the alternate-mode hooks
 template <bool DIM2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_alt_tp_kernel(PlanArgs a)
@@ -2354,6 +2361,7 @@ hipError_t init_device_kernels()
                          reinterpret_cast<const void *>(&lsc_plan_alt_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_alt_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_tp_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<true>),
+                         reinterpret_cast<const void *>(&lsc_plan_tp_prof_kernel),
                          reinterpret_cast<const void *>(&lsc_plan_spill_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_spill_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, true>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, true>),
@@ -2368,7 +2376,12 @@ hipError_t init_device_kernels()
 }
 
 // whether this launch takes the throughput build (and with it lsc_prep_kernel's bounds / order)
-static bool uses_throughput_build(const PlanArgs &a) { return a.cap_tp > 0 && !a.prof && !a.out_normal && !a.trace; }
+static bool uses_throughput_build(const PlanArgs &a)
+{
+    const bool alt = a.general_all || (a.reset_thr > 0.0 && a.ever);
+    // (the instrumented throughput kernel exists for 3-D worlds without the alternate-mode hooks, like the instrumented latency kernel)
+    return a.cap_tp > 0 && !(a.prof && (alt || a.dim2)) && !a.out_normal && !a.trace;
+}
 
 hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
 {
@@ -2381,7 +2394,8 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
         // throughput build: smaller capacity (an agent beyond it takes the second pass), two workgroups per CU
         t.cap = a.cap_tp;
         if (t.order || t.obs_bound) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
-        if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
+        if (a.prof) hipLaunchKernelGGL(lsc_plan_tp_prof_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
+        else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
         else { if (d2) hipLaunchKernelGGL(lsc_plan_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
         return hipGetLastError();
     }
