@@ -401,7 +401,7 @@ struct SmemT {
     double Tv[NCP * 3];         // per control point: -sum v n over its LSC rows
     double Tz[NCP * 3];         // per control point: -sum z n
     double K[NY * KLD];         // reduced Hessian (lower band); rows of its Cholesky factor after factor()
-    double red[2][5][NWAVE];    // per-wave partials of the block reductions, two banks used in turn (one barrier per reduction)
+    double red[2][5][SMALL ? 4 : NWAVE];    // per-wave partials of the block reductions, two banks used in turn (one barrier per reduction); SMALL: four waves
     double colbuf[2][2 * 64];   // column broadcast buffers of the two factorising waves (double-buffered by column parity)
     double mid2[BAND * BAND + 7];   // Schur contribution of the bottom-up sweep to the middle block (original indices); + room for the corrector-pass staging
     double dinv[NY + 1];            // 1 / d of the pivots of K = T D T^T taken top-down (unknown = index), stored by every lane as each is formed
@@ -420,10 +420,10 @@ struct SmemT {
     double Qh6[NC * NC];        // 2 w_c Q_base (cost gradient stencil)
     uint32_t xgp[NV];           // three global y indices per variable, one per byte
     uint32_t yop[NY], ypp[NY];  // four x indices (axis-major / point-major) per unknown, one per byte
-    unsigned char avalid[AXROWS];
+    unsigned char avalid[SMALL ? 4 : AXROWS];   // (SMALL: the cold start works the validity of a slot out itself)
     // agent constants
     double s0[3][3];            // c_{0,0..2} per axis
-    double x0c[NV];             // the same constants addressed by variable index (k*30 + t, t < 3)
+    double x0c[SMALL ? 1 : NV]; // the same constants addressed by variable index (k*30 + t, t < 3)  (SMALL: read from s0)
     double lo[3][M], hi[3][M];  // bounds per axis and segment (world box, intersected with the SFC)
     double goal[3];
     double reachL[3][28], reachU[3][28];   // per axis: bounds of c_{m,i} - c_{0,2} after K = 5m+i-2 steps (phase B pruning)
@@ -431,7 +431,7 @@ struct SmemT {
     int cnt[32];                // rows per control-point bucket
     int offs[32];               // exclusive prefix of cnt over the 27 buckets
     uint32_t offcnt[32];        // offs | cnt << 16 per bucket (LDS pass: both below 65536), one load per reduction unit
-    int wcnt[NWAVE][32];
+    int wcnt[SMALL ? 4 : NWAVE][32];
     // row reduction: slots = (bucket, part) pairs, one lane each; two granularities (predictor / corrector staging sizes differ)
     uint32_t slotP[RSLOT_P], slotC[RSLOT_C];   // first row | rows << 16 | bucket << 24
     unsigned short soffP[NB + 1], soffC[NB + 1];   // first slot of every bucket (+ total)
@@ -709,8 +709,10 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         terms = lt; ent = le;
         kconst = reinterpret_cast<double *>(le + 2 * n_entries + 2);
     } else {
+        // (round 5: the constant part of the entries IS kept -- 3.2 KB --: recomputing it in every assembly, with its index divisions and
+        //  its loads of the cost Hessian from L2, was half of what the assembly cost more here than in the latency build)
         terms = a.terms; ent = a.entries;
-        kconst = reinterpret_cast<double *>(S.dyn) - n_entries;     // not stored: recomputed in assemble(); rows start at S.dyn
+        kconst = reinterpret_cast<double *>(S.dyn);
     }
     double *rowbase;
     if constexpr (SPILL) rowbase = reinterpret_cast<double *>(ws);
@@ -871,7 +873,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         // rest at z_2d -- state constants and terminal target there, no rows -- and are overwritten on output
         if (dim2 && k == 2) c0 = c1 = c2 = md.z2d;
         S.s0[k][0] = c0; S.s0[k][1] = c1; S.s0[k][2] = c2;
-        S.x0c[k * SEGV] = c0; S.x0c[k * SEGV + 1] = c1; S.x0c[k * SEGV + 2] = c2;
+        if constexpr (TABLES_IN_LDS) { S.x0c[k * SEGV] = c0; S.x0c[k * SEGV + 1] = c1; S.x0c[k * SEGV + 2] = c2; }
         S.goal[k] = (dim2 && k == 2) ? md.z2d : (double)S.goalf[k];
         if (a.goal_out) a.goal_out[3 * qi + k] = S.goalf[k];
         for (int m = 0; m < M; m++) {
@@ -953,8 +955,10 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         }
         return v;
     };
-    if constexpr (TABLES_IN_LDS)
-        for (int e = tid; e < n_entries; e += NT) kconst[e] = kconst_of(ent[2 * e]);
+    for (int e = tid; e < n_entries; e += NT) kconst[e] = kconst_of(ent[2 * e]);
+    // Throughput build: the entry words of this lane's (at most two) Hessian entries never change -- kept in registers --, and the term
+    // words they point at are fetched from L2 in ONE batch in front of every row reduction (prefetch_terms), so that the assembly
+    // behind it finds them in registers: read where they were needed they cost up to three dependent L2 round trips per assembly.
     stamp(PH_SETUP);
 
     // ------------------------------------------------------------------ phase B: LSC rows
@@ -1315,7 +1319,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         else if (type < 4) { valid = i <= 4 && !(m == 0 && i < 2); h = a.vmax[3 * qi + k] * md.hv_scale; }
         else { valid = i <= 3 && !(m == 0 && i == 0); h = a.amax[3 * qi + k] * md.ha_scale; }
         if (dim2 && k == 2) valid = false;
-        S.avalid[sl] = valid ? 1 : 0;
+        if constexpr (TABLES_IN_LDS) S.avalid[sl] = valid ? 1 : 0;
         if constexpr (TABLES_IN_LDS) S.ah[sl] = h;
         S.as_[sl] = 1.0; S.az[sl] = 0.0; S.at1[sl] = 0.0; S.at2[sl] = 0.0;
     }
@@ -1341,11 +1345,24 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     const int nact = S.nact;
     const double nrow = (double)(n_ax + nact);
 
+    // state constant of variable v = k*SEGV + t (t < 3); existence of axis-row slot sl (the throughput build keeps neither table)
+    auto X0C = [&](int v) -> double {
+        if constexpr (TABLES_IN_LDS) return S.x0c[v];
+        else return S.s0[v / SEGV][v % SEGV];
+    };
+    auto AVALID = [&](int sl) -> double {
+        if constexpr (TABLES_IN_LDS) return (double)S.avalid[sl];
+        else {
+            const int type = sl / NV, kt = sl % NV, k = kt / SEGV, t = kt % SEGV, i = t % NC;
+            const bool valid = type < 2 ? t >= 3 : (type < 4 ? (i <= 4 && t >= 2) : (i <= 3 && t >= 1));
+            return (valid && !(dim2 && k == 2)) ? 1.0 : 0.0;
+        }
+    };
     // x from y : x_t = sum coef * y_glob  (+ state constants for t < 3)
     auto compute_x = [&](const double *yv, double *xv, bool with_const) {
         if (tid < NV) {
             double v;
-            if (xt < 3) v = with_const ? S.x0c[tid] : 0.0;
+            if (xt < 3) v = with_const ? X0C(tid) : 0.0;
             else {
                 const uint32_t gp = S.xgp[tid];
                 const double *c = S.xtc[xt];
@@ -1360,7 +1377,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     auto x_of = [&](const double *yv, double *xv, bool with_const, int v) {
         const int t = v % SEGV;
         double val;
-        if (t < 3) val = with_const ? S.x0c[v] : 0.0;
+        if (t < 3) val = with_const ? X0C(v) : 0.0;
         else {
             const uint32_t gp = S.xgp[v];
             const double *c = S.xtc[t];
@@ -1445,10 +1462,10 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 double w0, w1, w2, w3, w4, w5, w2m, w3m, w4m, w5m, w4mm, w5mm;
                 if (unit_w) {
                     // cold start: weight 1 on every existing row
-                    w0 = S.avalid[0 * NV + o0]; w1 = S.avalid[1 * NV + o0]; w2 = S.avalid[2 * NV + o0]; w3 = S.avalid[3 * NV + o0];
-                    w4 = S.avalid[4 * NV + o0]; w5 = S.avalid[5 * NV + o0];
-                    w2m = S.avalid[2 * NV + o1]; w3m = S.avalid[3 * NV + o1]; w4m = S.avalid[4 * NV + o1]; w5m = S.avalid[5 * NV + o1];
-                    w4mm = S.avalid[4 * NV + o2]; w5mm = S.avalid[5 * NV + o2];
+                    w0 = AVALID(0 * NV + o0); w1 = AVALID(1 * NV + o0); w2 = AVALID(2 * NV + o0); w3 = AVALID(3 * NV + o0);
+                    w4 = AVALID(4 * NV + o0); w5 = AVALID(5 * NV + o0);
+                    w2m = AVALID(2 * NV + o1); w3m = AVALID(3 * NV + o1); w4m = AVALID(4 * NV + o1); w5m = AVALID(5 * NV + o1);
+                    w4mm = AVALID(4 * NV + o2); w5mm = AVALID(5 * NV + o2);
                 } else {
                     const double z0 = S.az[0 * NV + o0], z1 = S.az[1 * NV + o0], z2 = S.az[2 * NV + o0], z3 = S.az[3 * NV + o0];
                     const double z4 = S.az[4 * NV + o0], z5 = S.az[5 * NV + o0];
@@ -1596,8 +1613,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             for (int e = tid; e < n_entries; e += NT) {
                 const uint32_t id = ent[2 * e], t0 = ent[2 * e + 1], t1 = ent[2 * e + 3];
                 double v;
-                if constexpr (TABLES_IN_LDS) v = kconst[e];
-                else v = kconst_of(id);
+                v = kconst[e];
                 // four terms per trip: the term words first, then the weights they point at (two LDS round trips per trip instead of
                 // two per term); terms past the entry's end get coefficient zero
                 for (uint32_t q = t0; q < t1; q += 4) {
@@ -2339,8 +2355,8 @@ size_t plan_smem_bytes(int n_terms, int n_entries, int rows, bool tables_in_lds)
     if (tables_in_lds) {
         b += sizeof(uint32_t) * (size_t)((n_terms + 1) & ~1);
         b += sizeof(uint32_t) * (size_t)(2 * n_entries + 2);
-        b += sizeof(double) * (size_t)n_entries;
     }
+    b += sizeof(double) * (size_t)n_entries;      // constant part of the Hessian entries (both layouts since round 5)
     b += (size_t)rows * (5 * sizeof(double) + 3 * sizeof(float) + sizeof(uint32_t));
     return (b + 15) & ~(size_t)15;
 }
