@@ -141,6 +141,13 @@ typedef struct {
                                   (at most 128 rows, (j, z) of a cell in 17 bits), with 32-bit search keys when their table fits
                                   LDS (else the double itself as key); 1 always the general search with the row bookkeeping in
                                   LDS; 2 the register-resident search with 64-bit keys.  Same paths in every case (tests)      */
+    int    solver;             /* QP solver of the LSC fast path (the reference: CPLEX with RootAlgorithm Dual, src/traj_optimizer.cpp:42-56).
+                                  1 (default via lsc_default_config): a dual active-set solve first -- Goldfarb-Idnani on the 39-unknown
+                                  reduced problem from the unconstrained optimum; measured: at most 9 of the ~2 000 rows are active at an
+                                  optimum and the slowest agent of a tick needs ~8-13 changes of the working set -- and the interior point
+                                  only when that gives up (more than 12 active rows, dependent rows, an infeasible QP: the interior point
+                                  then decides the status as before).  0: the interior point alone (rounds 1-4).  Same optimum within the
+                                  parity tolerances either way; planar worlds, the throughput build and the second pass keep solver 0   */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);
@@ -322,6 +329,12 @@ int lsc_iterations_total(lsc_ctx *ctx, long long *total, int reset);
  * lsc_iterations_total: what the kernels executed, next to the 27 (N - 1) rows per iteration of the reference's model
  * (bench.py: roofline.frac_executed). */
 int lsc_row_iterations_total(lsc_ctx *ctx, long long *total);
+
+/* Counters of the active-set solve (lsc_config.solver 1) since the last reset of lsc_iterations_total: out[0] agent-replans it finished,
+ * [1] agent-replans it handed to the interior point (working set beyond its capacity, dependent rows, no admissible step: the
+ * interior point then decides, infeasible verdicts included), [2] changes of the working set, [3] interior-point iterations of the
+ * handed-over agents.  Synchronises. */
+int lsc_solver_stats(lsc_ctx *ctx, long long out[4]);
 
 /* Diagnostics.  lsc_phase_profile: enable=1 selects the instrumented plan kernel and clears its counters, 0 goes
  * back to the production kernel, -1 only reads; out (may be NULL) gets [N][16] counts (100 MHz wall clock)

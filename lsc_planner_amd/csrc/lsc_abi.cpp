@@ -106,6 +106,31 @@ void build_model(const lsc_config &cfg, HostModel &H)
             m.Hc[a * NYA + b] = s;
         }
 
+    // inverse of the axis block of the reduced cost Hessian for T = 1 .. M terminal segments (Model::ginv): Gauss-Jordan with partial
+    // pivoting in long double (the block is positive definite: a plan whose jerk cost vanishes is fixed by the initial state)
+    for (int T = 1; T <= M; T++) {
+        long double A[NYA][2 * NYA];
+        for (int a = 0; a < NYA; a++) {
+            for (int b = 0; b < NYA; b++) { A[a][b] = m.Hc[a * NYA + b]; A[a][NYA + b] = a == b ? 1.0L : 0.0L; }
+            const int mterm = a == NYL ? M - 1 : ((a % 3) == 2 ? a / 3 : -1);       // y_a is c_{m,5} (or the last segment's end point)
+            if (mterm >= M - T) A[a][a] += 2.0L * cfg.terminal_weight;
+        }
+        for (int c = 0; c < NYA; c++) {
+            int piv = c;
+            for (int r = c + 1; r < NYA; r++) if (fabsl(A[r][c]) > fabsl(A[piv][c])) piv = r;
+            if (piv != c) for (int j = 0; j < 2 * NYA; j++) std::swap(A[c][j], A[piv][j]);
+            const long double d = A[c][c];
+            for (int j = 0; j < 2 * NYA; j++) A[c][j] /= d;
+            for (int r = 0; r < NYA; r++) {
+                if (r == c) continue;
+                const long double f = A[r][c];
+                if (f != 0.0L) for (int j = 0; j < 2 * NYA; j++) A[r][j] -= f * A[c][j];
+            }
+        }
+        for (int a = 0; a < NYA; a++)
+            for (int b = 0; b < NYA; b++) m.ginv[T - 1][a * NYA + b] = (double)(0.5L * (A[a][NYA + b] + A[b][NYA + a]));
+    }
+
     // Hessian assembly terms: K[(k,a),(k',b)] += Z[t][a] Z[t'][b] * Wx[(k,t),(k',t')]
     auto scomp = [](int k, int kk) { if (k > kk) std::swap(k, kk); return k == 0 ? kk : (k == 1 ? 2 + kk : 5); };  // xx xy xz yy yz zz
     auto axis_of = [](int g) { return yaxis(g); };
@@ -374,7 +399,7 @@ void lsc_default_config(lsc_config *cfg)
     cfg->planner_mode = 0; cfg->slack_mode = 0; cfg->slack_collision_weight = 100000.0; cfg->n_constraint_segments = -1;
     cfg->reset_threshold = 0.0;
     cfg->gap_tolerance = 1e-9;
-    cfg->world_dimension = 3; cfg->world_z_2d = 1.0; cfg->goal_search = 0;
+    cfg->world_dimension = 3; cfg->world_z_2d = 1.0; cfg->goal_search = 0; cfg->solver = 1;
 }
 
 lsc_ctx *lsc_create(const lsc_config *cfg)
@@ -578,12 +603,12 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMalloc(&c->d_order, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_obs_bound, sizeof(float) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
-    HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * 2 * (size_t)N));       // [N] iterations, [N] iterations x LSC rows
+    HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (2 * (size_t)N + 4)));       // [N] iterations, [N] iterations x LSC rows, [4] counters of the active-set solve
     HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));          // [N] plan kernel, [N] general kernel
     HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_dbg, sizeof(double) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_dbg, 0, sizeof(double) * 4 * (size_t)N));
-    HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * 2 * (size_t)N));
+    HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (2 * (size_t)N + 4)));
     {
         const size_t n = (size_t)N;
         float *in = nullptr;
@@ -899,6 +924,8 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.model = c->d_model; a.terms = c->d_terms; a.entries = c->d_entries;
     a.N = c->N; a.first = c->first; a.count = c->count; a.planner_seq = seq; a.cap = c->cap;
     a.dim2 = c->cfg.world_dimension == 2 ? 1 : 0;
+    a.solver = c->cfg.solver;
+    a.solver_stats = c->d_iters_acc ? c->d_iters_acc + 2 * (size_t)c->N : nullptr;      // (four counters behind the two per-agent blocks)
     a.cap_tp = (c->count > c->n_cu) ? c->cap_tp : 0; a.smem_tp = c->smem_tp;
     a.order = (c->count > 2 * c->n_cu) ? c->d_order : nullptr;   // more than one round of throughput workgroups
     a.obs_bound = a.cap_tp > 0 ? c->d_obs_bound : nullptr;       // obstacle-level pre-cull of the throughput build
@@ -1727,7 +1754,7 @@ int lsc_iterations_total(lsc_ctx *c, long long *total, int reset)
     long long t = 0;
     for (long long v : h) t += v;
     *total = t;
-    if (reset) HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * 2 * (size_t)c->N));
+    if (reset) HIPCHK(c, hipMemset(c->d_iters_acc, 0, sizeof(long long) * (2 * (size_t)c->N + 4)));
     return LSC_OK;
 }
 
@@ -1742,6 +1769,16 @@ int lsc_row_iterations_total(lsc_ctx *c, long long *total)
     long long t = 0;
     for (long long v : h) t += v;
     *total = t;
+    return LSC_OK;
+}
+
+// counters of the active-set solve since the last reset of lsc_iterations_total: agent-replans it finished, agent-replans it handed to
+// the interior point, changes of the working set, interior-point iterations of the handed-over agents
+int lsc_solver_stats(lsc_ctx *c, long long out[4])
+{
+    if (!c || !out || c->N == 0) return LSC_EINVAL;
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, c->d_iters_acc + 2 * (size_t)c->N, sizeof(long long) * 4, hipMemcpyDeviceToHost));
     return LSC_OK;
 }
 

@@ -659,9 +659,12 @@ static_assert(PH_COUNT == PROF_PHASES, "lsc_phase_profile copies PROF_PHASES cou
 //                   kernel 1.5 % (measured: six missions 184.2 -> 186.9 ms of kernel time with the flag, 184.x without)
 //   ArgsT         : the argument block as the caller holds it -- `const PlanArgs` (the kernel's by-value parameter) or KArgs (a block
 //                   of a batch launch, read where it lies in the kernarg segment)
-template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512, bool DIM2 = false, class ArgsT = const PlanArgs>
+//   SOLVER        : 0 the interior point alone; 1 a dual active-set solve first (gi_solve below: Goldfarb-Idnani from the unconstrained
+//                   optimum), the interior point only when that gives up
+template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512, bool DIM2 = false, class ArgsT = const PlanArgs, int SOLVER = 0>
 __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char *smem_raw, unsigned char *ws)
 {
+    static_assert(SOLVER == 0 || (!SPILL && !DIM2 && !PROF && NTT == 512), "the active-set solve exists for the 3-D latency build with its rows in LDS");
     constexpr int WS_FEW_ROWS = 200;
     constexpr int NT = NTT;             // shadow the namespace-level constants (those size the LDS arrays: maxima)
     constexpr int NWAVE = NTT / 64;
@@ -1874,7 +1877,275 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         __syncthreads();
     };
 
-    bool run = true;
+    // ---------------------------------------------------------------- dual active set (SOLVER == 1)
+    // Goldfarb & Idnani (1983) on the 39-unknown reduced problem  min 1/2 y'Hy + g'y  s.t.  G y <= h,  started from the unconstrained
+    // optimum with an empty working set: the most violated row is added (after dropping the rows whose multipliers the step would
+    // take below zero) until nothing is violated.  Why it pays here: measured on the CPU over six missions (tests/prototypes/
+    // active_set_study.py, profiles/r05_active_set_study.log) the optimum holds at most 9 active rows of the ~2 000, and the agent a
+    // tick waits for needs 8 changes of the working set in the median and 13 at the 99th percentile -- against 9-12 interior-point
+    // iterations of ~17 us.  A change costs one pass over the rows (the search for the most violated one) and a few dozen
+    // dependent operations on wave 0.  What keeps it small: the reduced Hessian is the SAME 13 x 13 block for every axis, agent and
+    // tick up to the number of terminal segments, so its inverse comes from the host (Model::ginv); the working set is capped at
+    // GQ rows, its Gram matrix S = G_W H^-1 G_W' is refactored per change (q <= 12).  Anything unusual -- more than GQ active rows,
+    // more than GI_CAP changes, a Gram matrix that is not positive definite (dependent rows), no admissible step (an infeasible
+    // QP) -- returns false and the interior point decides, as before.
+    constexpr int GS = (NY + 1) & ~1;                         // stride of a working-set row in y-space (40 for NY = 39)
+    constexpr int HV = (NYA * NYA + 7) & ~7;
+    constexpr int GQ = (HV + 2 * 12 * GS + 2 * 12 * 12 + 2 * 12 + 6 <= NY * KLD) ? 12 : 8;      // working-set capacity: what fits the idle K (12 for M = 5, 8 for M = 4)
+    constexpr int GI_CAP = 60;
+    int gi_changes = 0;
+    auto gi_solve = [&]() -> bool {
+        if constexpr (SOLVER != 1) return false;
+        else {
+        double *const gk = S.K;                       // the interior point's K is idle until then (re-zeroed on the way there)
+        double *const Hinv = gk;                      // [NYA][NYA]
+        double *const Nw = gk + HV;                   // [GQ][GS] rows of the working set in y-space
+        double *const Yw = Nw + GQ * GS;              // [GQ][GS] H^-1 times those
+        double *const Sm = Yw + GQ * GS;              // [GQ][GQ] Gram matrix
+        double *const Lm = Sm + GQ * GQ;              // [GQ][GQ] its Cholesky factor
+        double *const uw = Lm + GQ * GQ;              // [GQ] multipliers
+        double *const rwv = uw + GQ;                  // [GQ] multiplier rates of the current step
+        int *const wrow = reinterpret_cast<int *>(rwv + GQ);   // [GQ] row codes (index into amap, or n_ax + index into cmap)
+        static_assert(HV + 2 * GQ * GS + 2 * GQ * GQ + 2 * GQ + (GQ + 1) / 2 <= NY * KLD, "the working set fits the idle K");
+        double *const npv = S.rhs, *const hin = S.dy, *const gyv = S.gz;      // [40] each, idle here
+        const double INF = 1e300;
+        for (int i = tid; i < NYA * NYA; i += NT) Hinv[i] = md.ginv[S.tseg - 1][i];
+        for (int c = tid; c < nact; c += NT) rt1[cmap[c] & CMAP_MASK] = 0.0;      // "row is in the working set" marks (axis rows: S.at1, zero already)
+        if (tid < 40) S.y[tid] = 0.0;
+        __syncthreads();
+        compute_x(S.y, S.x, true);
+        __syncthreads();
+        if (tid < NV) {
+            double cg = cost_grad();
+            if (xterm) cg += 2.0 * md.w_t * (S.x[tid] - S.goal[xk]);
+            S.gx[tid] = cg;                           // gradient of the cost at y = 0, in x-space
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // unconstrained optimum y = -H^-1 Z' grad
+            if (lane < NY) {
+                const uint32_t yo = S.yop[lane];
+                gyv[lane] = S.ytc[lane][0] * S.gx[yo & 0xff] + S.ytc[lane][1] * S.gx[(yo >> 8) & 0xff] + S.ytc[lane][2] * S.gx[(yo >> 16) & 0xff] +
+                            S.ytc[lane][3] * S.gx[yo >> 24];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < NY) {
+                const int k = yaxis(lane), va = yvar(lane);
+                double acc = 0.0;
+#pragma unroll
+                for (int b = 0; b < NYA; b++) acc += Hinv[va * NYA + b] * gyv[yglob(k, b)];
+                S.y[lane] = -acc;
+            }
+        }
+        int q = 0;
+        for (;;) {
+            if (wave == 0) compute_x_wave0(S.y, S.x, true);
+            __syncthreads();
+            // ---- the most violated row outside the working set (violation over 1 + |right-hand side|; ties: lowest row)
+            double best = 0.0;
+            int bidx = 0;
+            for (int c = tid; c < n_ax; c += NT) {
+                const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
+                const double *xq = S.x + ak * SEGV + at;
+                double mark = S.at1[sl], x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl);
+                LSC_PIN(PV(mark), PV(x0), PV(x1), PV(x2), PV(hh));
+                const double v = (ax_row3(x0, x1, x2, type) - hh) / (1.0 + fabs(hh));
+                if (mark == 0.0 && v > best) { best = v; bidx = c; }
+            }
+            for (int c = tid; c < nact; c += NT) {
+                const uint32_t e = cmap[c];
+                const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
+                double mark = rt1[r], x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r];
+                float n0 = rn[r], n1 = rn[R + r], n2 = rn[2 * R + r];
+                LSC_PIN(PV(mark), PV(x0), PV(x1), PV(x2), PV(hh), PV(n0), PV(n1), PV(n2));
+                const double v = (hh - ((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2)) / (1.0 + fabs(hh));
+                if (mark == 0.0 && v > best) { best = v; bidx = n_ax + c; }
+            }
+            // one reduction: violation as float32 bits in the upper word, ~row in the lower -- as a double it orders like the pair
+            const unsigned long long key = best > 0.0 ? (((unsigned long long)__float_as_uint((float)best)) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)bidx) : 0ull;
+            block_reduce(__longlong_as_double((long long)key), 0.0, 0.0, 0.0, 0.0, 1, -1, -1, -1, -1);
+            const unsigned long long kmax = (unsigned long long)__double_as_longlong(rv[0]);
+            if (!(__uint_as_float((uint32_t)(kmax >> 32)) > 1e-10f)) break;                  // nothing violated: optimal
+            const int idx = (int)(0xffffffffu - (uint32_t)(kmax & 0xffffffffull));
+            if (wave == 0) {
+                // ---- the row: three x-variables with their coefficients, and the right-hand side
+                int v0, v1, v2;
+                double a0, a1, a2, hp;
+                if (idx < n_ax) {
+                    const uint32_t am = S.amap[idx]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
+                    const int kind = type >> 1;
+                    const double sg = (type & 1) ? -1.0 : 1.0;
+                    a0 = sg * (kind == 1 ? -1.0 : 1.0); a1 = sg * (kind == 0 ? 0.0 : (kind == 1 ? 1.0 : -2.0)); a2 = sg * (kind == 2 ? 1.0 : 0.0);
+                    v0 = ak * SEGV + at; v1 = kind >= 1 ? v0 + 1 : v0; v2 = kind == 2 ? v0 + 2 : v0;
+                    hp = AH(sl);
+                } else {
+                    const uint32_t e = cmap[idx - n_ax];
+                    const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
+                    a0 = -(double)rn[r]; a1 = -(double)rn[R + r]; a2 = -(double)rn[2 * R + r];
+                    v0 = cp; v1 = SEGV + cp; v2 = 2 * SEGV + cp;
+                    hp = -rrhs[r];
+                }
+                double viol = a0 * S.x[v0] + a1 * S.x[v1] + a2 * S.x[v2] - hp;
+                // its normal in y-space: x_v = sum_j xtc[t][j] y[xgp byte j]
+                auto zc = [&](int v) -> double {
+                    const uint32_t gp = S.xgp[v];
+                    const double *c = S.xtc[v % SEGV];
+                    return ((int)(gp & 0xff) == lane ? c[0] : 0.0) + ((int)((gp >> 8) & 0xff) == lane ? c[1] : 0.0) + ((int)(gp >> 16) == lane ? c[2] : 0.0);
+                };
+                const double np_g = lane < NY ? a0 * zc(v0) + a1 * zc(v1) + a2 * zc(v2) : 0.0;
+                if (lane < GS) npv[lane] = np_g;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                double hin_g = 0.0;
+                if (lane < NY) {
+                    const int k = yaxis(lane), va = yvar(lane);
+#pragma unroll
+                    for (int b = 0; b < NYA; b++) hin_g += Hinv[va * NYA + b] * npv[yglob(k, b)];
+                }
+                if (lane < GS) hin[lane] = hin_g;
+                const double nph = wave_sum(np_g * hin_g);            // n' H^-1 n > 0
+                double up = 0.0;
+                int code = 0;
+                for (;;) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // d = G_W H^-1 n ; r = S^-1 d
+                    double dw = 0.0, rw = 0.0;
+                    if (lane < q) for (int g2 = 0; g2 < NY; g2++) dw += Nw[lane * GS + g2] * hin[g2];
+                    if (q > 0) {
+                        bool pd = true;
+                        for (int j = 0; j < q; j++) {          // left-looking Cholesky of S, lanes = rows
+                            double aij = 0.0;
+                            if (lane < q && lane >= j) {
+                                aij = Sm[lane * GQ + j];
+                                for (int kk = 0; kk < j; kk++) aij -= Lm[lane * GQ + kk] * Lm[j * GQ + kk];
+                            }
+                            const double piv = lane_value(aij, j);
+                            if (!(piv > 1e-13 * Sm[j * GQ + j])) { pd = false; break; }
+                            const double inv = 1.0 / sqrt(piv);
+                            if (lane < q && lane >= j) Lm[lane * GQ + j] = aij * inv;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        }
+                        if (!pd) { code = 2; break; }
+                        double b = dw;
+                        for (int j = 0; j < q; j++) {          // L w = d
+                            const double wj = lane_value(b, j) / Lm[j * GQ + j];
+                            if (lane == j) b = wj;
+                            else if (lane > j && lane < q) b -= Lm[lane * GQ + j] * wj;
+                        }
+                        for (int i = q - 1; i >= 0; i--) {     // L' r = w
+                            const double ri = lane_value(b, i) / Lm[i * GQ + i];
+                            if (lane == i) b = ri;
+                            else if (lane < i) b -= Lm[i * GQ + lane] * ri;
+                        }
+                        rw = lane < q ? b : 0.0;
+                        if (lane < q) rwv[lane] = rw;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                    // primal direction z = H^-1 n - Y_W r (it keeps the working set active) and its slope against the new row
+                    double zg = hin_g;
+                    if (lane < NY) for (int w = 0; w < q; w++) zg -= Yw[w * GS + lane] * rwv[w];
+                    const double zn = wave_sum(np_g * zg);
+                    const double ratio = (lane < q && rw > 1e-13) ? uw[lane] / rw : INF;
+                    const double t1 = wave_min(ratio);
+                    const unsigned long long dropmask = __ballot(lane < q && ratio == t1);
+                    const double t2 = zn > 1e-12 * nph ? viol / zn : INF;
+                    if (t1 >= INF && t2 >= INF) { code = 1; break; }          // no admissible step: the rows contradict each other
+                    const double t = fmin(t1, t2);
+                    if (t2 < INF) {
+                        if (lane < NY) S.y[lane] -= t * zg;
+                        viol -= t * zn;
+                    }
+                    if (lane < q) uw[lane] = fmax(uw[lane] - t * rw, 0.0);
+                    up += t;
+                    gi_changes++;
+                    if (t2 <= t1) {
+                        // full step: the row joins the working set
+                        if (q == GQ) { code = 2; break; }
+                        if (lane < GS) { Nw[q * GS + lane] = np_g; Yw[q * GS + lane] = hin_g; }
+                        if (lane < q) { Sm[q * GQ + lane] = dw; Sm[lane * GQ + q] = dw; }
+                        if (lane == 0) {
+                            Sm[q * GQ + q] = nph; uw[q] = up; wrow[q] = idx;
+                            if (idx < n_ax) S.at1[S.amap[idx] & 1023] = 1.0;
+                            else rt1[cmap[idx - n_ax] & CMAP_MASK] = 1.0;
+                        }
+                        q++;
+                        break;
+                    }
+                    // partial step: row j of the working set reached multiplier zero and leaves (the last row takes its place)
+                    const int j = __ffsll((long long)dropmask) - 1, last = q - 1;
+                    if (lane == 0) {
+                        const int code_j = wrow[j];
+                        if (code_j < n_ax) S.at1[S.amap[code_j] & 1023] = 0.0;
+                        else rt1[cmap[code_j - n_ax] & CMAP_MASK] = 0.0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (j != last) {
+                        if (lane < GS) { Nw[j * GS + lane] = Nw[last * GS + lane]; Yw[j * GS + lane] = Yw[last * GS + lane]; }
+                        const double srow = lane < q ? Sm[last * GQ + lane] : 0.0;       // row `last` of S (symmetric)
+                        const double sll = Sm[last * GQ + last];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (lane < last && lane != j) { Sm[j * GQ + lane] = srow; Sm[lane * GQ + j] = srow; }
+                        if (lane == 0) { Sm[j * GQ + j] = sll; uw[j] = uw[last]; wrow[j] = wrow[last]; }
+                    }
+                    q--;
+                    if (gi_changes > GI_CAP) { code = 2; break; }
+                }
+                if (lane == 0) { S.sc[0] = (double)code; S.sc[1] = (double)q; S.sc[2] = (double)gi_changes; }
+            }
+            __syncthreads();
+            if (S.sc[0] != 0.0) return false;
+            q = (int)S.sc[1];
+            gi_changes = (int)S.sc[2];
+        }
+        // Nothing outside the working set is violated.  The rows INSIDE it were made active when they joined and every later step kept
+        // them active -- up to the accuracy of the Gram solve: with nearly dependent rows they can drift, and a marked row is never
+        // looked at again above.  So every row is checked once more, marks ignored; a violation here hands the agent to the interior point.
+        {
+            double worst = 0.0;
+            for (int c = tid; c < n_ax; c += NT) {
+                const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
+                const double *xq = S.x + ak * SEGV + at;
+                double x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl);
+                LSC_PIN(PV(x0), PV(x1), PV(x2), PV(hh));
+                worst = fmax(worst, (ax_row3(x0, x1, x2, type) - hh) / (1.0 + fabs(hh)));
+            }
+            for (int c = tid; c < nact; c += NT) {
+                const uint32_t e = cmap[c];
+                const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
+                double x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r];
+                float n0 = rn[r], n1 = rn[R + r], n2 = rn[2 * R + r];
+                LSC_PIN(PV(x0), PV(x1), PV(x2), PV(hh), PV(n0), PV(n1), PV(n2));
+                worst = fmax(worst, (hh - ((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2)) / (1.0 + fabs(hh)));
+            }
+            block_reduce(worst, 0.0, 0.0, 0.0, 0.0, 1, -1, -1, -1, -1);
+            if (rv[0] > 1e-9) return false;
+        }
+        // optimum: S.x holds it (formed at the top of the last round); objective like the interior point's residual pass
+        double objp = 0.0;
+        if (tid < NV) {
+            objp = 0.5 * cost_grad() * S.x[tid];
+            if (xterm) { const double e = S.x[tid] - S.goal[xk]; objp += md.w_t * e * e; }
+        }
+        block_reduce(objp, 0.0, 0.0, 0.0, 0.0, 0, -1, -1, -1, -1);
+        obj = rv[0];
+        return true;
+        }
+    };
+
+    bool run = true, run_gi_done = false;
     if (a.goal_err && a.goal_err[qi] != 0) {
         status = LSC_STATUS_GOAL_K;  // the goal planner ran out of LDS capacity: no goal, no plan
         run = false;
@@ -1887,16 +2158,31 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     } else if (overflow) {
         status = LSC_STATUS_CAPACITY_K;
         run = false;
-    } else if (attempt == 0) {
-        // An agent with few surviving LSC rows (most agents of a sparse swarm) is close to its unconstrained optimum: it
-        // starts a third as far from the boundary.  Over 36 missions this takes 10 % off the ticks of random swarms and
-        // leaves crossing swarms where they were (profiles/r02_solver_knob_sweeps.log).  Not in corridor worlds: there the
-        // box rows, which this count does not see, are what is active (the 256-agent forest loses 2.6 % with the rule).
-        prepare_warm((nact < WS_FEW_ROWS && !md.use_sfc) ? md.ws_mu0 * (1.0 / 3.0) : md.ws_mu0);
-        phase = ST_PRED;
+    } else if (SOLVER == 1 && gi_solve()) {
+        status = LSC_STATUS_OK_K;        // the active-set solve reached the optimum: obj and S.x are set
+        iters = gi_changes;
+        run = false;
+        run_gi_done = true;
     } else {
-        prepare_cold();
-        phase = ST_COLD;
+        if constexpr (SOLVER == 1) {
+            // the active-set solve gave up: the interior point starts from its own initial state (K zero outside the band, no marks)
+            for (int i = tid; i < NY * KLD; i += NT) S.K[i] = 0.0;
+            for (int c = tid; c < n_ax; c += NT) S.at1[S.amap[c] & 1023] = 0.0;
+            if (tid < 40) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
+            spent = gi_changes;          // (reported with the iterations, like the iterations of a failed warm start)
+            __syncthreads();
+        }
+        if (attempt == 0) {
+            // An agent with few surviving LSC rows (most agents of a sparse swarm) is close to its unconstrained optimum: it
+            // starts a third as far from the boundary.  Over 36 missions this takes 10 % off the ticks of random swarms and
+            // leaves crossing swarms where they were (profiles/r02_solver_knob_sweeps.log).  Not in corridor worlds: there the
+            // box rows, which this count does not see, are what is active (the 256-agent forest loses 2.6 % with the rule).
+            prepare_warm((nact < WS_FEW_ROWS && !md.use_sfc) ? md.ws_mu0 * (1.0 / 3.0) : md.ws_mu0);
+            phase = ST_PRED;
+        } else {
+            prepare_cold();
+            phase = ST_COLD;
+        }
     }
     stamp(PH_INIT);
 
@@ -2194,6 +2480,15 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         a.iters[qi] = iters;
         if (a.iters_acc) { a.iters_acc[qi] += iters; a.iters_acc[a.N + qi] += (long long)iters * S.nact; }
         if (a.nrows) a.nrows[qi] = S.nact;
+        if constexpr (SOLVER == 1) {
+            if (a.solver_stats) {
+                // [0] agent-replans the active-set solve finished, [1] those it handed to the interior point, [2] working-set changes, [3] interior-point iterations
+                const bool by_gi = run_gi_done;
+                atomicAdd((unsigned long long *)&a.solver_stats[by_gi ? 0 : 1], 1ull);
+                atomicAdd((unsigned long long *)&a.solver_stats[2], (unsigned long long)gi_changes);
+                if (!by_gi) atomicAdd((unsigned long long *)&a.solver_stats[3], (unsigned long long)(iters - gi_changes));
+            }
+        }
         if (a.dbg) { a.dbg[4 * qi] = S.sc[5]; a.dbg[4 * qi + 1] = S.sc[6]; a.dbg[4 * qi + 2] = spent > 0 ? 1000.0 + (double)spent : rv[3]; a.dbg[4 * qi + 3] = obj; }
         if constexpr (PROF) {
             stamp(PH_OUT);
@@ -2204,19 +2499,19 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     if constexpr (PROF) { if (tid == NT - 1 && a.prof) a.prof[(size_t)qi * PH_COUNT + PH_RED_GATHER] += t_acc[PH_RED_GATHER]; }
 }
 
-template <bool PROF, bool DIM2>
+template <bool PROF, bool DIM2, int SOLVER = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<PROF, false, false, NT, DIM2>(a, blockIdx.x, smem_raw, nullptr);
+    plan_agent<PROF, false, false, NT, DIM2, const PlanArgs, SOLVER>(a, blockIdx.x, smem_raw, nullptr);
 }
 
 // the same kernel with the alternate-mode hooks (contexts with reset_threshold > 0, BVC or a slack mode)
-template <bool DIM2>
+template <bool DIM2, int SOLVER = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_alt_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<false, false, true, NT, DIM2>(a, blockIdx.x, smem_raw, nullptr);
+    plan_agent<false, false, true, NT, DIM2, const PlanArgs, SOLVER>(a, blockIdx.x, smem_raw, nullptr);
 }
 
 // Throughput build for swarms larger than the chip (more agents in the shard than CUs): 256 lanes = one wave per SIMD, and
@@ -2248,7 +2543,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // (src/multi_sync_simulator_node.cpp:43-70) as a batch axis.  A 64-agent swarm is 64 workgroups on a 256-CU chip; four of them in ONE
 // dispatch are placed one per CU (four launches on four streams are not: measured 2.1-2.8x against 3.4-3.9x).
 // The swarm's argument block is read where it lies in the kernarg segment; the planning code is the same instantiation otherwise.
-template <bool ALT, bool DIM2>
+template <bool ALT, bool DIM2, int SOLVER = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_batch_kernel(PlanBatch)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -2258,7 +2553,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     KArgs *ka = nullptr;                                                             // (host pass of the single-source build)
 #endif
     if ((int)blockIdx.x >= ka->count) return;                                        // (swarms of a batch may differ in size)
-    plan_agent<false, false, ALT, NT, DIM2, KArgs>(*ka, blockIdx.x, smem_raw, nullptr);
+    plan_agent<false, false, ALT, NT, DIM2, KArgs, SOLVER>(*ka, blockIdx.x, smem_raw, nullptr);
 }
 
 // Preparation pass of the throughput build:
@@ -2381,6 +2676,8 @@ hipError_t init_device_kernels()
                          reinterpret_cast<const void *>(&lsc_plan_spill_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_spill_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, true>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, true>),
+                         reinterpret_cast<const void *>(&lsc_plan_kernel<false, false, 1>), reinterpret_cast<const void *>(&lsc_plan_alt_kernel<false, 1>),
+                         reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, false, 1>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, false, 1>),
                          reinterpret_cast<const void *>(&lsc_sfc_kernel)};
     for (const void *f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2416,7 +2713,10 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
         return hipGetLastError();
     }
     t.order = nullptr; t.obs_bound = nullptr;     // filled by lsc_prep_kernel only
-    if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_kernel<true>, dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL(lsc_plan_alt_kernel<false>, dim3(a.count), dim3(NT), smem, st, t); }
+    // solver 1: the active-set solve first (3-D worlds, production kernels); everything else keeps the interior point alone
+    const bool gi = a.solver == 1 && !d2 && !a.prof;
+    if (gi) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_kernel<false, 1>), dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL((lsc_plan_kernel<false, false, 1>), dim3(a.count), dim3(NT), smem, st, t); }
+    else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_kernel<true>, dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL(lsc_plan_alt_kernel<false>, dim3(a.count), dim3(NT), smem, st, t); }
     else if (a.prof) hipLaunchKernelGGL((lsc_plan_kernel<true, false>), dim3(a.count), dim3(NT), smem, st, t);
     else if (d2) hipLaunchKernelGGL((lsc_plan_kernel<false, true>), dim3(a.count), dim3(NT), smem, st, t);
     else hipLaunchKernelGGL((lsc_plan_kernel<false, false>), dim3(a.count), dim3(NT), smem, st, t);
@@ -2440,7 +2740,10 @@ hipError_t launch_plan_batch(const PlanArgs *a, int n, size_t smem, hipStream_t 
     }
     for (int i = n; i < PLAN_BATCH_MAX; i++) { b.a[i] = a[0]; b.a[i].count = 0; }
     if (grid == 0) return hipSuccess;
-    if (alt) { if (d2) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, true>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<true, false>), dim3(grid, n), dim3(NT), smem, st, b); }
+    bool gi = !d2;
+    for (int i = 0; i < n; i++) gi = gi && a[i].solver == 1;
+    if (gi) { if (alt) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, false, 1>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<false, false, 1>), dim3(grid, n), dim3(NT), smem, st, b); }
+    else if (alt) { if (d2) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, true>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<true, false>), dim3(grid, n), dim3(NT), smem, st, b); }
     else { if (d2) hipLaunchKernelGGL((lsc_plan_batch_kernel<false, true>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<false, false>), dim3(grid, n), dim3(NT), smem, st, b); }
     return hipGetLastError();
 }

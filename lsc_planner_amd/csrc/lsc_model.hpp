@@ -77,6 +77,11 @@ struct Model {
     // overwritten on output; the x / y iterates are those of the 26-unknown problem.
     int    dim2;
     double z2d;               // (double)(float)world/z_2d
+    // Inverse of the reduced cost Hessian of ONE axis, Z'(blockdiag(Qh) + 2 w_t E_T) Z, for T = 1 .. M terminal segments
+    // (src/traj_optimizer.cpp:329-372: the terminal weight sits on c_{m,5} of the last T segments).  The three axes share it and the
+    // cost does not couple them, so the 39 x 39 reduced Hessian is three copies of this 13 x 13 block: what the active-set solve
+    // (lsc_kernels.hip, gi_solve) needs of it is its inverse, formed once on the host in extended precision.
+    double ginv[M][NYA * NYA];
 };
 
 // Dense variant of the same elimination for the alternate planner modes (lsc_general.hip): axis-major y, with

@@ -43,6 +43,7 @@ class PlannerConfig:
     world_dimension: int = 3        # world/dimension: 2 = planar goal grid at z = world_z_2d
     world_z_2d: float = 1.0         # world/z_2d
     goal_search: str = "auto"      # goal planner's grid search: "auto" (register-resident, 32-bit keys when their table fits), "general", "key64" (register-resident, the double as key)
+    solver: str = "active_set"     # QP solver of the LSC fast path: "active_set" (dual active set first, interior point as fallback) or "interior_point"
     comm: tuple = None              # (world_size, rank, id bytes from comm_unique_id()): agent-sharded multi-GPU over RCCL
 
 
@@ -97,6 +98,7 @@ class SwarmPlanner:
         c.gap_tolerance = self.cfg.gap_tolerance
         c.world_dimension, c.world_z_2d = int(self.cfg.world_dimension), float(self.cfg.world_z_2d)
         c.goal_search = {"auto": 0, "general": 1, "key64": 2}[self.cfg.goal_search]
+        c.solver = {"active_set": 1, "interior_point": 0}[self.cfg.solver]
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:
@@ -364,6 +366,12 @@ class SwarmPlanner:
         t = ctypes.c_longlong()
         self._check(self.L.lsc_row_iterations_total(self.ctx, ctypes.byref(t)))
         return t.value
+
+    def solver_stats(self):
+        """Counters of the active-set solve since the last iterations_total(reset=True): dict(solved, handed_over, changes, ip_iterations)."""
+        out = (ctypes.c_longlong * 4)()
+        self._check(self.L.lsc_solver_stats(self.ctx, out))
+        return dict(solved=out[0], handed_over=out[1], changes=out[2], ip_iterations=out[3])
 
     def set_timing(self, on):
         self._check(self.L.lsc_set_timing(self.ctx, int(on)))
