@@ -138,6 +138,7 @@ struct Param {   // defaults = launch/testall_empty.launch
     std::string comm_file;   // rank 0 writes the RCCL rendezvous token here, the others read it
     // mode/planner, SlackMode, opt/slack_collision_weight, opt/N_constraint_segments (src/param.cpp:33-48, 72-76)
     int planner_mode = 0;              // 0 lsc, 1 bvc
+    int solver = 1;                    // lsc_config.solver: 1 dual active set first (default), 0 interior point alone
     int slack_mode = 0;                // 0 none, 1 dynamical_limit, 2 collision_constraint
     double slack_collision_weight = 100000.0;
     int N_constraint_segments = -1;

@@ -1,6 +1,10 @@
 // multi_sync_simulator.cpp -- headless MultiSyncSimulator (src/multi_sync_simulator.cpp) over the C ABI.
 //   lsc_sim --mission m.json [--world map.bt] [--max-iter 300] [--csv DIR] [--device 0] [--quiet]
 //           [--ranks W --rank R --comm-file PATH]     one process per GPU; or RANK / WORLD_SIZE / LOCAL_RANK from the env
+//           [--solver active_set|interior_point]      QP solver of the fast path (lsc_config.solver).  The active-set solve returns the exact
+//                                                     optimum: a PERFECTLY symmetric mission (multi_simple4, an unperturbed circle) then stays
+//                                                     symmetric and can tie in the priority rule for good -- the reference's remedy is
+//                                                     multisim/max_noise (0.02 in launch/simulation.launch): --max-noise 0.02
 // Loop: isFinished -> doStep -> update (ideal next state of every agent) -> plan (one lsc_replan_tick for the
 // swarm) -> savePlanningResult (safety ratio / collision accounting) -> optional result / summary CSV in the
 // reference's column layout, so that its replayer can read our runs.
@@ -25,7 +29,7 @@ class MultiSyncSimulator {
             std::fprintf(stderr, "[TrajPlanner] LSC does not need slack variables, fix to none\n");
             param.slack_mode = 0;
         }
-        cfg.planner_mode = param.planner_mode; cfg.slack_mode = param.slack_mode;
+        cfg.planner_mode = param.planner_mode; cfg.slack_mode = param.slack_mode; cfg.solver = param.solver;
         cfg.slack_collision_weight = param.slack_collision_weight; cfg.n_constraint_segments = param.N_constraint_segments;
         cfg.reset_threshold = param.multisim_reset_threshold;   // the disturbance checks of every shipped launch file (0.15)
         cfg.world_dimension = param.world_dimension; cfg.world_z_2d = param.world_z_2d;
@@ -363,6 +367,7 @@ int main(int argc, char **argv)
         else if (a == "--device") param.device = std::stoi(next());
         else if (a == "--quiet") quiet = true;
         else if (a == "--phase-stats") param.phase_stats = true;
+        else if (a == "--solver") { const std::string v = next(); if (v == "active_set") param.solver = 1; else if (v == "interior_point") param.solver = 0; else { std::fprintf(stderr, "lsc_sim: --solver active_set|interior_point\n"); return 2; } }
         else if (a == "--static-goal") param.goal_mode_prior_based = false;
         else if (a == "--planner") { const std::string v = next(); param.planner_mode = v == "bvc" ? 1 : 0; }
         else if (a == "--slack") { const std::string v = next(); param.slack_mode = v == "dynamical_limit" ? 1 : (v == "collision_constraint" ? 2 : 0); }
@@ -377,7 +382,7 @@ int main(int argc, char **argv)
         else if (a == "--ranks") param.world = std::stoi(next());
         else if (a == "--rank") param.rank = std::stoi(next());
         else if (a == "--comm-file") param.comm_file = next();
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats] [--dt T --horizon H] | lsc_sim --replay result.csv\n"); return 2; }
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats] [--solver active_set|interior_point] [--dt T --horizon H] | lsc_sim --replay result.csv\n"); return 2; }
     }
     if (!replay_file.empty()) {
         // MultiSyncReplayer (src/multi_sync_replayer.cpp): read a result CSV back -- needs no GPU -- and say what it holds

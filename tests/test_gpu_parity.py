@@ -275,14 +275,20 @@ def test_heterogeneous_radii_use_their_own_corridor_margin(L, oracle):
     pl.close()
 
 
-def test_prior_based_goal_planning_bitwise_and_mission_completes(L, oracle):
+@pytest.mark.parametrize("solver,noise", [("interior_point", 0.0), ("active_set", 0.02)])
+def test_prior_based_goal_planning_bitwise_and_mission_completes(L, oracle, solver, noise):
     """mode/goal = prior_based (the reference's default) on the empty map: device goals == oracle restatement of
     goalPlanningWithPriority bit for bit, ticks match, and the 20-agent circle swap reaches its goals without collision
-    (with static goals it deadlocks in the centre)."""
+    (with static goals it deadlocks in the centre).  The unperturbed circle is perfectly symmetric: it is flown by the interior point,
+    whose 1e-6 m of agent-dependent noise breaks the ties of the priority rule; the active-set solve (exact optimum: the symmetry would
+    survive, and two agents end in an infeasible QP on which the oracle agrees) flies it with the reference's goal noise
+    (multisim/max_noise, src/mission.cpp:386-395)."""
     from lsc_planner_amd.planner import next_state_host
     ms = L.circle_swap(20, 8.0)
     N = 20
-    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))
+    if noise > 0:
+        ms.goal[:, :3] += np.random.default_rng(20).uniform(0, noise, (N, 3)).astype(np.float32)
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based", solver=solver))
     sw = oracle_swarm(oracle, ms)
     state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
     traj = np.zeros((N, 3, 30), np.float32)

@@ -294,8 +294,10 @@ def test_throughput_build_agrees_with_the_latency_build(L, n, world, reset_thres
     tick's iterations and rows (lsc_prep_kernel), and runs the build with the disturbance checks compiled in."""
     from lsc_planner_amd.planner import next_state_host
     ms = L.random_swarm(n, world=world, seed=9)
-    tp = L.SwarmPlanner(ms, L.PlannerConfig(reset_threshold=reset_threshold))
-    lat = L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=64, reset_threshold=reset_threshold))
+    # (solver: the throughput build keeps the interior point, so the latency build is pinned to it too -- this test compares BUILDS;
+    #  what the active-set solve returns is held to the oracle everywhere else)
+    tp = L.SwarmPlanner(ms, L.PlannerConfig(reset_threshold=reset_threshold, solver="interior_point"))
+    lat = L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=64, reset_threshold=reset_threshold, solver="interior_point"))
     lds, thr = tp.row_capacity()
     assert 0 < thr < lds and lat.row_capacity()[1] == 0
     state, traj = _start(ms)
