@@ -664,7 +664,7 @@ static_assert(PH_COUNT == PROF_PHASES, "lsc_phase_profile copies PROF_PHASES cou
 template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512, bool DIM2 = false, class ArgsT = const PlanArgs, int SOLVER = 0>
 __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char *smem_raw, unsigned char *ws)
 {
-    static_assert(SOLVER == 0 || (!SPILL && !DIM2 && !PROF && NTT == 512), "the active-set solve exists for the 3-D latency build with its rows in LDS");
+    static_assert(SOLVER == 0 || (!SPILL && !DIM2 && !PROF), "the active-set solve exists for 3-D worlds with the rows in LDS");
     constexpr int WS_FEW_ROWS = 200;
     constexpr int NT = NTT;             // shadow the namespace-level constants (those size the LDS arrays: maxima)
     constexpr int NWAVE = NTT / 64;
@@ -2517,11 +2517,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // Throughput build for swarms larger than the chip (more agents in the shard than CUs): 256 lanes = one wave per SIMD, and
 // an LDS request of at most half a CU's 160 KB, so that two agents share a CU and one hides the other's latencies (the
 // solver is a chain of dependent LDS / cross-lane operations: VALU active 13 % of wave-cycles in the latency build).
-template <bool DIM2>
+template <bool DIM2, int SOLVER = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_tp_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<false, false, false, 256, DIM2>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
+    plan_agent<false, false, false, 256, DIM2, const PlanArgs, SOLVER>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
 }
 
 // ... its instrumented variant (lsc_phase_profile on a shard larger than the chip: where the throughput build's time goes)
@@ -2532,11 +2532,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ... and the throughput build with the alternate-mode hooks
-template <bool DIM2>
+template <bool DIM2, int SOLVER = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_alt_tp_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<false, false, true, 256, DIM2>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
+    plan_agent<false, false, true, 256, DIM2, const PlanArgs, SOLVER>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
 }
 
 // Several independent swarms in one launch (blockIdx.y = swarm, PlanBatch in lsc_kernels.h): the mission-list outer loop of the reference
@@ -2673,6 +2673,7 @@ hipError_t init_device_kernels()
                          reinterpret_cast<const void *>(&lsc_plan_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_tp_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_tp_prof_kernel),
+                         reinterpret_cast<const void *>(&lsc_plan_tp_kernel<false, 1>), reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<false, 1>),
                          reinterpret_cast<const void *>(&lsc_plan_spill_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_spill_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, true>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, true>),
@@ -2708,6 +2709,7 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
         t.cap = a.cap_tp;
         if (t.order || t.obs_bound) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
         if (a.prof) hipLaunchKernelGGL(lsc_plan_tp_prof_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
+        else if (a.solver == 1 && !d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL((lsc_plan_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); }
         else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
         else { if (d2) hipLaunchKernelGGL(lsc_plan_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
         return hipGetLastError();

@@ -284,9 +284,10 @@ def test_spatial_pre_cull_changes_nothing_but_the_time(L, n):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("solver", ["active_set", "interior_point"])
 @pytest.mark.parametrize("n,world,reset_threshold", [(320, (-12, -12, 0, 12, 12, 3.0), 0.0),
                                                      (600, (-16, -16, 0, 16, 16, 3.0), 0.15)])
-def test_throughput_build_agrees_with_the_latency_build(L, n, world, reset_threshold):
+def test_throughput_build_agrees_with_the_latency_build(L, n, world, reset_threshold, solver):
     """A shard with more agents than the GPU has CUs runs the 256-lane throughput build (two workgroups per CU, smaller LDS
     row capacity, assembly tables read from L2); max_rows_per_cp = 64 pins the 512-lane latency build.  Same rows, same
     statuses; costs and plans within the parity tolerances (block reductions combine 4 instead of 8 partial sums).
@@ -294,10 +295,8 @@ def test_throughput_build_agrees_with_the_latency_build(L, n, world, reset_thres
     tick's iterations and rows (lsc_prep_kernel), and runs the build with the disturbance checks compiled in."""
     from lsc_planner_amd.planner import next_state_host
     ms = L.random_swarm(n, world=world, seed=9)
-    # (solver: the throughput build keeps the interior point, so the latency build is pinned to it too -- this test compares BUILDS;
-    #  what the active-set solve returns is held to the oracle everywhere else)
-    tp = L.SwarmPlanner(ms, L.PlannerConfig(reset_threshold=reset_threshold, solver="interior_point"))
-    lat = L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=64, reset_threshold=reset_threshold, solver="interior_point"))
+    tp = L.SwarmPlanner(ms, L.PlannerConfig(reset_threshold=reset_threshold, solver=solver))
+    lat = L.SwarmPlanner(ms, L.PlannerConfig(max_rows_per_cp=64, reset_threshold=reset_threshold, solver=solver))
     lds, thr = tp.row_capacity()
     assert 0 < thr < lds and lat.row_capacity()[1] == 0
     state, traj = _start(ms)
