@@ -139,6 +139,27 @@ def algorithmic_flops(n_agents, iters_total):
     return float(iters_total) * ((n_agents - 1) * 1.0e3 + 0.3e6)
 
 
+# The active-set solve does other -- and much less -- arithmetic than the interior point SURVEY 8(d) prices, so it gets a model of its own
+# (DESIGN section 4.1): per change of the working set one pass over the rows (violation of every row: 3 multiply-adds, the normalisation,
+# the compare ~ 9 flop per row; the 414 bound / velocity / acceleration rows are always carried) plus ~2.6 kflop of small dense algebra
+# (H^-1 n: 39 x 13 multiply-adds; G_W H^-1 n, the direction and the Gram solve for a working set of <= 12 rows); per solve the start
+# (gradient, unconstrained optimum: ~2.5 kflop) and two more passes over the rows (the last search, the verification).
+GI_ROW_FLOP, GI_AXIS_ROWS, GI_DENSE_PER_CHANGE, GI_PER_SOLVE = 9.0, 414.0, 2.6e3, 2.5e3
+
+
+def active_set_flops(n_agents, stats, row_changes_total, rows_mean, all_rows):
+    """fp64 flops of the timed ticks under the model above.  row_changes_total = sum over agents of changes x LSC rows carried (device
+    accumulator), or changes x 27 (N - 1) when all_rows (the reference's row count); handed-over agents add SURVEY's interior-point model."""
+    solves = float(stats["solved"] + stats["handed_over"])
+    changes = float(stats["changes"])
+    rows = 27.0 * (n_agents - 1) if all_rows else rows_mean
+    rc = changes * 27.0 * (n_agents - 1) if all_rows else float(row_changes_total)
+    f = GI_ROW_FLOP * (rc + changes * GI_AXIS_ROWS) + changes * GI_DENSE_PER_CHANGE
+    f += solves * (GI_PER_SOLVE + 2.0 * GI_ROW_FLOP * (rows + GI_AXIS_ROWS))
+    f += float(stats["ip_iterations"]) * ((n_agents - 1) * 1.0e3 + 0.3e6)
+    return f
+
+
 def cpu_baseline(ms, seconds_target=12.0, max_ticks=120, static_goal=False):
     """Oracle (CPU restatement of the reference path) on the same mission from its start, sequential over agents
     like the reference, then once more with OpenMP over agents on all cores."""
@@ -323,6 +344,7 @@ def main():
     ap.add_argument("--agents-per-gpu", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-leg", action="store_true")
+    ap.add_argument("--no-ip-leg", action="store_true", help="skip the interior_point_leg (the timed ticks once more under --solver interior_point)")
     ap.add_argument("--no-prune", action="store_true")
     ap.add_argument("--static-goal", action="store_true", help="mode/goal=static instead of the reference default prior_based")
     ap.add_argument("--reset-threshold", type=float, default=0.15,
@@ -330,6 +352,9 @@ def main():
                          "(they never fire on this mission; the tick pays the scan and the hand-over launch, ~2.4 %%); 0 = off")
     ap.add_argument("--planner", default="lsc", choices=["lsc", "bvc"], help="mode/planner (bvc: the general dense kernel)")
     ap.add_argument("--slack", default="none", choices=["none", "dynamical_limit", "collision_constraint"])
+    ap.add_argument("--solver", default="active_set", choices=["active_set", "interior_point"],
+                    help="QP solver of the fast path (lsc_config.solver): active_set = the dual active-set solve first, the interior point as its "
+                         "fallback (the library's default); interior_point = the interior point alone (rounds 1-4)")
     ap.add_argument("--unfused", action="store_true",
                     help="single GPU only: use the multi-GPU tick sequence (plan shard, exchange, propagate) instead of the fused launch")
     ap.add_argument("--single-circle", action="store_true",
@@ -412,7 +437,7 @@ def main():
     def make_planner(comm):
         p = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode,
                                                reset_threshold=args.reset_threshold, planner_mode=args.planner,
-                                               slack_mode=args.slack, use_octomap=bt_path is not None, comm=comm))
+                                               slack_mode=args.slack, use_octomap=bt_path is not None, comm=comm, solver=args.solver))
         if bt_path is not None:
             p.load_octomap(bt_path)
         return p
@@ -512,18 +537,22 @@ def main():
     x_all = pl.kernel_times_ms(2) if native else np.zeros(0)
     g_all = pl.kernel_times_ms(3) if bt_path is not None and goal_mode == "prior_based" else np.zeros(0)
     c_all = pl.kernel_times_ms(4) if bt_path is not None else np.zeros(0)
+    sstats = pl.solver_stats()               # (counters of the active-set solve over the timed ticks; zeros under --solver interior_point)
     iters_total = pl.iterations_total(reset=False)
     rowit_total = pl.row_iterations_total()
     bad = int((status[first:first + count] != 0).sum().item())
     lrows = pl.row_counts()[first:first + count]
     pl.set_timing(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    it_t = torch.tensor([float(iters_total), float(rowit_total)], dtype=torch.float64, device=dev)
+    it_t = torch.tensor([float(iters_total), float(rowit_total), float(sstats["solved"]), float(sstats["handed_over"]), float(sstats["changes"]),
+                         float(sstats["ip_iterations"])], dtype=torch.float64, device=dev)
     if G > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     iters_total, rowit_total = float(it_t[0].item()), float(it_t[1].item())
+    sstats = dict(solved=float(it_t[2].item()), handed_over=float(it_t[3].item()), changes=float(it_t[4].item()), ip_iterations=float(it_t[5].item()))
+    gi = args.solver == "active_set" and (sstats["solved"] + sstats["handed_over"]) > 0
     # how long the mission is (untimed, after the measurement): ticks until every agent is within plan/goal_threshold of its goal
     mission_ticks = None
     k_mission = None
@@ -553,10 +582,16 @@ def main():
     result = None
     if rank == 0:
         value = n_agents * args.steps / elapsed
-        flops = algorithmic_flops(n_agents, iters_total / G) / max(k_n, 1)   # per launch of this rank's kernel
+        if gi:
+            # the active-set kernel: its own flop model (active_set_flops), with the reference's 27 (N - 1) rows (frac) and with the rows carried (frac_executed)
+            rows_mean = rowit_total / max(iters_total, 1.0)
+            flops = active_set_flops(n_agents, sstats, rowit_total, rows_mean, True) / G / max(k_n, 1)
+            flops_exec = active_set_flops(n_agents, sstats, rowit_total, rows_mean, False) / G / max(k_n, 1)
+        else:
+            flops = algorithmic_flops(n_agents, iters_total / G) / max(k_n, 1)   # per launch of this rank's kernel
+            # the same model charged with the rows the kernel really carried: (N-1) kflop per iteration = 27 (N-1) rows x ~37 flop
+            flops_exec = (rowit_total / G * (1.0e3 / 27.0) + iters_total / G * 0.3e6) / max(k_n, 1)
         ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        # the same model charged with the rows the kernel really carried: (N-1) kflop per iteration = 27 (N-1) rows x ~37 flop
-        flops_exec = (rowit_total / G * (1.0e3 / 27.0) + iters_total / G * 0.3e6) / max(k_n, 1)
         ach_exec = flops_exec / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         kname = "lsc_plan_kernel" if (args.reset_threshold <= 0 and args.planner == "lsc" and args.slack == "none") else "lsc_plan_alt_kernel"
         if count > torch.cuda.get_device_properties(dev).multi_processor_count:
@@ -591,7 +626,12 @@ def main():
                                         ("weak scaling over disjoint circles: the rows between agents of different ranks are all redundant and culled, so this "
                                          "curve is a best case (what it shows is the all-gather); --workload random1024 / forest256 shard ONE swarm" if G > 1 else
                                          "single GPU"))},
-            "qp": {"mean_ip_iterations": round(iters_total / (n_agents * args.steps), 2), "failed_agents_last_tick": bad,
+            "qp": {"solver": ("active set (Goldfarb-Idnani on the 39-unknown reduced problem from the unconstrained optimum), interior point as fallback" if gi
+                              else "interior point (reduced-space Mehrotra predictor-corrector, warm-started)"),
+                   "mean_working_set_changes": round(sstats["changes"] / max(sstats["solved"] + sstats["handed_over"], 1.0), 2) if gi else None,
+                   "handed_to_the_interior_point": int(sstats["handed_over"]) if gi else None,
+                   "mean_ip_iterations": round((sstats["ip_iterations"] / max(sstats["handed_over"], 1.0)) if gi else iters_total / (n_agents * args.steps), 2),
+                   "failed_agents_last_tick": bad,
                    "active_lsc_rows_last_tick_mean": float(np.mean(lrows)), "active_lsc_rows_last_tick_max": int(np.max(lrows)),
                    "reference_rows_per_agent": 27 * (n_agents - 1)},
             "roofline": {"kernel": kname, "bound": "valu_fp64", "achieved": round(ach, 5),
@@ -604,11 +644,20 @@ def main():
                          "avg_launch_ms": round(k_ms, 5), "launches": k_n,
                          "executed_rows_mean": float(np.mean(lrows)),
                          "utilisation": pmc_utilisation(kname + "@grid32768") if n_agents == 64 else (pmc_utilisation(kname + "@grid262144#random1024") if n_agents == 1024 else None),
-                         "note": "latency-bound: one 512-lane workgroup per agent; algorithmic flops = IP iterations x "
-                                 "((N-1) kflop + 0.3 Mflop) per SURVEY 8(d), which charges all 27(N-1) LSC rows; frac_executed "
-                                 "charges the rows the kernel carried after pruning the provably redundant ones (iterations x rows "
-                                 "accumulated on the device over the timed ticks, ~37 flop per row and iteration + 0.3 Mflop); "
-                                 "neither HBM nor MFMA bounds this kernel"},
+                         "flop_model": ("active-set solve: changes x (9 flop x (rows + 414) + 2.6 kflop) + solves x (2.5 kflop + two more row passes) [+ SURVEY's "
+                                        "interior-point model for handed-over agents]; frac with the reference's 27 (N-1) rows, frac_executed with the rows carried" if gi else
+                                        "SURVEY 8(d): IP iterations x ((N-1) kflop + 0.3 Mflop); frac_executed with the rows carried (~37 flop per row and iteration)"),
+                         "note": ("latency-bound: one 512-lane workgroup per agent, a tick ends with its slowest agent. The active-set solve needs ~20x fewer flops than "
+                                  "the interior point SURVEY 8(d) prices (a handful of rank-one steps instead of ~7 factorisations of a 39 x 39 system with "
+                                  "all rows reduced into it), so its fraction of the fp64 peak is LOWER than rounds 1-4's 1 % while the tick is 2.5-3x shorter: "
+                                  "the fraction measures arithmetic density, and this kernel's time is dependent chains and barriers, not arithmetic; "
+                                  "interior_point_leg prices the same ticks under the old solver and SURVEY's model for continuity; "
+                                  "neither HBM nor MFMA bounds this kernel" if gi else
+                                  "latency-bound: one 512-lane workgroup per agent; algorithmic flops = IP iterations x "
+                                  "((N-1) kflop + 0.3 Mflop) per SURVEY 8(d), which charges all 27(N-1) LSC rows; frac_executed "
+                                  "charges the rows the kernel carried after pruning the provably redundant ones (iterations x rows "
+                                  "accumulated on the device over the timed ticks, ~37 flop per row and iteration + 0.3 Mflop); "
+                                  "neither HBM nor MFMA bounds this kernel")},
         }
         result["per_rank"] = {"columns": ["plan_kernel_ms_mean", "plan_kernel_ms_p99", "goal_kernel_ms_mean", "corridor_kernel_ms_mean",
                                           "allgather_us_mean", "agents"], "ranks": per_rank,
@@ -649,11 +698,37 @@ def main():
                 "note": "one wave per agent alone on its SIMD issues one instruction per 5.7-8.5 cycles (profiles/r03_microbench.log): the cost of a node is its "
                         "instruction count; ticks measured after the timed region, " + str(len(gk)) + " launches"}
 
+    # ---- the same ticks under the interior point alone (the solver of rounds 1-4), priced with SURVEY 8(d)'s model: continuity of the roofline
+    if rank == 0 and G == 1 and gi and args.workload == "circle64" and not sharded and not args.no_ip_leg:
+        ipr = MissionRun(L, torch, ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode, reset_threshold=args.reset_threshold,
+                                                       planner_mode=args.planner, slack_mode=args.slack, solver="interior_point"), dev, torch.cuda.current_stream())
+        for _ in range(start_tick - 1):
+            ipr.tick()
+        torch.cuda.synchronize()
+        ipr.pl.iterations_total(reset=True)
+        ipr.pl.set_timing(True)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ipr.tick()
+        torch.cuda.synchronize()
+        dt_ip = time.perf_counter() - t1
+        kip = ipr.pl.kernel_times_ms(0)
+        it_ip = ipr.pl.iterations_total(reset=False)
+        fl = algorithmic_flops(n_agents, it_ip) / max(len(kip), 1)
+        ach_ip = fl / (float(kip.mean()) * 1e-3) / 1e12
+        result["interior_point_leg"] = {"value": round(n_agents * args.steps / dt_ip, 1), "ms_per_step": round(1e3 * dt_ip / args.steps, 4),
+                                        "tick_solve_ms": {"p50": round(float(np.percentile(kip, 50)), 4), "p99": round(float(np.percentile(kip, 99)), 4)},
+                                        "mean_ip_iterations": round(it_ip / (n_agents * args.steps), 2),
+                                        "roofline_frac_survey_model": round(ach_ip / FP64_VALU_PEAK_TFLOPS, 7),
+                                        "speedup_of_the_default_solver": round(value / (n_agents * args.steps / dt_ip), 3),
+                                        "note": "--solver interior_point on the same mission and tick window (its own closed loop: the plans agree within the parity tolerances, the missions drift apart)"}
+        ipr.close()
+
     # ---- several independent missions in flight together (the idle three quarters of the chip at 64 agents)
     if rank == 0 and G == 1 and args.missions > 1 and args.workload == "circle64" and not sharded:
         def cfg_of():
             return L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode, reset_threshold=args.reset_threshold,
-                                   planner_mode=args.planner, slack_mode=args.slack)
+                                   planner_mode=args.planner, slack_mode=args.slack, solver=args.solver)
         result["concurrent_missions"] = concurrent_missions_leg(L, torch, ms, cfg_of, dev, args.missions, start_tick, args.steps,
                                                                 torch.cuda.get_device_properties(dev).multi_processor_count)
         result["concurrent_missions"]["headline_value_single_mission"] = result["value"]
@@ -738,7 +813,7 @@ def main():
     # ---- per-tick latency through the host-buffer ABI (H2D + kernel + D2H, PCIe-inclusive): p50 / p99
     if not args.no_latency_leg and rank == 0 and G == 1 and not strong:
         from lsc_planner_amd.planner import next_state_host
-        pl2 = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode))
+        pl2 = L.SwarmPlanner(ms, L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode, solver=args.solver))
         st = np.zeros((n_agents, 9), np.float32)
         st[:, :3] = ms.start
         tj = np.zeros((n_agents, 3, 30), np.float32)

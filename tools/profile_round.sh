@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=$PWD
-BENCH="python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-latency-leg --missions 0"      # default --start-tick 60: timed launches = dispatches 59 .. 158 of the plan kernel
+BENCH="python $ROOT/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-latency-leg --missions 0 --no-ip-leg"      # default --start-tick 60: timed launches = dispatches 59 .. 158 of the plan kernel
 FOREST="python $ROOT/tools/config_runs.py --only forest256p,forest256,forest256x4p,forest256x4 --ticks 30 --warmup 5"
 LARGE="python $ROOT/tools/config_runs.py --only random1024 --ticks 30 --warmup 5"
 GENERAL="python $ROOT/tools/general_profile.py --modes bvc,collision_constraint,gust"      # lsc_general_kernel under load
