@@ -664,7 +664,7 @@ static_assert(PH_COUNT == PROF_PHASES, "lsc_phase_profile copies PROF_PHASES cou
 template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512, bool DIM2 = false, class ArgsT = const PlanArgs, int SOLVER = 0>
 __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char *smem_raw, unsigned char *ws)
 {
-    static_assert(SOLVER == 0 || (!SPILL && !DIM2 && !PROF), "the active-set solve exists for 3-D worlds with the rows in LDS");
+    static_assert(SOLVER == 0 || (!SPILL && !DIM2), "the active-set solve exists for 3-D worlds with the rows in LDS");
     constexpr int WS_FEW_ROWS = 200;
     constexpr int NT = NTT;             // shadow the namespace-level constants (those size the LDS arrays: maxima)
     constexpr int NWAVE = NTT / 64;
@@ -1940,6 +1940,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             }
         }
         int q = 0;
+        stamp(PH_INIT);                  // (instrumented build: the start of the active-set solve is booked under "ip_init")
         for (;;) {
             if (wave == 0) compute_x_wave0(S.y, S.x, true);
             __syncthreads();
@@ -1967,6 +1968,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             const unsigned long long key = best > 0.0 ? (((unsigned long long)__float_as_uint((float)best)) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)bidx) : 0ull;
             block_reduce(__longlong_as_double((long long)key), 0.0, 0.0, 0.0, 0.0, 1, -1, -1, -1, -1);
             const unsigned long long kmax = (unsigned long long)__double_as_longlong(rv[0]);
+            stamp(PH_P1);                // ("residual_pass": x from y and the search for the most violated row)
             if (!(__uint_as_float((uint32_t)(kmax >> 32)) > 1e-10f)) break;                  // nothing violated: optimal
             const int idx = (int)(0xffffffffu - (uint32_t)(kmax & 0xffffffffull));
             if (wave == 0) {
@@ -2009,16 +2011,22 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 const double nph = wave_sum(np_g * hin_g);            // n' H^-1 n > 0
                 double up = 0.0;
                 int code = 0;
+                // The Cholesky factor L of the Gram matrix S = G_W H^-1 G_W' is KEPT across changes: a row that joins appends one row to L
+                // -- the forward substitution L w = d that the step needs anyway, and l_qq^2 = n'H^-1 n - w'w --; only a row that leaves (rare)
+                // refactors.  The substitutions run from registers: lane i holds row i and column i of L and 1 / l_ii, every step is a
+                // v_readlane and a multiply-add (q <= GQ steps each way), no LDS round trip on the chain.
+                bool refactor = false;
+                // coefficients of the new row in y-space, sparse: x-variable v_i enters with a_i, x_v = sum_j xtc[t][j] y[xgp byte j]
+                const uint32_t gp0 = S.xgp[v0], gp1 = S.xgp[v1], gp2 = S.xgp[v2];
+                const double *c0 = S.xtc[v0 % SEGV], *c1 = S.xtc[v1 % SEGV], *c2 = S.xtc[v2 % SEGV];
                 for (;;) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // d = G_W H^-1 n ; r = S^-1 d
-                    double dw = 0.0, rw = 0.0;
-                    if (lane < q) for (int g2 = 0; g2 < NY; g2++) dw += Nw[lane * GS + g2] * hin[g2];
-                    if (q > 0) {
+                    if (refactor) {
+                        // left-looking Cholesky of S from scratch, lanes = rows (after a row left the working set)
                         bool pd = true;
-                        for (int j = 0; j < q; j++) {          // left-looking Cholesky of S, lanes = rows
+                        for (int j = 0; j < q; j++) {
                             double aij = 0.0;
                             if (lane < q && lane >= j) {
                                 aij = Sm[lane * GQ + j];
@@ -2033,16 +2041,43 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         }
                         if (!pd) { code = 2; break; }
+                        refactor = false;
+                    }
+                    // d = G_W H^-1 n = Y_W n, with the (at most nine) non-zeros of n
+                    double dw = 0.0, rw = 0.0, wfw = 0.0;
+                    if (lane < q) {
+                        const double *yr = Yw + lane * GS;
+                        double y00 = yr[gp0 & 0xff], y01 = yr[(gp0 >> 8) & 0xff], y02 = yr[gp0 >> 16], y10 = yr[gp1 & 0xff], y11 = yr[(gp1 >> 8) & 0xff], y12 = yr[gp1 >> 16],
+                               y20 = yr[gp2 & 0xff], y21 = yr[(gp2 >> 8) & 0xff], y22 = yr[gp2 >> 16];
+                        LSC_PIN(PV(y00), PV(y01), PV(y02), PV(y10), PV(y11), PV(y12), PV(y20), PV(y21), PV(y22));
+                        dw = a0 * (c0[0] * y00 + c0[1] * y01 + c0[2] * y02);
+                        if (v1 != v0) dw += a1 * (c1[0] * y10 + c1[1] * y11 + c1[2] * y12);
+                        if (v2 != v0) dw += a2 * (c2[0] * y20 + c2[1] * y21 + c2[2] * y22);
+                    }
+                    if (q > 0) {
+                        double Lr[GQ], Lc[GQ];                  // row `lane` and column `lane` of L
+                        const int lq = lane < GQ ? lane : GQ - 1;
+#pragma unroll
+                        for (int j = 0; j < GQ; j++) { Lr[j] = Lm[lq * GQ + j]; Lc[j] = Lm[j * GQ + lq]; }
+                        double dinvl = Lr[0];
+#pragma unroll
+                        for (int j = 1; j < GQ; j++) dinvl = lane == j ? Lr[j] : dinvl;
+                        dinvl = 1.0 / dinvl;                    // 1 / l_ii on lane i (lanes beyond q: unused)
                         double b = dw;
-                        for (int j = 0; j < q; j++) {          // L w = d
-                            const double wj = lane_value(b, j) / Lm[j * GQ + j];
-                            if (lane == j) b = wj;
-                            else if (lane > j && lane < q) b -= Lm[lane * GQ + j] * wj;
+#pragma unroll
+                        for (int j = 0; j < GQ; j++) {          // L w = d
+                            if (j < q) {
+                                const double wj = lane_value(b, j) * lane_value(dinvl, j);
+                                b = lane == j ? wj : ((lane > j && lane < q) ? fma(-Lr[j], wj, b) : b);
+                            }
                         }
-                        for (int i = q - 1; i >= 0; i--) {     // L' r = w
-                            const double ri = lane_value(b, i) / Lm[i * GQ + i];
-                            if (lane == i) b = ri;
-                            else if (lane < i) b -= Lm[i * GQ + lane] * ri;
+                        wfw = lane < q ? b : 0.0;
+#pragma unroll
+                        for (int i = GQ - 1; i >= 0; i--) {     // L' r = w
+                            if (i < q) {
+                                const double ri = lane_value(b, i) * lane_value(dinvl, i);
+                                b = lane == i ? ri : (lane < i ? fma(-Lc[i], ri, b) : b);
+                            }
                         }
                         rw = lane < q ? b : 0.0;
                         if (lane < q) rwv[lane] = rw;
@@ -2068,12 +2103,14 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     up += t;
                     gi_changes++;
                     if (t2 <= t1) {
-                        // full step: the row joins the working set
+                        // full step: the row joins the working set; L gets the row (w, sqrt(n'H^-1 n - w'w)) -- that radicand IS the slope zn
                         if (q == GQ) { code = 2; break; }
+                        const double lqq2 = nph - wave_sum(wfw * wfw);
+                        if (!(lqq2 > 1e-13 * nph)) { code = 2; break; }
                         if (lane < GS) { Nw[q * GS + lane] = np_g; Yw[q * GS + lane] = hin_g; }
-                        if (lane < q) { Sm[q * GQ + lane] = dw; Sm[lane * GQ + q] = dw; }
+                        if (lane < q) { Sm[q * GQ + lane] = dw; Sm[lane * GQ + q] = dw; Lm[q * GQ + lane] = wfw; Lm[lane * GQ + q] = 0.0; }
                         if (lane == 0) {
-                            Sm[q * GQ + q] = nph; uw[q] = up; wrow[q] = idx;
+                            Sm[q * GQ + q] = nph; Lm[q * GQ + q] = sqrt(lqq2); uw[q] = up; wrow[q] = idx;
                             if (idx < n_ax) S.at1[S.amap[idx] & 1023] = 1.0;
                             else rt1[cmap[idx - n_ax] & CMAP_MASK] = 1.0;
                         }
@@ -2101,11 +2138,13 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                         if (lane == 0) { Sm[j * GQ + j] = sll; uw[j] = uw[last]; wrow[j] = wrow[last]; }
                     }
                     q--;
+                    refactor = true;
                     if (gi_changes > GI_CAP) { code = 2; break; }
                 }
                 if (lane == 0) { S.sc[0] = (double)code; S.sc[1] = (double)q; S.sc[2] = (double)gi_changes; }
             }
             __syncthreads();
+            stamp(PH_FACTOR);            // ("cholesky": the step on wave 0 -- normal, direction, ratio test, update of the working set)
             if (S.sc[0] != 0.0) return false;
             q = (int)S.sc[1];
             gi_changes = (int)S.sc[2];
@@ -2141,6 +2180,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         }
         block_reduce(objp, 0.0, 0.0, 0.0, 0.0, 0, -1, -1, -1, -1);
         obj = rv[0];
+        stamp(PH_P2);                    // ("affine_pass": the verification pass and the objective)
         return true;
         }
     };
@@ -2678,6 +2718,7 @@ hipError_t init_device_kernels()
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, true>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, true>),
                          reinterpret_cast<const void *>(&lsc_plan_kernel<false, false, 1>), reinterpret_cast<const void *>(&lsc_plan_alt_kernel<false, 1>),
+                         reinterpret_cast<const void *>(&lsc_plan_kernel<true, false, 1>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, false, 1>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, false, 1>),
                          reinterpret_cast<const void *>(&lsc_sfc_kernel)};
     for (const void *f : fns) {
@@ -2719,6 +2760,7 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     const bool gi = a.solver == 1 && !d2 && !a.prof;
     if (gi) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_kernel<false, 1>), dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL((lsc_plan_kernel<false, false, 1>), dim3(a.count), dim3(NT), smem, st, t); }
     else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_kernel<true>, dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL(lsc_plan_alt_kernel<false>, dim3(a.count), dim3(NT), smem, st, t); }
+    else if (a.prof && a.solver == 1) hipLaunchKernelGGL((lsc_plan_kernel<true, false, 1>), dim3(a.count), dim3(NT), smem, st, t);
     else if (a.prof) hipLaunchKernelGGL((lsc_plan_kernel<true, false>), dim3(a.count), dim3(NT), smem, st, t);
     else if (d2) hipLaunchKernelGGL((lsc_plan_kernel<false, true>), dim3(a.count), dim3(NT), smem, st, t);
     else hipLaunchKernelGGL((lsc_plan_kernel<false, false>), dim3(a.count), dim3(NT), smem, st, t);

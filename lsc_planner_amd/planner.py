@@ -6,7 +6,8 @@ set_current_state / set_obs_prev_trajs / plan / get_traj / get_qp_cost / get_pla
 `plan()` is one C-ABI call for all agents (include/lsc_planner_amd.h).
 """
 import ctypes
-from dataclasses import dataclass
+import os
+from dataclasses import dataclass, field
 
 import numpy as np
 
@@ -43,7 +44,10 @@ class PlannerConfig:
     world_dimension: int = 3        # world/dimension: 2 = planar goal grid at z = world_z_2d
     world_z_2d: float = 1.0         # world/z_2d
     goal_search: str = "auto"      # goal planner's grid search: "auto" (register-resident, 32-bit keys when their table fits), "general", "key64" (register-resident, the double as key)
-    solver: str = "active_set"     # QP solver of the LSC fast path: "active_set" (dual active set first, interior point as fallback) or "interior_point"
+    # QP solver of the LSC fast path: "active_set" (dual active set first, interior point as fallback: the library's default) or
+    # "interior_point" (the interior point alone, rounds 1-4).  LSC_SOLVER in the environment changes the default of this harness, so that
+    # whole test files can be run through the other solver (tests/test_gpu_round5.py).
+    solver: str = field(default_factory=lambda: os.environ.get("LSC_SOLVER", "active_set"))
     comm: tuple = None              # (world_size, rank, id bytes from comm_unique_id()): agent-sharded multi-GPU over RCCL
 
 

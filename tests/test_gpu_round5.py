@@ -155,3 +155,51 @@ def test_batch_launch_with_ragged_swarms_modes_and_refusals(L):
         fly(ms[:2], [L.PlannerConfig(reset_threshold=0.15), L.PlannerConfig()], 1, True)
     with pytest.raises(L.LscError, match="planar|classes|launch failed"):
         fly(mp, [L.PlannerConfig(world_dimension=2, world_z_2d=0.8), L.PlannerConfig()], 1, True)
+
+
+def test_the_interior_point_alone_still_passes_the_parity_files():
+    """The library's default solver is the active-set solve, so the rest of the suite holds THAT to the oracle, the HiGHS pins and the
+    fuzzers.  The interior point stays in the product -- it takes every agent the active-set solve hands over (infeasible QPs, working
+    sets beyond its capacity), planar worlds and the second pass -- so the parity, pin, soak and edge files run once more with
+    LSC_SOLVER=interior_point (the harness's default solver)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "tests", f) for f in ("test_gpu_parity.py", "test_gpu_edges.py", "test_gpu_round3.py", "test_gpu_soak.py")]
+    env = dict(os.environ, LSC_SOLVER="interior_point")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "not lds_held_before"] + files, env=env, cwd=root,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_active_set_solver_statistics_and_hand_over(L):
+    """lsc_solver_stats: on the bench mission every agent-replan is finished by the active-set solve (nothing handed over); a scene with an
+    infeasible QP (an agent inside another's collision model) is handed to the interior point, which returns the infeasible verdict and
+    keeps the stale plan -- the statuses of both solvers agree."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.circle_swap(64, 8.0)
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))
+    state = np.zeros((64, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((64, 3, 30), np.float32)
+    pl.iterations_total(reset=True)
+    for _ in range(70):
+        g = pl.plan(state, ms.goal, traj)
+        assert (g["status"] == 0).all()
+        traj = g["traj"]; state = next_state_host(traj)
+    st = pl.solver_stats()
+    assert st["solved"] == 64 * 70 and st["handed_over"] == 0 and st["ip_iterations"] == 0 and 0 < st["changes"] < 64 * 70 * 12
+    pl.close()
+    ms = L.circle_swap(3, circle_radius=2.0, z=1.0, world=(-5, -5, 0, 5, 5, 2.5))
+    ms.start[1] = ms.start[0] + np.array([0.05, 0.0, 0.0], np.float32)
+    out = {}
+    for solver in ("active_set", "interior_point"):
+        pl = L.SwarmPlanner(ms, L.PlannerConfig(solver=solver))
+        state = np.zeros((3, 9), np.float32); state[:, :3] = ms.start
+        pl.iterations_total(reset=True)
+        out[solver] = pl.plan(state, ms.goal, np.zeros((3, 3, 30), np.float32))
+        if solver == "active_set":
+            st = pl.solver_stats()
+            assert st["handed_over"] >= 1 and st["solved"] + st["handed_over"] == 3
+        pl.close()
+    assert np.array_equal(out["active_set"]["status"], out["interior_point"]["status"]) and (out["active_set"]["status"] != 0).any()

@@ -28,11 +28,12 @@ def main():
     ap.add_argument("--random", action="store_true", help="seeded random swarm in a 40 x 40 x 5 m world (BASELINE configs[4]) instead of the circle")
     ap.add_argument("--max-rows-per-cp", type=int, default=0,
                     help="explicit LDS row capacity: a swarm larger than the chip then takes the 512-lane latency build instead of the 256-lane throughput build")
+    ap.add_argument("--solver", default="active_set", choices=["active_set", "interior_point"])
     a = ap.parse_args()
     N = a.agents
     R = a.radius or 8.0 * max(1.0, (N / 64.0) ** 0.5)
     ms = L.random_swarm(N, seed=20260929) if a.random else L.circle_swap(N, R, world=(-R - 2, -R - 2, 0, R + 2, R + 2, 2.5))
-    pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="static" if a.static_goal else "prior_based", max_rows_per_cp=a.max_rows_per_cp))
+    pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="static" if a.static_goal else "prior_based", max_rows_per_cp=a.max_rows_per_cp, solver=a.solver))
     state = np.zeros((N, 9), np.float32)
     state[:, :3] = ms.start
     traj = np.zeros((N, 3, 30), np.float32)
