@@ -30,8 +30,15 @@ case, every row between agents of different ranks is culled (config.scaling_note
 from the committed leaf fixture) as ONE swarm sharded over the G ranks: strong scaling, every cross-rank LSC row active; the line
 then carries the per-rank plan-kernel time and the all-gather time, which is where the latency floor shows.
 
-One JSON line on rank 0 with `roofline` (plan kernel), `roofline_sweep` (dense LSC sweep, HBM-bound) and
-`cpu_baseline` (the oracle = CPU restatement of the reference path, timed on this box's host cores).
+One JSON line on rank 0 with `roofline` (plan kernel), `roofline_sweep{,_large}` (dense LSC sweep: HBM view, bound by the fp64 GJK),
+`cpu_baseline` (the oracle = CPU restatement of the reference path, timed on this box's host cores), and -- single GPU, circle workload --
+`interior_point_leg` (the timed ticks once more under --solver interior_point, priced with SURVEY 8(d)'s flop model: continuity with
+rounds 1-4), `concurrent_missions` (--missions K independent swarms planned by ONE launch per tick, lsc_tick_device_fused_batch) and
+`latency_host_abi_ms` (PCIe-inclusive per-tick latency through lsc_replan_tick).
+
+--solver: the QP solver of the fast path (lsc_config.solver).  Default active_set: a dual active-set solve with the interior point as its
+fallback; a tick of the headline is TWO launches (the plan kernel and the -- normally empty -- hand-over launch of the alternate-mode
+kernel that multisim/reset_threshold > 0 asks for).
 """
 import argparse
 import json
@@ -619,7 +626,8 @@ def main():
                                    + ("plan kernel -> in-place RCCL all-gather of the new trajectories -> state propagation, "
                                       "one stream, per tick)" if sharded else
                                       ("goal search, corridor and plan launches per tick, states propagated in the plan launch)" if bt_path is not None else
-                                       "one fused launch per tick: goal planning + LSC + QP + state propagation)")),
+                                       "one fused launch per tick: goal planning + LSC + QP + state propagation"
+                                       + (" + the hand-over launch of the alternate-mode kernel (empty unless an agent is disturbed)" if args.reset_threshold > 0 else "") + ")")),
                        "agents": n_agents, "parallelism": f"agent-shard x{G}", "prune_redundant_rows": not args.no_prune,
                        "planner_mode": args.planner, "slack_mode": args.slack, "reset_threshold": args.reset_threshold,
                        "scaling_note": ("one swarm: every agent's rows against agents of other ranks are live" if strong else

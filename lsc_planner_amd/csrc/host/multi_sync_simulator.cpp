@@ -1,5 +1,5 @@
 // multi_sync_simulator.cpp -- headless MultiSyncSimulator (src/multi_sync_simulator.cpp) over the C ABI.
-//   lsc_sim --mission m.json [--world map.bt] [--max-iter 300] [--csv DIR] [--device 0] [--quiet]
+//   lsc_sim --mission m.json [--mission m2.json ...] [--mission-dir DIR] [--world map.bt] [--max-iter 300] [--csv DIR] [--device 0] [--quiet]
 //           [--ranks W --rank R --comm-file PATH]     one process per GPU; or RANK / WORLD_SIZE / LOCAL_RANK from the env
 //           [--solver active_set|interior_point]      QP solver of the fast path (lsc_config.solver).  The active-set solve returns the exact
 //                                                     optimum: a PERFECTLY symmetric mission (multi_simple4, an unperturbed circle) then stays
@@ -13,6 +13,8 @@
 #include <iostream>
 #include <thread>
 
+#include <dirent.h>
+#include <algorithm>
 #include "lsc_host.hpp"
 
 namespace DynamicPlanning {
@@ -354,12 +356,25 @@ int main(int argc, char **argv)
 {
     using namespace DynamicPlanning;
     Param param;
-    std::string mission_file, world_file, replay_file;
+    std::string world_file, replay_file;
+    std::vector<std::string> mission_files;      // Param::mission_file_names (src/param.cpp:106-122): flown back to back, src/multi_sync_simulator_node.cpp:43-70
     bool quiet = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
-        if (a == "--mission") mission_file = next();
+        if (a == "--mission") mission_files.push_back(next());            // (may be repeated)
+        else if (a == "--mission-dir") {
+            // every *.json of a directory in name order, like the node's mission list
+            const std::string dir = next();
+            std::vector<std::string> found;
+            if (DIR *d = opendir(dir.c_str())) {
+                while (dirent *e = readdir(d)) { const std::string n = e->d_name; if (n.size() > 5 && n.substr(n.size() - 5) == ".json") found.push_back(dir + "/" + n); }
+                closedir(d);
+            }
+            std::sort(found.begin(), found.end());
+            if (found.empty()) { std::fprintf(stderr, "lsc_sim: no *.json in %s\n", dir.c_str()); return 2; }
+            mission_files.insert(mission_files.end(), found.begin(), found.end());
+        }
         else if (a == "--replay") replay_file = next();
         else if (a == "--world") { world_file = next(); param.world_use_octomap = true; }
         else if (a == "--max-iter") param.multisim_max_planner_iteration = std::stoi(next());
@@ -382,7 +397,7 @@ int main(int argc, char **argv)
         else if (a == "--ranks") param.world = std::stoi(next());
         else if (a == "--rank") param.rank = std::stoi(next());
         else if (a == "--comm-file") param.comm_file = next();
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats] [--solver active_set|interior_point] [--dt T --horizon H] | lsc_sim --replay result.csv\n"); return 2; }
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--mission m2.json ...] [--mission-dir DIR] [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats] [--solver active_set|interior_point] [--dt T --horizon H] | lsc_sim --replay result.csv\n"); return 2; }
     }
     if (!replay_file.empty()) {
         // MultiSyncReplayer (src/multi_sync_replayer.cpp): read a result CSV back -- needs no GPU -- and say what it holds
@@ -403,7 +418,7 @@ int main(int argc, char **argv)
             return 3;
         }
     }
-    if (mission_file.empty()) { std::fprintf(stderr, "lsc_sim: --mission is required\n"); return 2; }
+    if (mission_files.empty()) { std::fprintf(stderr, "lsc_sim: --mission (or --mission-dir) is required\n"); return 2; }
     if ((int)((param.horizon + 1e-9) / param.dt) != lsc_segments()) {
         std::fprintf(stderr, "lsc_sim: horizon %g / dt %g = %d segments; this binary is linked with the M = %d library (lsc_sim: M = 5, lsc_sim_m4: M = 4)\n",
                      param.horizon, param.dt, (int)((param.horizon + 1e-9) / param.dt), lsc_segments());
@@ -415,15 +430,23 @@ int main(int argc, char **argv)
         if (const char *r = std::getenv("RANK")) param.rank = std::atoi(r);
         if (const char *lr = std::getenv("LOCAL_RANK")) param.device = std::atoi(lr);
     }
-    try {
-        Mission mission;
-        mission.initialize(mission_file, world_file, param.world_dimension, param.world_z_2d);
-        if (param.multisim_max_noise > 0.0) mission.addNoise(param.multisim_max_noise, param.world_dimension, param.multisim_noise_seed);   // src/mission.cpp:317
-        MultiSyncSimulator sim(param, mission);
-        sim.run(quiet);
-        return sim.is_collided ? 1 : 0;
-    } catch (const std::exception &e) {
-        std::fprintf(stderr, "%s\n", e.what());
-        return 3;
+    // The mission list, one simulator after the other like the reference's node (result CSVs are per swarm size and are rewritten by a
+    // later mission of the same size; the summary CSV gets one line per mission).  Independent missions IN FLIGHT TOGETHER are the
+    // device-resident form: lsc_tick_device_fused_batch (bench.py --missions K).
+    int rc = 0;
+    for (size_t mi = 0; mi < mission_files.size(); mi++) {
+        try {
+            Mission mission;
+            mission.initialize(mission_files[mi], world_file, param.world_dimension, param.world_z_2d);
+            if (param.multisim_max_noise > 0.0) mission.addNoise(param.multisim_max_noise, param.world_dimension, param.multisim_noise_seed);   // src/mission.cpp:317
+            if (mission_files.size() > 1) std::printf("[MultiSyncSimulator] mission %zu of %zu: %s\n", mi + 1, mission_files.size(), mission_files[mi].c_str());
+            MultiSyncSimulator sim(param, mission);
+            sim.run(quiet);
+            if (sim.is_collided) rc = 1;
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "%s\n", e.what());
+            return 3;
+        }
     }
+    return rc;
 }

@@ -1940,10 +1940,11 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             }
         }
         int q = 0;
+        if (wave == 0) compute_x_wave0(S.y, S.x, true);
+        __syncthreads();
         stamp(PH_INIT);                  // (instrumented build: the start of the active-set solve is booked under "ip_init")
         for (;;) {
-            if (wave == 0) compute_x_wave0(S.y, S.x, true);
-            __syncthreads();
+            // (S.x is current: formed by wave 0 right behind the step that changed y, in front of the barrier that ended it)
             // ---- the most violated row outside the working set (violation over 1 + |right-hand side|; ties: lowest row)
             double best = 0.0;
             int bidx = 0;
@@ -2008,7 +2009,6 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     for (int b = 0; b < NYA; b++) hin_g += Hinv[va * NYA + b] * npv[yglob(k, b)];
                 }
                 if (lane < GS) hin[lane] = hin_g;
-                const double nph = wave_sum(np_g * hin_g);            // n' H^-1 n > 0
                 double up = 0.0;
                 int code = 0;
                 // The Cholesky factor L of the Gram matrix S = G_W H^-1 G_W' is KEPT across changes: a row that joins appends one row to L
@@ -2062,7 +2062,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                         double dinvl = Lr[0];
 #pragma unroll
                         for (int j = 1; j < GQ; j++) dinvl = lane == j ? Lr[j] : dinvl;
-                        dinvl = 1.0 / dinvl;                    // 1 / l_ii on lane i (lanes beyond q: unused)
+                        dinvl = rcp_nr(dinvl);                  // 1 / l_ii on lane i (lanes beyond q: unused)
                         double b = dw;
 #pragma unroll
                         for (int j = 0; j < GQ; j++) {          // L w = d
@@ -2088,11 +2088,14 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     // primal direction z = H^-1 n - Y_W r (it keeps the working set active) and its slope against the new row
                     double zg = hin_g;
                     if (lane < NY) for (int w = 0; w < q; w++) zg -= Yw[w * GS + lane] * rwv[w];
-                    const double zn = wave_sum(np_g * zg);
-                    const double ratio = (lane < q && rw > 1e-13) ? uw[lane] / rw : INF;
-                    const double t1 = wave_min(ratio);
+                    // one staged reduction for the four wave-wide numbers of a step: n'H^-1 n, the slope n'z, w'w, the smallest multiplier ratio
+                    const double ratio = (lane < q && rw > 1e-13) ? uw[lane] * rcp_nr(rw) : INF;
+                    double red4[5] = {np_g * hin_g, np_g * zg, wfw * wfw, ratio, 0.0};
+                    const int rop[5] = {0, 0, 0, 2, -1};
+                    wave_reduce5(red4, rop);
+                    const double nph = red4[0], zn = red4[1], wsq = red4[2], t1 = red4[3];
                     const unsigned long long dropmask = __ballot(lane < q && ratio == t1);
-                    const double t2 = zn > 1e-12 * nph ? viol / zn : INF;
+                    const double t2 = zn > 1e-12 * nph ? viol * rcp_nr(zn) : INF;
                     if (t1 >= INF && t2 >= INF) { code = 1; break; }          // no admissible step: the rows contradict each other
                     const double t = fmin(t1, t2);
                     if (t2 < INF) {
@@ -2105,7 +2108,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     if (t2 <= t1) {
                         // full step: the row joins the working set; L gets the row (w, sqrt(n'H^-1 n - w'w)) -- that radicand IS the slope zn
                         if (q == GQ) { code = 2; break; }
-                        const double lqq2 = nph - wave_sum(wfw * wfw);
+                        const double lqq2 = nph - wsq;
                         if (!(lqq2 > 1e-13 * nph)) { code = 2; break; }
                         if (lane < GS) { Nw[q * GS + lane] = np_g; Yw[q * GS + lane] = hin_g; }
                         if (lane < q) { Sm[q * GQ + lane] = dw; Sm[lane * GQ + q] = dw; Lm[q * GQ + lane] = wfw; Lm[lane * GQ + q] = 0.0; }
@@ -2142,6 +2145,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     if (gi_changes > GI_CAP) { code = 2; break; }
                 }
                 if (lane == 0) { S.sc[0] = (double)code; S.sc[1] = (double)q; S.sc[2] = (double)gi_changes; }
+                if (code == 0) compute_x_wave0(S.y, S.x, true);      // x for the next search, on the wave that holds the new y
             }
             __syncthreads();
             stamp(PH_FACTOR);            // ("cholesky": the step on wave 0 -- normal, direction, ratio test, update of the working set)

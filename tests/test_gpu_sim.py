@@ -90,6 +90,37 @@ def test_default_solver_flies_the_reference_mission_with_the_launch_file_s_noise
         assert float(r.stdout.split("safety ratio between agent:")[1].split()[0]) >= 1.0 - 1e-3
 
 
+def test_mission_list_is_flown_back_to_back_like_the_reference_s_node(ticks, tmp_path):
+    """lsc_sim --mission a --mission b / --mission-dir DIR: the outer loop of src/multi_sync_simulator_node.cpp:43-70 over
+    Param::mission_file_names (src/param.cpp:106-122) -- one summary line per mission, each equal to the mission flown alone."""
+    ms = golden_mission(ticks, "multi_simple4")
+    d = tmp_path / "missions"
+    d.mkdir()
+    _write_mission(str(d / "a_simple4.json"), ms)
+    ms2 = golden_mission(ticks, "multi_simple4")
+    ms2.goal[:, :2] *= 0.8                                        # a second, different mission of the same swarm size
+    _write_mission(str(d / "b_simple4_short.json"), ms2)
+    noise = ["--max-noise", "0.02", "--noise-seed", "5"]
+    alone = []
+    for f in ("a_simple4.json", "b_simple4_short.json"):
+        o = tmp_path / ("alone_" + f)
+        o.mkdir()
+        r = subprocess.run([SIM, "--mission", str(d / f), "--csv", str(o), "--quiet"] + noise, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        alone.append(list(csv.DictReader(open(o / "summary_LSC_4agents.csv")))[0])
+    o = tmp_path / "list"
+    o.mkdir()
+    r = subprocess.run([SIM, "--mission-dir", str(d), "--csv", str(o), "--quiet"] + noise, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mission 1 of 2" in r.stdout and "mission 2 of 2" in r.stdout
+    rows = list(csv.DictReader(open(o / "summary_LSC_4agents.csv")))
+    assert len(rows) == 2
+    for a, b in zip(alone, rows):
+        for col in ("total_flight_time", "total_flight_distance", "is_collided", "safety_ratio_agent"):
+            assert a[col] == b[col], (col, a[col], b[col])
+    assert rows[0]["total_flight_time"] != rows[1]["total_flight_time"]
+
+
 def test_simulator_trajectory_equals_python_host_layer(ticks, tmp_path):
     """Same mission through the Python harness: the C++ and Python host layers feed the ABI identically."""
     import lsc_planner_amd as L
