@@ -664,7 +664,7 @@ static_assert(PH_COUNT == PROF_PHASES, "lsc_phase_profile copies PROF_PHASES cou
 template <bool PROF, bool SPILL, bool ALT = false, int NTT = 512, bool DIM2 = false, class ArgsT = const PlanArgs, int SOLVER = 0>
 __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char *smem_raw, unsigned char *ws)
 {
-    static_assert(SOLVER == 0 || (!SPILL && !DIM2), "the active-set solve exists for 3-D worlds with the rows in LDS");
+    static_assert(SOLVER == 0 || !SPILL, "the active-set solve keeps its rows in LDS");
     constexpr int WS_FEW_ROWS = 200;
     constexpr int NT = NTT;             // shadow the namespace-level constants (those size the LDS arrays: maxima)
     constexpr int NWAVE = NTT / 64;
@@ -1894,6 +1894,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     constexpr int GQ = (HV + 2 * 12 * GS + 2 * 12 * 12 + 2 * 12 + 6 <= NY * KLD) ? 12 : 8;      // working-set capacity: what fits the idle K (12 for M = 5, 8 for M = 4)
     constexpr int GI_CAP = 60;
     int gi_changes = 0;
+    bool gi_infeasible = false;          // the active-set solve proved the QP infeasible (see "no admissible step")
     auto gi_solve = [&]() -> bool {
         if constexpr (SOLVER != 1) return false;
         else {
@@ -1918,6 +1919,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         if (tid < NV) {
             double cg = cost_grad();
             if (xterm) cg += 2.0 * md.w_t * (S.x[tid] - S.goal[xk]);
+            if (dim2 && xk == 2) cg = 0.0;            // planar world: z is not a variable (src/traj_optimizer.cpp:264-266): no cost, no rows, y_z rests at z_2d
             S.gx[tid] = cg;                           // gradient of the cost at y = 0, in x-space
         }
         __syncthreads();
@@ -1936,7 +1938,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 double acc = 0.0;
 #pragma unroll
                 for (int b = 0; b < NYA; b++) acc += Hinv[va * NYA + b] * gyv[yglob(k, b)];
-                S.y[lane] = -acc;
+                S.y[lane] = (dim2 && k == 2) ? md.z2d : -acc;
             }
         }
         int q = 0;
@@ -2007,6 +2009,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     const int k = yaxis(lane), va = yvar(lane);
 #pragma unroll
                     for (int b = 0; b < NYA; b++) hin_g += Hinv[va * NYA + b] * npv[yglob(k, b)];
+                    if (dim2 && k == 2) hin_g = 0.0;            // (planar world: the z unknowns never move)
                 }
                 if (lane < GS) hin[lane] = hin_g;
                 double up = 0.0;
@@ -2096,7 +2099,15 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     const double nph = red4[0], zn = red4[1], wsq = red4[2], t1 = red4[3];
                     const unsigned long long dropmask = __ballot(lane < q && ratio == t1);
                     const double t2 = zn > 1e-12 * nph ? viol * rcp_nr(zn) : INF;
-                    if (t1 >= INF && t2 >= INF) { code = 1; break; }          // no admissible step: the rows contradict each other
+                    if (t1 >= INF && t2 >= INF) {
+                        // No admissible step: the new row is a non-negative combination of working-set rows pointing the other way -- the rows
+                        // contradict each other (Farkas), the QP is infeasible.  With a violation that is not round-off (> 1e-6 of the row's
+                        // scale) the verdict is final: code 3, status 1, no interior-point run (an infeasible agent used to cost the tick the
+                        // ~26 iterations of two diverging interior-point starts); a marginal one is left to the interior point like every
+                        // other irregularity.
+                        code = viol > 1e-6 * (1.0 + fabs(hp)) ? 3 : 1;
+                        break;
+                    }
                     const double t = fmin(t1, t2);
                     if (t2 < INF) {
                         if (lane < NY) S.y[lane] -= t * zg;
@@ -2149,7 +2160,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             }
             __syncthreads();
             stamp(PH_FACTOR);            // ("cholesky": the step on wave 0 -- normal, direction, ratio test, update of the working set)
-            if (S.sc[0] != 0.0) return false;
+            if (S.sc[0] != 0.0) { gi_infeasible = S.sc[0] == 3.0; return false; }
             q = (int)S.sc[1];
             gi_changes = (int)S.sc[2];
         }
@@ -2178,7 +2189,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         }
         // optimum: S.x holds it (formed at the top of the last round); objective like the interior point's residual pass
         double objp = 0.0;
-        if (tid < NV) {
+        if (tid < NV && !(dim2 && xk == 2)) {          // (planar world: the cost runs over `k < dim`, src/traj_optimizer.cpp:330, 367)
             objp = 0.5 * cost_grad() * S.x[tid];
             if (xterm) { const double e = S.x[tid] - S.goal[xk]; objp += md.w_t * e * e; }
         }
@@ -2204,6 +2215,11 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         run = false;
     } else if (SOLVER == 1 && gi_solve()) {
         status = LSC_STATUS_OK_K;        // the active-set solve reached the optimum: obj and S.x are set
+        iters = gi_changes;
+        run = false;
+        run_gi_done = true;
+    } else if (SOLVER == 1 && gi_infeasible) {
+        status = LSC_STATUS_INFEASIBLE_K;    // proved by the active-set solve: the stale plan is kept (src/traj_planner.cpp:1553-1584)
         iters = gi_changes;
         run = false;
         run_gi_done = true;
@@ -2723,6 +2739,8 @@ hipError_t init_device_kernels()
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, true>),
                          reinterpret_cast<const void *>(&lsc_plan_kernel<false, false, 1>), reinterpret_cast<const void *>(&lsc_plan_alt_kernel<false, 1>),
                          reinterpret_cast<const void *>(&lsc_plan_kernel<true, false, 1>),
+                         reinterpret_cast<const void *>(&lsc_plan_kernel<false, true, 1>), reinterpret_cast<const void *>(&lsc_plan_alt_kernel<true, 1>),
+                         reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, true, 1>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, true, 1>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, false, 1>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<true, false, 1>),
                          reinterpret_cast<const void *>(&lsc_sfc_kernel)};
     for (const void *f : fns) {
@@ -2761,8 +2779,9 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     }
     t.order = nullptr; t.obs_bound = nullptr;     // filled by lsc_prep_kernel only
     // solver 1: the active-set solve first (3-D worlds, production kernels); everything else keeps the interior point alone
-    const bool gi = a.solver == 1 && !d2 && !a.prof;
-    if (gi) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_kernel<false, 1>), dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL((lsc_plan_kernel<false, false, 1>), dim3(a.count), dim3(NT), smem, st, t); }
+    const bool gi = a.solver == 1 && !a.prof;
+    if (gi && d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_kernel<true, 1>), dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL((lsc_plan_kernel<false, true, 1>), dim3(a.count), dim3(NT), smem, st, t); }
+    else if (gi) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_kernel<false, 1>), dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL((lsc_plan_kernel<false, false, 1>), dim3(a.count), dim3(NT), smem, st, t); }
     else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_kernel<true>, dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL(lsc_plan_alt_kernel<false>, dim3(a.count), dim3(NT), smem, st, t); }
     else if (a.prof && a.solver == 1) hipLaunchKernelGGL((lsc_plan_kernel<true, false, 1>), dim3(a.count), dim3(NT), smem, st, t);
     else if (a.prof) hipLaunchKernelGGL((lsc_plan_kernel<true, false>), dim3(a.count), dim3(NT), smem, st, t);
@@ -2788,9 +2807,10 @@ hipError_t launch_plan_batch(const PlanArgs *a, int n, size_t smem, hipStream_t 
     }
     for (int i = n; i < PLAN_BATCH_MAX; i++) { b.a[i] = a[0]; b.a[i].count = 0; }
     if (grid == 0) return hipSuccess;
-    bool gi = !d2;
+    bool gi = true;
     for (int i = 0; i < n; i++) gi = gi && a[i].solver == 1;
-    if (gi) { if (alt) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, false, 1>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<false, false, 1>), dim3(grid, n), dim3(NT), smem, st, b); }
+    if (gi && d2) { if (alt) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, true, 1>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<false, true, 1>), dim3(grid, n), dim3(NT), smem, st, b); }
+    else if (gi) { if (alt) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, false, 1>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<false, false, 1>), dim3(grid, n), dim3(NT), smem, st, b); }
     else if (alt) { if (d2) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, true>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<true, false>), dim3(grid, n), dim3(NT), smem, st, b); }
     else { if (d2) hipLaunchKernelGGL((lsc_plan_batch_kernel<false, true>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<false, false>), dim3(grid, n), dim3(NT), smem, st, b); }
     return hipGetLastError();

@@ -255,7 +255,7 @@ def main():
                "circle80": lambda: L.circle_swap(80, 10.0, world=(-12, -12, 0, 12, 12, 2.5)),
                "random64a": lambda: L.random_swarm(64, world=(-6, -6, 0, 6, 6, 2.5), seed=11),
                "random64b": lambda: L.random_swarm(64, world=(-5, -5, 0, 5, 5, 2.5), seed=12),
-               "random128": lambda: L.random_swarm(128, world=(-8, -8, 0, 8, 8, 2.5), seed=13)}
+               "random128": lambda: L.random_swarm(128, world=(-8, -8, 0, 8, 8, 2.5), seed=13), "circle20": lambda: L.circle_swap(20, 8.0)}
     ax_shift, n_ax_rows = ax_shift_table()
     print("decision rule (written before the run): build a dual active-set kernel only if the tick-max number of working-set changes is <= 25 "
           "on >= 99 % of the crossing ticks", flush=True)
@@ -303,6 +303,7 @@ def main():
                         x = xp + Z @ y_c
                         cost = 0.5 * x @ qp.P @ x + qp.c @ x + qp.cst
                         r.update(cold_changes=cnt_c["adds"] + cnt_c["drops"], active=cnt_c["final_size"], cost=cost,
+                                 plan_dev=float(np.abs(x.reshape(3, SEGV) - o["traj"][qi].astype(np.float64)).max()) if o["status"][qi] == 0 else None,
                                  cost_rel_err=abs(cost - o["cost"][qi]) / (abs(o["cost"][qi]) + 1e-2) if o["status"][qi] == 0 else None)
                         act_keys = {keys[w] for w in Wc}
                         if prev_active[qi] is not None and tick >= a.from_tick:
@@ -340,6 +341,7 @@ def main():
         mism = sum(1 for x in allr if (x["status"] == 0) != (x["oracle_status"] == 0))
         gaveup = sum(1 for x in allr if x["status"] == 2 or x.get("warm_status") == 2)
         wdev = np.array([x["warm_cost_dev"] for x in allr if x.get("warm_cost_dev") is not None])
+        pdev = np.array([x["plan_dev"] for x in allr if x.get("plan_dev") is not None])
         print(f"{name}: {N} agents, ticks {a.from_tick}..{a.to_tick}, {len(allr)} agent-ticks, rows per QP {allr[0]['rows']}\n"
               f"   optimal active set: median {np.median(act):.0f}, p99 {np.percentile(act, 99):.0f}, max {act.max()} (of 39 unknowns)\n"
               f"   cold start   changes per agent-tick: median {np.median(cold):.0f}, p99 {np.percentile(cold, 99):.0f}, max {cold.max()}; tick-max: median {np.median(tmax_c):.0f}, p99 {np.percentile(tmax_c, 99):.0f}\n"
@@ -348,7 +350,7 @@ def main():
               f"   predicted-vs-optimal active set, symmetric difference: median {np.median(sym):.0f}, p99 {np.percentile(sym, 99):.0f}, max {sym.max()}\n"
               f"   ticks with tick-max warm changes <= 25: {100.0 * np.mean(tmax_w <= 25):.1f} %   (<= 15: {100.0 * np.mean(tmax_w <= 15):.1f} %, <= 40: {100.0 * np.mean(tmax_w <= 40):.1f} %)\n"
               f"   optimum vs the oracle's interior point: max |cost difference| / (|cost| + 0.01) {errs.max() if len(errs) else float('nan'):.2e} over {len(errs)} solved QPs; "
-              f"feasibility verdicts that differ: {mism}; runs that gave up (cycling guard, 400 changes): {gaveup}; warm vs cold optimum: max {wdev.max() if len(wdev) else float('nan'):.2e}",
+              f"plan (control points) vs the oracle's float32 plan: p99 {np.percentile(pdev, 99):.2e} m, max {pdev.max():.2e} m; feasibility verdicts that differ: {mism}; runs that gave up (cycling guard, 400 changes): {gaveup}; warm vs cold optimum: max {wdev.max() if len(wdev) else float('nan'):.2e}",
               flush=True)
         grand.append((name, tmax_w))
     allt = np.concatenate([t for _, t in grand])

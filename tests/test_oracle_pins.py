@@ -55,7 +55,8 @@ def _check_against_highs(qp, status, cost):
         st, xo, co, _, _ = qp.solve()
         assert st == 0 and co == cost
         vo = max(np.max(lo - A @ xo), np.max(A @ xo - hi), np.max(qp.lo - xo), np.max(xo - qp.hi))
-        assert vo <= 1e-9 and obj - cost <= 1e-5 * abs(cost), (vo, obj, cost)
+        # (+ 1e-7: near the goal the cost goes to 1e-3 and HiGHS's shortfall stays ~1e-8 absolute -- seen once the oracle finished its optimum exactly, round 5)
+        assert vo <= 1e-9 and obj - cost <= 1e-5 * abs(cost) + 1e-7, (vo, obj, cost)
         return "highs_short"
     ms_, t = H.min_violation(A, lo, hi, qp.lo, qp.hi)
     assert ms_ == "Optimal" and t > 1e-7, (ms_, t)          # the rows cannot all hold: certificate of infeasibility

@@ -7,19 +7,25 @@ here.  The QP solve is floating point: north_star allows 1e-3 relative cost; the
 
 Exceptions, each used by name where it applies:
 """
+import os
+
 COST_RTOL = 1e-6
 COST_ATOL = 1e-8
 TRAJ_ATOL = 2e-5
+# LSC_SOLVER=interior_point (tests/test_gpu_round5.py runs the parity files once more through the interior point alone): that solver stops
+# at a duality gap of 1e-9 (1 + |f|), which along flat directions of the cost leaves a plan up to ~1e-4 m from the optimum the oracle now
+# returns exactly (measured 8.9e-5 m at tick 28 of the 20-agent circle, HiGHS arbitrating); rounds 1-4 compared two interior points, whose
+# errors were similar.  The cost tolerance does not move.
+if os.environ.get("LSC_SOLVER") == "interior_point":
+    TRAJ_ATOL = 1e-4
 
 # Seeded fuzzing of tiny swarms with extreme parameters (vmax 0.2..3, amax 0.5..6, radii 0.05..0.4, goals outside the world,
 # coincident agents): optima with nearly flat directions -- the plan may move 3-4e-5 m at 1e-9 relative cost.
 FUZZ_TRAJ_ATOL = 5e-5
-# The same with dt = 0.5 (the M = 4 build): the jerk weights are (0.2 / 0.5)^5 = 1/100 of the dt = 0.2 ones, so the same cost slack moves a
-# plan ten times as far.  What is left after the oracle's right-hand sides were corrected in round 4 (tests/test_oracle_pins.py; the
-# 8.2e-5 m of tests/golden/fuzz_found_m4_4602619.npz was that defect): one seed in 320 k fuzzed agent-ticks (7500378, variants m4 and
-# planar_m4; tests/golden/fuzz_found_planar_m4_7500378.npz) with kernel and oracle 2.5e-10 and 3.3e-10 relative above HiGHS's cost and 4.0e-5 / 8.2e-5 m from its plan, on opposite
-# sides: 1.2e-4 m apart.  Everything else: <= 4.3e-5 m.
-FUZZ_TRAJ_ATOL_HALF_SECOND = 2e-4
+# The same with dt = 0.5 (the M = 4 build): 2e-4 in round 4, for ONE genuinely flat optimum on which the oracle's and the kernel's interior
+# points stopped on opposite sides of HiGHS's plan (tests/golden/fuzz_found_planar_m4_7500378.npz).  Since round 5 the oracle finishes its
+# optimum exactly (oracle/lsc_oracle.c: orc_gi_polish) and the product's default solver is exact too: the exception is gone.
+FUZZ_TRAJ_ATOL_HALF_SECOND = FUZZ_TRAJ_ATOL
 # ... and with the 1e5 slack penalty a grossly violated limit makes |f| ~ 1e7; both solvers stop on criteria relative to |f|
 # and their plans may then differ by centimetres at 4e-8 relative cost: plans are compared below this objective only.
 # (1e4 until round 4.  Slack-mode QPs can have a face of optima -- tests/golden/fuzz_found_7301082.npz: one value, no one plan -- and they
