@@ -115,10 +115,19 @@ class GI:
     """Goldfarb-Idnani dual active set for  min 1/2 y'Hy + g'y  s.t.  G y <= h  (H positive definite), dense algebra, no factor
     updates: this counts working-set changes, it is not a fast solver."""
 
-    def __init__(self, H, g, G, h, tol=1e-9):
+    def __init__(self, H, g, G, h, tol=1e-9, rule="rhs"):
         self.H, self.g, self.G, self.h, self.tol = H, g, G, h, tol
         self.L = np.linalg.cholesky(H)
         self.n = len(g)
+        # selection rule of the row that joins: violation over 1 + |h| ("rhs", what the kernel does), the raw violation ("raw"), or the
+        # violation over sqrt(n'H^-1 n) = the distance of the row's plane in the metric of the cost ("metric")
+        if rule == "raw":
+            self.scale = np.ones(len(h))
+        elif rule == "metric":
+            Y = np.linalg.solve(self.L, G.T)
+            self.scale = np.sqrt(np.maximum((Y * Y).sum(0), 1e-300))
+        else:
+            self.scale = 1.0 + np.abs(h)
 
     def _hsolve(self, B):
         return np.linalg.solve(self.L.T, np.linalg.solve(self.L, B))
@@ -148,7 +157,7 @@ class GI:
             cnt["repair_drops"] += 1
             y, u = self.eqp(W)
         u = np.maximum(u, 0.0)
-        scale = 1.0 + np.abs(h)
+        scale = self.scale
         while True:
             if cnt["adds"] + cnt["drops"] > max_changes:
                 return 2, y, None, cnt
@@ -156,7 +165,7 @@ class GI:
             viol = s / scale
             viol[W] = 0.0
             p = int(np.argmin(viol))
-            if viol[p] >= -tol:
+            if (s / (1.0 + np.abs(h)))[p] >= -tol if False else (np.where(np.isin(np.arange(len(h)), W), 0.0, s / (1.0 + np.abs(h))).min() >= -tol):
                 cost = 0.5 * y @ self.H @ y + self.g @ y
                 cnt["final_size"] = len(W)
                 self.W = list(W)
@@ -249,6 +258,7 @@ def main():
     ap.add_argument("--from-tick", type=int, default=40)
     ap.add_argument("--to-tick", type=int, default=140)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--rule", default="rhs", choices=["rhs", "raw", "metric"])
     ap.add_argument("--agents-stride", type=int, default=1, help="study every k-th agent (all agents fly)")
     a = ap.parse_args()
     catalog = {"circle64": lambda: L.circle_swap(64, 8.0), "circle48": lambda: L.circle_swap(48, 6.0),
@@ -295,7 +305,7 @@ def main():
                     gy = Z.T @ (qp.P @ xp + qp.c)
                     Gy, hy = G @ Z, h - G @ xp
                     keys = row_keys(order, N - 1, hi_idx, lo_idx)
-                    gi = GI(Hy, gy, Gy, hy)
+                    gi = GI(Hy, gy, Gy, hy, rule=a.rule)
                     st_c, y_c, cost_c, cnt_c = gi.solve()
                     r = {"agent": qi, "status": st_c, "oracle_status": int(o["status"][qi]), "rows": len(hy)}
                     if st_c == 0:
