@@ -669,14 +669,29 @@ static int orc_ld_solve(int n, long double *Mx, long double *rhs)
  * 1e-11 of its scale) and the multipliers in zout, 1 when no admissible step exists (infeasible rows) or after 500 changes of the working set. */
 static int orc_gi_polish(int n, const double *H, const double *g, int R, const double *A, const double *b, double *yout, double *zout, int *changes_out)
 {
-    long double *Hi = (long double *)malloc(sizeof(long double) * (size_t)n * n);       /* H^-1, column by column */
-    long double *Mx = (long double *)malloc(sizeof(long double) * (size_t)n * n), *col = (long double *)malloc(sizeof(long double) * (size_t)n);
+    long double *Hi = (long double *)malloc(sizeof(long double) * (size_t)n * n);       /* H^-1 by Gauss-Jordan on [H | I] with partial pivoting */
+    long double *Mx = (long double *)malloc(sizeof(long double) * (size_t)n * 2 * n), *col = NULL;
     int rc = 1, changes = 0;
-    for (int c = 0; c < n; c++) {
-        for (int i = 0; i < n * n; i++) Mx[i] = H[i];
-        for (int i = 0; i < n; i++) col[i] = i == c ? 1.0L : 0.0L;
-        if (orc_ld_solve(n, Mx, col)) { free(Hi); free(Mx); free(col); *changes_out = 0; return 1; }
-        for (int i = 0; i < n; i++) Hi[i * n + c] = col[i];
+    {
+        const int w = 2 * n;
+        int sing = 0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < w; j++) Mx[i * w + j] = j < n ? (long double)H[i * n + j] : (j - n == i ? 1.0L : 0.0L);
+        for (int c = 0; c < n && !sing; c++) {
+            int piv = c;
+            for (int r = c + 1; r < n; r++) if (fabsl(Mx[r * w + c]) > fabsl(Mx[piv * w + c])) piv = r;
+            if (fabsl(Mx[piv * w + c]) < 1e-300L) { sing = 1; break; }
+            if (piv != c) for (int j = 0; j < w; j++) { long double t = Mx[c * w + j]; Mx[c * w + j] = Mx[piv * w + j]; Mx[piv * w + j] = t; }
+            const long double d = Mx[c * w + c];
+            for (int j = 0; j < w; j++) Mx[c * w + j] /= d;
+            for (int r = 0; r < n; r++) {
+                if (r == c) continue;
+                const long double f = Mx[r * w + c];
+                if (f != 0) for (int j = c; j < w; j++) Mx[r * w + j] -= f * Mx[c * w + j];
+            }
+        }
+        if (sing) { free(Hi); free(Mx); *changes_out = 0; return 1; }
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Hi[i * n + j] = Mx[i * w + n + j];
     }
     long double *y = (long double *)malloc(sizeof(long double) * (size_t)n), *hn = (long double *)malloc(sizeof(long double) * (size_t)n),
                 *zv = (long double *)malloc(sizeof(long double) * (size_t)n);
