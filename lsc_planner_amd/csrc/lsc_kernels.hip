@@ -627,6 +627,10 @@ __device__ __forceinline__ void pin_values(double (&a)[11])
     asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7), LSC_P(a, 8), LSC_P(a, 9),
                  LSC_P(a, 10));
 }
+__device__ __forceinline__ void pin_values(double (&a)[12])
+{
+    asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7), LSC_P(a, 8), LSC_P(a, 9), LSC_P(a, 10), LSC_P(a, 11));
+}
 __device__ __forceinline__ void pin_values(double (&a)[13])
 {
     asm volatile("" : LSC_P(a, 0), LSC_P(a, 1), LSC_P(a, 2), LSC_P(a, 3), LSC_P(a, 4), LSC_P(a, 5), LSC_P(a, 6), LSC_P(a, 7), LSC_P(a, 8), LSC_P(a, 9),
@@ -1427,11 +1431,18 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         __syncthreads();
         const int nused = op4 >= 0 ? 5 : (op3 >= 0 ? 4 : (op2 >= 0 ? 3 : (op1 >= 0 ? 2 : 1)));
         double t = 0.0;
-        if (lane < nused) {
-            const int op = lane == 0 ? op0 : (lane == 1 ? op1 : (lane == 2 ? op2 : (lane == 3 ? op3 : op4)));
-            t = bank[lane][0];
+        {
+            // (the partials of all waves in ONE batch of loads: read where they were combined they were a chain of four LDS round trips)
+            const int ls = lane < nused ? lane : 0;
+            const int op = ls == 0 ? op0 : (ls == 1 ? op1 : (ls == 2 ? op2 : (ls == 3 ? op3 : op4)));
+            double bw[NWAVE];
 #pragma unroll
-            for (int w = 1; w < NWAVE; w++) t = op == 0 ? t + bank[lane][w] : (op == 1 ? fmax(t, bank[lane][w]) : fmin(t, bank[lane][w]));
+            for (int w = 0; w < NWAVE; w++) bw[w] = bank[ls][w];
+#pragma unroll
+            for (int w = 0; w < NWAVE; w++) asm volatile("" : "+v"(bw[w]));
+            t = bw[0];
+#pragma unroll
+            for (int w = 1; w < NWAVE; w++) t = op == 0 ? t + bw[w] : (op == 1 ? fmax(t, bw[w]) : fmin(t, bw[w]));
         }
         rv[0] = lane_value(t, 0);
         if (op1 >= 0) rv[1] = lane_value(t, 1);
@@ -1886,7 +1897,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     // iterations of ~17 us.  A change costs one pass over the rows (the search for the most violated one) and a few dozen
     // dependent operations on wave 0.  What keeps it small: the reduced Hessian is the SAME 13 x 13 block for every axis, agent and
     // tick up to the number of terminal segments, so its inverse comes from the host (Model::ginv); the working set is capped at
-    // GQ rows, its Gram matrix S = G_W H^-1 G_W' is refactored per change (q <= 12).  Anything unusual -- more than GQ active rows,
+    // GQ rows, the inverse of its Gram matrix S = G_W H^-1 G_W' is updated per change (q <= 12).  Anything unusual -- more than GQ active rows,
     // more than GI_CAP changes, a Gram matrix that is not positive definite (dependent rows), no admissible step (an infeasible
     // QP) -- returns false and the interior point decides, as before.
     constexpr int GS = (NY + 1) & ~1;                         // stride of a working-set row in y-space (40 for NY = 39)
@@ -1900,21 +1911,40 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         else {
         double *const gk = S.K;                       // the interior point's K is idle until then (re-zeroed on the way there)
         double *const Hinv = gk;                      // [NYA][NYA]
-        double *const Nw = gk + HV;                   // [GQ][GS] rows of the working set in y-space
-        double *const Yw = Nw + GQ * GS;              // [GQ][GS] H^-1 times those
-        double *const Sm = Yw + GQ * GS;              // [GQ][GQ] Gram matrix
-        double *const Lm = Sm + GQ * GQ;              // [GQ][GQ] its Cholesky factor
-        double *const uw = Lm + GQ * GQ;              // [GQ] multipliers
+        double *const Yw = gk + HV + GQ * GS;         // [GQ][GS] H^-1 times the rows of the working set (y-space); [GQ][GS] in front of it: spare
+        double *const Si = Yw + GQ * GS;              // [GQ][GQ] inverse of the Gram matrix G_W H^-1 G_W'  ([GQ][GQ] more behind it: spare)
+        double *const uw = Si + 2 * GQ * GQ;          // [GQ] multipliers
         double *const rwv = uw + GQ;                  // [GQ] multiplier rates of the current step
         int *const wrow = reinterpret_cast<int *>(rwv + GQ);   // [GQ] row codes (index into amap, or n_ax + index into cmap)
         static_assert(HV + 2 * GQ * GS + 2 * GQ * GQ + 2 * GQ + (GQ + 1) / 2 <= NY * KLD, "the working set fits the idle K");
-        double *const npv = S.rhs, *const hin = S.dy, *const gyv = S.gz;      // [40] each, idle here
+        double *const gyv = S.gz;                     // [40], idle here
+        // gi_hz[t][a] = (H^-1 Z' e_t)_a for the variable t of an axis (SEGV x NYA, the same for the three axes): H^-1 times a row's normal is
+        // then three of these per lane instead of a 13-term product behind an LDS round trip.  Kept in the interior point's idle slack array
+        // S.as_ (AXROWS >= SEGV * NYA doubles; set back to 1.0 on the way to the interior point).
+        double *const gi_hz = S.as_;
+        static_assert(SEGV * NYA <= AXROWS, "gi_hz fits the slack array");
         const double INF = 1e300;
         for (int i = tid; i < NYA * NYA; i += NT) Hinv[i] = md.ginv[S.tseg - 1][i];
-        for (int c = tid; c < nact; c += NT) rt1[cmap[c] & CMAP_MASK] = 0.0;      // "row is in the working set" marks (axis rows: S.at1, zero already)
+        // Selection scale of every row, 1 / (1 + |right-hand side|), formed ONCE per solve (it was two divisions per lane in every search:
+        // ~80 of a search's ~190 instructions per wave); a row inside the working set carries scale 0 -- its mark: it can never be the most
+        // violated one.  Kept in the interior point's idle t2 arrays (S.at2, rt2; prepare_warm / prepare_cold rewrite both on the way there).
+        for (int c = tid; c < n_ax; c += NT) { const int sl = S.amap[c] & 1023; S.at2[sl] = 1.0 / (1.0 + fabs(AH(sl))); }
+        for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt2[r] = 1.0 / (1.0 + fabs(rrhs[r])); }
         if (tid < 40) S.y[tid] = 0.0;
+        for (int i = tid; i < GQ * GS + 2 * GQ * GQ + 2 * GQ; i += NT) Yw[i] = 0.0;      // Yw, Si, uw, rwv: rows beyond the working set meet zeros
         __syncthreads();
         compute_x(S.y, S.x, true);
+        for (int i = tid; i < SEGV * NYA; i += NT) {
+            const int t = i / NYA, va = i % NYA;
+            const uint32_t gp = S.xgp[t];                 // (axis 0: yvar() of its bytes = the variable's indices inside an axis)
+            const double c0 = S.xtc[t][0], c1 = S.xtc[t][1], c2 = S.xtc[t][2];
+            const int i0 = yvar((int)(gp & 0xff)), i1 = yvar((int)((gp >> 8) & 0xff)), i2 = yvar((int)((gp >> 16) & 0xff));
+            double acc = 0.0;
+            if (c0 != 0.0) acc = c0 * Hinv[va * NYA + i0];
+            if (c1 != 0.0) acc += c1 * Hinv[va * NYA + i1];
+            if (c2 != 0.0) acc += c2 * Hinv[va * NYA + i2];
+            gi_hz[i] = acc;
+        }
         __syncthreads();
         if (tid < NV) {
             double cg = cost_grad();
@@ -1953,19 +1983,19 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             for (int c = tid; c < n_ax; c += NT) {
                 const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
                 const double *xq = S.x + ak * SEGV + at;
-                double mark = S.at1[sl], x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl);
-                LSC_PIN(PV(mark), PV(x0), PV(x1), PV(x2), PV(hh));
-                const double v = (ax_row3(x0, x1, x2, type) - hh) / (1.0 + fabs(hh));
-                if (mark == 0.0 && v > best) { best = v; bidx = c; }
+                double sc = S.at2[sl], x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl);
+                LSC_PIN(PV(sc), PV(x0), PV(x1), PV(x2), PV(hh));
+                const double v = (ax_row3(x0, x1, x2, type) - hh) * sc;
+                if (v > best) { best = v; bidx = c; }
             }
             for (int c = tid; c < nact; c += NT) {
                 const uint32_t e = cmap[c];
                 const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
-                double mark = rt1[r], x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r];
+                double sc = rt2[r], x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r];
                 float n0 = rn[r], n1 = rn[R + r], n2 = rn[2 * R + r];
-                LSC_PIN(PV(mark), PV(x0), PV(x1), PV(x2), PV(hh), PV(n0), PV(n1), PV(n2));
-                const double v = (hh - ((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2)) / (1.0 + fabs(hh));
-                if (mark == 0.0 && v > best) { best = v; bidx = n_ax + c; }
+                LSC_PIN(PV(sc), PV(x0), PV(x1), PV(x2), PV(hh), PV(n0), PV(n1), PV(n2));
+                const double v = (hh - ((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2)) * sc;
+                if (v > best) { best = v; bidx = n_ax + c; }
             }
             // one reduction: violation as float32 bits in the upper word, ~row in the lower -- as a double it orders like the pair
             const unsigned long long key = best > 0.0 ? (((unsigned long long)__float_as_uint((float)best)) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)bidx) : 0ull;
@@ -1975,128 +2005,99 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             if (!(__uint_as_float((uint32_t)(kmax >> 32)) > 1e-10f)) break;                  // nothing violated: optimal
             const int idx = (int)(0xffffffffu - (uint32_t)(kmax & 0xffffffffull));
             if (wave == 0) {
-                // ---- the row: three x-variables with their coefficients, and the right-hand side
-                int v0, v1, v2;
+                // ---- the step, on wave 0 alone.  A lone wave hides no latency: every LDS round trip costs its ~100 cycles in full, so the
+                // step is laid out as FOUR batches of independent loads, each waited for once (the first version -- loads where they were
+                // used, a Cholesky factor with two substitutions, guards on a working-set size the compiler held in a vector register -- made
+                // ~30 round trips and ~850 instructions: 2.7 us per change; profiles/r05_step_rewrite.log).
+                q = __builtin_amdgcn_readfirstlane(q);        // (uniform by construction; in a scalar register the guards below are scalar branches)
+                // batch 1: the row's word -> three x-variables with their coefficients
+                int v0, v1, v2, rsl = 0;
                 double a0, a1, a2, hp;
-                if (idx < n_ax) {
+                bool is_ax = idx < n_ax;
+                if (is_ax) {
                     const uint32_t am = S.amap[idx]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
                     const int kind = type >> 1;
                     const double sg = (type & 1) ? -1.0 : 1.0;
                     a0 = sg * (kind == 1 ? -1.0 : 1.0); a1 = sg * (kind == 0 ? 0.0 : (kind == 1 ? 1.0 : -2.0)); a2 = sg * (kind == 2 ? 1.0 : 0.0);
                     v0 = ak * SEGV + at; v1 = kind >= 1 ? v0 + 1 : v0; v2 = kind == 2 ? v0 + 2 : v0;
-                    hp = AH(sl);
+                    rsl = sl;
                 } else {
                     const uint32_t e = cmap[idx - n_ax];
                     const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
-                    a0 = -(double)rn[r]; a1 = -(double)rn[R + r]; a2 = -(double)rn[2 * R + r];
                     v0 = cp; v1 = SEGV + cp; v2 = 2 * SEGV + cp;
-                    hp = -rrhs[r];
+                    rsl = r;
+                    a0 = a1 = a2 = 0.0;
                 }
-                double viol = a0 * S.x[v0] + a1 * S.x[v1] + a2 * S.x[v2] - hp;
-                // its normal in y-space: x_v = sum_j xtc[t][j] y[xgp byte j]
-                auto zc = [&](int v) -> double {
-                    const uint32_t gp = S.xgp[v];
-                    const double *c = S.xtc[v % SEGV];
-                    return ((int)(gp & 0xff) == lane ? c[0] : 0.0) + ((int)((gp >> 8) & 0xff) == lane ? c[1] : 0.0) + ((int)(gp >> 16) == lane ? c[2] : 0.0);
+                // batch 2: right-hand side, normal, the point, the variables' y-indices and coefficients, and this lane's entries of
+                // H^-1 Z' e_v (gi_hz: one table for every axis, built at the start of the solve)
+                const int t0 = v0 % SEGV, t1 = v1 % SEGV, t2 = v2 % SEGV, k0 = v0 / SEGV, k1 = v1 / SEGV, k2 = v2 / SEGV;
+                const int lk = lane < NY ? yaxis(lane) : 3, lva = lane < NY ? yvar(lane) : 0;
+                {
+                    double hh = is_ax ? AH(rsl) : -rrhs[rsl];
+                    float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+                    if (!is_ax) { n0 = rn[rsl]; n1 = rn[R + rsl]; n2 = rn[2 * R + rsl]; }
+                    LSC_PIN(PV(hh), PV(n0), PV(n1), PV(n2));
+                    hp = hh;
+                    if (!is_ax) { a0 = -(double)n0; a1 = -(double)n1; a2 = -(double)n2; }
+                }
+                double x0 = S.x[v0], x1 = S.x[v1], x2 = S.x[v2];
+                uint32_t gp0 = S.xgp[v0], gp1 = S.xgp[v1], gp2 = S.xgp[v2];
+                double c00 = S.xtc[t0][0], c01 = S.xtc[t0][1], c02 = S.xtc[t0][2], c10 = S.xtc[t1][0], c11 = S.xtc[t1][1], c12 = S.xtc[t1][2],
+                       c20 = S.xtc[t2][0], c21 = S.xtc[t2][1], c22 = S.xtc[t2][2];
+                double h0 = gi_hz[t0 * NYA + lva], h1 = gi_hz[t1 * NYA + lva], h2 = gi_hz[t2 * NYA + lva];
+                LSC_PIN(PV(x0), PV(x1), PV(x2), PV(gp0), PV(gp1), PV(gp2), PV(c00), PV(c01), PV(c02), PV(c10), PV(c11), PV(c12), PV(c20), PV(c21), PV(c22),
+                        PV(h0), PV(h1), PV(h2));
+                double viol = a0 * x0 + a1 * x1 + a2 * x2 - hp;
+                // the row's normal in y-space (x_v = sum_j xtc[t][j] y[xgp byte j]) and H^-1 times it
+                auto zc = [&](uint32_t gp, double c0_, double c1_, double c2_) -> double {
+                    return ((int)(gp & 0xff) == lane ? c0_ : 0.0) + ((int)((gp >> 8) & 0xff) == lane ? c1_ : 0.0) + ((int)(gp >> 16) == lane ? c2_ : 0.0);
                 };
-                const double np_g = lane < NY ? a0 * zc(v0) + a1 * zc(v1) + a2 * zc(v2) : 0.0;
-                if (lane < GS) npv[lane] = np_g;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                double hin_g = 0.0;
-                if (lane < NY) {
-                    const int k = yaxis(lane), va = yvar(lane);
-#pragma unroll
-                    for (int b = 0; b < NYA; b++) hin_g += Hinv[va * NYA + b] * npv[yglob(k, b)];
-                    if (dim2 && k == 2) hin_g = 0.0;            // (planar world: the z unknowns never move)
-                }
-                if (lane < GS) hin[lane] = hin_g;
+                const double np_g = lane < NY ? a0 * zc(gp0, c00, c01, c02) + a1 * zc(gp1, c10, c11, c12) + a2 * zc(gp2, c20, c21, c22) : 0.0;
+                double hin_g = (lk == k0 ? a0 * h0 : 0.0) + (lk == k1 ? a1 * h1 : 0.0) + (lk == k2 ? a2 * h2 : 0.0);
+                if (dim2 && lk == 2) hin_g = 0.0;            // (planar world: the z unknowns never move)
                 double up = 0.0;
                 int code = 0;
-                // The Cholesky factor L of the Gram matrix S = G_W H^-1 G_W' is KEPT across changes: a row that joins appends one row to L
-                // -- the forward substitution L w = d that the step needs anyway, and l_qq^2 = n'H^-1 n - w'w --; only a row that leaves (rare)
-                // refactors.  The substitutions run from registers: lane i holds row i and column i of L and 1 / l_ii, every step is a
-                // v_readlane and a multiply-add (q <= GQ steps each way), no LDS round trip on the chain.
-                bool refactor = false;
-                // coefficients of the new row in y-space, sparse: x-variable v_i enters with a_i, x_v = sum_j xtc[t][j] y[xgp byte j]
-                const uint32_t gp0 = S.xgp[v0], gp1 = S.xgp[v1], gp2 = S.xgp[v2];
-                const double *c0 = S.xtc[v0 % SEGV], *c1 = S.xtc[v1 % SEGV], *c2 = S.xtc[v2 % SEGV];
+                // The INVERSE of the Gram matrix S = G_W H^-1 G_W' is kept across changes (Si, q x q, lane i holds row i): the multiplier rates
+                // r = S^-1 d are then GQ multiply-adds per lane with d_j read from lane j (v_readlane) -- no dependent chain beyond that --, a
+                // row that joins borders the inverse ([S d; d' nu]^-1 = [Si + r r'/delta, -r/delta; -r'/delta, 1/delta], delta = nu - d'r, the
+                // Schur complement = the slope of the new row along the step), a row that leaves removes its row and column (Si' = A - b b'/c).
+                // What a Cholesky factor had and this has not -- backward stability when rows are nearly dependent -- is bounded by the test
+                // on delta below and caught by the verification pass behind the solve: either way the interior point decides.
+                // Rows / columns beyond q hold zeros or stale finite numbers and meet r_j = d_j = 0: the loops run over all GQ, unguarded.
+                const int lq = lane < GQ ? lane : GQ - 1, lg = lane < GS ? lane : GS - 1;
                 for (;;) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (refactor) {
-                        // left-looking Cholesky of S from scratch, lanes = rows (after a row left the working set)
-                        bool pd = true;
-                        for (int j = 0; j < q; j++) {
-                            double aij = 0.0;
-                            if (lane < q && lane >= j) {
-                                aij = Sm[lane * GQ + j];
-                                for (int kk = 0; kk < j; kk++) aij -= Lm[lane * GQ + kk] * Lm[j * GQ + kk];
-                            }
-                            const double piv = lane_value(aij, j);
-                            if (!(piv > 1e-13 * Sm[j * GQ + j])) { pd = false; break; }
-                            const double inv = 1.0 / sqrt(piv);
-                            if (lane < q && lane >= j) Lm[lane * GQ + j] = aij * inv;
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        }
-                        if (!pd) { code = 2; break; }
-                        refactor = false;
-                    }
+                    // batch 3: everything the working set contributes
+                    double Sr[GQ], Yc[GQ];                      // row `lane` of the inverse; entry `lane` of every H^-1 n_w
+                    const double *yr = Yw + lq * GS;
+                    double y00 = yr[gp0 & 0xff], y01 = yr[(gp0 >> 8) & 0xff], y02 = yr[gp0 >> 16], y10 = yr[gp1 & 0xff], y11 = yr[(gp1 >> 8) & 0xff], y12 = yr[gp1 >> 16],
+                           y20 = yr[gp2 & 0xff], y21 = yr[(gp2 >> 8) & 0xff], y22 = yr[gp2 >> 16];
+#pragma unroll
+                    for (int j = 0; j < GQ; j++) { Sr[j] = Si[lq * GQ + j]; Yc[j] = Yw[j * GS + lg]; }
+                    double uwl = uw[lq], yl = S.y[lg];
+                    LSC_PIN(PV(y00), PV(y01), PV(y02), PV(y10), PV(y11), PV(y12), PV(y20), PV(y21), PV(y22), PV(uwl), PV(yl));
+                    pin_values(Sr);
+                    pin_values(Yc);
                     // d = G_W H^-1 n = Y_W n, with the (at most nine) non-zeros of n
-                    double dw = 0.0, rw = 0.0, wfw = 0.0;
-                    if (lane < q) {
-                        const double *yr = Yw + lane * GS;
-                        double y00 = yr[gp0 & 0xff], y01 = yr[(gp0 >> 8) & 0xff], y02 = yr[gp0 >> 16], y10 = yr[gp1 & 0xff], y11 = yr[(gp1 >> 8) & 0xff], y12 = yr[gp1 >> 16],
-                               y20 = yr[gp2 & 0xff], y21 = yr[(gp2 >> 8) & 0xff], y22 = yr[gp2 >> 16];
-                        LSC_PIN(PV(y00), PV(y01), PV(y02), PV(y10), PV(y11), PV(y12), PV(y20), PV(y21), PV(y22));
-                        dw = a0 * (c0[0] * y00 + c0[1] * y01 + c0[2] * y02);
-                        if (v1 != v0) dw += a1 * (c1[0] * y10 + c1[1] * y11 + c1[2] * y12);
-                        if (v2 != v0) dw += a2 * (c2[0] * y20 + c2[1] * y21 + c2[2] * y22);
-                    }
-                    if (q > 0) {
-                        double Lr[GQ], Lc[GQ];                  // row `lane` and column `lane` of L
-                        const int lq = lane < GQ ? lane : GQ - 1;
+                    double dw = a0 * (c00 * y00 + c01 * y01 + c02 * y02) + a1 * (c10 * y10 + c11 * y11 + c12 * y12) + a2 * (c20 * y20 + c21 * y21 + c22 * y22);
+                    dw = lane < q ? dw : 0.0;
+                    double rw = 0.0;
 #pragma unroll
-                        for (int j = 0; j < GQ; j++) { Lr[j] = Lm[lq * GQ + j]; Lc[j] = Lm[j * GQ + lq]; }
-                        double dinvl = Lr[0];
-#pragma unroll
-                        for (int j = 1; j < GQ; j++) dinvl = lane == j ? Lr[j] : dinvl;
-                        dinvl = rcp_nr(dinvl);                  // 1 / l_ii on lane i (lanes beyond q: unused)
-                        double b = dw;
-#pragma unroll
-                        for (int j = 0; j < GQ; j++) {          // L w = d
-                            if (j < q) {
-                                const double wj = lane_value(b, j) * lane_value(dinvl, j);
-                                b = lane == j ? wj : ((lane > j && lane < q) ? fma(-Lr[j], wj, b) : b);
-                            }
-                        }
-                        wfw = lane < q ? b : 0.0;
-#pragma unroll
-                        for (int i = GQ - 1; i >= 0; i--) {     // L' r = w
-                            if (i < q) {
-                                const double ri = lane_value(b, i) * lane_value(dinvl, i);
-                                b = lane == i ? ri : (lane < i ? fma(-Lc[i], ri, b) : b);
-                            }
-                        }
-                        rw = lane < q ? b : 0.0;
-                        if (lane < q) rwv[lane] = rw;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    }
+                    for (int j = 0; j < GQ; j++) rw = fma(Sr[j], lane_value(dw, j), rw);          // r = S^-1 d
+                    rw = lane < q ? rw : 0.0;
                     // primal direction z = H^-1 n - Y_W r (it keeps the working set active) and its slope against the new row
                     double zg = hin_g;
-                    if (lane < NY) for (int w = 0; w < q; w++) zg -= Yw[w * GS + lane] * rwv[w];
-                    // one staged reduction for the four wave-wide numbers of a step: n'H^-1 n, the slope n'z, w'w, the smallest multiplier ratio
-                    const double ratio = (lane < q && rw > 1e-13) ? uw[lane] * rcp_nr(rw) : INF;
-                    double red4[5] = {np_g * hin_g, np_g * zg, wfw * wfw, ratio, 0.0};
+#pragma unroll
+                    for (int w = 0; w < GQ; w++) zg = fma(-Yc[w], lane_value(rw, w), zg);
+                    zg = lane < NY ? zg : 0.0;
+                    // one staged reduction for the four wave-wide numbers of a step: n'H^-1 n, the slope n'z, d'r, the smallest multiplier ratio
+                    const double ratio = (lane < q && rw > 1e-13) ? uwl * rcp_nr(rw) : INF;
+                    double red4[5] = {np_g * hin_g, np_g * zg, dw * rw, ratio, 0.0};
                     const int rop[5] = {0, 0, 0, 2, -1};
                     wave_reduce5(red4, rop);
-                    const double nph = red4[0], zn = red4[1], wsq = red4[2], t1 = red4[3];
+                    const double nph = red4[0], zn = red4[1], dtr = red4[2], t1 = red4[3];
                     const unsigned long long dropmask = __ballot(lane < q && ratio == t1);
                     const double t2 = zn > 1e-12 * nph ? viol * rcp_nr(zn) : INF;
                     if (t1 >= INF && t2 >= INF) {
@@ -2110,49 +2111,64 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     }
                     const double t = fmin(t1, t2);
                     if (t2 < INF) {
-                        if (lane < NY) S.y[lane] -= t * zg;
+                        if (lane < NY) S.y[lane] = yl - t * zg;
                         viol -= t * zn;
                     }
-                    if (lane < q) uw[lane] = fmax(uw[lane] - t * rw, 0.0);
+                    if (lane < q) uw[lane] = fmax(uwl - t * rw, 0.0);
                     up += t;
                     gi_changes++;
                     if (t2 <= t1) {
-                        // full step: the row joins the working set; L gets the row (w, sqrt(n'H^-1 n - w'w)) -- that radicand IS the slope zn
+                        // full step: the row joins the working set; the inverse is bordered with (r, delta), delta = n'H^-1 n - d'r
                         if (q == GQ) { code = 2; break; }
-                        const double lqq2 = nph - wsq;
-                        if (!(lqq2 > 1e-13 * nph)) { code = 2; break; }
-                        if (lane < GS) { Nw[q * GS + lane] = np_g; Yw[q * GS + lane] = hin_g; }
-                        if (lane < q) { Sm[q * GQ + lane] = dw; Sm[lane * GQ + q] = dw; Lm[q * GQ + lane] = wfw; Lm[lane * GQ + q] = 0.0; }
+                        const double delta = nph - dtr;
+                        if (!(delta > 1e-11 * nph)) { code = 2; break; }
+                        const double idl = 1.0 / delta;
+                        if (lane < GS) Yw[q * GS + lane] = hin_g;
+                        const double rs_ = rw * idl;
+#pragma unroll
+                        for (int j = 0; j < GQ; j++) Sr[j] = fma(rs_, lane_value(rw, j), Sr[j]);
+                        if (lane < q) {
+#pragma unroll
+                            for (int j = 0; j < GQ; j++) Si[lane * GQ + j] = Sr[j];
+                            Si[lane * GQ + q] = -rs_;
+                            Si[q * GQ + lane] = -rs_;
+                        }
                         if (lane == 0) {
-                            Sm[q * GQ + q] = nph; Lm[q * GQ + q] = sqrt(lqq2); uw[q] = up; wrow[q] = idx;
-                            if (idx < n_ax) S.at1[S.amap[idx] & 1023] = 1.0;
-                            else rt1[cmap[idx - n_ax] & CMAP_MASK] = 1.0;
+                            Si[q * GQ + q] = idl; uw[q] = up; wrow[q] = idx;
+                            if (is_ax) S.at2[rsl] = 0.0;            // (scale 0 = inside the working set)
+                            else rt2[rsl] = 0.0;
                         }
                         q++;
                         break;
                     }
-                    // partial step: row j of the working set reached multiplier zero and leaves (the last row takes its place)
-                    const int j = __ffsll((long long)dropmask) - 1, last = q - 1;
+                    // partial step: row jd of the working set reached multiplier zero and leaves (the last row takes its place)
+                    const int jd = __ffsll((long long)dropmask) - 1, last = q - 1;
                     if (lane == 0) {
-                        const int code_j = wrow[j];
-                        if (code_j < n_ax) S.at1[S.amap[code_j] & 1023] = 0.0;
-                        else rt1[cmap[code_j - n_ax] & CMAP_MASK] = 0.0;
+                        const int code_j = wrow[jd];
+                        if (code_j < n_ax) { const int sl = S.amap[code_j] & 1023; S.at2[sl] = 1.0 / (1.0 + fabs(AH(sl))); }
+                        else { const int r = cmap[code_j - n_ax] & CMAP_MASK; rt2[r] = 1.0 / (1.0 + fabs(rrhs[r])); }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (j != last) {
-                        if (lane < GS) { Nw[j * GS + lane] = Nw[last * GS + lane]; Yw[j * GS + lane] = Yw[last * GS + lane]; }
-                        const double srow = lane < q ? Sm[last * GQ + lane] : 0.0;       // row `last` of S (symmetric)
-                        const double sll = Sm[last * GQ + last];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        if (lane < last && lane != j) { Sm[j * GQ + lane] = srow; Sm[lane * GQ + j] = srow; }
-                        if (lane == 0) { Sm[j * GQ + j] = sll; uw[j] = uw[last]; wrow[j] = wrow[last]; }
+                    {
+                        // inverse without row / column jd:  T = A - b b' / c  (c = Si[jd][jd], b = column jd), then row / column `last` -> jd
+                        const double cjj = Si[jd * GQ + jd];
+                        const double bi = Si[lq * GQ + jd] * (1.0 / cjj);
+                        double Tn[GQ];
+#pragma unroll
+                        for (int k = 0; k < GQ; k++) Tn[k] = fma(-bi, Si[jd * GQ + k], Sr[k]);
+                        pin_values(Tn);
+                        if (lane < q && lane != jd) {
+                            const int ir = lane == last ? jd : lane;
+#pragma unroll
+                            for (int k = 0; k < GQ; k++) {
+                                if (k < q && k != jd) Si[ir * GQ + (k == last ? jd : k)] = Tn[k];
+                            }
+                        }
+                    }
+                    if (jd != last) {
+                        if (lane < GS) Yw[jd * GS + lane] = Yw[last * GS + lane];
+                        if (lane == 0) { uw[jd] = uw[last]; wrow[jd] = wrow[last]; }
                     }
                     q--;
-                    refactor = true;
                     if (gi_changes > GI_CAP) { code = 2; break; }
                 }
                 if (lane == 0) { S.sc[0] = (double)code; S.sc[1] = (double)q; S.sc[2] = (double)gi_changes; }
@@ -2227,7 +2243,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         if constexpr (SOLVER == 1) {
             // the active-set solve gave up: the interior point starts from its own initial state (K zero outside the band, no marks)
             for (int i = tid; i < NY * KLD; i += NT) S.K[i] = 0.0;
-            for (int c = tid; c < n_ax; c += NT) S.at1[S.amap[c] & 1023] = 0.0;
+            for (int i = tid; i < AXROWS; i += NT) S.as_[i] = 1.0;            // (held gi_hz; slots of rows that do not exist keep s = 1 for the whole solve)
             if (tid < 40) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
             spent = gi_changes;          // (reported with the iterations, like the iterations of a failed warm start)
             __syncthreads();
