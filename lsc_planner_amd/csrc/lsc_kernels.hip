@@ -708,11 +708,15 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     // workgroups per CU hide that latency -- and spends the LDS on row capacity instead.
     const uint32_t *terms, *ent;
     double *kconst;
+    // (SOLVER == 1: everything only the interior point needs -- these tables, the constant part of the Hessian entries, the slot tables of the
+    //  row reduction, its zeroed arrays -- is set up where the active-set solve hands over to it, once in ~2 000 agent-replans: ip_late_setup)
     if constexpr (TABLES_IN_LDS) {
         uint32_t *lt = S.dyn;                                       // [n_terms]
         uint32_t *le = lt + ((n_terms + 1) & ~1);                   // [n_entries+1][2] : (gi<<16|gj), first term
-        for (int i = tid; i < n_terms; i += NT) lt[i] = a.terms[i];
-        for (int i = tid; i < 2 * n_entries + 2; i += NT) le[i] = a.entries[i];
+        if constexpr (SOLVER != 1) {
+            for (int i = tid; i < n_terms; i += NT) lt[i] = a.terms[i];
+            for (int i = tid; i < 2 * n_entries + 2; i += NT) le[i] = a.entries[i];
+        }
         terms = lt; ent = le;
         kconst = reinterpret_cast<double *>(le + 2 * n_entries + 2);
     } else {
@@ -787,17 +791,22 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     const bool checks = ALT && a.reset_thr > 0.0 && a.planner_seq >= 2 && a.planner_mode == 0 && a.ever != nullptr;
     bool own_now = false, own_slack = false;
     if (tid == 0) S.gen = ALT ? a.general_all : 0;
+    // (with prior_based goals the pass over the other agents below does these checks on its way: one round trip to the states instead of
+    //  two, one barrier less)
+    int any_slack = 0;
     if (checks) {
         own_now = off_plan(qi);
         own_slack = own_now || a.ever[qi] != 0;
-        int any = own_slack ? 1 : 0;
-        for (int qj = tid; qj < N; qj += NT) {
-            const bool nw = off_plan(qj);
-            if (nw) a.ever[qj] = 1;
-            any |= (nw || a.ever[qj] != 0) ? 1 : 0;
+        any_slack = own_slack ? 1 : 0;
+        if (a.goal_mode != 1) {
+            for (int qj = tid; qj < N; qj += NT) {
+                const bool nw = off_plan(qj);
+                if (nw) a.ever[qj] = 1;
+                any_slack |= (nw || a.ever[qj] != 0) ? 1 : 0;
+            }
+            __syncthreads();              // S.gen was initialised by lane 0 above
+            if (any_slack) S.gen = 1;     // every writer stores the same value; read after the next barrier
         }
-        __syncthreads();              // S.gen was initialised by lane 0 above
-        if (any) S.gen = 1;           // every writer stores the same value; read after the next barrier
     }
     const bool rest = ALT && (own_now || a.planner_mode == 1);   // own initial trajectory = current position (reset, or BVC)
     // ---- goal planning (TrajPlanner::goalPlanning, src/traj_planner.cpp:477-538)
@@ -821,8 +830,16 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         double best = 1e9;
         int bq = 0x7fffffff;
         for (int qj = tid; qj < N; qj += NT) {
+            bool slack_j = false;
+            if (checks) {
+                const bool nw = off_plan(qj);
+                const int ev = a.ever[qj];
+                if (nw) a.ever[qj] = 1;
+                slack_j = nw || ev != 0;
+                any_slack |= slack_j ? 1 : 0;
+            }
             if (qj == qi) continue;
-            if (checks && (own_slack || a.ever[qj] != 0 || off_plan(qj))) continue;   // slack obstacle: no retreat candidate (:548-551)
+            if (checks && (own_slack || slack_j)) continue;   // slack obstacle: no retreat candidate (:548-551)
             const float *opos = a.state + 9 * qj, *ogoal = a.goal + 3 * qj;
             const double obs_dist_to_goal = distf(opos, ogoal);
             const double dist_to_obs = distf(opos, pos);
@@ -841,6 +858,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         if (lane == 0) S.red[0][0][wave] = wmin;
         if (tid == 0) S.itmp = 0x7fffffff;
         __syncthreads();
+        if (checks && any_slack) S.gen = 1;       // (initialised by lane 0 in front of that barrier; every writer stores the same value; read behind the next one)
         double dmin = S.red[0][0][0];
 #pragma unroll
         for (int w = 1; w < NWAVE; w++) dmin = fmin(dmin, S.red[0][0][w]);
@@ -882,6 +900,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         S.s0[k][0] = c0; S.s0[k][1] = c1; S.s0[k][2] = c2;
         if constexpr (TABLES_IN_LDS) { S.x0c[k * SEGV] = c0; S.x0c[k * SEGV + 1] = c1; S.x0c[k * SEGV + 2] = c2; }
         S.goal[k] = (dim2 && k == 2) ? md.z2d : (double)S.goalf[k];
+        S.vlim[k] = a.vmax[3 * qi + k] * md.hv_scale; S.alim[k] = a.amax[3 * qi + k] * md.ha_scale;      // (every later phase reads these: no second trip to HBM)
         if (a.goal_out) a.goal_out[3 * qi + k] = S.goalf[k];
         for (int m = 0; m < M; m++) {
             double lo = (double)md.world_min[k], hi = (double)md.world_max[k];
@@ -962,7 +981,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         }
         return v;
     };
-    for (int e = tid; e < n_entries; e += NT) kconst[e] = kconst_of(ent[2 * e]);
+    if constexpr (SOLVER != 1) for (int e = tid; e < n_entries; e += NT) kconst[e] = kconst_of(ent[2 * e]);
     // Throughput build: the entry words of this lane's (at most two) Hessian entries never change -- kept in registers --, and the term
     // words they point at are fetched from L2 in ONE batch in front of every row reduction (prefetch_terms), so that the assembly
     // behind it finds them in registers: read where they were needed they cost up to three dependent L2 round trips per assembly.
@@ -973,8 +992,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     // (redundant constraints: removing them does not change the feasible set, hence not the optimum).
     {
         const double r_a = a.radius[qi], dw_a = a.downwash[qi];
-        const double dlx = a.vmax[3 * qi] * md.hv_scale, dly = a.vmax[3 * qi + 1] * md.hv_scale,
-                     dlz = a.vmax[3 * qi + 2] * md.hv_scale;   // largest step between consecutive control points
+        const double dlx = S.vlim[0], dly = S.vlim[1], dlz = S.vlim[2];   // largest step between consecutive control points (vmax dt / n)
         const int n_units = (ALT && S.gen) ? 0 : n_obs * M;    // alternate-mode QP: rows are built by lsc_general_kernel
         const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         // Reachable box of every control point relative to c_{0,2}.  Consecutive control points differ by at most
@@ -986,7 +1004,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         //  everybody waited for.  The scan adds in another order than the walk -- a few ulp, against a 1e-9 pad per step.)
         if (tid < 96) {
             const int k = tid >> 5, j = tid & 31;
-            const double V = a.vmax[3 * qi + k] * md.hv_scale, A = a.amax[3 * qi + k] * md.ha_scale;
+            const double V = S.vlim[k], A = S.alim[k];
             const double d0 = S.s0[k][2] - S.s0[k][1];
             const bool in = j >= 1 && j < 28;
             double lo = in ? fmax(-V, d0 - (double)j * A) - 1e-9 : 0.0;
@@ -1248,6 +1266,34 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         }
         __syncthreads();
     }
+    // slot tables of the row reduction (interior point), in two halves around a barrier: offsets by one half-wave per table, then the entries
+    auto slot_offsets = [&](int which, int b, int c, int total) {
+        const int cap_slots = which == 0 ? RSLOT_P : RSLOT_C, min_rpl = 4;
+        int rpl = (total + (cap_slots - NB) - 1) / (cap_slots - NB);
+        rpl = rpl < min_rpl ? min_rpl : rpl;
+        const int parts = b < NB ? (c + rpl - 1) / rpl : 0;
+        int pin = parts;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const int up = __shfl_up(pin, d, 32);
+            if (b >= d) pin += up;
+        }
+        unsigned short *so = which == 0 ? S.soffP : S.soffC;
+        if (b <= NB) so[b] = (unsigned short)(pin - parts);
+        if (b == 0) S.rpl[which] = rpl;
+    };
+    auto slot_entries = [&]() {
+        for (int q = tid; q < 2 * NB; q += NT) {
+            const int which = q >= NB, b = which ? q - NB : q;
+            const unsigned short *so = which ? S.soffC : S.soffP;
+            uint32_t *sl = which ? S.slotC : S.slotP;
+            const int rpl = S.rpl[which], cnt = S.cnt[b + 3], r0 = S.offs[b];
+            for (int p = 0, s = so[b]; p * rpl < cnt; p++, s++) {
+                const int n = cnt - p * rpl < rpl ? cnt - p * rpl : rpl;
+                sl[s] = (uint32_t)(r0 + p * rpl) | ((uint32_t)n << 16) | ((uint32_t)b << 24);
+            }
+        }
+    };
     // bucket offsets, and (rows in LDS) the slot tables of the row reduction -- bucket b is cut into parts of rpl rows; rpl is the smallest
     // that fits the staging --: one lane per bucket (and table), offsets by 32-lane prefix sums.  (One lane walking the 27 buckets for
     // the offsets and two walking them with a division each for the tables were ~900 instructions on a wave everybody waited for.)
@@ -1274,35 +1320,10 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 S.nact = total;
             }
         }
-        if constexpr (!SPILL) {
-            const int cap_slots = which == 0 ? RSLOT_P : RSLOT_C, min_rpl = 4;
-            int rpl = (total + (cap_slots - NB) - 1) / (cap_slots - NB);
-            rpl = rpl < min_rpl ? min_rpl : rpl;
-            const int parts = b < NB ? (c + rpl - 1) / rpl : 0;
-            int pin = parts;
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) {
-                const int up = __shfl_up(pin, d, 32);
-                if (b >= d) pin += up;
-            }
-            unsigned short *so = which == 0 ? S.soffP : S.soffC;
-            if (b <= NB) so[b] = (unsigned short)(pin - parts);
-            if (b == 0) S.rpl[which] = rpl;
-        }
+        if constexpr (!SPILL && SOLVER != 1) slot_offsets(which, b, c, total);
     }
     __syncthreads();
-    if constexpr (!SPILL) {
-        for (int q = tid; q < 2 * NB; q += NT) {
-            const int which = q >= NB, b = which ? q - NB : q;
-            const unsigned short *so = which ? S.soffC : S.soffP;
-            uint32_t *sl = which ? S.slotC : S.slotP;
-            const int rpl = S.rpl[which], cnt = S.cnt[b + 3], r0 = S.offs[b];
-            for (int p = 0, s = so[b]; p * rpl < cnt; p++, s++) {
-                const int n = cnt - p * rpl < rpl ? cnt - p * rpl : rpl;
-                sl[s] = (uint32_t)(r0 + p * rpl) | ((uint32_t)n << 16) | ((uint32_t)b << 24);
-            }
-        }
-    }
+    if constexpr (!SPILL && SOLVER != 1) slot_entries();
     // scatter from arrival order to the compact, bucket-sorted layout
     for (int k = tid; k < S.nact; k += NT) {
         const TmpRow t = tmp_rows[k];
@@ -1323,17 +1344,12 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         bool valid;
         double h;
         if (type < 2) { valid = !(m == 0 && i < 3); h = type == 0 ? S.hi[k][m] : -S.lo[k][m]; }
-        else if (type < 4) { valid = i <= 4 && !(m == 0 && i < 2); h = a.vmax[3 * qi + k] * md.hv_scale; }
-        else { valid = i <= 3 && !(m == 0 && i == 0); h = a.amax[3 * qi + k] * md.ha_scale; }
+        else if (type < 4) { valid = i <= 4 && !(m == 0 && i < 2); h = S.vlim[k]; }
+        else { valid = i <= 3 && !(m == 0 && i == 0); h = S.alim[k]; }
         if (dim2 && k == 2) valid = false;
         if constexpr (TABLES_IN_LDS) S.avalid[sl] = valid ? 1 : 0;
         if constexpr (TABLES_IN_LDS) S.ah[sl] = h;
-        S.as_[sl] = 1.0; S.az[sl] = 0.0; S.at1[sl] = 0.0; S.at2[sl] = 0.0;
-    }
-    if (tid < 3) {
-        int tq = tid;                         // (opaque copy: the index 3 qi + tid of phase B's reach boxes is not kept alive for this)
-        asm volatile("" : "+v"(tq));
-        S.vlim[tq] = a.vmax[3 * qi + tq] * md.hv_scale; S.alim[tq] = a.amax[3 * qi + tq] * md.ha_scale;
+        if constexpr (SOLVER != 1) { S.as_[sl] = 1.0; S.az[sl] = 0.0; S.at1[sl] = 0.0; S.at2[sl] = 0.0; }
     }
     // right-hand side of axis row sl
     auto AH = [&](int sl) -> double {
@@ -1343,10 +1359,12 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             return type == 0 ? S.hi[k][m] : (type == 1 ? -S.lo[k][m] : (type < 4 ? S.vlim[k] : S.alim[k]));
         }
     };
-    if (tid < 40) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
-    for (int i = tid; i < NY * KLD; i += NT) S.K[i] = 0.0;
-    for (int i = tid; i < NCP * 3; i += NT) { S.Tv[i] = 0.0; S.Tz[i] = 0.0; }
-    for (int i = tid; i < W_SIZE; i += NT) S.W[i] = 0.0;
+    if constexpr (SOLVER != 1) {
+        if (tid < 40) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
+        for (int i = tid; i < NY * KLD; i += NT) S.K[i] = 0.0;
+        for (int i = tid; i < NCP * 3; i += NT) { S.Tv[i] = 0.0; S.Tz[i] = 0.0; }
+        for (int i = tid; i < W_SIZE; i += NT) S.W[i] = 0.0;
+    }
     __syncthreads();
     const bool overflow = S.flag != 0;
     const int nact = S.nact;
@@ -1963,12 +1981,19 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < NY) {
-                const int k = yaxis(lane), va = yvar(lane);
+            {
+                // (all 2 x 13 operands in one batch of loads: taken where they are used they are eight dependent LDS round trips on this lone wave)
+                const int ls = lane < NY ? lane : 0;
+                const int k = yaxis(ls), va = yvar(ls);
+                double hv[NYA], gv[NYA];
+#pragma unroll
+                for (int b = 0; b < NYA; b++) { hv[b] = Hinv[va * NYA + b]; gv[b] = gyv[yglob(k, b)]; }
+                pin_values(hv);
+                pin_values(gv);
                 double acc = 0.0;
 #pragma unroll
-                for (int b = 0; b < NYA; b++) acc += Hinv[va * NYA + b] * gyv[yglob(k, b)];
-                S.y[lane] = (dim2 && k == 2) ? md.z2d : -acc;
+                for (int b = 0; b < NYA; b++) acc += hv[b] * gv[b];
+                if (lane < NY) S.y[lane] = (dim2 && k == 2) ? md.z2d : -acc;
             }
         }
         int q = 0;
@@ -2242,10 +2267,26 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     } else {
         if constexpr (SOLVER == 1) {
             // the active-set solve gave up: the interior point starts from its own initial state (K zero outside the band, no marks)
+            // ip_late_setup: the state the interior point expects at its start, built here instead of on every agent's way to the active-set solve
+            if constexpr (TABLES_IN_LDS) {
+                uint32_t *lt = S.dyn, *le = lt + ((n_terms + 1) & ~1);
+                for (int i = tid; i < n_terms; i += NT) lt[i] = a.terms[i];
+                for (int i = tid; i < 2 * n_entries + 2; i += NT) le[i] = a.entries[i];
+            }
             for (int i = tid; i < NY * KLD; i += NT) S.K[i] = 0.0;
-            for (int i = tid; i < AXROWS; i += NT) S.as_[i] = 1.0;            // (held gi_hz; slots of rows that do not exist keep s = 1 for the whole solve)
+            // (S.as_ held gi_hz, S.at2 the selection scales; slots of rows that do not exist keep s = 1, z = t1 = t2 = 0 for the whole solve)
+            for (int i = tid; i < AXROWS; i += NT) { S.as_[i] = 1.0; S.az[i] = 0.0; S.at1[i] = 0.0; S.at2[i] = 0.0; }
+            for (int i = tid; i < NCP * 3; i += NT) { S.Tv[i] = 0.0; S.Tz[i] = 0.0; }
+            for (int i = tid; i < W_SIZE; i += NT) S.W[i] = 0.0;
             if (tid < 40) { S.y[tid] = 0.0; S.dy[tid] = 0.0; }
+            if (tid < 64) {
+                const int which = tid >> 5, b = tid & 31;
+                slot_offsets(which, b, b < NB ? S.cnt[b + 3] : 0, nact);
+            }
             spent = gi_changes;          // (reported with the iterations, like the iterations of a failed warm start)
+            __syncthreads();
+            for (int e = tid; e < n_entries; e += NT) kconst[e] = kconst_of(ent[2 * e]);
+            slot_entries();
             __syncthreads();
         }
         if (attempt == 0) {
