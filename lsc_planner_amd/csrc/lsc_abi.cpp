@@ -129,6 +129,12 @@ void build_model(const lsc_config &cfg, HostModel &H)
         }
         for (int a = 0; a < NYA; a++)
             for (int b = 0; b < NYA; b++) m.ginv[T - 1][a * NYA + b] = (double)(0.5L * (A[a][NYA + b] + A[b][NYA + a]));
+        for (int t = 0; t < SEGV; t++)
+            for (int a = 0; a < NYA; a++) {
+                double acc = 0.0;
+                for (int j = 0; j < m.x_n[t]; j++) acc += m.x_c[t][j] * m.ginv[T - 1][a * NYA + m.x_i[t][j]];
+                m.ghz[T - 1][t * NYA + a] = acc;
+            }
     }
 
     // Hessian assembly terms: K[(k,a),(k',b)] += Z[t][a] Z[t'][b] * Wx[(k,t),(k',t')]

@@ -1266,6 +1266,20 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         }
         __syncthreads();
     }
+    // SOLVER == 1: this solve's H^-1 block and its table H^-1 Z' e_t (Model::ginv, ghz) are fetched HERE -- the GJK pass and its registers are
+    // behind, the values travel while the rows are bucketed and sorted -- and stored at the start of the active-set solve (fetched there, the
+    // trip to L2 stood in front of the solve: ~0.7 us per agent-tick)
+    constexpr int GI_NPRE = (SEGV * NYA + NTT - 1) / NTT;
+    static_assert(NYA * NYA <= NTT, "one lane per entry of the inverse block");
+    double gi_pre_h = 0.0, gi_pre_z[GI_NPRE];
+#pragma unroll
+    for (int u = 0; u < GI_NPRE; u++) gi_pre_z[u] = 0.0;
+    if constexpr (SOLVER == 1) {
+        const double *gsrc = md.ginv[S.tseg - 1], *zsrc = md.ghz[S.tseg - 1];
+        gi_pre_h = gsrc[tid < NYA * NYA ? tid : 0];
+#pragma unroll
+        for (int u = 0; u < GI_NPRE; u++) gi_pre_z[u] = zsrc[tid + u * NTT < SEGV * NYA ? tid + u * NTT : 0];
+    }
     // slot tables of the row reduction (interior point), in two halves around a barrier: offsets by one half-wave per table, then the entries
     auto slot_offsets = [&](int which, int b, int c, int total) {
         const int cap_slots = which == 0 ? RSLOT_P : RSLOT_C, min_rpl = 4;
@@ -1942,7 +1956,9 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         double *const gi_hz = S.as_;
         static_assert(SEGV * NYA <= AXROWS, "gi_hz fits the slack array");
         const double INF = 1e300;
-        for (int i = tid; i < NYA * NYA; i += NT) Hinv[i] = md.ginv[S.tseg - 1][i];
+        if (tid < NYA * NYA) Hinv[tid] = gi_pre_h;
+#pragma unroll
+        for (int u = 0; u < GI_NPRE; u++) if (tid + u * NT < SEGV * NYA) gi_hz[tid + u * NT] = gi_pre_z[u];
         // Selection scale of every row, 1 / (1 + |right-hand side|), formed ONCE per solve (it was two divisions per lane in every search:
         // ~80 of a search's ~190 instructions per wave); a row inside the working set carries scale 0 -- its mark: it can never be the most
         // violated one.  Kept in the interior point's idle t2 arrays (S.at2, rt2; prepare_warm / prepare_cold rewrite both on the way there).
@@ -1950,19 +1966,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt2[r] = 1.0 / (1.0 + fabs(rrhs[r])); }
         if (tid < 40) S.y[tid] = 0.0;
         for (int i = tid; i < GQ * GS + 2 * GQ * GQ + 2 * GQ; i += NT) Yw[i] = 0.0;      // Yw, Si, uw, rwv: rows beyond the working set meet zeros
-        __syncthreads();
-        compute_x(S.y, S.x, true);
-        for (int i = tid; i < SEGV * NYA; i += NT) {
-            const int t = i / NYA, va = i % NYA;
-            const uint32_t gp = S.xgp[t];                 // (axis 0: yvar() of its bytes = the variable's indices inside an axis)
-            const double c0 = S.xtc[t][0], c1 = S.xtc[t][1], c2 = S.xtc[t][2];
-            const int i0 = yvar((int)(gp & 0xff)), i1 = yvar((int)((gp >> 8) & 0xff)), i2 = yvar((int)((gp >> 16) & 0xff));
-            double acc = 0.0;
-            if (c0 != 0.0) acc = c0 * Hinv[va * NYA + i0];
-            if (c1 != 0.0) acc += c1 * Hinv[va * NYA + i1];
-            if (c2 != 0.0) acc += c2 * Hinv[va * NYA + i2];
-            gi_hz[i] = acc;
-        }
+        if (tid < NV) S.x[tid] = xt < 3 ? X0C(tid) : 0.0;       // x at y = 0: the state constants
         __syncthreads();
         if (tid < NV) {
             double cg = cost_grad();
@@ -2000,12 +2004,31 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         if (wave == 0) compute_x_wave0(S.y, S.x, true);
         __syncthreads();
         stamp(PH_INIT);                  // (instrumented build: the start of the active-set solve is booked under "ip_init")
+        // What the search needs of this lane's first axis row and first LSC row never changes during the solve: kept in registers, so that a
+        // search is ONE batch of loads (the point and the two scales) instead of row word -> row data -> value.
+        const bool s_has_ax = tid < n_ax, s_has_l = tid < nact;
+        const uint32_t s_am = S.amap[s_has_ax ? tid : 0];
+        const int s_sl = s_am & 1023, s_type = (s_am >> 10) & 7, s_xo = (int)((s_am >> 13) & 3) * SEGV + (int)(s_am >> 15);
+        const double s_hh = AH(s_sl);
+        const uint32_t s_e = s_has_l ? cmap[tid] : 0u;
+        const int s_r = s_e & CMAP_MASK, s_cp = s_e >> CMAP_SHIFT;
+        const double s_lh = rrhs[s_r];
+        const float s_n0 = rn[s_r], s_n1 = rn[R + s_r], s_n2 = rn[2 * R + s_r];
         for (;;) {
             // (S.x is current: formed by wave 0 right behind the step that changed y, in front of the barrier that ended it)
             // ---- the most violated row outside the working set (violation over 1 + |right-hand side|; ties: lowest row)
             double best = 0.0;
             int bidx = 0;
-            for (int c = tid; c < n_ax; c += NT) {
+            double lv = 0.0;
+            {
+                double sc = S.at2[s_sl], x0 = S.x[s_xo], x1 = S.x[s_xo + 1], x2 = S.x[s_xo + 2];
+                double lsc_ = rt2[s_r], p0 = S.x[s_cp], p1 = S.x[SEGV + s_cp], p2 = S.x[2 * SEGV + s_cp];
+                LSC_PIN(PV(sc), PV(x0), PV(x1), PV(x2), PV(lsc_), PV(p0), PV(p1), PV(p2));
+                const double v = (ax_row3(x0, x1, x2, s_type) - s_hh) * sc;
+                if (s_has_ax && v > best) { best = v; bidx = tid; }
+                lv = (s_lh - ((double)s_n0 * p0 + (double)s_n1 * p1 + (double)s_n2 * p2)) * lsc_;
+            }
+            for (int c = tid + NT; c < n_ax; c += NT) {
                 const uint32_t am = S.amap[c]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
                 const double *xq = S.x + ak * SEGV + at;
                 double sc = S.at2[sl], x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl);
@@ -2013,7 +2036,8 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 const double v = (ax_row3(x0, x1, x2, type) - hh) * sc;
                 if (v > best) { best = v; bidx = c; }
             }
-            for (int c = tid; c < nact; c += NT) {
+            if (s_has_l && lv > best) { best = lv; bidx = n_ax + tid; }
+            for (int c = tid + NT; c < nact; c += NT) {
                 const uint32_t e = cmap[c];
                 const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
                 double sc = rt2[r], x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r];

@@ -82,6 +82,9 @@ struct Model {
     // cost does not couple them, so the 39 x 39 reduced Hessian is three copies of this 13 x 13 block: what the active-set solve
     // (lsc_kernels.hip, gi_solve) needs of it is its inverse, formed once on the host in extended precision.
     double ginv[M][NYA * NYA];
+    // ghz[T-1][t][a] = (ginv[T-1] Z' e_t)_a: H^-1 times the y-space image of the variable t of an axis.  H^-1 times a row's normal (three
+    // x-variables) is three of these per lane.
+    double ghz[M][SEGV * NYA];
 };
 
 // Dense variant of the same elimination for the alternate planner modes (lsc_general.hip): axis-major y, with
