@@ -759,6 +759,27 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     if (tid < 32) S.cnt[tid] = 0;
     if (tid == 0) { S.flag = 0; S.ntmp = 0; }
     const float dtf = (float)md.dt;
+    // What goal planning reads of the other agents (lane = agent) is requested HERE, at the top of the kernel: position, desired goal, three points of its previous plan,
+    // its disturbance flag -- one trip to HBM for the checks and the priority rule together
+    struct ScanIn { float s[3], g[3], tl[3], tf[3], t1[3]; int ev; };
+    auto scan_load = [&](int qj) {
+        ScanIn r;
+        const float *sp = a.state + 9 * qj, *gp = a.goal + 3 * qj, *pt = a.traj_prev + (size_t)qj * NV;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            r.s[k] = sp[k]; r.g[k] = gp[k];
+            r.tl[k] = pt[k * SEGV + (M - 1) * NC + DEG]; r.tf[k] = pt[k * SEGV + DEG]; r.t1[k] = pt[k * SEGV + NC];
+        }
+        r.ev = a.ever ? (int)a.ever[qj] : 0;
+        return r;
+    };
+    ScanIn sc0;
+    if (a.goal_mode == 1) sc0 = scan_load(tid < N ? tid : 0);
+    else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) sc0.s[k] = sc0.g[k] = sc0.tl[k] = sc0.tf[k] = sc0.t1[k] = 0.f;
+        sc0.ev = 0;
+    }
     if (tid < NV) {
 #pragma clang fp contract(off)
         const int k = tid / SEGV, c = tid % SEGV, m = c / NC, i = c % NC;
@@ -829,24 +850,29 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         const int cl = (M - 1) * NC + DEG, cf = DEG;   // control points [M-1][n] and [0][n]
         double best = 1e9;
         int bq = 0x7fffffff;
+        bool first_round = true;
         for (int qj = tid; qj < N; qj += NT) {
+            const ScanIn in = first_round ? sc0 : scan_load(qj);      // (first round: fetched at the top of the kernel)
+            first_round = false;
             bool slack_j = false;
             if (checks) {
-                const bool nw = off_plan(qj);
-                const int ev = a.ever[qj];
+                // off_plan(qj) on the fetched values
+                const float ex = in.t1[0] - in.s[0], ey = in.t1[1] - in.s[1], ez = in.t1[2] - in.s[2];
+                const float e2 = ex * ex + ey * ey + ez * ez;
+                const bool nw = sqrt((double)e2) > a.reset_thr;
                 if (nw) a.ever[qj] = 1;
-                slack_j = nw || ev != 0;
+                slack_j = nw || in.ev != 0;
                 any_slack |= slack_j ? 1 : 0;
             }
             if (qj == qi) continue;
             if (checks && (own_slack || slack_j)) continue;   // slack obstacle: no retreat candidate (:548-551)
-            const float *opos = a.state + 9 * qj, *ogoal = a.goal + 3 * qj;
+            const float *opos = in.s, *ogoal = in.g;
             const double obs_dist_to_goal = distf(opos, ogoal);
             const double dist_to_obs = distf(opos, pos);
             if (obs_dist_to_goal < a.goal_threshold) continue;                 // :560-562
-            const float *pt = a.traj_prev + (size_t)qj * NV;                     // obs_prev_trajs (unshifted previous plan)
-            const float ax = pt[cl] - pt[cf], ay = pt[SEGV + cl] - pt[SEGV + cf], az = pt[2 * SEGV + cl] - pt[2 * SEGV + cf];
-            const float bx = pt[cf] - pos[0], by = pt[SEGV + cf] - pos[1], bz = pt[2 * SEGV + cf] - pos[2];
+            // obs_prev_trajs (unshifted previous plan): its last and its sixth control point
+            const float ax = in.tl[0] - in.tf[0], ay = in.tl[1] - in.tf[1], az = in.tl[2] - in.tf[2];
+            const float bx = in.tf[0] - pos[0], by = in.tf[1] - pos[1], bz = in.tf[2] - pos[2];
             const float dp = ax * bx + ay * by + az * bz;
             if (dist_to_goal > a.goal_threshold && (double)dp > 0.0) continue;   // same direction :564-566
             if (dist_to_goal < a.goal_threshold || obs_dist_to_goal < dist_to_goal) {
@@ -1168,6 +1194,8 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     int c = m * NC + i;
                     pa[i] = F3{S.pinit[c], S.pinit[SEGV + c], S.pinit[2 * SEGV + c]};
                 }
+                // (fetching the first round's segments ahead -- at the top of the kernel, or in front of the reach boxes' barrier -- was tried: the
+                //  22 registers held across phase A / the cull code went to scratch, 64-96 B per lane on every instantiation)
                 load_segment(a.state, a.traj_prev, qj, m, a.planner_seq, dtf, po);
                 const double r_o = a.radius_obs[qj];
                 const double downwash = (dw_a * r_a + a.downwash_obs[qj] * r_o) / (r_a + r_o);
