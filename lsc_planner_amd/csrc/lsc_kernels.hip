@@ -2277,17 +2277,16 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 LSC_PIN(PV(x0), PV(x1), PV(x2), PV(hh), PV(n0), PV(n1), PV(n2));
                 worst = fmax(worst, (hh - ((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2)) / (1.0 + fabs(hh)));
             }
-            block_reduce(worst, 0.0, 0.0, 0.0, 0.0, 1, -1, -1, -1, -1);
+            // the objective at S.x (formed at the top of the last round) rides on the same block reduction: like the interior point's residual pass
+            double objp = 0.0;
+            if (tid < NV && !(dim2 && xk == 2)) {          // (planar world: the cost runs over `k < dim`, src/traj_optimizer.cpp:330, 367)
+                objp = 0.5 * cost_grad() * S.x[tid];
+                if (xterm) { const double e = S.x[tid] - S.goal[xk]; objp += md.w_t * e * e; }
+            }
+            block_reduce(worst, objp, 0.0, 0.0, 0.0, 1, 0, -1, -1, -1);
             if (rv[0] > 1e-9) return false;
+            obj = rv[1];
         }
-        // optimum: S.x holds it (formed at the top of the last round); objective like the interior point's residual pass
-        double objp = 0.0;
-        if (tid < NV && !(dim2 && xk == 2)) {          // (planar world: the cost runs over `k < dim`, src/traj_optimizer.cpp:330, 367)
-            objp = 0.5 * cost_grad() * S.x[tid];
-            if (xterm) { const double e = S.x[tid] - S.goal[xk]; objp += md.w_t * e * e; }
-        }
-        block_reduce(objp, 0.0, 0.0, 0.0, 0.0, 0, -1, -1, -1, -1);
-        obj = rv[0];
         stamp(PH_P2);                    // ("affine_pass": the verification pass and the objective)
         return true;
         }
@@ -2647,7 +2646,11 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         if (status == LSC_STATUS_OK_K) a.cost[qi] = obj;
         a.status[qi] = status;
         a.iters[qi] = iters;
-        if (a.iters_acc) { a.iters_acc[qi] += iters; a.iters_acc[a.N + qi] += (long long)iters * S.nact; }
+        // (atomics without a return value: a read-modify-write in program order put a trip to HBM in front of the end of every workgroup)
+        if (a.iters_acc) {
+            atomicAdd((unsigned long long *)&a.iters_acc[qi], (unsigned long long)(long long)iters);
+            atomicAdd((unsigned long long *)&a.iters_acc[a.N + qi], (unsigned long long)((long long)iters * S.nact));
+        }
         if (a.nrows) a.nrows[qi] = S.nact;
         if constexpr (SOLVER == 1) {
             if (a.solver_stats) {
