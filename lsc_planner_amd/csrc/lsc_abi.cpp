@@ -106,6 +106,8 @@ void build_model(const lsc_config &cfg, HostModel &H)
             m.Hc[a * NYA + b] = s;
         }
 
+    for (int t = 0; t < SEGV; t++)
+        for (int a = 0; a < NYA; a++) m.gzt[t * NYA + a] = Zm[t][a];
     // inverse of the axis block of the reduced cost Hessian for T = 1 .. M terminal segments (Model::ginv): Gauss-Jordan with partial
     // pivoting in long double (the block is positive definite: a plan whose jerk cost vanishes is fixed by the initial state)
     for (int T = 1; T <= M; T++) {

@@ -1299,14 +1299,17 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     // trip to L2 stood in front of the solve: ~0.7 us per agent-tick)
     constexpr int GI_NPRE = (SEGV * NYA + NTT - 1) / NTT;
     static_assert(NYA * NYA <= NTT, "one lane per entry of the inverse block");
-    double gi_pre_h = 0.0, gi_pre_z[GI_NPRE];
+    double gi_pre_h = 0.0, gi_pre_z[GI_NPRE], gi_pre_n[GI_NPRE];
 #pragma unroll
-    for (int u = 0; u < GI_NPRE; u++) gi_pre_z[u] = 0.0;
+    for (int u = 0; u < GI_NPRE; u++) { gi_pre_z[u] = 0.0; gi_pre_n[u] = 0.0; }
     if constexpr (SOLVER == 1) {
         const double *gsrc = md.ginv[S.tseg - 1], *zsrc = md.ghz[S.tseg - 1];
         gi_pre_h = gsrc[tid < NYA * NYA ? tid : 0];
 #pragma unroll
-        for (int u = 0; u < GI_NPRE; u++) gi_pre_z[u] = zsrc[tid + u * NTT < SEGV * NYA ? tid + u * NTT : 0];
+        for (int u = 0; u < GI_NPRE; u++) {
+            const int i = tid + u * NTT < SEGV * NYA ? tid + u * NTT : 0;
+            gi_pre_z[u] = zsrc[i]; gi_pre_n[u] = md.gzt[i];
+        }
     }
     // slot tables of the row reduction (interior point), in two halves around a barrier: offsets by one half-wave per table, then the entries
     auto slot_offsets = [&](int which, int b, int c, int total) {
@@ -1982,11 +1985,12 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         // then three of these per lane instead of a 13-term product behind an LDS round trip.  Kept in the interior point's idle slack array
         // S.as_ (AXROWS >= SEGV * NYA doubles; set back to 1.0 on the way to the interior point).
         double *const gi_hz = S.as_;
+        double *const gi_zt = S.az;                   // Z itself, laid out the same way (Model::gzt): a row's normal in y-space by the same lookup
         static_assert(SEGV * NYA <= AXROWS, "gi_hz fits the slack array");
         const double INF = 1e300;
         if (tid < NYA * NYA) Hinv[tid] = gi_pre_h;
 #pragma unroll
-        for (int u = 0; u < GI_NPRE; u++) if (tid + u * NT < SEGV * NYA) gi_hz[tid + u * NT] = gi_pre_z[u];
+        for (int u = 0; u < GI_NPRE; u++) if (tid + u * NT < SEGV * NYA) { gi_hz[tid + u * NT] = gi_pre_z[u]; gi_zt[tid + u * NT] = gi_pre_n[u]; }
         // Selection scale of every row, 1 / (1 + |right-hand side|), formed ONCE per solve (it was two divisions per lane in every search:
         // ~80 of a search's ~190 instructions per wave); a row inside the working set carries scale 0 -- its mark: it can never be the most
         // violated one.  Kept in the interior point's idle t2 arrays (S.at2, rt2; prepare_warm / prepare_cold rewrite both on the way there).
@@ -2090,7 +2094,10 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 // batch 1: the row's word -> three x-variables with their coefficients
                 int v0, v1, v2, rsl = 0;
                 double a0, a1, a2, hp;
-                bool is_ax = idx < n_ax;
+                // (conditions that are the same on every lane by construction are SAID to be: the compiler takes anything derived from an LDS
+                //  load for divergent and builds exec-mask branches and loops around it)
+                auto uni = [](bool b_) { return __builtin_amdgcn_readfirstlane((int)b_) != 0; };
+                const bool is_ax = idx < n_ax;
                 if (is_ax) {
                     const uint32_t am = S.amap[idx]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
                     const int kind = type >> 1;
@@ -2122,15 +2129,15 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 double c00 = S.xtc[t0][0], c01 = S.xtc[t0][1], c02 = S.xtc[t0][2], c10 = S.xtc[t1][0], c11 = S.xtc[t1][1], c12 = S.xtc[t1][2],
                        c20 = S.xtc[t2][0], c21 = S.xtc[t2][1], c22 = S.xtc[t2][2];
                 double h0 = gi_hz[t0 * NYA + lva], h1 = gi_hz[t1 * NYA + lva], h2 = gi_hz[t2 * NYA + lva];
+                double z0 = gi_zt[t0 * NYA + lva], z1 = gi_zt[t1 * NYA + lva], z2 = gi_zt[t2 * NYA + lva];
                 LSC_PIN(PV(x0), PV(x1), PV(x2), PV(gp0), PV(gp1), PV(gp2), PV(c00), PV(c01), PV(c02), PV(c10), PV(c11), PV(c12), PV(c20), PV(c21), PV(c22),
-                        PV(h0), PV(h1), PV(h2));
+                        PV(h0), PV(h1), PV(h2), PV(z0), PV(z1), PV(z2));
                 double viol = a0 * x0 + a1 * x1 + a2 * x2 - hp;
-                // the row's normal in y-space (x_v = sum_j xtc[t][j] y[xgp byte j]) and H^-1 times it
-                auto zc = [&](uint32_t gp, double c0_, double c1_, double c2_) -> double {
-                    return ((int)(gp & 0xff) == lane ? c0_ : 0.0) + ((int)((gp >> 8) & 0xff) == lane ? c1_ : 0.0) + ((int)(gp >> 16) == lane ? c2_ : 0.0);
-                };
-                const double np_g = lane < NY ? a0 * zc(gp0, c00, c01, c02) + a1 * zc(gp1, c10, c11, c12) + a2 * zc(gp2, c20, c21, c22) : 0.0;
-                double hin_g = (lk == k0 ? a0 * h0 : 0.0) + (lk == k1 ? a1 * h1 : 0.0) + (lk == k2 ? a2 * h2 : 0.0);
+                // the row's normal in y-space and H^-1 times it: this lane's entries of Z' e_v and of H^-1 Z' e_v for the row's three variables
+                // (lanes beyond the unknowns have lk = 3: both stay zero)
+                const double m0 = lk == k0 ? a0 : 0.0, m1 = lk == k1 ? a1 : 0.0, m2 = lk == k2 ? a2 : 0.0;
+                const double np_g = m0 * z0 + m1 * z1 + m2 * z2;
+                double hin_g = m0 * h0 + m1 * h1 + m2 * h2;
                 if (dim2 && lk == 2) hin_g = 0.0;            // (planar world: the z unknowns never move)
                 double up = 0.0;
                 int code = 0;
@@ -2164,10 +2171,17 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
 #pragma unroll
                     for (int j = 0; j < GQ; j++) rw = fma(Sr[j], lane_value(dw, j), rw);          // r = S^-1 d
                     rw = lane < q ? rw : 0.0;
+                    // r to every lane through LDS (one store, one batch of broadcast loads): read lane by lane it was 4 issue slots per entry,
+                    // twice (the direction here, the update of the inverse below)
+                    if (lane < GQ) rwv[lane] = rw;
+                    double rb[GQ];
+#pragma unroll
+                    for (int w = 0; w < GQ; w++) rb[w] = rwv[w];
+                    pin_values(rb);
                     // primal direction z = H^-1 n - Y_W r (it keeps the working set active) and its slope against the new row
                     double zg = hin_g;
 #pragma unroll
-                    for (int w = 0; w < GQ; w++) zg = fma(-Yc[w], lane_value(rw, w), zg);
+                    for (int w = 0; w < GQ; w++) zg = fma(-Yc[w], rb[w], zg);
                     zg = lane < NY ? zg : 0.0;
                     // one staged reduction for the four wave-wide numbers of a step: n'H^-1 n, the slope n'z, d'r, the smallest multiplier ratio
                     const double ratio = (lane < q && rw > 1e-13) ? uwl * rcp_nr(rw) : INF;
@@ -2177,33 +2191,33 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     const double nph = red4[0], zn = red4[1], dtr = red4[2], t1 = red4[3];
                     const unsigned long long dropmask = __ballot(lane < q && ratio == t1);
                     const double t2 = zn > 1e-12 * nph ? viol * rcp_nr(zn) : INF;
-                    if (t1 >= INF && t2 >= INF) {
+                    if (uni(t1 >= INF && t2 >= INF)) {
                         // No admissible step: the new row is a non-negative combination of working-set rows pointing the other way -- the rows
                         // contradict each other (Farkas), the QP is infeasible.  With a violation that is not round-off (> 1e-6 of the row's
                         // scale) the verdict is final: code 3, status 1, no interior-point run (an infeasible agent used to cost the tick the
                         // ~26 iterations of two diverging interior-point starts); a marginal one is left to the interior point like every
                         // other irregularity.
-                        code = viol > 1e-6 * (1.0 + fabs(hp)) ? 3 : 1;
+                        code = uni(viol > 1e-6 * (1.0 + fabs(hp))) ? 3 : 1;
                         break;
                     }
                     const double t = fmin(t1, t2);
-                    if (t2 < INF) {
+                    if (uni(t2 < INF)) {
                         if (lane < NY) S.y[lane] = yl - t * zg;
                         viol -= t * zn;
                     }
                     if (lane < q) uw[lane] = fmax(uwl - t * rw, 0.0);
                     up += t;
                     gi_changes++;
-                    if (t2 <= t1) {
+                    if (uni(t2 <= t1)) {
                         // full step: the row joins the working set; the inverse is bordered with (r, delta), delta = n'H^-1 n - d'r
-                        if (q == GQ) { code = 2; break; }
+                        if (uni(q == GQ)) { code = 2; break; }
                         const double delta = nph - dtr;
-                        if (!(delta > 1e-11 * nph)) { code = 2; break; }
+                        if (uni(!(delta > 1e-11 * nph))) { code = 2; break; }
                         const double idl = 1.0 / delta;
                         if (lane < GS) Yw[q * GS + lane] = hin_g;
                         const double rs_ = rw * idl;
 #pragma unroll
-                        for (int j = 0; j < GQ; j++) Sr[j] = fma(rs_, lane_value(rw, j), Sr[j]);
+                        for (int j = 0; j < GQ; j++) Sr[j] = fma(rs_, rb[j], Sr[j]);
                         if (lane < q) {
 #pragma unroll
                             for (int j = 0; j < GQ; j++) Si[lane * GQ + j] = Sr[j];
@@ -2215,11 +2229,11 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                             if (is_ax) S.at2[rsl] = 0.0;            // (scale 0 = inside the working set)
                             else rt2[rsl] = 0.0;
                         }
-                        q++;
+                        q = __builtin_amdgcn_readfirstlane(q + 1);
                         break;
                     }
                     // partial step: row jd of the working set reached multiplier zero and leaves (the last row takes its place)
-                    const int jd = __ffsll((long long)dropmask) - 1, last = q - 1;
+                    const int jd = __builtin_amdgcn_readfirstlane(__ffsll((long long)dropmask) - 1), last = q - 1;
                     if (lane == 0) {
                         const int code_j = wrow[jd];
                         if (code_j < n_ax) { const int sl = S.amap[code_j] & 1023; S.at2[sl] = 1.0 / (1.0 + fabs(AH(sl))); }
@@ -2241,12 +2255,13 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                             }
                         }
                     }
-                    if (jd != last) {
+                    if (uni(jd != last)) {
                         if (lane < GS) Yw[jd * GS + lane] = Yw[last * GS + lane];
                         if (lane == 0) { uw[jd] = uw[last]; wrow[jd] = wrow[last]; }
                     }
-                    q--;
-                    if (gi_changes > GI_CAP) { code = 2; break; }
+                    q = __builtin_amdgcn_readfirstlane(q - 1);
+                    gi_changes = __builtin_amdgcn_readfirstlane(gi_changes);
+                    if (uni(gi_changes > GI_CAP)) { code = 2; break; }
                 }
                 if (lane == 0) { S.sc[0] = (double)code; S.sc[1] = (double)q; S.sc[2] = (double)gi_changes; }
                 if (code == 0) compute_x_wave0(S.y, S.x, true);      // x for the next search, on the wave that holds the new y

@@ -85,6 +85,8 @@ struct Model {
     // ghz[T-1][t][a] = (ginv[T-1] Z' e_t)_a: H^-1 times the y-space image of the variable t of an axis.  H^-1 times a row's normal (three
     // x-variables) is three of these per lane.
     double ghz[M][SEGV * NYA];
+    // gzt[t][a] = Z[t][a]: the y-space image of the variable t of an axis as a dense row (the same lookup for a row's normal itself)
+    double gzt[SEGV * NYA];
 };
 
 // Dense variant of the same elimination for the alternate planner modes (lsc_general.hip): axis-major y, with
