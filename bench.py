@@ -147,11 +147,13 @@ def algorithmic_flops(n_agents, iters_total):
 
 
 # The active-set solve does other -- and much less -- arithmetic than the interior point SURVEY 8(d) prices, so it gets a model of its own
-# (DESIGN section 4.1): per change of the working set one pass over the rows (violation of every row: 3 multiply-adds, the normalisation,
-# the compare ~ 9 flop per row; the 414 bound / velocity / acceleration rows are always carried) plus ~2.6 kflop of small dense algebra
-# (H^-1 n: 39 x 13 multiply-adds; G_W H^-1 n, the direction and the Gram solve for a working set of <= 12 rows); per solve the start
-# (gradient, unconstrained optimum: ~2.5 kflop) and two more passes over the rows (the last search, the verification).
-GI_ROW_FLOP, GI_AXIS_ROWS, GI_DENSE_PER_CHANGE, GI_PER_SOLVE = 9.0, 414.0, 2.6e3, 2.5e3
+# (DESIGN section 4.1): per change of the working set one pass over the rows (violation of every row: 3 multiply-adds, the scale,
+# the compare ~ 8 flop per row; the 414 bound / velocity / acceleration rows are always carried) plus ~2.6 kflop of small dense algebra
+# (the row's normal and H^-1 times it from the per-variable tables: 2 x 39 x 9; G_W H^-1 n: 12 x 21; the multiplier rates from the kept
+# inverse of the Gram matrix and its update: 2 x 12 x 12 x 2; the direction: 39 x 12 x 2; x from y: 90 x 6 -- the loops run over all 12
+# working-set slots, ~3.2 kflop as executed, ~1.9 kflop at the typical four rows); per solve the start (gradient, unconstrained optimum:
+# ~2.5 kflop) and two more passes over the rows (the last search, the verification).
+GI_ROW_FLOP, GI_AXIS_ROWS, GI_DENSE_PER_CHANGE, GI_PER_SOLVE = 8.0, 414.0, 2.6e3, 2.5e3
 
 
 def active_set_flops(n_agents, stats, row_changes_total, rows_mean, all_rows):

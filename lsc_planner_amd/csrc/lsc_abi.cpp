@@ -137,6 +137,21 @@ void build_model(const lsc_config &cfg, HostModel &H)
                 for (int j = 0; j < m.x_n[t]; j++) acc += m.x_c[t][j] * m.ginv[T - 1][a * NYA + m.x_i[t][j]];
                 m.ghz[T - 1][t * NYA + a] = acc;
             }
+        // unconstrained optimum as a linear map of (s0, goal): gradient at y = 0 in x-space = Qh (segment 0) x0 - 2 w_t goal on the terminal points
+        for (int j = 0; j < 4; j++) {
+            long double gy[NYA];
+            for (int b = 0; b < NYA; b++) {
+                long double acc = 0.0L;
+                if (j < 3) { for (int t = 0; t < NC; t++) acc += (long double)Zm[t][b] * (long double)m.Qh[t * NC + j]; }
+                else { for (int mm = M - T; mm < M; mm++) acc += (long double)Zm[mm * NC + DEG][b] * (-2.0L * cfg.terminal_weight); }
+                gy[b] = acc;
+            }
+            for (int a = 0; a < NYA; a++) {
+                long double acc = 0.0L;
+                for (int b = 0; b < NYA; b++) acc += (long double)m.ginv[T - 1][a * NYA + b] * gy[b];
+                m.gy0[T - 1][a * 4 + j] = (double)(-acc);
+            }
+        }
     }
 
     // Hessian assembly terms: K[(k,a),(k',b)] += Z[t][a] Z[t'][b] * Wx[(k,t),(k',t')]

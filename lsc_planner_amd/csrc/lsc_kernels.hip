@@ -1298,18 +1298,18 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     // behind, the values travel while the rows are bucketed and sorted -- and stored at the start of the active-set solve (fetched there, the
     // trip to L2 stood in front of the solve: ~0.7 us per agent-tick)
     constexpr int GI_NPRE = (SEGV * NYA + NTT - 1) / NTT;
-    static_assert(NYA * NYA <= NTT, "one lane per entry of the inverse block");
-    double gi_pre_h = 0.0, gi_pre_z[GI_NPRE], gi_pre_n[GI_NPRE];
+    double gi_pre_z[GI_NPRE], gi_pre_n[GI_NPRE], gi_pre_y[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < GI_NPRE; u++) { gi_pre_z[u] = 0.0; gi_pre_n[u] = 0.0; }
     if constexpr (SOLVER == 1) {
-        const double *gsrc = md.ginv[S.tseg - 1], *zsrc = md.ghz[S.tseg - 1];
-        gi_pre_h = gsrc[tid < NYA * NYA ? tid : 0];
+        const double *zsrc = md.ghz[S.tseg - 1], *ysrc = md.gy0[S.tseg - 1] + 4 * (tid < NY ? yvar(tid) : 0);
 #pragma unroll
         for (int u = 0; u < GI_NPRE; u++) {
             const int i = tid + u * NTT < SEGV * NYA ? tid + u * NTT : 0;
             gi_pre_z[u] = zsrc[i]; gi_pre_n[u] = md.gzt[i];
         }
+#pragma unroll
+        for (int j = 0; j < 4; j++) gi_pre_y[j] = ysrc[j];      // (the unconstrained optimum is linear in the state constants and the goal: Model::gy0)
     }
     // slot tables of the row reduction (interior point), in two halves around a barrier: offsets by one half-wave per table, then the entries
     auto slot_offsets = [&](int which, int b, int c, int total) {
@@ -1988,50 +1988,22 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         double *const gi_zt = S.az;                   // Z itself, laid out the same way (Model::gzt): a row's normal in y-space by the same lookup
         static_assert(SEGV * NYA <= AXROWS, "gi_hz fits the slack array");
         const double INF = 1e300;
-        if (tid < NYA * NYA) Hinv[tid] = gi_pre_h;
 #pragma unroll
         for (int u = 0; u < GI_NPRE; u++) if (tid + u * NT < SEGV * NYA) { gi_hz[tid + u * NT] = gi_pre_z[u]; gi_zt[tid + u * NT] = gi_pre_n[u]; }
         // Selection scale of every row, 1 / (1 + |right-hand side|), formed ONCE per solve (it was two divisions per lane in every search:
         // ~80 of a search's ~190 instructions per wave); a row inside the working set carries scale 0 -- its mark: it can never be the most
-        // violated one.  Kept in the interior point's idle t2 arrays (S.at2, rt2; prepare_warm / prepare_cold rewrite both on the way there).
+        // violated one.  Kept in the interior point's idle t2 arrays (S.at2, rt2; ip_late_setup / prepare_* rewrite both on the way there).
         for (int c = tid; c < n_ax; c += NT) { const int sl = S.amap[c] & 1023; S.at2[sl] = 1.0 / (1.0 + fabs(AH(sl))); }
         for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt2[r] = 1.0 / (1.0 + fabs(rrhs[r])); }
-        if (tid < 40) S.y[tid] = 0.0;
         for (int i = tid; i < GQ * GS + 2 * GQ * GQ + 2 * GQ; i += NT) Yw[i] = 0.0;      // Yw, Si, uw, rwv: rows beyond the working set meet zeros
-        if (tid < NV) S.x[tid] = xt < 3 ? X0C(tid) : 0.0;       // x at y = 0: the state constants
-        __syncthreads();
-        if (tid < NV) {
-            double cg = cost_grad();
-            if (xterm) cg += 2.0 * md.w_t * (S.x[tid] - S.goal[xk]);
-            if (dim2 && xk == 2) cg = 0.0;            // planar world: z is not a variable (src/traj_optimizer.cpp:264-266): no cost, no rows, y_z rests at z_2d
-            S.gx[tid] = cg;                           // gradient of the cost at y = 0, in x-space
+        // unconstrained optimum y = -H^-1 Z' grad(x0): a linear map of this axis' state constants and goal coordinate, its matrix from the host
+        if (tid < 40) {
+            const int k = tid < NY ? yaxis(tid) : 0;
+            double yv = gi_pre_y[0] * S.s0[k][0] + gi_pre_y[1] * S.s0[k][1] + gi_pre_y[2] * S.s0[k][2] + gi_pre_y[3] * S.goal[k];
+            if (dim2 && k == 2) yv = md.z2d;          // planar world: z is not a variable (src/traj_optimizer.cpp:264-266): no cost, no rows, y_z rests at z_2d
+            S.y[tid] = tid < NY ? yv : 0.0;
         }
         __syncthreads();
-        if (wave == 0) {
-            // unconstrained optimum y = -H^-1 Z' grad
-            if (lane < NY) {
-                const uint32_t yo = S.yop[lane];
-                gyv[lane] = S.ytc[lane][0] * S.gx[yo & 0xff] + S.ytc[lane][1] * S.gx[(yo >> 8) & 0xff] + S.ytc[lane][2] * S.gx[(yo >> 16) & 0xff] +
-                            S.ytc[lane][3] * S.gx[yo >> 24];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            {
-                // (all 2 x 13 operands in one batch of loads: taken where they are used they are eight dependent LDS round trips on this lone wave)
-                const int ls = lane < NY ? lane : 0;
-                const int k = yaxis(ls), va = yvar(ls);
-                double hv[NYA], gv[NYA];
-#pragma unroll
-                for (int b = 0; b < NYA; b++) { hv[b] = Hinv[va * NYA + b]; gv[b] = gyv[yglob(k, b)]; }
-                pin_values(hv);
-                pin_values(gv);
-                double acc = 0.0;
-#pragma unroll
-                for (int b = 0; b < NYA; b++) acc += hv[b] * gv[b];
-                if (lane < NY) S.y[lane] = (dim2 && k == 2) ? md.z2d : -acc;
-            }
-        }
         int q = 0;
         if (wave == 0) compute_x_wave0(S.y, S.x, true);
         __syncthreads();

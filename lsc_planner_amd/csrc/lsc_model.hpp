@@ -87,6 +87,9 @@ struct Model {
     double ghz[M][SEGV * NYA];
     // gzt[t][a] = Z[t][a]: the y-space image of the variable t of an axis as a dense row (the same lookup for a row's normal itself)
     double gzt[SEGV * NYA];
+    // gy0[T-1][a][0..2 | 3]: the unconstrained optimum of an axis is linear in its three state constants and its goal coordinate,
+    //   y*_a = sum_j gy0[a][j] s0_j + gy0[a][3] goal  ( = -ginv Z' (Qh x0 + terminal gradient) ), formed on the host.
+    double gy0[M][NYA * 4];
 };
 
 // Dense variant of the same elimination for the alternate planner modes (lsc_general.hip): axis-major y, with
