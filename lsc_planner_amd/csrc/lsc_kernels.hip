@@ -1993,8 +1993,9 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         // Selection scale of every row, 1 / (1 + |right-hand side|), formed ONCE per solve (it was two divisions per lane in every search:
         // ~80 of a search's ~190 instructions per wave); a row inside the working set carries scale 0 -- its mark: it can never be the most
         // violated one.  Kept in the interior point's idle t2 arrays (S.at2, rt2; ip_late_setup / prepare_* rewrite both on the way there).
-        for (int c = tid; c < n_ax; c += NT) { const int sl = S.amap[c] & 1023; S.at2[sl] = 1.0 / (1.0 + fabs(AH(sl))); }
-        for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt2[r] = 1.0 / (1.0 + fabs(rrhs[r])); }
+        // (hardware reciprocal + Newton: the scale only ranks violations, an ulp is nothing to it -- a division is ~40 instructions)
+        for (int c = tid; c < n_ax; c += NT) { const int sl = S.amap[c] & 1023; S.at2[sl] = rcp_nr(1.0 + fabs(AH(sl))); }
+        for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt2[r] = rcp_nr(1.0 + fabs(rrhs[r])); }
         for (int i = tid; i < GQ * GS + 2 * GQ * GQ + 2 * GQ; i += NT) Yw[i] = 0.0;      // Yw, Si, uw, rwv: rows beyond the working set meet zeros
         // unconstrained optimum y = -H^-1 Z' grad(x0): a linear map of this axis' state constants and goal coordinate, its matrix from the host
         if (tid < 40) {
@@ -2005,7 +2006,24 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         }
         __syncthreads();
         int q = 0;
-        if (wave == 0) compute_x_wave0(S.y, S.x, true);
+        // x from y on wave 0 (variables lane and lane + 64), with what never changes during the solve -- the y-indices and coefficients of the two
+        // variables, their state constants -- held in registers: one batch of six loads of y per call
+        const int xv0 = lane, xv1 = lane + 64 < NV ? lane + 64 : lane;
+        const uint32_t xg0 = S.xgp[xv0], xg1 = S.xgp[xv1];
+        const double xa00 = S.xtc[xv0 % SEGV][0], xa01 = S.xtc[xv0 % SEGV][1], xa02 = S.xtc[xv0 % SEGV][2];
+        const double xa10 = S.xtc[xv1 % SEGV][0], xa11 = S.xtc[xv1 % SEGV][1], xa12 = S.xtc[xv1 % SEGV][2];
+        const bool xs0 = xv0 % SEGV < 3, xs1 = xv1 % SEGV < 3;
+        const double xk0 = xs0 ? X0C(xv0) : 0.0, xk1 = xs1 ? X0C(xv1) : 0.0;
+        auto gi_x = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double y00 = S.y[xg0 & 0xff], y01 = S.y[(xg0 >> 8) & 0xff], y02 = S.y[xg0 >> 16], y10 = S.y[xg1 & 0xff], y11 = S.y[(xg1 >> 8) & 0xff], y12 = S.y[xg1 >> 16];
+            LSC_PIN(PV(y00), PV(y01), PV(y02), PV(y10), PV(y11), PV(y12));
+            S.x[xv0] = xs0 ? xk0 : xa00 * y00 + xa01 * y01 + xa02 * y02;
+            if (lane + 64 < NV) S.x[xv1] = xs1 ? xk1 : xa10 * y10 + xa11 * y11 + xa12 * y12;
+        };
+        if (wave == 0) gi_x();
         __syncthreads();
         stamp(PH_INIT);                  // (instrumented build: the start of the active-set solve is booked under "ip_init")
         // What the search needs of this lane's first axis row and first LSC row never changes during the solve: kept in registers, so that a
@@ -2155,12 +2173,12 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
 #pragma unroll
                     for (int w = 0; w < GQ; w++) zg = fma(-Yc[w], rb[w], zg);
                     zg = lane < NY ? zg : 0.0;
-                    // one staged reduction for the four wave-wide numbers of a step: n'H^-1 n, the slope n'z, d'r, the smallest multiplier ratio
+                    // one staged reduction for the three wave-wide numbers of a step: n'H^-1 n, the slope n'z, the smallest multiplier ratio
                     const double ratio = (lane < q && rw > 1e-13) ? uwl * rcp_nr(rw) : INF;
-                    double red4[5] = {np_g * hin_g, np_g * zg, dw * rw, ratio, 0.0};
-                    const int rop[5] = {0, 0, 0, 2, -1};
+                    double red4[5] = {np_g * hin_g, np_g * zg, ratio, 0.0, 0.0};
+                    const int rop[5] = {0, 0, 2, -1, -1};
                     wave_reduce5(red4, rop);
-                    const double nph = red4[0], zn = red4[1], dtr = red4[2], t1 = red4[3];
+                    const double nph = red4[0], zn = red4[1], t1 = red4[2];
                     const unsigned long long dropmask = __ballot(lane < q && ratio == t1);
                     const double t2 = zn > 1e-12 * nph ? viol * rcp_nr(zn) : INF;
                     if (uni(t1 >= INF && t2 >= INF)) {
@@ -2181,11 +2199,12 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     up += t;
                     gi_changes++;
                     if (uni(t2 <= t1)) {
-                        // full step: the row joins the working set; the inverse is bordered with (r, delta), delta = n'H^-1 n - d'r
+                        // full step: the row joins the working set; the inverse is bordered with (r, delta), delta = n'H^-1 n - d'r -- which IS the
+                        // slope n'z of the new row along the step (z = H^-1 n - Y_W r), already reduced: no reduction of its own
                         if (uni(q == GQ)) { code = 2; break; }
-                        const double delta = nph - dtr;
+                        const double delta = zn;
                         if (uni(!(delta > 1e-11 * nph))) { code = 2; break; }
-                        const double idl = 1.0 / delta;
+                        const double idl = rcp_nr(delta);
                         if (lane < GS) Yw[q * GS + lane] = hin_g;
                         const double rs_ = rw * idl;
 #pragma unroll
@@ -2208,8 +2227,8 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     const int jd = __builtin_amdgcn_readfirstlane(__ffsll((long long)dropmask) - 1), last = q - 1;
                     if (lane == 0) {
                         const int code_j = wrow[jd];
-                        if (code_j < n_ax) { const int sl = S.amap[code_j] & 1023; S.at2[sl] = 1.0 / (1.0 + fabs(AH(sl))); }
-                        else { const int r = cmap[code_j - n_ax] & CMAP_MASK; rt2[r] = 1.0 / (1.0 + fabs(rrhs[r])); }
+                        if (code_j < n_ax) { const int sl = S.amap[code_j] & 1023; S.at2[sl] = rcp_nr(1.0 + fabs(AH(sl))); }
+                        else { const int r = cmap[code_j - n_ax] & CMAP_MASK; rt2[r] = rcp_nr(1.0 + fabs(rrhs[r])); }
                     }
                     {
                         // inverse without row / column jd:  T = A - b b' / c  (c = Si[jd][jd], b = column jd), then row / column `last` -> jd
@@ -2236,7 +2255,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     if (uni(gi_changes > GI_CAP)) { code = 2; break; }
                 }
                 if (lane == 0) { S.sc[0] = (double)code; S.sc[1] = (double)q; S.sc[2] = (double)gi_changes; }
-                if (code == 0) compute_x_wave0(S.y, S.x, true);      // x for the next search, on the wave that holds the new y
+                if (code == 0) gi_x();               // x for the next search, on the wave that holds the new y
             }
             __syncthreads();
             stamp(PH_FACTOR);            // ("cholesky": the step on wave 0 -- normal, direction, ratio test, update of the working set)
@@ -2254,7 +2273,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 const double *xq = S.x + ak * SEGV + at;
                 double x0 = xq[0], x1 = xq[1], x2 = xq[2], hh = AH(sl);
                 LSC_PIN(PV(x0), PV(x1), PV(x2), PV(hh));
-                worst = fmax(worst, (ax_row3(x0, x1, x2, type) - hh) / (1.0 + fabs(hh)));
+                worst = fmax(worst, (ax_row3(x0, x1, x2, type) - hh) * rcp_nr(1.0 + fabs(hh)));
             }
             for (int c = tid; c < nact; c += NT) {
                 const uint32_t e = cmap[c];
@@ -2262,7 +2281,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 double x0 = S.x[cp], x1 = S.x[SEGV + cp], x2 = S.x[2 * SEGV + cp], hh = rrhs[r];
                 float n0 = rn[r], n1 = rn[R + r], n2 = rn[2 * R + r];
                 LSC_PIN(PV(x0), PV(x1), PV(x2), PV(hh), PV(n0), PV(n1), PV(n2));
-                worst = fmax(worst, (hh - ((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2)) / (1.0 + fabs(hh)));
+                worst = fmax(worst, (hh - ((double)n0 * x0 + (double)n1 * x1 + (double)n2 * x2)) * rcp_nr(1.0 + fabs(hh)));
             }
             // the objective at S.x (formed at the top of the last round) rides on the same block reduction: like the interior point's residual pass
             double objp = 0.0;
