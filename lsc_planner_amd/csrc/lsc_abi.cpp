@@ -216,6 +216,16 @@ void build_model(const lsc_config &cfg, HostModel &H)
     }
     if (n != (m.dim2 ? AXVALID_2D : AXVALID_3D)) { std::fprintf(stderr, "lsc: axis row count %d\n", n); std::abort(); }
     m.n_ax = n;
+    for (int i = 0; i < n; i++) {
+        const uint32_t sl = m.amap[i], type = sl / NV, kt = sl % NV;
+        m.amap32[i] = sl | (type << 10) | ((kt / SEGV) << 13) | ((kt % SEGV) << 15);
+    }
+    for (int v = 0; v < NV; v++) {
+        const int k = v / SEGV, t = v % SEGV;
+        m.xgp32[v] = (uint32_t)yglob(k, m.x_i[t][0]) | ((uint32_t)yglob(k, m.x_i[t][1]) << 8) | ((uint32_t)yglob(k, m.x_i[t][2]) << 16);
+    }
+    for (int t = 0; t < SEGV; t++)
+        for (int j = 0; j < 3; j++) m.xtcm[t][j] = m.x_n[t] < j + 1 ? 0.0 : m.x_c[t][j];
     m.sigma_pow = 3;
     // (no environment overrides: everything that changes the solve is an lsc_config field)
 }

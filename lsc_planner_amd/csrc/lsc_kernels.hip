@@ -949,10 +949,6 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         int T = (int)((M * md.dt - flight + 1e-9) / md.dt);
         S.tseg = T > 1 ? T : 1;
     }
-    for (int i = tid; i < n_ax; i += NT) {
-        const uint32_t sl = md.amap[i], type = sl / NV, kt = sl % NV;
-        S.amap[i] = sl | (type << 10) | ((kt / SEGV) << 13) | ((kt % SEGV) << 15);
-    }
     // per-lane solver constants -> LDS tables (see Smem)
     // lanes 0..89 (x / objective) and the last 90 (row gather) work on variable (xk, xt).  Computed twice -- here for the tables
     // of phase A and again behind phase B, from a copy of tid the compiler cannot see through -- so that the pair is not live
@@ -966,18 +962,35 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         xt = vq >= 0 ? vq % SEGV : 0;
     };
     lane_variable();
-    if (tid < NV) {
-        const int xn = md.x_n[xt];
-        S.xgp[tid] = (uint32_t)yglob(xk, md.x_i[xt][0]) | ((uint32_t)yglob(xk, md.x_i[xt][1]) << 8) |
-                     ((uint32_t)yglob(xk, md.x_i[xt][2]) << 16);
-        if (xk == 0) {
-            S.xtc[xt][0] = xn < 1 ? 0.0 : md.x_c[xt][0];
-            S.xtc[xt][1] = xn < 2 ? 0.0 : md.x_c[xt][1];
-            S.xtc[xt][2] = xn < 3 ? 0.0 : md.x_c[xt][2];
+    // Agent-independent tables.  SOLVER == 1: plain copies of the host's images (Model::amap32, xgp32, xtcm, Qh) -- every workgroup used to derive
+    // them behind dependent loads of the model's fields.  (At the top of the kernel, with its first loads, the copies cost four spilled registers;
+    // here none.)  The interior-point instantiations keep deriving them: with the copies THEY spilled a register.
+    if constexpr (SOLVER == 1) {
+        for (int i = tid; i < n_ax; i += NT) S.amap[i] = md.amap32[i];
+        for (int i = tid; i < NV; i += NT) S.xgp[i] = md.xgp32[i];
+        for (int i = tid; i < SEGV * 3; i += NT) S.xtc[i / 3][i % 3] = md.xtcm[i / 3][i % 3];
+        for (int i = tid; i < NC * NC; i += NT) S.Qh6[i] = md.Qh[i];
+    } else {
+        for (int i = tid; i < n_ax; i += NT) {
+            const uint32_t sl = md.amap[i], type = sl / NV, kt = sl % NV;
+            S.amap[i] = sl | (type << 10) | ((kt / SEGV) << 13) | ((kt % SEGV) << 15);
         }
-    } else if (tid >= 128 && tid < 128 + NC * NC) {
-        S.Qh6[tid - 128] = md.Qh[tid - 128];
-    } else if (tid >= 192 && tid < 192 + NY) {
+        if (tid < NV) {
+            const int xn = md.x_n[xt];
+            S.xgp[tid] = (uint32_t)yglob(xk, md.x_i[xt][0]) | ((uint32_t)yglob(xk, md.x_i[xt][1]) << 8) |
+                         ((uint32_t)yglob(xk, md.x_i[xt][2]) << 16);
+            if (xk == 0) {
+                S.xtc[xt][0] = xn < 1 ? 0.0 : md.x_c[xt][0];
+                S.xtc[xt][1] = xn < 2 ? 0.0 : md.x_c[xt][1];
+                S.xtc[xt][2] = xn < 3 ? 0.0 : md.x_c[xt][2];
+            }
+        } else if (tid >= 128 && tid < 128 + NC * NC) {
+            S.Qh6[tid - 128] = md.Qh[tid - 128];
+        }
+    }
+    // (what follows is the interior point's alone: with SOLVER == 1 it is built in ip_late_setup)
+    auto ip_ytables = [&]() {
+      if (tid >= 192 && tid < 192 + NY) {
         const int g = tid - 192;
         const int yk = yaxis(g);
         const int va = yvar(g);
@@ -990,7 +1003,9 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                    ((uint32_t)(yk * SEGV + t3) << 24);
         S.ypp[g] = (uint32_t)(t0 * 3 + yk) | ((uint32_t)(t1 * 3 + yk) << 8) | ((uint32_t)(t2 * 3 + yk) << 16) |
                    ((uint32_t)(t3 * 3 + yk) << 24);
-    }
+      }
+    };
+    if constexpr (SOLVER != 1) ip_ytables();
     __syncthreads();
     // constant part of every Hessian entry: cost Hessian (same axis) + terminal weight on c_{m,5}
     auto kconst_of = [&](uint32_t id) -> double {
@@ -2325,6 +2340,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         if constexpr (SOLVER == 1) {
             // the active-set solve gave up: the interior point starts from its own initial state (K zero outside the band, no marks)
             // ip_late_setup: the state the interior point expects at its start, built here instead of on every agent's way to the active-set solve
+            ip_ytables();
             if constexpr (TABLES_IN_LDS) {
                 uint32_t *lt = S.dyn, *le = lt + ((n_terms + 1) & ~1);
                 for (int i = tid; i < n_terms; i += NT) lt[i] = a.terms[i];

@@ -90,6 +90,13 @@ struct Model {
     // gy0[T-1][a][0..2 | 3]: the unconstrained optimum of an axis is linear in its three state constants and its goal coordinate,
     //   y*_a = sum_j gy0[a][j] s0_j + gy0[a][3] goal  ( = -ginv Z' (Qh x0 + terminal gradient) ), formed on the host.
     double gy0[M][NYA * 4];
+    // The kernels' LDS tables that do not depend on the agent, as the kernels hold them (built once here instead of by every workgroup in every
+    // tick behind dependent loads of the fields above): amap32[i] = slot | type << 10 | axis << 13 | t << 15 of valid axis row i;
+    // xgp32[k * SEGV + t] = the (at most three) unknowns of variable (k, t) as y-indices, one per byte; xtcm[t][j] = their coefficients, zero
+    // beyond x_n[t].
+    uint32_t amap32[AXVALID_3D + 2];
+    uint32_t xgp32[NV];
+    double   xtcm[SEGV][3];
 };
 
 // Dense variant of the same elimination for the alternate planner modes (lsc_general.hip): axis-major y, with
