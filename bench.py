@@ -658,7 +658,7 @@ def main():
                          "avg_launch_ms": round(k_ms, 5), "launches": k_n,
                          "executed_rows_mean": float(np.mean(lrows)),
                          "utilisation": pmc_utilisation(kname + "@grid32768") if n_agents == 64 else (pmc_utilisation(kname + "@grid262144#random1024") if n_agents == 1024 else None),
-                         "flop_model": ("active-set solve: changes x (9 flop x (rows + 414) + 2.6 kflop) + solves x (2.5 kflop + two more row passes) [+ SURVEY's "
+                         "flop_model": ("active-set solve: changes x (8 flop x (rows + 414) + 2.6 kflop) + solves x (2.5 kflop + two more row passes) [+ SURVEY's "
                                         "interior-point model for handed-over agents]; frac with the reference's 27 (N-1) rows, frac_executed with the rows carried" if gi else
                                         "SURVEY 8(d): IP iterations x ((N-1) kflop + 0.3 Mflop); frac_executed with the rows carried (~37 flop per row and iteration)"),
                          "note": ("latency-bound: one 512-lane workgroup per agent, a tick ends with its slowest agent. The active-set solve needs ~20x fewer flops than "
