@@ -147,7 +147,9 @@ typedef struct {
                                   optimum and the slowest agent of a tick needs ~8-13 changes of the working set -- and the interior point
                                   only when that gives up (more than 12 active rows, dependent rows, an infeasible QP: the interior point
                                   then decides the status as before).  0: the interior point alone (rounds 1-4).  Same optimum within the
-                                  parity tolerances either way; planar worlds, the throughput build and the second pass keep solver 0   */
+                                  parity tolerances either way; the second pass (rows in HBM) keeps solver 0.  2: a test mode -- the
+                                  active-set solve runs and then hands EVERY agent to the interior point (exercises the hand-over path,
+                                  where everything only the interior point needs is set up); results = the interior point's           */
 } lsc_config;
 
 void lsc_default_config(lsc_config *cfg);

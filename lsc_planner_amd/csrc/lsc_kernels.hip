@@ -2326,12 +2326,12 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     } else if (overflow) {
         status = LSC_STATUS_CAPACITY_K;
         run = false;
-    } else if (SOLVER == 1 && gi_solve()) {
+    } else if (SOLVER == 1 && gi_solve() && a.solver != 2) {      // (solver 2: test mode -- the solve runs and hands EVERY agent over)
         status = LSC_STATUS_OK_K;        // the active-set solve reached the optimum: obj and S.x are set
         iters = gi_changes;
         run = false;
         run_gi_done = true;
-    } else if (SOLVER == 1 && gi_infeasible) {
+    } else if (SOLVER == 1 && gi_infeasible && a.solver != 2) {
         status = LSC_STATUS_INFEASIBLE_K;    // proved by the active-set solve: the stale plan is kept (src/traj_planner.cpp:1553-1584)
         iters = gi_changes;
         run = false;
@@ -2906,18 +2906,18 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
         t.cap = a.cap_tp;
         if (t.order || t.obs_bound) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
         if (a.prof) hipLaunchKernelGGL(lsc_plan_tp_prof_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
-        else if (a.solver == 1 && !d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL((lsc_plan_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); }
+        else if (a.solver >= 1 && !d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL((lsc_plan_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); }
         else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
         else { if (d2) hipLaunchKernelGGL(lsc_plan_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
         return hipGetLastError();
     }
     t.order = nullptr; t.obs_bound = nullptr;     // filled by lsc_prep_kernel only
     // solver 1: the active-set solve first (3-D worlds, production kernels); everything else keeps the interior point alone
-    const bool gi = a.solver == 1 && !a.prof;
+    const bool gi = a.solver >= 1 && !a.prof;
     if (gi && d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_kernel<true, 1>), dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL((lsc_plan_kernel<false, true, 1>), dim3(a.count), dim3(NT), smem, st, t); }
     else if (gi) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_kernel<false, 1>), dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL((lsc_plan_kernel<false, false, 1>), dim3(a.count), dim3(NT), smem, st, t); }
     else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_kernel<true>, dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL(lsc_plan_alt_kernel<false>, dim3(a.count), dim3(NT), smem, st, t); }
-    else if (a.prof && a.solver == 1) hipLaunchKernelGGL((lsc_plan_kernel<true, false, 1>), dim3(a.count), dim3(NT), smem, st, t);
+    else if (a.prof && a.solver >= 1) hipLaunchKernelGGL((lsc_plan_kernel<true, false, 1>), dim3(a.count), dim3(NT), smem, st, t);
     else if (a.prof) hipLaunchKernelGGL((lsc_plan_kernel<true, false>), dim3(a.count), dim3(NT), smem, st, t);
     else if (d2) hipLaunchKernelGGL((lsc_plan_kernel<false, true>), dim3(a.count), dim3(NT), smem, st, t);
     else hipLaunchKernelGGL((lsc_plan_kernel<false, false>), dim3(a.count), dim3(NT), smem, st, t);
@@ -2942,7 +2942,7 @@ hipError_t launch_plan_batch(const PlanArgs *a, int n, size_t smem, hipStream_t 
     for (int i = n; i < PLAN_BATCH_MAX; i++) { b.a[i] = a[0]; b.a[i].count = 0; }
     if (grid == 0) return hipSuccess;
     bool gi = true;
-    for (int i = 0; i < n; i++) gi = gi && a[i].solver == 1;
+    for (int i = 0; i < n; i++) gi = gi && a[i].solver >= 1;
     if (gi && d2) { if (alt) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, true, 1>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<false, true, 1>), dim3(grid, n), dim3(NT), smem, st, b); }
     else if (gi) { if (alt) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, false, 1>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<false, false, 1>), dim3(grid, n), dim3(NT), smem, st, b); }
     else if (alt) { if (d2) hipLaunchKernelGGL((lsc_plan_batch_kernel<true, true>), dim3(grid, n), dim3(NT), smem, st, b); else hipLaunchKernelGGL((lsc_plan_batch_kernel<true, false>), dim3(grid, n), dim3(NT), smem, st, b); }

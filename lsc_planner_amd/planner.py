@@ -102,7 +102,7 @@ class SwarmPlanner:
         c.gap_tolerance = self.cfg.gap_tolerance
         c.world_dimension, c.world_z_2d = int(self.cfg.world_dimension), float(self.cfg.world_z_2d)
         c.goal_search = {"auto": 0, "general": 1, "key64": 2}[self.cfg.goal_search]
-        c.solver = {"active_set": 1, "interior_point": 0}[self.cfg.solver]
+        c.solver = {"active_set": 1, "interior_point": 0, "hand_over": 2}[self.cfg.solver]      # (hand_over: test mode, see lsc_config.solver)
         self._c = c
         self.ctx = self.L.lsc_create(ctypes.byref(c))
         if not self.ctx:

@@ -203,3 +203,33 @@ def test_active_set_solver_statistics_and_hand_over(L):
             assert st["solved"] + st["handed_over"] == 3
         pl.close()
     assert np.array_equal(out["active_set"]["status"], out["interior_point"]["status"]) and (out["active_set"]["status"] != 0).any()
+
+
+def test_hand_over_path_returns_the_interior_points_plans(L):
+    """Everything only the interior point needs (assembly tables, Hessian constants, slot tables of the row reduction, its zeroed arrays and
+    y-tables) is built where the active-set solve hands an agent over -- once in ~2 000 agent-replans in the field.  solver = "hand_over"
+    (lsc_config.solver 2) is the test mode that makes EVERY agent take that path: the active-set solve runs, then the interior point starts
+    from the state the late set-up leaves.  Its plans must be the interior point's own (solver = "interior_point": the same algorithm from
+    the same start, another instantiation of the kernel) -- over the crossing of the bench mission, a corridor world and a planar world."""
+    from lsc_planner_amd.planner import next_state_host
+    cases = [(L.circle_swap(64, 8.0), dict(goal_mode="prior_based"), 45, 25), (L.circle_swap(12, 3.0), dict(world_dimension=2, world_z_2d=1.0), 12, 1)]
+    for ms, kw, ticks, first in cases:
+        pls = {s: L.SwarmPlanner(ms, L.PlannerConfig(solver=s, **kw)) for s in ("interior_point", "hand_over")}
+        N = ms.qn
+        state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
+        traj = np.zeros((N, 3, 30), np.float32)
+        pls["hand_over"].iterations_total(reset=True)
+        worst = 0.0
+        for tick in range(1, ticks + 1):
+            g = {s: p.plan(state, ms.goal, traj) for s, p in pls.items()}
+            assert np.array_equal(g["interior_point"]["status"], g["hand_over"]["status"]), tick
+            if tick >= first:
+                worst = max(worst, float(np.abs(g["interior_point"]["traj"] - g["hand_over"]["traj"]).max()))
+                ok = g["interior_point"]["status"] == 0
+                assert np.allclose(g["interior_point"]["cost"][ok], g["hand_over"]["cost"][ok], rtol=1e-9, atol=1e-12), tick
+            traj = g["interior_point"]["traj"]; state = next_state_host(traj)
+        st = pls["hand_over"].solver_stats()
+        assert st["solved"] == 0 and st["handed_over"] == N * ticks and st["ip_iterations"] > 0, st
+        assert worst <= 1e-6, worst          # (float32 plans of two instantiations of one algorithm: equal up to the last bit of a rounding)
+        for p in pls.values():
+            p.close()
