@@ -961,7 +961,7 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.solver_stats = c->d_iters_acc ? c->d_iters_acc + 2 * (size_t)c->N : nullptr;      // (four counters behind the two per-agent blocks)
     a.cap_tp = (c->count > c->n_cu) ? c->cap_tp : 0; a.smem_tp = c->smem_tp;
     a.order = (c->count > 2 * c->n_cu) ? c->d_order : nullptr;   // more than one round of throughput workgroups
-    a.obs_bound = a.cap_tp > 0 ? c->d_obs_bound : nullptr;       // obstacle-level pre-cull of the throughput build
+    a.obs_bound = c->d_obs_bound;                                // obstacle-level pre-cull (throughput build; latency build of large swarms: launch_plan decides)
     a.state = d_state; a.goal = d_goal; a.traj_prev = d_prev;
     a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
     a.vmax = c->d_vmax; a.amax = c->d_amax; a.vnom = c->d_vnom;

@@ -2904,6 +2904,7 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     if (uses_throughput_build(a)) {
         // throughput build: smaller capacity (an agent beyond it takes the second pass), two workgroups per CU
         t.cap = a.cap_tp;
+        if (a.cap_tp <= 0) t.obs_bound = nullptr;
         if (t.order || t.obs_bound) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
         if (a.prof) hipLaunchKernelGGL(lsc_plan_tp_prof_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
         else if (a.solver >= 1 && !d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL((lsc_plan_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); }
@@ -2911,7 +2912,12 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
         else { if (d2) hipLaunchKernelGGL(lsc_plan_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
         return hipGetLastError();
     }
-    t.order = nullptr; t.obs_bound = nullptr;     // filled by lsc_prep_kernel only
+    // Latency build of a LARGE swarm (a shard of at most one agent per CU out of >= 512 agents: the sharded 1024-agent swarm): without the
+    // obstacle-level cull every workgroup walks all 5 (N - 1) units through the unit-level cull -- ten passes of loads and two barriers each
+    // at N = 1024, 18.6 of an agent's 50.6 us.  The bounding spheres cost one small launch (lsc_prep_kernel, ~4 us) in front of the tick.
+    t.order = nullptr;                            // filled by lsc_prep_kernel only
+    if (t.obs_bound && a.N >= 512 && !a.out_normal) hipLaunchKernelGGL(lsc_prep_kernel, dim3((32 * a.N + 255) / 256), dim3(256), 0, st, t);
+    else t.obs_bound = nullptr;
     // solver 1: the active-set solve first (3-D worlds, production kernels); everything else keeps the interior point alone
     const bool gi = a.solver >= 1 && !a.prof;
     if (gi && d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_kernel<true, 1>), dim3(a.count), dim3(NT), smem, st, t); else hipLaunchKernelGGL((lsc_plan_kernel<false, true, 1>), dim3(a.count), dim3(NT), smem, st, t); }
