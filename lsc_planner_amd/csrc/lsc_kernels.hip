@@ -1980,7 +1980,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     // QP) -- returns false and the interior point decides, as before.
     constexpr int GS = (NY + 1) & ~1;                         // stride of a working-set row in y-space (40 for NY = 39)
     constexpr int HV = (NYA * NYA + 7) & ~7;
-    constexpr int GQ = (HV + 2 * 12 * GS + 2 * 12 * 12 + 2 * 12 + 6 <= NY * KLD) ? 12 : 8;      // working-set capacity: what fits the idle K (12 for M = 5, 8 for M = 4)
+    constexpr int GQ = (12 * GS + 12 * 12 + 2 * 12 + 6 <= NY * KLD) ? 12 : 8;      // working-set capacity: what fits the idle K (12 in the M = 5 and the M = 4 build)
     constexpr int GI_CAP = 60;
     int gi_changes = 0;
     bool gi_infeasible = false;          // the active-set solve proved the QP infeasible (see "no admissible step")
@@ -1988,13 +1988,12 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         if constexpr (SOLVER != 1) return false;
         else {
         double *const gk = S.K;                       // the interior point's K is idle until then (re-zeroed on the way there)
-        double *const Hinv = gk;                      // [NYA][NYA]
-        double *const Yw = gk + HV + GQ * GS;         // [GQ][GS] H^-1 times the rows of the working set (y-space); [GQ][GS] in front of it: spare
-        double *const Si = Yw + GQ * GS;              // [GQ][GQ] inverse of the Gram matrix G_W H^-1 G_W'  ([GQ][GQ] more behind it: spare)
-        double *const uw = Si + 2 * GQ * GQ;          // [GQ] multipliers
+        double *const Yw = gk;                        // [GQ][GS] H^-1 times the rows of the working set (y-space)
+        double *const Si = Yw + GQ * GS;              // [GQ][GQ] inverse of the Gram matrix G_W H^-1 G_W'
+        double *const uw = Si + GQ * GQ;              // [GQ] multipliers
         double *const rwv = uw + GQ;                  // [GQ] multiplier rates of the current step
         int *const wrow = reinterpret_cast<int *>(rwv + GQ);   // [GQ] row codes (index into amap, or n_ax + index into cmap)
-        static_assert(HV + 2 * GQ * GS + 2 * GQ * GQ + 2 * GQ + (GQ + 1) / 2 <= NY * KLD, "the working set fits the idle K");
+        static_assert(GQ * GS + GQ * GQ + 2 * GQ + (GQ + 1) / 2 <= NY * KLD, "the working set fits the idle K");
         double *const gyv = S.gz;                     // [40], idle here
         // gi_hz[t][a] = (H^-1 Z' e_t)_a for the variable t of an axis (SEGV x NYA, the same for the three axes): H^-1 times a row's normal is
         // then three of these per lane instead of a 13-term product behind an LDS round trip.  Kept in the interior point's idle slack array
@@ -2011,7 +2010,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         // (hardware reciprocal + Newton: the scale only ranks violations, an ulp is nothing to it -- a division is ~40 instructions)
         for (int c = tid; c < n_ax; c += NT) { const int sl = S.amap[c] & 1023; S.at2[sl] = rcp_nr(1.0 + fabs(AH(sl))); }
         for (int c = tid; c < nact; c += NT) { const int r = cmap[c] & CMAP_MASK; rt2[r] = rcp_nr(1.0 + fabs(rrhs[r])); }
-        for (int i = tid; i < GQ * GS + 2 * GQ * GQ + 2 * GQ; i += NT) Yw[i] = 0.0;      // Yw, Si, uw, rwv: rows beyond the working set meet zeros
+        for (int i = tid; i < GQ * GS + GQ * GQ + 2 * GQ; i += NT) Yw[i] = 0.0;      // Yw, Si, uw, rwv: rows beyond the working set meet zeros
         // unconstrained optimum y = -H^-1 Z' grad(x0): a linear map of this axis' state constants and goal coordinate, its matrix from the host
         if (tid < 40) {
             const int k = tid < NY ? yaxis(tid) : 0;
@@ -2357,6 +2356,9 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 slot_offsets(which, b, b < NB ? S.cnt[b + 3] : 0, nact);
             }
             spent = gi_changes;          // (reported with the iterations, like the iterations of a failed warm start)
+#ifdef LSC_HANDOVER_COLD
+            attempt = 1;
+#endif
             __syncthreads();
             for (int e = tid; e < n_entries; e += NT) kconst[e] = kconst_of(ent[2 * e]);
             slot_entries();

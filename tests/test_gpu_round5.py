@@ -233,3 +233,37 @@ def test_hand_over_path_returns_the_interior_points_plans(L):
         assert worst <= 1e-6, worst          # (float32 plans of two instantiations of one algorithm: equal up to the last bit of a rounding)
         for p in pls.values():
             p.close()
+
+
+def test_instance_where_a_handed_over_agent_carries_the_interior_points_tolerance():
+    """Found by the M = 4 fuzzer (seed 8500018, tick 4): ten agents in a 12 m world, half-second segments.  Agent 9 needs more than the 12
+    rows the active-set solve's working set holds, is handed to the interior point, and its plan is 5.8e-5 m from the oracle's exact optimum
+    at 4.2e-10 relative higher cost -- the interior point's stopping tolerance along a flat direction, not the active-set solve's doing: the
+    plan is bit-identical to solver = interior_point.  Pins (a) that agreement, (b) statuses and costs within the table, (c) every agent the
+    active-set solve finished itself within TRAJ_ATOL of the oracle, the handed-over ones within the interior point's 1e-4 m."""
+    import os
+    import lsc_planner_amd as L
+    from lsc_planner_amd.mission import Mission
+    from lsc_planner_amd.planner import PlannerConfig
+    from tolerances import COST_ATOL, COST_RTOL, FUZZ_TRAJ_ATOL_HALF_SECOND
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_found_m4_handover_8500018.npz"))
+    L.load_library(4)
+    ms = Mission(d["state"][:, :3].copy(), d["goal"].copy(), d["wmin"], d["wmax"], d["radius"], d["dw"], d["vmax"], d["amax"], d["vnom"], name="replay")
+    res = {}
+    for solver in ("active_set", "interior_point"):
+        pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="static", dt=0.5, horizon=2.0, solver=solver))
+        assert pl.M == 4
+        pl.plan(d["state"], d["goal"], d["traj"])           # (sequence number 1 takes the current-velocity model: only to move it on)
+        pl.iterations_total(reset=True)
+        res[solver] = pl.plan(d["state"], d["goal"], d["traj"])
+        if solver == "active_set":
+            st = pl.solver_stats()
+            assert st["solved"] + st["handed_over"] == 10 and 1 <= st["handed_over"] <= 5, st
+        pl.close()
+    g, ip = res["active_set"], res["interior_point"]
+    assert np.array_equal(g["status"], d["ostatus"]) and (g["status"] == 0).all()
+    assert (np.abs(g["cost"] - d["ocost"]) <= COST_RTOL * np.abs(d["ocost"]) + COST_ATOL).all()
+    diff = np.abs(g["traj"].astype(np.float64) - d["otraj"]).reshape(10, -1).max(1)
+    assert diff.max() <= FUZZ_TRAJ_ATOL_HALF_SECOND, diff
+    assert np.array_equal(g["traj"][9], ip["traj"][9]) and g["cost"][9] == ip["cost"][9]      # the handed-over agent: the interior point's plan
+    assert diff[9] > 2e-5 and g["cost"][9] > d["ocost"][9]                                       # ... which is what is off, on the costlier side
