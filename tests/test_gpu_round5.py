@@ -268,3 +268,33 @@ def test_instance_where_a_handed_over_agent_carries_the_interior_points_toleranc
     assert diff.max() <= FUZZ_TRAJ_ATOL_HALF_SECOND, diff
     assert np.array_equal(g["traj"][9], ip["traj"][9]) and g["cost"][9] == ip["cost"][9]      # the handed-over agent: the interior point's plan
     assert g["cost"][9] >= d["ocost"][9]                                                         # ... on the costlier side of the exact optimum
+
+
+def test_shards_of_a_large_swarm_cull_obstacles_and_plan_the_same_bits(L):
+    """A shard of at most one agent per CU out of a swarm of >= 512 agents runs the 512-lane latency build with the obstacle-level sphere
+    cull in front of its unit-level cull (lsc_prep_kernel ahead of the tick: launch_plan).  Same rows in the same order as without any
+    cull (prune = 3), hence bit-identical plans, costs, statuses, iteration and row counts -- 1024 agents as two of the eight shards a
+    node would hold (the first and one in the middle), six ticks."""
+    from lsc_planner_amd.planner import next_state_host
+    n = 1024
+    ms = L.random_swarm(n, seed=20260929)
+    shards = [(0, 128), (512, 128)]
+    with_cull = [L.SwarmPlanner(ms, L.PlannerConfig(prune=1, goal_mode="prior_based")) for _ in shards]
+    without = [L.SwarmPlanner(ms, L.PlannerConfig(prune=3, goal_mode="prior_based")) for _ in shards]
+    for (first, count), a, b in zip(shards, with_cull, without):
+        a.set_shard(first, count); b.set_shard(first, count)
+    whole = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))          # (the throughput build: flies the mission)
+    state = np.zeros((n, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((n, 3, 30), np.float32)
+    for tick in range(1, 7):
+        g = whole.plan(state, ms.goal, traj)
+        for (first, count), a, b in zip(shards, with_cull, without):
+            ga, gb = a.plan(state, ms.goal, traj), b.plan(state, ms.goal, traj)
+            for k in ("traj", "cost", "status", "iters"):
+                assert np.array_equal(ga[k], gb[k]), (tick, first, k)
+            assert np.array_equal(a.row_counts()[first:first + count], b.row_counts()[first:first + count]), (tick, first)
+            assert np.array_equal(ga["status"], g["status"][first:first + count]), (tick, first)
+        traj = g["traj"]; state = next_state_host(traj)
+    assert 0 < with_cull[0].row_counts()[:128].mean() < 27 * (n - 1) / 10
+    for p in with_cull + without + [whole]:
+        p.close()
