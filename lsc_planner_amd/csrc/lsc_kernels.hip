@@ -1073,21 +1073,31 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         int n_list = n_units;
         if (cull) {
             if (tid == 0) S.listfull = 0;
-            if (tid < M) {
-                const int m = tid;
-                double b = 0.0;
-                for (int i = 0; i < NC; i++) {
-                    const int K = 5 * m + i - 2;
-                    if (K < 1) continue;
-                    double d2 = 0.0, r2 = 0.0;
-                    for (int k = 0; k < 3; k++) {
-                        const double dd = S.s0[k][2] - (double)S.pinit[k * SEGV + m * NC + i];
-                        const double e = fmax(fabs(S.reachL[k][K]), fabs(S.reachU[k][K]));
-                        d2 += dd * dd; r2 += e * e;
-                    }
-                    b = fmax(b, sqrt(d2) + sqrt(r2));
+            // Reach of every control point (distance from c_{0,2} + radius of its reachable box), per segment (cullB) and overall (cullA), one
+            // lane of wave 0 per control point.  (Five lanes walking six points each, then one lane walking all thirty, were ~450 instructions on
+            // lone lanes and a barrier of their own: ~1.5 us per agent-tick of a large swarm.)
+            if (wave == 0) {
+                const int c = lane < SEGV ? lane : SEGV - 1, K = 5 * (c / NC) + (c % NC) - 2;
+                const int Kc = K >= 1 ? K : 1;
+                double d2 = 0.0, r2 = 0.0;
+                for (int k = 0; k < 3; k++) {
+                    const double dd = S.s0[k][2] - (double)S.pinit[k * SEGV + c];
+                    const double e = fmax(fabs(S.reachL[k][Kc]), fabs(S.reachU[k][Kc]));
+                    d2 += dd * dd; r2 += e * e;
                 }
-                S.cullB[m] = b;
+                const double bc = (lane < SEGV && K >= 1) ? sqrt(d2) + sqrt(r2) : 0.0;
+                const double ra2 = wave_max(lane < SEGV ? d2 : 0.0), bm = wave_max(bc);
+                double *const ct = reinterpret_cast<double *>(&S.colbuf[0][0]);      // (the factorisation's buffers are idle in phase B)
+                if (lane < SEGV) ct[lane] = bc;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < M) {
+                    double bb = 0.0;
+                    for (int i = 0; i < NC; i++) bb = fmax(bb, ct[lane * NC + i]);
+                    S.cullB[lane] = bb;
+                }
+                if (lane == 0) { S.cullA[0] = sqrt(ra2); S.cullA[1] = bm; }
             }
             __syncthreads();
             // Obstacle level first (throughput build: lsc_prep_kernel left a bounding sphere (B_o, rho_o) of every agent's
@@ -1100,17 +1110,6 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             const bool lvl0 = a.obs_bound != nullptr && n_obs <= (SPILL ? 0x7fffffff : 16 * R);
             int n_o = n_obs;
             if (lvl0) {
-                if (tid == 0) {
-                    double ra2 = 0.0, bm = 0.0;
-                    for (int c = 0; c < SEGV; c++) {
-                        double d2 = 0.0;
-                        for (int k = 0; k < 3; k++) { const double dd = S.s0[k][2] - (double)S.pinit[k * SEGV + c]; d2 += dd * dd; }
-                        ra2 = fmax(ra2, d2);
-                    }
-                    for (int m = 0; m < M; m++) bm = fmax(bm, S.cullB[m]);
-                    S.cullA[0] = sqrt(ra2); S.cullA[1] = bm;
-                }
-                __syncthreads();
                 int tot0 = 0;
                 for (int base = 0; base < n_obs; base += NT) {
                     const int oi = base + tid;
