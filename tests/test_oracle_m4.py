@@ -99,9 +99,10 @@ def test_fuzz_found_flat_optimum_of_the_half_second_segments(oracle):
     relative above it -- both inside the 1e-9 gap tolerance -- with their plans 8.2e-5 m and 4.0e-5 m from HiGHS's on opposite sides, and
     the plan tolerance of the dt = 0.5 build was widened to 2e-4 m for this one instance.  Since round 5 the oracle finishes its optimum
     exactly (orc_gi_polish): it sits on HiGHS's plan, the recorded interior-point plan is 4.0e-5 m away -- inside FUZZ_TRAJ_ATOL --, and the
-    exception is gone from tests/tolerances.py."""
+    2e-4 exception is gone from tests/tolerances.py.  (What the dt = 0.5 fuzzers keep is the interior point's own 1e-4 m, for agents the
+    active-set solve hands over: tests/golden/fuzz_found_m4_handover_8500018.npz, tests/test_gpu_round5.py.)"""
     from tolerances import FUZZ_TRAJ_ATOL, FUZZ_TRAJ_ATOL_HALF_SECOND
-    assert FUZZ_TRAJ_ATOL_HALF_SECOND == FUZZ_TRAJ_ATOL
+    assert FUZZ_TRAJ_ATOL <= FUZZ_TRAJ_ATOL_HALF_SECOND <= 1e-4
     O = oracle
     Z = np.load(os.path.join(GOLDEN, "fuzz_found_planar_m4_7500378.npz"))
     a, tick, hc = 2, int(Z["tick"]), 53.583029793744
