@@ -254,6 +254,76 @@ def rotated_mission(L, ms, angle, name):
                    name=name)
 
 
+def tick_runs(L, runs, batch):
+    """One tick of several independent missions: one launch for all of them (lsc_tick_device_fused_batch) or one launch each."""
+    if not batch:
+        for r in runs:
+            r.tick()
+        return
+    for r in runs:
+        r.seq += 1
+    L.tick_device_fused_batch([r.pl for r in runs], [r.states[0] for r in runs], [r.goal for r in runs], [r.prev for r in runs],
+                              [r.nxt for r in runs], [r.states[1] for r in runs], [r.cost for r in runs], [r.status for r in runs],
+                              [r.iters for r in runs], [r.seq for r in runs], runs[0].stream)
+    for r in runs:
+        r.states.reverse()
+        r.prev, r.nxt = r.nxt, r.prev
+
+
+def mission_list_missions(L, ms, ids, total):
+    """Mission j of the list: the headline swarm turned about the vertical axis (j = 0: the headline swarm itself); congruent missions with
+    other numbers, the same family concurrent_missions flies on one GPU."""
+    return [ms if j == 0 else rotated_mission(L, ms, 2.0 * np.pi * (j / (7.0 * total) + 0.013 * j), f"{getattr(ms, 'name', 'mission')}_rot{j}") for j in ids]
+
+
+def mission_list_leg(L, torch, dist, ms, cfg_of, dev, K, start_tick, steps, G, rank, local_rank):
+    """The headline configuration on G GPUs WITHOUT a collective: the reference's outer loop is a mission list
+    (src/multi_sync_simulator_node.cpp:43-70, src/param.cpp:106-122; testall_*.launch: 30 missions per swarm size), independent missions
+    share nothing, so rank r flies missions [r K, (r + 1) K) of a list of G K -- K in flight together, ONE launch per tick
+    (lsc_tick_device_fused_batch).  Timed like the headline: fast-forward to start_tick untimed, barrier + synchronize, `steps` ticks,
+    barrier + synchronize, the slowest rank's time.  Returns (summary on rank 0 / None, this rank's device-side numbers)."""
+    from lsc_planner_amd.sharded import mission_list_ids, mission_list_summary
+    missions = mission_list_missions(L, ms, mission_list_ids(G, rank, K), G * K)
+    runs = [MissionRun(L, torch, m, cfg_of(), dev, torch.cuda.current_stream()) for m in missions]
+
+    def sync():
+        if G > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(start_tick - 1):
+        tick_runs(L, runs, True)
+    sync()
+    for r in runs:
+        r.pl.iterations_total(reset=True)
+    runs[0].pl.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tick_runs(L, runs, True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    kb = runs[0].pl.kernel_times_ms(0)               # the batch launch is clocked on the first context
+    runs[0].pl.set_timing(False)
+    stats = {"solved": 0.0, "handed_over": 0.0, "changes": 0.0, "ip_iterations": 0.0}
+    it_total = rowit_total = 0.0
+    for r in runs:
+        st = r.pl.solver_stats()
+        for k in stats:
+            stats[k] += float(st[k])
+        it_total += float(r.pl.iterations_total(reset=False))
+        rowit_total += float(r.pl.row_iterations_total())
+    failed = sum(int((r.status != 0).sum().item()) for r in runs)
+    agents = sum(m.qn for m in missions)
+    props = torch.cuda.get_device_properties(dev)
+    uuid = str(getattr(props, "uuid", "")) + "/" + str(getattr(props, "pci_bus_id", ""))
+    summary = mission_list_summary(dist if G > 1 else None, rank, G, agents, steps, elapsed, float(np.percentile(kb, 99)) if len(kb) else 0.0,
+                                   torch.cuda.current_device(), uuid if uuid != "/" else "", failed)
+    mine = {"kernel_ms": kb, "stats": stats, "iters_total": it_total, "rowit_total": rowit_total, "agents": agents,
+            "missions": [getattr(m, "name", "mission") for m in missions], "traj": [r.prev.clone() for r in runs]}
+    for r in runs:
+        r.close()
+    return summary, mine
+
+
 def concurrent_missions_leg(L, torch, ms, cfg_of, dev, K, start_tick, steps, n_cu):
     """The reference's outer loop -- a directory of missions flown back to back (src/multi_sync_simulator_node.cpp:43-70,
     src/param.cpp:106-122; testall_*.launch: 30 missions per swarm size) -- as a batch axis: K independent 64-agent missions, one
@@ -262,19 +332,7 @@ def concurrent_missions_leg(L, torch, ms, cfg_of, dev, K, start_tick, steps, n_c
     -- through the batch launch, and, for comparison, as K launches on K streams --; the plans of all three runs must be the same bits."""
     missions = [ms] + [rotated_mission(L, ms, 2.0 * np.pi * (m / (7.0 * K) + 0.013 * m), f"{getattr(ms, 'name', 'mission')}_rot{m}") for m in range(1, K)]
 
-    def tick_all(runs, batch):
-        if not batch:
-            for r in runs:
-                r.tick()
-            return
-        for r in runs:
-            r.seq += 1
-        L.tick_device_fused_batch([r.pl for r in runs], [r.states[0] for r in runs], [r.goal for r in runs], [r.prev for r in runs],
-                                  [r.nxt for r in runs], [r.states[1] for r in runs], [r.cost for r in runs], [r.status for r in runs],
-                                  [r.iters for r in runs], [r.seq for r in runs], runs[0].stream)
-        for r in runs:
-            r.states.reverse()
-            r.prev, r.nxt = r.nxt, r.prev
+    tick_all = lambda runs, batch: tick_runs(L, runs, batch)
 
     def fly(runs, batch=False):
         for _ in range(start_tick - 1):
@@ -344,6 +402,68 @@ def concurrent_missions_leg(L, torch, ms, cfg_of, dev, K, start_tick, steps, n_c
     }
 
 
+def mission_list_main(args, L, torch, dist, dev, G, rank, local_rank, json_fd):
+    """`bench.py --gpus N --mission-list`: the headline configuration (BASELINE configs[2]) on N GPUs as a mission list -- no collective
+    on the data path.  One JSON line on rank 0 with the contract's keys, `mission_list` (per-rank values, devices, tick p99),
+    `roofline` of the batch launch and -- one GPU only -- `cpu_baseline`."""
+    K = max(args.missions, 1)
+    ms, layout = weak_scaling_mission(L, 1, args.agents_per_gpu)
+    goal_mode = "static" if args.static_goal else "prior_based"
+    cfg_of = lambda: L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode, reset_threshold=args.reset_threshold,
+                                     solver=args.solver)
+    start_tick = max(args.start_tick if args.start_tick is not None else 60, args.warmup + 1)
+    summary, mine = mission_list_leg(L, torch, dist, ms, cfg_of, dev, K, start_tick, args.steps, G, rank, local_rank)
+    if rank == 0:
+        kb = mine["kernel_ms"]
+        st = mine["stats"]
+        gi = args.solver == "active_set" and (st["solved"] + st["handed_over"]) > 0
+        n = ms.qn
+        rows_mean = mine["rowit_total"] / max(mine["iters_total"], 1.0)
+        if gi:
+            flops = active_set_flops(n, st, mine["rowit_total"], rows_mean, True) / max(len(kb), 1)
+            flops_exec = active_set_flops(n, st, mine["rowit_total"], rows_mean, False) / max(len(kb), 1)
+        else:
+            flops = algorithmic_flops(n, mine["iters_total"]) / max(len(kb), 1)
+            flops_exec = (mine["rowit_total"] * (1.0e3 / 27.0) + mine["iters_total"] * 0.3e6) / max(len(kb), 1)
+        k_ms = float(kb.mean()) if len(kb) else 0.0
+        ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        ach_exec = flops_exec / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        p = lambda a, q: round(float(np.percentile(a, q)), 4) if len(a) else None
+        elapsed = summary["elapsed_s_max_over_ranks"]
+        result = {
+            "metric": "agent-replans/sec (whole node)", "value": round(summary["value"], 1), "unit": "agent-replans/s",
+            "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "mission-list", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "tick_solve_ms": {"p50": p(kb, 50), "p99": p(kb, 99), "p99_max_over_ranks": round(summary["tick_p99_ms_max_over_ranks"], 4),
+                              "note": "device time of the ONE launch per tick that plans this rank's K missions (HIP events, rank 0); a batch tick ends with "
+                                      "the slowest agent of the K missions"},
+            "p99_tick_ms": {"device_resident": round(summary["tick_p99_ms_max_over_ranks"], 4), "device_resident_samples": args.steps,
+                            "note": "largest per-rank p99 of the batch launch over the timed steps"},
+            "config": {"tick_window": [start_tick, start_tick + args.steps - 1],
+                       "workload": f"mission list of {G * K} independent missions: {layout} (mission 0) and the same swarm turned about the vertical axis, empty map, "
+                                   f"LSC mode, dt 0.2 s, M=5 n=5, mode/goal={goal_mode}, {K} missions in flight per GPU, ONE launch per tick and GPU "
+                                   "(lsc_tick_device_fused_batch: goal planning + LSC + QP + state propagation of all K missions"
+                                   + (" + the hand-over launch of the alternate-mode kernel" if args.reset_threshold > 0 else "") + "), device-resident; "
+                                   "no collective: independent missions share nothing (the reference's node flies them back to back, "
+                                   "src/multi_sync_simulator_node.cpp:43-70)",
+                       "agents": summary["agents_in_flight"], "agents_per_mission": n, "missions_per_gpu": K, "missions": G * K,
+                       "parallelism": f"mission-list x{G} (rank r flies missions [r K, (r + 1) K))", "reset_threshold": args.reset_threshold,
+                       "scaling_note": "fixed work per GPU (K missions each); the single-mission headline of the plain `bench.py` line is the latency figure, "
+                                       "this line the throughput one"},
+            "mission_list": summary,
+            "roofline": {"kernel": "lsc_plan_batch_kernel", "bound": "valu_fp64", "achieved": round(ach, 5), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / FP64_VALU_PEAK_TFLOPS, 7), "frac_executed": round(ach_exec / FP64_VALU_PEAK_TFLOPS, 7),
+                         "avg_launch_ms": round(k_ms, 5), "launches": int(len(kb)), "traffic": None,
+                         "note": "rank 0's batch launch (K missions x 64 workgroups on 256 CUs), flop model of the single-mission line; latency-bound like it"},
+        }
+        result["cpu_baseline"] = cpu_baseline(ms, static_goal=args.static_goal) if (G == 1 and not args.no_cpu_baseline) else None
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
+    if G > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,6 +502,11 @@ def main():
                     help="extra leg (single GPU, circle64 workload): this many independent 64-agent missions in flight together, one context and "
                          "stream each -- the reference's mission-list outer loop as a batch axis; reported as `concurrent_missions` NEXT TO the "
                          "single-mission headline, never instead of it; 0 or 1 = skip")
+    ap.add_argument("--mission-list", action="store_true",
+                    help="the headline configuration on --gpus N WITHOUT a collective: every rank flies --missions K independent 64-agent "
+                         "missions of a list of N K (one launch per tick, lsc_tick_device_fused_batch); value = sum over the ranks / the slowest "
+                         "rank's time, \"scaling\": \"mission-list\".  Without this flag a --gpus N > 1 line still carries the same measurement as its "
+                         "`mission_list` object next to the all-gather workload")
     ap.add_argument("--sweep-agents", type=int, default=1024,
                     help="extra leg: dense LSC sweep at this swarm size (HBM-meaningful working set); 0 = skip")
     args = ap.parse_args()
@@ -433,6 +558,12 @@ def main():
     elif args.unfused:
         token = L.comm_unique_id()                       # world-size-1 communicator: the same code path on one GPU
     sharded = token is not None
+
+    if args.mission_list:
+        if args.workload != "circle64" or args.planner != "lsc" or args.slack != "none":
+            raise SystemExit("bench.py --mission-list flies the headline configuration (circle64, LSC mode)")
+        mission_list_main(args, L, torch, dist, dev, G, rank, local_rank, json_fd)
+        return
 
     strong = args.workload != "circle64"
     bt_path = None
@@ -592,6 +723,14 @@ def main():
         dist.all_gather(per_rank, mine)
     per_rank = [[round(float(v), 4) for v in r.tolist()] for r in per_rank]
 
+    ml_summary = None
+    if G > 1 and args.workload == "circle64" and args.missions > 1 and args.planner == "lsc" and args.slack == "none":
+        # every rank takes part (barriers around its timed region); the headline above is unaffected
+        ms1, _ = weak_scaling_mission(L, 1, args.agents_per_gpu)
+        ml_cfg = lambda: L.PlannerConfig(device=local_rank, prune=not args.no_prune, goal_mode=goal_mode, reset_threshold=args.reset_threshold,
+                                         solver=args.solver)
+        ml_summary, _ = mission_list_leg(L, torch, dist, ms1, ml_cfg, dev, args.missions, start_tick, args.steps, G, rank, local_rank)
+
     result = None
     if rank == 0:
         value = n_agents * args.steps / elapsed
@@ -648,8 +787,13 @@ def main():
                    "failed_agents_last_tick": bad,
                    "active_lsc_rows_last_tick_mean": float(np.mean(lrows)), "active_lsc_rows_last_tick_max": int(np.max(lrows)),
                    "reference_rows_per_agent": 27 * (n_agents - 1)},
-            "roofline": {"kernel": kname, "bound": "valu_fp64", "achieved": round(ach, 5),
-                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP64_VALU_PEAK_TFLOPS, 7),
+            "roofline": {"kernel": kname, "bound": "valu_fp64", "achieved": round(ach_exec if n_agents > 256 else ach, 5),
+                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         # N > 256: the reference's 27 (N - 1) rows per agent are never touched (~70 of 27 621 survive the culls at N = 1024), so the
+                         # line leads with the rows the kernel carried and keeps the reference-row figure under its own name
+                         "frac": round((ach_exec if n_agents > 256 else ach) / FP64_VALU_PEAK_TFLOPS, 7),
+                         "frac_basis": "rows carried (frac_executed)" if n_agents > 256 else "the reference's 27 (N - 1) rows per agent",
+                         "frac_reference_rows": round(ach / FP64_VALU_PEAK_TFLOPS, 7),
                          "frac_executed": round(ach_exec / FP64_VALU_PEAK_TFLOPS, 7),
                          "executed_rows_per_iteration_mean": round(rowit_total / max(iters_total, 1.0), 1),
                          "traffic": traffic,
@@ -677,6 +821,12 @@ def main():
                                           "allgather_us_mean", "agents"], "ranks": per_rank,
                               "note": "device time per tick of each rank's launches (HIP events on the tick's stream); the tick of a sharded swarm "
                                       "ends with its slowest rank plus the all-gather"}
+        if ml_summary is not None:
+            ml_summary["value"] = round(ml_summary["value"], 1)
+            ml_summary["note"] = (f"the SAME headline configuration without a collective: every rank flies {args.missions} independent {args.agents_per_gpu}-agent missions "
+                                  "of one mission list, one launch per tick (bench.py --mission-list makes this the headline of the line); value = agent-replans "
+                                  "of all ranks / the slowest rank's time over the same tick window")
+            result["mission_list"] = ml_summary
         if sharded:
             result["rccl"] = {"world_size": G, "native": native,
                               "collective": "ncclAllGather, in place, on the tick's stream" if native else
@@ -848,8 +998,14 @@ def main():
                                          "note": "lsc_replan_tick, entry to return, clocked inside the C ABI: host buffers in/out, "
                                                  "PCIe-inclusive, synchronous (through_python_wrapper adds the ctypes harness)"}
         # SURVEY 8(d) defines the per-tick solve time PCIe-inclusive: promote it next to the device-resident numbers
+        ts = result["tick_solve_ms"]
+        whole = ts["p99_whole_mission"] is not None and ts["whole_mission_samples"] >= 200
         result["p99_tick_ms"] = {"host_abi_pcie_inclusive": result["latency_host_abi_ms"]["p99"],
-                                 "device_resident": result["tick_solve_ms"]["p99"]}
+                                 "device_resident": ts["p99_whole_mission"] if whole else ts["p99"],
+                                 "device_resident_samples": ts["whole_mission_samples"] if whole else args.steps,
+                                 "p99_timed_window": ts["p99"],
+                                 "note": "device_resident: HIP events around the per-tick launch over EVERY tick of the mission when that gives >= 200 samples "
+                                         "(a 20-step window's p99 is its maximum); p99_timed_window: the same over the timed steps only"}
         pl2.close()
 
     if rank == 0 and G == 1 and not args.no_cpu_baseline and not strong:

@@ -120,7 +120,8 @@ struct Param {   // defaults = launch/testall_empty.launch
     double control_input_weight = 0.01, terminal_weight = 1.0;
     double multisim_time_step = 0.2, multisim_record_time_step = 0.1, multisim_reset_threshold = 0.15;
     int multisim_max_planner_iteration = 300;
-    double multisim_max_noise = 0.0;   // multisim/max_noise (src/param.cpp; 0.02 in testall_*.launch): uniform noise on the desired goals
+    double multisim_max_noise = 0.0;   // multisim/max_noise (src/param.cpp:22; 0.0 in testall_*.launch:47, 0.02 in simulation.launch:47): uniform noise on the desired goals
+    int on_deadlock = 0;               // lsc_sim --on-deadlock: 0 report + apply the goal noise once, 1 report, 2 ignore (multi_sync_simulator.cpp: checkDeadlock)
     bool phase_stats = false;          // lsc_sim --phase-stats: per-phase PlanningTimeStatistics from the instrumented plan kernel
     unsigned multisim_noise_seed = 0;  // 0 = std::random_device like the reference (src/mission.cpp:387); else reproducible
     bool multisim_save_result = false;

@@ -5,6 +5,11 @@
 //                                                     optimum: a PERFECTLY symmetric mission (multi_simple4, an unperturbed circle) then stays
 //                                                     symmetric and can tie in the priority rule for good -- the reference's remedy is
 //                                                     multisim/max_noise (0.02 in launch/simulation.launch): --max-noise 0.02
+//           [--on-deadlock noise|report|ignore]       what to do when no agent's horizon end point has moved for 20 ticks while goals
+//                                                     are unmet (the reference's own, unused, bookkeeping: src/traj_planner.cpp:396-409).
+//                                                     noise (default): say so and apply the reference's remedy once -- goal noise of
+//                                                     max(--max-noise, 0.02), Mission::addNoise -- so that a run with the launch files'
+//                                                     max_noise 0 still ends; report: say so and fly on; ignore: the reference's silence
 // Loop: isFinished -> doStep -> update (ideal next state of every agent) -> plan (one lsc_replan_tick for the
 // swarm) -> savePlanningResult (safety ratio / collision accounting) -> optional result / summary CSV in the
 // reference's column layout, so that its replayer can read our runs.
@@ -21,7 +26,7 @@ namespace DynamicPlanning {
 
 class MultiSyncSimulator {
   public:
-    MultiSyncSimulator(const Param &p, const Mission &m) : param(p), mission(m) {
+    MultiSyncSimulator(const Param &p, const Mission &m, int mission_index = 0) : param(p), mission(m), mission_index(mission_index) {
         for (int qi = 0; qi < mission.qn; qi++) agents.emplace_back(new TrajPlanner(qi, param, mission));
         lsc_config cfg;
         lsc_default_config(&cfg);
@@ -72,21 +77,27 @@ class MultiSyncSimulator {
     // file system); lsc_comm_init is collective and must precede lsc_set_agents.
     void initComm() {
         if (param.comm_file.empty()) throw std::invalid_argument("[MultiSyncSimulator] --ranks needs --comm-file");
+        // One token per mission of a mission list (every mission builds its own context and communicator): a rank that is ahead must
+        // never read the token of the mission before.  The first mission keeps the plain name.
+        const std::string token = mission_index == 0 ? param.comm_file : param.comm_file + "." + std::to_string(mission_index);
         unsigned char id[LSC_COMM_ID_BYTES];
         if (param.rank == 0) {
             check(lsc_comm_unique_id(id));
-            const std::string tmp = param.comm_file + ".tmp";
+            const std::string tmp = token + ".tmp";
             { std::ofstream f(tmp, std::ios::binary); f.write(reinterpret_cast<const char *>(id), sizeof(id)); }
-            std::rename(tmp.c_str(), param.comm_file.c_str());
+            std::rename(tmp.c_str(), token.c_str());
         } else {
             for (int tries = 0;; tries++) {
-                std::ifstream f(param.comm_file, std::ios::binary);
+                std::ifstream f(token, std::ios::binary);
                 if (f && f.read(reinterpret_cast<char *>(id), sizeof(id))) break;
-                if (tries > 600) throw std::runtime_error("[MultiSyncSimulator] no rendezvous token in " + param.comm_file);
+                if (tries > 600) throw std::runtime_error("[MultiSyncSimulator] no rendezvous token in " + token);
                 std::this_thread::sleep_for(std::chrono::milliseconds(100));
             }
         }
         check(lsc_comm_init(ctx, param.world, param.rank, id));
+        // lsc_comm_init is collective: when it returns on rank 0 every rank has read the token.  Remove it, so that a later run with
+        // the same --comm-file (or the next mission of a list) cannot pick up a stale one.
+        if (param.rank == 0) std::remove(token.c_str());
         sharded = true;
     }
 
@@ -169,6 +180,7 @@ class MultiSyncSimulator {
             agents[qi]->acceptPlan(h_next.data() + (size_t)LSC_NV * qi, h_cost[qi], h_status[qi], last_tick_ms * 1e-3 / N);
         }
         total_ticks++; total_tick_ms += last_tick_ms;
+        checkDeadlock();
         // TrajOptimizer::solve exports the model of a failed solve (log/QPmodel.lp, src/traj_optimizer.cpp:99-102); like there the
         // file is overwritten by every failure, so it holds the last one.  Best effort: a swarm with slack rows is not dumped.
         // The rank that OWNS the first failed agent writes it (only its context holds that agent's corridor and plan inputs; every
@@ -198,6 +210,55 @@ class MultiSyncSimulator {
         savePlanningResult();
         if (param.multisim_save_result && param.rank == 0) savePlanningResultAsCSV();
         return true;
+    }
+
+    // The reference's deadlock bookkeeping (src/traj_planner.cpp:396-409, "Not used in this work"): an agent whose horizon end point
+    // traj_curr[M-1][n] has not moved by SP_EPSILON_FLOAT since the previous plan while it is farther than goal_threshold from its goal.
+    // Swarm-level here: NO agent's end point moved for 20 consecutive ticks and somebody's goal is unmet.  With the exact optimum of the
+    // active-set solve a perfectly symmetric mission ties in the priority rule (:540-577, strict comparisons) for good -- the reference's
+    // remedy is multisim/max_noise (src/mission.cpp:386-395; 0.02 in launch/simulation.launch).  Deterministic on every rank (same plans).
+    void checkDeadlock() {
+        if (param.on_deadlock == 2) return;
+        const int N = mission.qn;
+        bool moved = false, unmet = false;
+        if (endpoints.empty()) { endpoints.assign(N, point3d(SP_INFINITY, SP_INFINITY, SP_INFINITY)); }
+        for (int qi = 0; qi < N; qi++) {
+            const traj_t t = agents[qi]->getTraj();
+            const point3d e = t[LSC_M - 1][LSC_NC - 1];
+            if ((e - endpoints[qi]).norm() >= SP_EPSILON_FLOAT) moved = true;
+            if ((e - mission.agents[qi].desired_goal_position).norm() > param.goal_threshold) unmet = true;
+            endpoints[qi] = e;
+        }
+        still_ticks = (!moved && unmet) ? still_ticks + 1 : 0;
+        // second sign of the same trap: the same agents' QPs infeasible tick after tick (an agent keeps its stale plan on a failure,
+        // src/traj_planner.cpp:1548-1585, and two mirror-image agents that block each other head-on never get out of it)
+        std::vector<int> failed;
+        for (int qi = 0; qi < N; qi++) if (agents[qi]->last_status == LSC_STATUS_INFEASIBLE) failed.push_back(qi);
+        failed_ticks = (!failed.empty() && failed == failed_prev) ? failed_ticks + 1 : 0;
+        failed_prev = failed;
+        if (failed_ticks == 20 && !failure_reported) {
+            failure_reported = true;
+            if (param.rank == 0) {
+                std::string ids;
+                for (int q : failed) ids += (ids.empty() ? "" : ",") + std::to_string(q);
+                std::fprintf(stderr, "[MultiSyncSimulator] stuck: the QPs of agents %s have been infeasible for 20 ticks (tick %d); they keep their stale plans "
+                                     "(the reference's failure semantics) and will not recover. On a symmetric mission start with the reference's remedy: "
+                                     "multisim/max_noise (lsc_sim --max-noise 0.02, launch/simulation.launch:47)\n", ids.c_str(), total_ticks);
+            }
+        }
+        if (still_ticks != 20 || deadlock_reported) return;
+        deadlock_reported = true;
+        deadlock_tick = total_ticks;
+        const double noise = std::max(param.multisim_max_noise, 0.02);
+        if (param.rank == 0)
+            std::fprintf(stderr, "[MultiSyncSimulator] deadlock: no agent's horizon end point has moved for 20 ticks (tick %d) while goals are unmet. "
+                                 "A symmetric mission ties in the priority rule under an exact QP optimum; the reference's remedy is "
+                                 "multisim/max_noise (launch/simulation.launch:47: 0.02; lsc_sim --max-noise 0.02)%s\n", total_ticks,
+                         param.on_deadlock == 0 ? " -- applying it now (--on-deadlock report|ignore to fly on as is)" : "");
+        if (param.on_deadlock != 0) return;
+        // Mission::addNoise on the desired goals, seeded (the same draw on every rank); the simulator's and the agents' copies
+        mission.addNoise(noise, param.world_dimension, param.multisim_noise_seed ? param.multisim_noise_seed : 20260930u);
+        for (int qi = 0; qi < N; qi++) agents[qi]->setDesiredGoal(mission.agents[qi].desired_goal_position);
     }
 
     // :358-380 (GOTO)
@@ -331,7 +392,7 @@ class MultiSyncSimulator {
 
     bool is_collided = false, phase_stats_on = false;
     double safety_ratio_agent = SP_INFINITY, total_flight_time = 0, total_distance = 0;
-    int total_ticks = 0;
+    int total_ticks = 0, deadlock_tick = 0;
     double total_tick_ms = 0, last_tick_ms = 0;
 
   private:
@@ -344,7 +405,10 @@ class MultiSyncSimulator {
     std::vector<double> h_cost;
     std::vector<int> h_status, h_iters;
     std::vector<std::vector<point3d>> points;
-    bool initial_update = true, sharded = false;
+    bool initial_update = true, sharded = false, deadlock_reported = false, failure_reported = false;
+    int mission_index = 0, still_ticks = 0, failed_ticks = 0;
+    std::vector<int> failed_prev;        // agents whose QP was infeasible in the previous tick
+    std::vector<point3d> endpoints;      // horizon end point of every agent's previous plan
     double sim_start_time = 0, sim_current_time = 0, planning_time_sum = 0;
     long N_average = 0;
     std::string file_name_param;
@@ -383,6 +447,7 @@ int main(int argc, char **argv)
         else if (a == "--quiet") quiet = true;
         else if (a == "--phase-stats") param.phase_stats = true;
         else if (a == "--solver") { const std::string v = next(); if (v == "active_set") param.solver = 1; else if (v == "interior_point") param.solver = 0; else { std::fprintf(stderr, "lsc_sim: --solver active_set|interior_point\n"); return 2; } }
+        else if (a == "--on-deadlock") { const std::string v = next(); if (v == "noise") param.on_deadlock = 0; else if (v == "report") param.on_deadlock = 1; else if (v == "ignore") param.on_deadlock = 2; else { std::fprintf(stderr, "lsc_sim: --on-deadlock noise|report|ignore\n"); return 2; } }
         else if (a == "--static-goal") param.goal_mode_prior_based = false;
         else if (a == "--planner") { const std::string v = next(); param.planner_mode = v == "bvc" ? 1 : 0; }
         else if (a == "--slack") { const std::string v = next(); param.slack_mode = v == "dynamical_limit" ? 1 : (v == "collision_constraint" ? 2 : 0); }
@@ -397,7 +462,7 @@ int main(int argc, char **argv)
         else if (a == "--ranks") param.world = std::stoi(next());
         else if (a == "--rank") param.rank = std::stoi(next());
         else if (a == "--comm-file") param.comm_file = next();
-        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--mission m2.json ...] [--mission-dir DIR] [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats] [--solver active_set|interior_point] [--dt T --horizon H] | lsc_sim --replay result.csv\n"); return 2; }
+        else { std::fprintf(stderr, "usage: lsc_sim --mission m.json [--mission m2.json ...] [--mission-dir DIR] [--world map.bt] [--max-iter N] [--csv DIR] [--device D] [--static-goal] [--quiet] [--ranks W --rank R --comm-file PATH] [--planner lsc|bvc] [--slack none|dynamical_limit|collision_constraint] [--constraint-segments K] [--reset-threshold T] [--dimension 2|3] [--z-2d Z] [--max-noise X [--noise-seed S]] [--phase-stats] [--solver active_set|interior_point] [--on-deadlock noise|report|ignore] [--dt T --horizon H] | lsc_sim --replay result.csv\n"); return 2; }
     }
     if (!replay_file.empty()) {
         // MultiSyncReplayer (src/multi_sync_replayer.cpp): read a result CSV back -- needs no GPU -- and say what it holds
@@ -440,7 +505,7 @@ int main(int argc, char **argv)
             mission.initialize(mission_files[mi], world_file, param.world_dimension, param.world_z_2d);
             if (param.multisim_max_noise > 0.0) mission.addNoise(param.multisim_max_noise, param.world_dimension, param.multisim_noise_seed);   // src/mission.cpp:317
             if (mission_files.size() > 1) std::printf("[MultiSyncSimulator] mission %zu of %zu: %s\n", mi + 1, mission_files.size(), mission_files[mi].c_str());
-            MultiSyncSimulator sim(param, mission);
+            MultiSyncSimulator sim(param, mission, (int)mi);
             sim.run(quiet);
             if (sim.is_collided) rc = 1;
         } catch (const std::exception &e) {

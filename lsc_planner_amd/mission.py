@@ -86,7 +86,11 @@ def random_swarm(n, world=(-20, -20, 0, 20, 20, 5), seed=20260929, min_sep=0.6, 
     hi = np.asarray(world[3:], float) - shrink
 
     def sample():
+        # (the same draws and the same accept / reject decisions as a scan over all points placed so far, found through a cell hash:
+        #  a point closer than min_sep lies in one of the 27 cells around p -- swarms of 8192 agents in seconds instead of minutes)
         pts = []
+        cells = {}
+        cs = np.array([min_sep, min_sep, min_sep * downwash])
         draws = 0
         while len(pts) < n:
             draws += 1
@@ -98,14 +102,25 @@ def random_swarm(n, world=(-20, -20, 0, 20, 20, 5), seed=20260929, min_sep=0.6, 
                 c = np.floor(p / edt_res).astype(int) + 32768 - np.asarray(edt_key_min)
                 if (c < 0).any() or (c >= np.asarray(edt.shape)).any() or edt[c[0], c[1], c[2]] < min_clearance:
                     continue
-            for q in pts:
-                d = p - q
-                d[2] /= downwash
-                if np.dot(d, d) < min_sep * min_sep:
-                    ok = False
+            key = tuple(np.floor(p / cs).astype(int))
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    for dz in (-1, 0, 1):
+                        for q in cells.get((key[0] + dx, key[1] + dy, key[2] + dz), ()):
+                            d = p - q
+                            d[2] /= downwash
+                            if np.dot(d, d) < min_sep * min_sep:
+                                ok = False
+                                break
+                        if not ok:
+                            break
+                    if not ok:
+                        break
+                if not ok:
                     break
             if ok:
                 pts.append(p)
+                cells.setdefault(key, []).append(p)
         return np.asarray(pts)
 
     start = sample()

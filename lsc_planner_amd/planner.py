@@ -401,6 +401,12 @@ def tick_device_fused_batch(planners, states, goals, trajs_prev, trajs_next, sta
     (lsc_tick_device_fused_batch): every argument is a list with one entry per swarm; results are those of tick_device_fused."""
     n = len(planners)
     L = planners[0].L
+    # one library (liblsc_hip.so and liblsc_hip_m4.so lay the same lsc_ctx symbol out with different array sizes: a context of the other
+    # build would be read with the wrong sizes) and every context once (its stale-plan / hand-over buffers belong to ONE swarm of the launch)
+    if not all(p.L is L for p in planners):
+        raise LscError("tick_device_fused_batch: planners of different libraries (segment counts) in one batch")
+    if len({int(getattr(p.ctx, "value", p.ctx) or 0) for p in planners}) != n:
+        raise LscError("tick_device_fused_batch: the same planner (context) more than once in one batch")
     vp = ctypes.c_void_p
 
     def ptrs(ts):

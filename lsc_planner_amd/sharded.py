@@ -39,6 +39,45 @@ def all_gather_rows(dist, table, rank, rows):
     dist.all_gather_into_tensor(table.view(-1), mine.reshape(-1))
 
 
+def mission_list_ids(world_size, rank, missions_per_rank):
+    """The reference's node flies a LIST of missions (src/multi_sync_simulator_node.cpp:43-70, src/param.cpp:106-122).  Independent
+    missions need no exchange at all, so a list of world_size * missions_per_rank missions is cut into contiguous blocks like the agents of
+    a swarm are: rank r flies missions [r K, (r + 1) K) -- K of them in flight together, one launch per tick (lsc_tick_device_fused_batch)."""
+    return list(range(rank * missions_per_rank, (rank + 1) * missions_per_rank))
+
+
+def mission_list_summary(dist, rank, world_size, agents_planned, steps, elapsed_s, tick_p99_ms, device_index, device_uuid="", failed=0):
+    """Rank bookkeeping of `bench.py --gpus N --mission-list`: every rank reports what it flew; rank 0 returns the whole-job line
+    (sum of the agent-replans over the ranks divided by the SLOWEST rank's time, the per-rank values, the largest per-rank tick p99) and
+    checks that world_size processes each drove a device of their own.  No data-path collective: the only communication is this
+    report (and the barriers around the timed region).  Ranks other than 0 return None."""
+    mine = {"rank": rank, "agents": int(agents_planned), "steps": int(steps), "elapsed_s": float(elapsed_s), "tick_p99_ms": float(tick_p99_ms),
+            "device_index": int(device_index), "device_uuid": str(device_uuid), "failed_agents_last_tick": int(failed)}
+    if dist is not None and dist.is_initialized() and world_size > 1:
+        box = [None] * world_size
+        dist.all_gather_object(box, mine)
+    else:
+        box = [mine]
+    if rank != 0:
+        return None
+    if len(box) != world_size or sorted(b["rank"] for b in box) != list(range(world_size)):
+        raise RuntimeError(f"mission list: {world_size} ranks expected, reports from {[b['rank'] for b in box]}")
+    if len({b["device_index"] for b in box}) != world_size:
+        raise RuntimeError(f"mission list: ranks share a device: {[(b['rank'], b['device_index']) for b in box]}")
+    uu = [b["device_uuid"] for b in box if b["device_uuid"]]
+    if len(set(uu)) != len(uu):
+        raise RuntimeError(f"mission list: two ranks report the same device uuid: {uu}")
+    slowest = max(b["elapsed_s"] for b in box)
+    total = sum(b["agents"] * b["steps"] for b in box)
+    return {"value": total / slowest, "elapsed_s_max_over_ranks": slowest,
+            "per_rank_values": [round(b["agents"] * b["steps"] / b["elapsed_s"], 1) for b in sorted(box, key=lambda b: b["rank"])],
+            "per_rank_devices": [b["device_index"] for b in sorted(box, key=lambda b: b["rank"])],
+            "tick_p99_ms_max_over_ranks": max(b["tick_p99_ms"] for b in box),
+            "per_rank_tick_p99_ms": [round(b["tick_p99_ms"], 4) for b in sorted(box, key=lambda b: b["rank"])],
+            "agents_in_flight": sum(b["agents"] for b in box),
+            "failed_agents_last_tick": sum(b["failed_agents_last_tick"] for b in box)}
+
+
 class ShardedSwarm:
     """Generic sharded tick loop.  `tick_fn(state, goal, traj_prev, traj_next, planner_seq, first, count)` writes the
     shard's rows of traj_next: the HIP path on GPUs, the oracle in the gloo CPU tests; everything else is identical.

@@ -315,3 +315,53 @@ def test_prior_based_goal_planning_bitwise_and_mission_completes(L, oracle, solv
             break
     assert tick < 220, "mission did not finish"
     pl.close()
+
+
+@pytest.mark.parametrize("name,n_ticks", [("multi_simple4", 120), ("multi_circle20", 240)])
+def test_symmetric_missions_under_the_default_solver_follow_the_oracle_tick_by_tick(L, oracle, ticks, name, n_ticks):
+    """BASELINE configs[0] / configs[1] in closed loop under the DEFAULT solver (the exact active-set solve) with multisim/max_noise = 0 as
+    launch/testall_empty.launch:47 sets it, held to the (exact) oracle at EVERY tick: goals bit for bit (goalPlanningWithPriority,
+    src/traj_planner.cpp:540-608), statuses equal, costs and plans within the tolerance table.  Both missions are PERFECTLY symmetric
+    (agent i and its partner are mirror images), the exact optimum keeps them so, and the strict comparisons of the priority rule
+    (:566-577) tie for good.  The documented outcome -- the oracle's as much as the kernel's, so a property of the reference's rule under
+    an exact QP solver, not a kernel artefact:
+      multi_simple4 : agents 0 and 1 -- head-on along the x axis -- stop 1.15 m from their goals (tick ~19) while the diagonal pair arrives,
+                      and every plan's end point stands still from tick ~50 on;
+      multi_circle20: four agents' QPs turn infeasible in the crowd (tick ~205), two of them (2 and 18, mirror images) never recover --
+                      an agent keeps its stale plan on a failure (src/traj_planner.cpp:1548-1585).
+    lsc_sim reports both and applies the reference's remedy, multisim/max_noise, to the first (tests/test_gpu_sim.py); profiles/
+    r06_closed_loop_default_solver.log is this loop's print-out (tests/closed_loop_default.py)."""
+    from lsc_planner_amd.planner import next_state_host
+    ms = golden_mission(ticks, name)
+    N = ms.qn
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))          # the library's default solver
+    sw = oracle_swarm(oracle, ms)
+    state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
+    traj = np.zeros((N, 3, 30), np.float32)
+    still = 0
+    failed_ticks = np.zeros(N, int)
+    for tick in range(1, n_ticks + 1):
+        g = pl.plan(state, ms.goal, traj)
+        og = oracle.goal_prior_based(state, ms.goal, traj, tick)
+        assert np.array_equal(pl.last_goals(), og), tick
+        sw.stale[:] = traj if tick > 1 else 0
+        o = sw.tick(state, og, traj, tick, nthreads=8)
+        assert np.array_equal(g["status"], o["status"]), (tick, g["status"], o["status"])
+        ok = g["status"] == 0
+        assert (np.abs(g["cost"] - o["cost"])[ok] <= (COST_RTOL * np.abs(o["cost"]) + COST_ATOL)[ok]).all(), tick
+        assert np.abs(g["traj"] - o["traj"]).max() <= TRAJ_ATOL, tick              # (a failed agent keeps its stale plan in both)
+        still = still + 1 if np.abs(g["traj"][:, :, 29] - traj[:, :, 29]).max() < 1e-5 else 0
+        failed_ticks = np.where(g["status"] == 1, failed_ticks + 1, 0)
+        traj = g["traj"]
+        state = next_state_host(traj)
+        p = state[:, :3].astype(np.float64).copy(); p[:, 2] /= 2.0
+        D = np.linalg.norm(p[:, None] - p[None], axis=2) + np.eye(N) * 9
+        assert D.min() >= 0.3 - 1e-4, tick                                          # nobody collides while waiting
+    dist = np.linalg.norm(state[:, :3] - ms.goal, axis=1)
+    assert dist.max() > 0.1, "the mission finished: the symmetry was broken somewhere"
+    if name == "multi_simple4":
+        assert (g["status"] == 0).all() and still >= 50 and np.abs(dist[:2] - 1.15).max() < 1e-3 and dist[2:].max() < 1e-3, (still, dist)
+    else:
+        assert np.nonzero(failed_ticks >= 20)[0].tolist() == [2, 18], failed_ticks
+        assert (dist[[2, 18]] > 8.0).all() and (np.delete(dist, [2, 18]) < 0.1).all(), dist
+    pl.close()

@@ -13,10 +13,12 @@ pytestmark = pytest.mark.gpu
 
 SIM = os.path.join(ROOT, "lsc_planner_amd", "lsc_sim")
 # The golden mission multi_simple4 is PERFECTLY symmetric.  The active-set solve (lsc_sim's default) returns the exact optimum, the swarm
-# stays symmetric to the last float32 bit and ties in the priority rule for good; an interior point -- the oracle's, the kernel's, and by
-# all appearances the reference's CPLEX -- leaves 1e-6 m of agent-dependent noise that breaks the tie.  Runs that are held to the oracle's
-# mission (55 ticks) therefore name the interior point; the reference's own remedy is multisim/max_noise (launch/simulation.launch: 0.02).
-EXACT = ["--solver", "interior_point"]
+# stays symmetric to the last float32 bit and ties in the priority rule for good (the exact oracle does the same, tick by tick:
+# test_gpu_parity.py::test_symmetric_missions_under_the_default_solver_follow_the_oracle_tick_by_tick); an interior point leaves 1e-6 m of
+# agent-dependent noise that breaks the tie.  lsc_sim notices the deadlock (the reference's own bookkeeping, src/traj_planner.cpp:396-409) and
+# applies the reference's remedy, multisim/max_noise (launch/simulation.launch:47: 0.02), so the DEFAULT run ends.  Only the tests whose
+# subject IS the interior point (its 55-tick mission, the instrumented kernel) name it.
+INTERIOR_POINT = ["--solver", "interior_point"]
 
 
 def _write_mission(path, ms):
@@ -34,11 +36,14 @@ def test_headless_simulator_runs_the_reference_mission(ticks, tmp_path):
     ms = golden_mission(ticks, "multi_simple4")
     mp = tmp_path / "multi_simple4.json"
     _write_mission(str(mp), ms)
-    r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(tmp_path), "--quiet"] + EXACT, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(tmp_path), "--quiet"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr                 # 0 = finished without collision
     out = r.stdout
+    # default solver, max_noise 0 (launch/testall_empty.launch:47): the swarm gridlocks in the middle (tick ~50), the simulator says so
+    # 20 ticks later, applies the goal noise once, and the mission ends
+    assert "deadlock: no agent's horizon end point has moved for 20 ticks" in r.stderr and "applying it now" in r.stderr, r.stderr
     t = float(out.split("total flight time:")[1].split()[0])
-    assert 5.0 < t < 16.0                                          # oracle mission: 55 ticks = 10.8 s
+    assert 14.0 < t < 32.0, t                                      # 10.8 s of flight (oracle mission, interior point) + the wait for the verdict
     ratio = float(out.split("safety ratio between agent:")[1].split()[0])
     assert ratio >= 1.0 - 1e-3
     # result CSV in the reference's schema: 15 columns per agent, 2 record steps per tick
@@ -57,7 +62,7 @@ def test_result_csv_round_trip_through_the_reader(ticks, tmp_path):
     ms = golden_mission(ticks, "multi_simple4")
     mp = tmp_path / "multi_simple4.json"
     _write_mission(str(mp), ms)
-    r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(tmp_path), "--quiet"] + EXACT, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(tmp_path), "--quiet"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     flight = float(r.stdout.split("total flight time:")[1].split()[0])
     dist = float(r.stdout.split("total distance:")[1].split()[0])
@@ -72,12 +77,34 @@ def test_result_csv_round_trip_through_the_reader(ticks, tmp_path):
     for q in range(4):
         w = lines[1 + q].split()
         assert w[3] == "0.15"
-        assert np.linalg.norm(np.array(w[5:8], float) - ms.goal[q]) < 0.15, (q, w)
+        assert np.linalg.norm(np.array(w[5:8], float) - ms.goal[q]) < 0.15, (q, w)      # (goal threshold 0.1 + the remedy's noise, <= 0.02 per axis)
+
+
+def test_symmetric_mission_gridlocks_under_the_exact_optimum_and_the_simulator_says_so(ticks, tmp_path):
+    """configs[0] as testall_empty.launch flies it (max_noise 0), default solver, remedy OFF: the two head-on agents stop 1.15 m from their
+    goals and stay there until --max-iter -- the exact oracle's behaviour too (test_gpu_parity.py) --, lsc_sim prints the deadlock line ONCE and
+    names the reference's remedy; --on-deadlock ignore is the reference's silence.  The interior point's 1e-6 m of noise breaks the tie:
+    that run is the oracle's 55-tick mission."""
+    ms = golden_mission(ticks, "multi_simple4")
+    mp = tmp_path / "multi_simple4.json"
+    _write_mission(str(mp), ms)
+    r = subprocess.run([SIM, "--mission", str(mp), "--max-iter", "150", "--on-deadlock", "report"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr                 # nobody collides while waiting
+    assert r.stderr.count("deadlock: no agent's horizon end point has moved for 20 ticks") == 1 and "--max-noise 0.02" in r.stderr
+    assert "applying it now" not in r.stderr
+    assert float(r.stdout.split("total flight time:")[1].split()[0]) == 0.0          # isFinished() never held
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("[MultiSyncSimulator] iter ")][-1]
+    assert "max dist to goal 1.150" in last and "qp failures 0" in last, last
+    q = subprocess.run([SIM, "--mission", str(mp), "--max-iter", "150", "--on-deadlock", "ignore", "--quiet"], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0 and "deadlock" not in q.stderr and float(q.stdout.split("total flight time:")[1].split()[0]) == 0.0
+    ip = subprocess.run([SIM, "--mission", str(mp), "--quiet"] + INTERIOR_POINT, capture_output=True, text=True, timeout=300)
+    assert ip.returncode == 0 and "deadlock" not in ip.stderr, ip.stderr
+    assert 5.0 < float(ip.stdout.split("total flight time:")[1].split()[0]) < 16.0   # oracle mission: 55 ticks = 10.8 s
 
 
 def test_default_solver_flies_the_reference_mission_with_the_launch_file_s_noise(ticks, tmp_path):
     """lsc_sim's default solver -- the active-set solve -- on the reference's 4-agent mission with multisim/max_noise = 0.02 as
-    launch/simulation.launch sets it (the mission itself is perfectly symmetric, see EXACT): finishes without collision in about the
+    launch/simulation.launch sets it (the mission itself is perfectly symmetric, see INTERIOR_POINT): finishes without collision in about the
     oracle's time, for three seeds."""
     ms = golden_mission(ticks, "multi_simple4")
     mp = tmp_path / "multi_simple4.json"
@@ -221,7 +248,7 @@ def test_goal_noise_like_the_published_runs(ticks, tmp_path):
     outs = []
     for d in ("a", "b", "c"):
         (tmp_path / d).mkdir()
-        args = [SIM, "--mission", str(mp), "--csv", str(tmp_path / d), "--quiet"] + (EXACT if d == "c" else ["--max-noise", "0.02", "--noise-seed", "7"])
+        args = [SIM, "--mission", str(mp), "--csv", str(tmp_path / d), "--quiet"] + ([] if d == "c" else ["--max-noise", "0.02", "--noise-seed", "7"])
         r = subprocess.run(args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         rows = list(csv.reader(open(tmp_path / d / "result_LSC_4agents.csv")))[1:]
@@ -360,7 +387,7 @@ def test_phase_stats_fill_the_planning_time_columns(ticks, tmp_path):
         d = tmp_path / tag
         d.mkdir()
         # (the instrumented kernel is the interior point's: both runs name it, so that "the run itself is the same" can be held to the digit)
-        r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(d), "--quiet", "--reset-threshold", "0"] + EXACT + extra,
+        r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(d), "--quiet", "--reset-threshold", "0"] + INTERIOR_POINT + extra,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         outs[tag] = list(csv.DictReader(open(d / "summary_LSC_4agents.csv")))[0]

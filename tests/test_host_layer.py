@@ -175,6 +175,78 @@ def test_sharded_stepping_gloo_equals_single_process(oracle, tmp_path, world):
         assert np.array_equal(np.load(tmp_path / f"rank{r}.npy").reshape(5, 3, 30), traj), r
 
 
+_ML_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from lsc_planner_amd.sharded import mission_list_ids, mission_list_summary
+rank, world = int(sys.argv[2]), int(sys.argv[3])
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[4]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+K = 4
+ids = mission_list_ids(world, rank, K)
+# stand-in numbers for what bench.py's mission_list_leg measures on a GPU: K missions of 64 agents, 20 steps, rank 1 is the slow one
+same_device = len(sys.argv) > 6 and sys.argv[6] == "same-device"
+try:
+    out = mission_list_summary(dist, rank, world, 64 * len(ids), 20, 0.001 * (1 + rank), 0.05 + 0.01 * rank, 0 if same_device else rank, f"uuid-{rank}", failed=rank)
+    res = {"ids": ids, "summary": out}
+except RuntimeError as e:
+    res = {"ids": ids, "error": str(e)}
+json.dump(res, open(sys.argv[5] + f"/ml_rank{rank}.json", "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_mission_list_rank_bookkeeping_gloo(tmp_path):
+    """bench.py --gpus 2 --mission-list, the part that needs no GPU: rank r flies missions [r K, (r + 1) K) of the list; rank 0's line is the
+    sum of the agent-replans over the SLOWEST rank's time, carries the per-rank values and the largest per-rank tick p99, and refuses a run
+    in which two ranks drove the same device (outer loop: src/multi_sync_simulator_node.cpp:43-70)."""
+    import json
+    import socket
+    w = tmp_path / "ml_worker.py"
+    w.write_text(_ML_WORKER)
+    for mode in ("", "same-device"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        procs = [subprocess.Popen([sys.executable, str(w), ROOT, str(r), "2", str(port), str(tmp_path)] + ([mode] if mode else [])) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=240) == 0
+        r0, r1 = (json.load(open(tmp_path / f"ml_rank{r}.json")) for r in range(2))
+        assert r0["ids"] == [0, 1, 2, 3] and r1["ids"] == [4, 5, 6, 7]
+        if mode:
+            assert "ranks share a device" in r0["error"]
+            continue
+        assert r1["summary"] is None
+        sm = r0["summary"]
+        assert sm["agents_in_flight"] == 512 and sm["elapsed_s_max_over_ranks"] == 0.002
+        assert abs(sm["value"] - 2 * 256 * 20 / 0.002) < 1e-6
+        assert sm["per_rank_values"] == [round(256 * 20 / 0.001, 1), round(256 * 20 / 0.002, 1)] and sm["per_rank_devices"] == [0, 1]
+        assert abs(sm["tick_p99_ms_max_over_ranks"] - 0.06) < 1e-12 and sm["failed_agents_last_tick"] == 1
+
+
+def test_mission_list_of_the_bench_is_the_concurrent_missions_family():
+    """The missions of `bench.py --mission-list` on one GPU are the ones `concurrent_missions` flies (mission 0 = the headline swarm, the
+    others that swarm turned about the vertical axis); with more ranks the list is longer and every mission distinct."""
+    import importlib.util
+    import lsc_planner_amd as L
+    from lsc_planner_amd.sharded import mission_list_ids
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ms, _ = bench.weak_scaling_mission(L, 1)
+    one = bench.mission_list_missions(L, ms, mission_list_ids(1, 0, 4), 4)
+    assert one[0] is ms and len(one) == 4
+    for m in range(1, 4):
+        ref = bench.rotated_mission(L, ms, 2.0 * np.pi * (m / (7.0 * 4) + 0.013 * m), "x")
+        assert np.array_equal(one[m].start, ref.start) and np.array_equal(one[m].goal, ref.goal)
+    seen = []
+    for r in range(2):
+        for m in bench.mission_list_missions(L, ms, mission_list_ids(2, r, 4), 8):
+            assert m.qn == 64 and not any(np.array_equal(m.start, o) for o in seen)
+            seen.append(m.start)
+    assert len(seen) == 8
+
+
 def test_weak_scaling_workload_of_the_bench_is_one_circle_per_rank():
     """bench.py --gpus G: G circles of 64 agents in one world, rank r owning circle r (lsc_comm_info's partitioning), each an
     exact translate of the single-GPU mission and far enough from the others that no row between circles can be active."""
