@@ -66,7 +66,7 @@ EXPORTS = [
     "lsc_set_distmap", "lsc_replan_tick", "lsc_tick_device", "lsc_tick_device_fused", "lsc_propagate_device", "lsc_safety_ratio", "lsc_sweep_device", "lsc_sweep_device_f32",
     "lsc_gjk_batch", "lsc_kernel_time_ms", "lsc_kernel_times_ms", "lsc_set_timing", "lsc_last_row_counts", "lsc_iterations_total", "lsc_phase_profile", "lsc_goal_profile", "lsc_goal_key_table", "lsc_general_profile", "lsc_dump_qp", "lsc_solver_residuals", "lsc_solver_trace", "lsc_edt_from_bt", "lsc_free_host", "lsc_last_goals", "lsc_set_goal_trace", "lsc_get_goal_trace",
     "lsc_last_bucket_max", "lsc_row_capacity", "lsc_comm_unique_id", "lsc_comm_init", "lsc_comm_info", "lsc_tick_device_sharded", "lsc_replan_tick_all",
-    "lsc_row_iterations_total", "lsc_tick_device_fused_batch", "lsc_solver_stats",
+    "lsc_row_iterations_total", "lsc_tick_device_fused_batch", "lsc_solver_stats", "lsc_neighbour_counts",
 ]
 
 
@@ -133,6 +133,7 @@ def load_library(segments=5):
     L.lsc_kernel_times_ms.argtypes = [vp, ctypes.c_int, dp, ctypes.c_long, ctypes.POINTER(ctypes.c_long)]
     L.lsc_set_timing.argtypes = [vp, ctypes.c_int]
     L.lsc_last_row_counts.argtypes = [vp, ip]
+    L.lsc_neighbour_counts.argtypes = [vp, ip]
     L.lsc_last_bucket_max.argtypes = [vp, ip]
     L.lsc_row_capacity.argtypes = [vp, ip, ip]
     L.lsc_phase_profile.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]

@@ -309,6 +309,9 @@ struct lsc_ctx {
     std::vector<int> nb_seq;
     int *d_nrows = nullptr, *d_bmax = nullptr, *d_order = nullptr;
     float *d_obs_bound = nullptr;
+    // neighbour lists of large swarms (lsc_neigh.hip): one allocation (base neigh.seg_bound ... see lsc_set_agents); neigh.cnt == nullptr: not in use
+    NeighArgs neigh = {};
+    void *d_neigh = nullptr;
     long long *d_iters_acc = nullptr;
     long long *d_prof = nullptr;
     double *d_dbg = nullptr;
@@ -497,6 +500,8 @@ static void free_agents(lsc_ctx *c)
                     c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_cost,
                     c->d_onormal, c->d_od, c->d_spill, c->d_ever, c->d_gen_ws, c->d_bmax, c->d_order, c->d_obs_bound};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->d_neigh) (void)hipFree(c->d_neigh);
+    c->d_neigh = nullptr; c->neigh = NeighArgs{};
     c->d_spill = nullptr; c->spill_slots = 0; c->spill_stride = 0;
     c->d_bmax = nullptr; c->d_order = nullptr; c->d_obs_bound = nullptr; c->d_ever = nullptr; c->d_gen_ws = nullptr; c->gen_slots = 0; c->gen_stride = 0;
     if (c->h_in) { (void)hipHostFree(c->h_in); c->h_in = nullptr; }
@@ -636,6 +641,43 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMalloc(&c->d_order, sizeof(int) * (size_t)N));
     HIPCHK(c, hipMalloc(&c->d_obs_bound, sizeof(float) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
+    if (N >= NEIGH_MIN_AGENTS && (N - 1) * M <= 0xffff && c->cfg.prune == 1 && !getenv("LSC_NO_NEIGHBOUR_LISTS")) {
+        // Neighbour lists (lsc_neigh.hip).  Cell size: about the distance inside which a unit can matter at all for an agent at its
+        // velocity limit over the horizon (2 x reach + radii; the query visits ~5 x 5 cells then); any size is correct, the size only
+        // decides how many cells a query visits and how many agents share a bucket.  LSC_NEIGH_CELL overrides it (measurements).
+        NeighArgs &g = c->neigh;
+        double vm = 0.0, rm = 0.0, dmin = 1e300, dmax = 0.0;
+        for (int i = 0; i < N; i++) {
+            for (int k = 0; k < 3; k++) vm = std::max(vm, max_vel[3 * i + k]);
+            rm = std::max(rm, radius[i]); dmin = std::min(dmin, dw_obs[i]); dmin = std::min(dmin, downwash[i]);
+            dmax = std::max(dmax, dw_obs[i]); dmax = std::max(dmax, downwash[i]);
+        }
+        double cell = 2.0 * vm * M * c->cfg.dt + 4.0 * rm;
+        if (const char *e = getenv("LSC_NEIGH_CELL")) { const double v = atof(e); if (v > 0.0) cell = v; }
+        if (!(cell > 1e-3)) cell = 1e-3;
+        g.sc_max = std::max(1.0, 1.0 / dmin); g.zscale = std::max(1.0, dmax);
+        g.inv_cell = 1.0 / cell; g.inv_cell_z = 1.0 / (cell * g.zscale);
+        unsigned H = 1024;
+        while (H < 4u * (unsigned)N) H <<= 1;
+        g.hmask = H - 1; g.ovf_cap = 4096; g.list_cap = 1024; g.tag = 0;
+        // (capacities the tests shrink to drive the overflow paths: an agent without a list culls by itself, results do not change)
+        if (const char *e = getenv("LSC_NEIGH_OVF_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 65536) g.ovf_cap = v; }
+        if (const char *e = getenv("LSC_NEIGH_LIST_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 65536) g.list_cap = v; }
+        const size_t b_seg = sizeof(float) * 4 * M * (size_t)N, b_reach = sizeof(float) * M * (size_t)N, b_cells = 32 * (size_t)H, b_glob = 64,
+                     b_ovf = sizeof(unsigned short) * (size_t)g.ovf_cap, b_list = sizeof(unsigned short) * (size_t)g.list_cap * N, b_cnt = sizeof(int) * (size_t)N;
+        auto al16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+        const size_t total = al16(b_seg) + al16(b_reach) + al16(b_cells) + al16(b_glob) + al16(b_ovf) + al16(b_list) + al16(b_cnt);
+        HIPCHK(c, hipMalloc(&c->d_neigh, total));
+        HIPCHK(c, hipMemset(c->d_neigh, 0, total));         // tag 0 everywhere: the first tick's tag is 1
+        unsigned char *p = static_cast<unsigned char *>(c->d_neigh);
+        g.seg_bound = reinterpret_cast<float *>(p); p += al16(b_seg);
+        g.reach = reinterpret_cast<float *>(p); p += al16(b_reach);
+        g.cells = reinterpret_cast<unsigned long long *>(p); p += al16(b_cells);
+        g.glob = reinterpret_cast<unsigned long long *>(p); p += al16(b_glob);
+        g.ovf = reinterpret_cast<unsigned short *>(p); p += al16(b_ovf);
+        g.list = reinterpret_cast<unsigned short *>(p); p += al16(b_list);
+        g.cnt = reinterpret_cast<int *>(p);
+    }
     HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (2 * (size_t)N + 4)));       // [N] iterations, [N] iterations x LSC rows, [4] counters of the active-set solve
     HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));          // [N] plan kernel, [N] general kernel
     HIPCHK(c, hipMemset(c->d_prof, 0, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));
@@ -962,6 +1004,8 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.cap_tp = (c->count > c->n_cu) ? c->cap_tp : 0; a.smem_tp = c->smem_tp;
     a.order = (c->count > 2 * c->n_cu) ? c->d_order : nullptr;   // more than one round of throughput workgroups
     a.obs_bound = c->d_obs_bound;                                // obstacle-level pre-cull (throughput build; latency build of large swarms: launch_plan decides)
+    a.neigh = c->neigh.cnt ? &c->neigh : nullptr;                // neighbour lists of a large swarm: run_plan launches their kernels and sets the three fields below
+    a.nl_list = nullptr; a.nl_count = nullptr; a.nl_cap = 0;
     a.state = d_state; a.goal = d_goal; a.traj_prev = d_prev;
     a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
     a.vmax = c->d_vmax; a.amax = c->d_amax; a.vnom = c->d_vnom;
@@ -1043,11 +1087,24 @@ static int planar_inputs_ok(lsc_ctx *c, const float *state, const float *prev_tr
     return LSC_OK;
 }
 
-static int run_plan(lsc_ctx *c, const PlanArgs &a, hipStream_t st, int general_hint = -1)
+static int run_plan(lsc_ctx *c, const PlanArgs &a_in, hipStream_t st, int general_hint = -1)
 {
     const size_t smem = plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, c->cap);
     hipEvent_t e1 = nullptr;
     if (c->timing && timing_begin(c, 0, st, &e1) != LSC_OK) return LSC_EHIP;
+    PlanArgs a = a_in;
+    if (a.neigh && a.count > 0 && !a.out_normal && !a.general_all && !a.trace) {
+        // large swarm: bounds of every agent + the grid, then the shard's unit lists (two small launches on the tick's stream, inside the timed region)
+        NeighArgs &g = *a.neigh;
+        if (++g.tag == 0) { HIPCHK(c, hipMemsetAsync(g.cells, 0, 32 * ((size_t)g.hmask + 1), st)); HIPCHK(c, hipMemsetAsync(g.glob, 0, 64, st)); g.tag = 1; }
+        g.N = a.N; g.first = a.first; g.count = a.count; g.planner_seq = a.planner_seq; g.dtf = (float)c->hm.m.dt; g.dim2 = a.dim2;
+        g.hv_scale = c->hm.m.hv_scale; g.ha_scale = c->hm.m.ha_scale; g.z2d = c->hm.m.z2d;
+        g.state = a.state; g.traj_prev = a.traj_prev;
+        g.radius = a.radius; g.radius_obs = a.radius_obs; g.downwash = a.downwash; g.downwash_obs = a.downwash_obs; g.vmax = a.vmax; g.amax = a.amax;
+        g.order = (a.cap_tp > 0) ? a.order : nullptr; g.iters = a.iters; g.nrows = a.nrows; g.obs_bound = a.obs_bound;
+        HIPCHK(c, launch_neigh(g, st));
+        a.nl_list = g.list; a.nl_count = g.cnt; a.nl_cap = g.list_cap;
+    }
     HIPCHK(c, launch_plan(a, smem, st));
     if (c->d_spill) HIPCHK(c, launch_plan_spill(a, c->spill_slots, plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, 0), st));
     if (want_general(c, general_hint)) HIPCHK(c, launch_general(a, c->gen_slots, st));
@@ -1891,6 +1948,15 @@ int lsc_last_row_counts(lsc_ctx *c, int *rows /*[N]*/)
 {
     if (!c || !rows || c->N == 0) return LSC_EINVAL;
     HIPCHK(c, hipMemcpy(rows, c->d_nrows, sizeof(int) * (size_t)c->N, hipMemcpyDeviceToHost));
+    return LSC_OK;
+}
+
+// read-back of the neighbour-list lengths of the last tick (diagnostics)
+int lsc_neighbour_counts(lsc_ctx *c, int *units /*[N]*/)
+{
+    if (!c || !units || c->N == 0) return LSC_EINVAL;
+    if (!c->neigh.cnt) { c->err = "this context builds no neighbour lists (fewer than 512 agents, prune != 1, or LSC_NO_NEIGHBOUR_LISTS)"; return LSC_ESTATE; }
+    HIPCHK(c, hipMemcpy(units, c->neigh.cnt, sizeof(int) * (size_t)c->N, hipMemcpyDeviceToHost));
     return LSC_OK;
 }
 

@@ -16,6 +16,7 @@
 namespace lsc {
 
 struct PlanArgs;
+struct NeighArgs;
 // an argument block read where it lies, in the kernarg segment: constant address space => scalar loads, no private copy
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const __attribute__((address_space(4))) PlanArgs KArgs;
@@ -36,6 +37,11 @@ struct PlanArgs {
     float *obs_bound;          // throughput build: [N][4] bounding sphere of every agent's predicted control points, or null
     int cap_tp;                // > 0: use the 256-lane throughput build with this row capacity and smem_tp bytes of LDS
     size_t smem_tp;
+    NeighArgs *neigh;          // HOST pointer (never read on the device), or null: the context's neighbour-list buffers; launch_plan runs the two
+                               // kernels of lsc_neigh.hip in front of the tick of a large swarm and fills the three fields below
+    const unsigned short *nl_list;   // [N][nl_cap] per agent: the units (obstacle * M + segment) phase B has to look at, ascending
+    const int *nl_count;       // [N] entries of the agent's list; < 0: no list (capacity overflow), the agent culls by itself
+    int nl_cap;
     const float *state;        // [N][9]
     const float *goal;         // [N][3] current goal (mode/goal static) or desired goal (prior_based)
     int goal_mode;             // 0 static, 1 prior_based: goalPlanningWithPriority runs in phase A of the plan kernel
@@ -78,6 +84,37 @@ struct PlanArgs {
     size_t gen_stride;
 };
 constexpr int PROF_PHASES = 16;
+
+// Neighbour lists of a large swarm (lsc_neigh.hip): which (obstacle, segment) units can carry a row that survives the pruning of phase B,
+// found through a uniform grid instead of a walk over all N - 1 obstacles per agent (the loop being replaced: `for oi < N_obs`,
+// src/traj_planner.cpp:1335-1407).  Two launches in front of the tick: build (bounds of every agent + one grid insertion each), query
+// (one workgroup per agent of the shard: the cells its reach overlaps -> sphere tests -> a sorted unit list in HBM).
+constexpr int NEIGH_SLOTS = 12;                  // agents a grid bucket holds (one 32-byte sector: a tagged counter + 12 indices); the rest overflows
+constexpr int NEIGH_MIN_AGENTS = 512;            // swarms below this keep the in-kernel cull
+struct NeighArgs {
+    int N, first, count, planner_seq;
+    float dtf;
+    int dim2;
+    double hv_scale, ha_scale, z2d;              // Model::hv_scale, ha_scale, z2d
+    const float *state, *traj_prev;
+    const double *radius, *radius_obs, *downwash, *downwash_obs, *vmax, *amax;
+    int *order;                                  // launch order of the throughput build (longest agent first), or null
+    const int *iters, *nrows;
+    float *obs_bound;                            // [N][4] bounding sphere of all predicted control points (the in-kernel cull's, kept for agents without a list)
+    float *seg_bound;                            // [N][M][4] bounding sphere of the predicted control points of each segment
+    float *reach;                                // [N][M] per segment max_i(|c_{0,2} - p_{m,i}| + reach radius of c_{m,i}), rounded up
+    unsigned long long *cells;                   // [hmask + 1][4] buckets: tag << 32 | count, then NEIGH_SLOTS agent indices (16 bit)
+    unsigned long long *glob;                    // [8] tagged maxima: obstacle-side radius, overflow count, cell bounding box (6)
+    unsigned short *ovf;                         // [ovf_cap] agents whose bucket was full
+    int ovf_cap;
+    unsigned tag, hmask;                         // tag of this tick (buckets of older ticks count as empty: nothing is ever cleared)
+    double inv_cell, inv_cell_z;                 // 1 / cell size in x, y and in z (z cells are downwash times taller)
+    double sc_max, zscale;                       // max(1, 1 / smallest downwash), max(1, largest downwash)
+    unsigned short *list;                        // [N][list_cap]
+    int *cnt;                                    // [N]
+    int list_cap;
+};
+hipError_t launch_neigh(const NeighArgs &a, hipStream_t st);
 
 // Several independent swarms -- one argument block each -- planned by ONE launch (blockIdx.y = swarm): the reference flies a list of
 // missions back to back (src/multi_sync_simulator_node.cpp:43-70, src/param.cpp:106-122), and a 64-agent swarm is 64 workgroups on a

@@ -17,47 +17,13 @@
 #include "lsc_gjk.hpp"
 #include "lsc_model.hpp"
 #include "lsc_kernels.h"
+#include "lsc_predict.hpp"
 #include "lsc_wave.hpp"
 
 namespace lsc {
 
 constexpr int NT = 512;      // lanes per agent workgroup: 8 waves, 2 per SIMD (register budget 256 per lane)
 constexpr int NWAVE = NT / 64;
-
-// ---------------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------------
-// Predicted / initial control points of agent q for segment m.
-//   planner_seq < 2 : pos + vel * m_intp * dt   (float32, src/traj_planner.cpp:699-712, 1030-1037)
-//   else            : previous plan shifted by one segment, last segment = 6 x previous end point
-__device__ __forceinline__ void load_segment(const float *__restrict__ state, const float *__restrict__ traj_prev, int q,
-                                             int m, int planner_seq, float dtf, F3 out[6])
-{
-#pragma clang fp contract(off)   // float32 semantics of octomath::Vector3: no fused multiply-add
-    if (planner_seq < 2) {
-        const float *s = state + 9 * q;
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            float mi = (float)((double)m + (double)i / (double)DEG);
-            float ax = (s[3] * mi) * dtf, ay = (s[4] * mi) * dtf, az = (s[5] * mi) * dtf;
-            out[i] = F3{s[0] + ax, s[1] + ay, s[2] + az};
-        }
-    } else {
-        const float *t = traj_prev + (size_t)q * NV;
-        if (m < M - 1) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                int c = (m + 1) * NC + i;
-                out[i] = F3{t[c], t[SEGV + c], t[2 * SEGV + c]};
-            }
-        } else {
-            int c = (M - 1) * NC + DEG;
-            F3 e = F3{t[c], t[SEGV + c], t[2 * SEGV + c]};
-#pragma unroll
-            for (int i = 0; i < 6; i++) out[i] = e;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Dense LSC sweep: one lane per (agent, obstacle, segment).  Output is what CollisionConstraints holds
@@ -1069,8 +1035,14 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         const int prune_mode = md.prune == 3 ? 1 : md.prune;      // 3: exact test only (parity tests of the cull itself)
         uint16_t *ulist = reinterpret_cast<uint16_t *>(rrhs);     // rrhs, rn, cmap (24 B per row) are first written by the scatter
         const int list_cap = SPILL ? 0x7fffffff : 4 * R + 6 * R + 2 * R;
-        bool cull = md.prune == 1 && !a.out_normal && n_units > NT && n_units <= 0xffff;
-        int n_list = n_units;
+        // Large swarms: the units worth looking at come as a list from lsc_neigh.hip (built through a uniform grid in front of the tick: a
+        // superset of what the cull below keeps, in the same ascending order -- the exact per-row test decides in both cases, so the rows
+        // are the same); an agent without a list (capacity overflow there) culls by itself.
+        const int n_given = (a.nl_count != nullptr && md.prune == 1 && !a.out_normal && n_units > 0) ? a.nl_count[qi] : -1;
+        const bool given = n_given >= 0;
+        const unsigned short *glist = a.nl_list + (size_t)qi * a.nl_cap;
+        bool cull = !given && md.prune == 1 && !a.out_normal && n_units > NT && n_units <= 0xffff;
+        int n_list = given ? n_given : n_units;
         if (cull) {
             if (tid == 0) S.listfull = 0;
             // Reach of every control point (distance from c_{0,2} + radius of its reachable box), per segment (cullB) and overall (cullA), one
@@ -1193,7 +1165,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         for (int base = 0; base < n_list; base += NT) {
             const int pos_u = base + tid;
             const bool live = pos_u < n_list;
-            const int u = live ? (cull ? (int)ulist[pos_u] : pos_u) : 0;
+            const int u = live ? (given ? (int)glist[pos_u] : (cull ? (int)ulist[pos_u] : pos_u)) : 0;
             const int oi = live ? u / M : 0, m = live ? u % M : 0;
             const int qj = oi < qi ? oi : oi + 1;
             F3 nrm = F3{0.f, 0.f, 0.f};
@@ -2908,7 +2880,8 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
         // throughput build: smaller capacity (an agent beyond it takes the second pass), two workgroups per CU
         t.cap = a.cap_tp;
         if (a.cap_tp <= 0) t.obs_bound = nullptr;
-        if (t.order || t.obs_bound) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
+        // (with neighbour lists -- a.nl_count -- both the bounds and the launch order were left by lsc_neigh.hip's kernels in front of this call)
+        if ((t.order || t.obs_bound) && !a.nl_count) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
         if (a.prof) hipLaunchKernelGGL(lsc_plan_tp_prof_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
         else if (a.solver >= 1 && !d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL((lsc_plan_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); }
         else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
@@ -2919,7 +2892,8 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     // obstacle-level cull every workgroup walks all 5 (N - 1) units through the unit-level cull -- ten passes of loads and two barriers each
     // at N = 1024, 18.6 of an agent's 50.6 us.  The bounding spheres cost one small launch (lsc_prep_kernel, ~4 us) in front of the tick.
     t.order = nullptr;                            // filled by lsc_prep_kernel only
-    if (t.obs_bound && a.N >= 512 && !a.out_normal) hipLaunchKernelGGL(lsc_prep_kernel, dim3((32 * a.N + 255) / 256), dim3(256), 0, st, t);
+    if (a.nl_count) {}                            // (bounds left by lsc_neigh.hip's build kernel: an agent without a list falls back to them)
+    else if (t.obs_bound && a.N >= 512 && !a.out_normal) hipLaunchKernelGGL(lsc_prep_kernel, dim3((32 * a.N + 255) / 256), dim3(256), 0, st, t);
     else t.obs_bound = nullptr;
     // solver 1: the active-set solve first (3-D worlds, production kernels); everything else keeps the interior point alone
     const bool gi = a.solver >= 1 && !a.prof;
@@ -2946,6 +2920,7 @@ hipError_t launch_plan_batch(const PlanArgs *a, int n, size_t smem, hipStream_t 
         if (alt_i != alt || (a[i].dim2 != 0) != d2 || a[i].prof || a[i].out_normal || a[i].trace) return hipErrorInvalidValue;
         b.a[i] = a[i];
         b.a[i].order = nullptr; b.a[i].obs_bound = nullptr;      // (filled by lsc_prep_kernel only: the throughput build is not batched)
+        b.a[i].nl_count = nullptr; b.a[i].nl_list = nullptr; b.a[i].neigh = nullptr;
         grid = a[i].count > grid ? a[i].count : grid;
     }
     for (int i = n; i < PLAN_BATCH_MAX; i++) { b.a[i] = a[0]; b.a[i].count = 0; }
@@ -2964,7 +2939,7 @@ hipError_t launch_plan_spill(const PlanArgs &a, int slots, size_t smem, hipStrea
     if (a.count == 0 || slots < 1 || !a.spill_ws) return hipSuccess;
     const int grid = a.count < slots ? a.count : slots;
     PlanArgs t = a;
-    if (!uses_throughput_build(a)) t.obs_bound = nullptr;      // (bounds of this tick exist only behind the throughput launch)
+    if (!uses_throughput_build(a) && !a.nl_count) t.obs_bound = nullptr;      // (bounds of this tick exist only behind the throughput launch or the neighbour-list build)
     if (a.dim2) hipLaunchKernelGGL(lsc_plan_spill_kernel<true>, dim3(grid), dim3(NT), smem, st, t);
     else hipLaunchKernelGGL(lsc_plan_spill_kernel<false>, dim3(grid), dim3(NT), smem, st, t);
     return hipGetLastError();

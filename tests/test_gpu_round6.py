@@ -1,0 +1,144 @@
+"""Round 6: neighbour lists of large swarms (lsc_neigh.hip) -- the obstacle loop of TrajPlanner::generateLSC
+(src/traj_planner.cpp:1335-1407) through a uniform grid instead of a walk over all N - 1 obstacles per agent."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import lsc_planner_amd as L
+    return L
+
+
+def _start(ms):
+    state = np.zeros((ms.qn, 9), np.float32)
+    state[:, :3] = ms.start
+    return state, np.zeros((ms.qn, 3, 30), np.float32)
+
+
+class _Env:
+    """Environment variables lsc_set_agents reads (capacities / cell size of the neighbour lists) for the planners created inside."""
+
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _fly(L, planners, ms, ticks, check):
+    from lsc_planner_amd.planner import next_state_host
+    state, traj = _start(ms)
+    for tick in range(1, ticks + 1):
+        g = [p.plan(state, ms.goal, traj) for p in planners]
+        check(tick, g)
+        traj = g[0]["traj"]
+        state = next_state_host(traj)
+
+
+@pytest.mark.parametrize("n,world,ticks", [(1024, (-20, -20, 0, 20, 20, 5), 40), (640, (-9, -9, 0, 9, 9, 3.0), 25)])
+def test_neighbour_lists_change_nothing_but_the_time(L, n, world, ticks):
+    """Swarms of >= 512 agents get their (obstacle, segment) units as a sorted list from the grid kernels instead of walking all obstacles:
+    a superset of what the in-kernel cull keeps, in the same order, and the exact per-row test decides in both cases -- so plans, costs,
+    statuses, iteration and row counts are bit-identical to the context without lists (LSC_NO_NEIGHBOUR_LISTS: the round-5 cull) and to
+    prune = 3 (no cull at all), tick after tick of a mission in which the swarm mixes (the second world is crowded: 640 agents in
+    18 x 18 x 3 m)."""
+    ms = L.random_swarm(n, world=world, seed=20260930, min_sep=0.5)
+    a = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
+    with _Env(LSC_NO_NEIGHBOUR_LISTS=1):
+        b = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
+    c = L.SwarmPlanner(ms, L.PlannerConfig(prune=3))
+    assert a.neighbour_counts() is not None and b.neighbour_counts() is None and c.neighbour_counts() is None
+    seen = []
+
+    def check(tick, g):
+        for k in ("traj", "cost", "status", "iters"):
+            assert np.array_equal(g[0][k], g[1][k]), (tick, k)
+            if tick <= 6 or tick % 8 == 0:
+                assert np.array_equal(g[0][k], g[2][k]), (tick, k)
+        assert np.array_equal(a.row_counts(), b.row_counts()), tick
+        units = a.neighbour_counts()
+        assert (units >= 0).mean() > (0.999 if n == 1024 else 0.5), tick    # (nearly) every agent had a list: in the crowded world some exceed its 1024 units
+        units = np.where(units < 0, 5 * (n - 1), units)
+        assert (units * 6 >= a.row_counts()).all(), tick                  # ... that held every unit its rows came from
+        seen.append(units.mean())
+
+    _fly(L, [a, b, c], ms, ticks, check)
+    assert max(seen) < 5 * (n - 1) / 4, seen                              # and a list is a fraction of the 5 (N - 1) units there are
+    for p in (a, b, c):
+        p.close()
+
+
+@pytest.mark.parametrize("env", [dict(LSC_NEIGH_CELL=1000.0),                       # one bucket for everybody: 12 slots + the overflow list
+                                 dict(LSC_NEIGH_CELL=1000.0, LSC_NEIGH_OVF_CAP=16),  # ... which overflows too: nobody gets a list
+                                 dict(LSC_NEIGH_LIST_CAP=40),                        # lists too short for the crowded agents: those cull by themselves
+                                 dict(LSC_NEIGH_CELL=0.02),                          # queries of more cells than a workgroup visits: no lists
+                                 dict(LSC_NEIGH_CELL=0.7)])                          # many cells, several buckets met twice through the hash
+def test_neighbour_list_overflow_paths_plan_the_same_bits(L, env):
+    """Every capacity of the neighbour lists has a way out that changes no result: a full bucket spills into an overflow list every query
+    walks; a full overflow list, a query over too many cells, too many candidates or a list beyond its capacity leave the agent without a
+    list (count -1) and its own phase B culls as it did in round 5."""
+    ms = L.random_swarm(600, world=(-12, -12, 0, 12, 12, 3.0), seed=11)
+    with _Env(**env):
+        a = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
+    b = L.SwarmPlanner(ms, L.PlannerConfig(prune=3))
+    none, some = [], []
+
+    def check(tick, g):
+        for k in ("traj", "cost", "status", "iters"):
+            assert np.array_equal(g[0][k], g[1][k]), (tick, k)
+        assert np.array_equal(a.row_counts(), b.row_counts()), tick
+        u = a.neighbour_counts()
+        none.append(int((u < 0).sum())); some.append(int((u >= 0).sum()))
+
+    _fly(L, [a, b], ms, 8, check)
+    if "LSC_NEIGH_OVF_CAP" in env or env.get("LSC_NEIGH_CELL") == 0.02:
+        assert sum(some) == 0, (none, some)
+    elif "LSC_NEIGH_LIST_CAP" in env:
+        assert sum(none) > 0 and sum(some) > 0, (none, some)
+    else:
+        assert sum(none) == 0, (none, some)
+    a.close(); b.close()
+
+
+def test_neighbour_lists_of_a_shard_and_of_the_four_segment_build(L):
+    """A shard (lsc_set_shard) gets lists for its own agents only -- the grid holds the whole swarm --, and the M = 4 library builds its
+    lists with four segments per obstacle: both plan the bits of the context without lists."""
+    import lsc_planner_amd as LL
+    from lsc_planner_amd.planner import next_state_host
+    ms = L.random_swarm(768, world=(-16, -16, 0, 16, 16, 4.0), seed=5)
+    whole = L.SwarmPlanner(ms, L.PlannerConfig(prune=3))
+    part = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
+    whole.set_shard(300, 200); part.set_shard(300, 200)        # (the same build of the plan kernel: 200 agents take the 512-lane one)
+    state, traj = _start(ms)
+    full = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
+    for tick in range(1, 6):
+        g, h = whole.plan(state, ms.goal, traj), part.plan(state, ms.goal, traj)
+        for k in ("traj", "cost", "status", "iters"):
+            assert np.array_equal(g[k], h[k]), (tick, k)
+        assert (part.neighbour_counts()[300:500] >= 0).all()
+        traj = full.plan(state, ms.goal, traj)["traj"]; state = next_state_host(traj)
+    whole.close(); part.close(); full.close()
+    cfg = dict(dt=0.5, horizon=2.0)
+    a = LL.SwarmPlanner(ms, LL.PlannerConfig(prune=1, **cfg)); b = LL.SwarmPlanner(ms, LL.PlannerConfig(prune=3, **cfg))
+    state, traj = _start(ms)
+    traj = np.zeros((ms.qn, 3, 24), np.float32)
+    for tick in range(1, 6):
+        g, h = a.plan(state, ms.goal, traj), b.plan(state, ms.goal, traj)
+        for k in ("traj", "cost", "status"):
+            assert np.array_equal(g[k], h[k]), (tick, k)
+        assert (a.neighbour_counts() >= 0).all()
+        traj = g["traj"]; state = next_state_host(traj, dt=0.5)
+    a.close(); b.close()
