@@ -317,12 +317,16 @@ int lsc_get_goal_trace(lsc_ctx *ctx, int *path_cells, int *path_len, int *flags,
 
 /* Active (non-redundant) LSC rows each agent's QP carried in the last tick, [N] (diagnostics). */
 int lsc_last_row_counts(lsc_ctx *ctx, int *rows);
-/* Neighbour lists of the last tick (diagnostics), [N]: how many (obstacle, segment) units the LSC build of each agent of the shard was
- * handed instead of walking all 5 (N - 1) of them (the obstacle loop of TrajPlanner::generateLSC, src/traj_planner.cpp:1335-1407).
- * Swarms of >= 512 agents get such lists, built through a uniform grid in front of the tick; -1: the agent had no list (capacity
- * overflow) and culled by itself; agents outside the shard keep what an earlier tick left.  Returns LSC_ESTATE when the context builds
- * no lists (small swarm, prune != 1, LSC_NO_NEIGHBOUR_LISTS set when lsc_set_agents ran).  Results never depend on the lists. */
-int lsc_neighbour_counts(lsc_ctx *ctx, int *units);
+/* Neighbour lists of the last tick (diagnostics).  Swarms of >= 512 agents do not walk all N - 1 other agents per agent (the loops of
+ * TrajPlanner::generateLSC, src/traj_planner.cpp:1335-1407, and goalPlanningWithPriority, :540-608): a uniform grid built in front of
+ * the tick hands every agent of the shard
+ *   units [N]               how many (obstacle, segment) units its LSC build looks at instead of all 5 (N - 1); -1: no list (capacity
+ *                           overflow), the agent culled by itself;
+ *   priority_candidates [N] (optional, may be NULL) how many agents lie within priority_dist_threshold of it -- all the priority rule can
+ *                           act on; -1: no list, the agent scanned everybody; 0 when goals are not planned in the plan kernel.
+ * Agents outside the shard keep what an earlier tick left.  Returns LSC_ESTATE when the context builds no lists (small swarm, prune != 1,
+ * LSC_NO_NEIGHBOUR_LISTS set when lsc_set_agents ran).  Results never depend on the lists. */
+int lsc_neighbour_counts(lsc_ctx *ctx, int *units, int *priority_candidates);
 /* LSC rows one agent may carry in LDS before the second pass (rows in HBM) takes it over: *lds_rows for the 512-lane latency
  * build (shards of at most one agent per CU), *throughput_rows for the 256-lane build that larger shards use (two workgroups
  * per CU, half the LDS each; 0 = not available, e.g. when max_rows_per_cp was set explicitly). */

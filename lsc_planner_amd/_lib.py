@@ -133,7 +133,7 @@ def load_library(segments=5):
     L.lsc_kernel_times_ms.argtypes = [vp, ctypes.c_int, dp, ctypes.c_long, ctypes.POINTER(ctypes.c_long)]
     L.lsc_set_timing.argtypes = [vp, ctypes.c_int]
     L.lsc_last_row_counts.argtypes = [vp, ip]
-    L.lsc_neighbour_counts.argtypes = [vp, ip]
+    L.lsc_neighbour_counts.argtypes = [vp, ip, ip]
     L.lsc_last_bucket_max.argtypes = [vp, ip]
     L.lsc_row_capacity.argtypes = [vp, ip, ip]
     L.lsc_phase_profile.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong)]

@@ -312,6 +312,7 @@ struct lsc_ctx {
     // neighbour lists of large swarms (lsc_neigh.hip): one allocation (base neigh.seg_bound ... see lsc_set_agents); neigh.cnt == nullptr: not in use
     NeighArgs neigh = {};
     void *d_neigh = nullptr;
+    bool neigh_always = false;           // LSC_NEIGH_ALWAYS (measurements, tests): lists whenever the context has them, not only where they pay
     long long *d_iters_acc = nullptr;
     long long *d_prof = nullptr;
     double *d_dbg = nullptr;
@@ -646,6 +647,7 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         // velocity limit over the horizon (2 x reach + radii; the query visits ~5 x 5 cells then); any size is correct, the size only
         // decides how many cells a query visits and how many agents share a bucket.  LSC_NEIGH_CELL overrides it (measurements).
         NeighArgs &g = c->neigh;
+        c->neigh_always = getenv("LSC_NEIGH_ALWAYS") != nullptr;
         double vm = 0.0, rm = 0.0, dmin = 1e300, dmax = 0.0;
         for (int i = 0; i < N; i++) {
             for (int k = 0; k < 3; k++) vm = std::max(vm, max_vel[3 * i + k]);
@@ -659,14 +661,15 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         g.inv_cell = 1.0 / cell; g.inv_cell_z = 1.0 / (cell * g.zscale);
         unsigned H = 1024;
         while (H < 4u * (unsigned)N) H <<= 1;
-        g.hmask = H - 1; g.ovf_cap = 4096; g.list_cap = 1024; g.tag = 0;
+        g.hmask = H - 1; g.ovf_cap = 4096; g.list_cap = 1024; g.plist_cap = NEIGH_PRIO_CAP; g.tag = 0;
         // (capacities the tests shrink to drive the overflow paths: an agent without a list culls by itself, results do not change)
         if (const char *e = getenv("LSC_NEIGH_OVF_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 65536) g.ovf_cap = v; }
         if (const char *e = getenv("LSC_NEIGH_LIST_CAP")) { const int v = atoi(e); if (v >= 1 && v <= 65536) g.list_cap = v; }
-        const size_t b_seg = sizeof(float) * 4 * M * (size_t)N, b_reach = sizeof(float) * M * (size_t)N, b_cells = 32 * (size_t)H, b_glob = 64,
-                     b_ovf = sizeof(unsigned short) * (size_t)g.ovf_cap, b_list = sizeof(unsigned short) * (size_t)g.list_cap * N, b_cnt = sizeof(int) * (size_t)N;
+        const size_t b_seg = sizeof(float) * 4 * M * (size_t)N, b_reach = sizeof(float) * M * (size_t)N, b_cells = 32 * (size_t)H, b_glob = 128,
+                     b_ovf = sizeof(unsigned short) * (size_t)g.ovf_cap, b_list = sizeof(unsigned short) * (size_t)g.list_cap * N, b_cnt = sizeof(int) * (size_t)N,
+                     b_plist = sizeof(unsigned short) * (size_t)g.plist_cap * N, b_view = sizeof(NeighView);
         auto al16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
-        const size_t total = al16(b_seg) + al16(b_reach) + al16(b_cells) + al16(b_glob) + al16(b_ovf) + al16(b_list) + al16(b_cnt);
+        const size_t total = al16(b_seg) + al16(b_reach) + al16(b_cells) + al16(b_glob) + al16(b_ovf) + al16(b_list) + 2 * al16(b_cnt) + al16(b_plist) + al16(b_view);
         HIPCHK(c, hipMalloc(&c->d_neigh, total));
         HIPCHK(c, hipMemset(c->d_neigh, 0, total));         // tag 0 everywhere: the first tick's tag is 1
         unsigned char *p = static_cast<unsigned char *>(c->d_neigh);
@@ -676,7 +679,13 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         g.glob = reinterpret_cast<unsigned long long *>(p); p += al16(b_glob);
         g.ovf = reinterpret_cast<unsigned short *>(p); p += al16(b_ovf);
         g.list = reinterpret_cast<unsigned short *>(p); p += al16(b_list);
-        g.cnt = reinterpret_cast<int *>(p);
+        g.cnt = reinterpret_cast<int *>(p); p += al16(b_cnt);
+        g.pcnt = reinterpret_cast<int *>(p); p += al16(b_cnt);
+        g.plist = reinterpret_cast<unsigned short *>(p); p += al16(b_plist);
+        NeighView v;
+        v.list = g.list; v.cnt = g.cnt; v.plist = g.plist; v.pcnt = g.pcnt; v.cap = g.list_cap; v.pcap = g.plist_cap;
+        HIPCHK(c, hipMemcpy(p, &v, sizeof(v), hipMemcpyHostToDevice));
+        g.view = reinterpret_cast<const NeighView *>(p);
     }
     HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (2 * (size_t)N + 4)));       // [N] iterations, [N] iterations x LSC rows, [4] counters of the active-set solve
     HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));          // [N] plan kernel, [N] general kernel
@@ -1005,7 +1014,7 @@ static int fill_plan_args(lsc_ctx *c, PlanArgs &a, const float *d_state, const f
     a.order = (c->count > 2 * c->n_cu) ? c->d_order : nullptr;   // more than one round of throughput workgroups
     a.obs_bound = c->d_obs_bound;                                // obstacle-level pre-cull (throughput build; latency build of large swarms: launch_plan decides)
     a.neigh = c->neigh.cnt ? &c->neigh : nullptr;                // neighbour lists of a large swarm: run_plan launches their kernels and sets the three fields below
-    a.nl_list = nullptr; a.nl_count = nullptr; a.nl_cap = 0;
+    a.nv = nullptr;
     a.state = d_state; a.goal = d_goal; a.traj_prev = d_prev;
     a.radius = c->d_radius; a.radius_obs = c->d_radius_obs; a.downwash = c->d_downwash; a.downwash_obs = c->d_downwash_obs;
     a.vmax = c->d_vmax; a.amax = c->d_amax; a.vnom = c->d_vnom;
@@ -1093,17 +1102,26 @@ static int run_plan(lsc_ctx *c, const PlanArgs &a_in, hipStream_t st, int genera
     hipEvent_t e1 = nullptr;
     if (c->timing && timing_begin(c, 0, st, &e1) != LSC_OK) return LSC_EHIP;
     PlanArgs a = a_in;
-    if (a.neigh && a.count > 0 && !a.out_normal && !a.general_all && !a.trace) {
+    // Neighbour lists cost two launches (~25 us at 1024 agents) and save every workgroup its walks over all N agents (cull: ~5 us per agent at
+    // N = 1024, priority rule: ~4 us; both grow with N).  Worth it when the shard takes more than one round of workgroups or the swarm is
+    // large; a one-round shard of a 1024-agent swarm is faster with the in-kernel walks (profiles/r06_neighbour_lists.log).
+    const bool lists_pay = a.N >= 2048 || (a.cap_tp > 0 && a.count > 2 * c->n_cu) || c->neigh_always;
+    if (a.neigh && lists_pay && a.count > 0 && !a.out_normal && !a.general_all && !a.trace) {
         // large swarm: bounds of every agent + the grid, then the shard's unit lists (two small launches on the tick's stream, inside the timed region)
         NeighArgs &g = *a.neigh;
-        if (++g.tag == 0) { HIPCHK(c, hipMemsetAsync(g.cells, 0, 32 * ((size_t)g.hmask + 1), st)); HIPCHK(c, hipMemsetAsync(g.glob, 0, 64, st)); g.tag = 1; }
+        if (++g.tag == 0) { HIPCHK(c, hipMemsetAsync(g.cells, 0, 32 * ((size_t)g.hmask + 1), st)); HIPCHK(c, hipMemsetAsync(g.glob, 0, 128, st)); g.tag = 1; }
         g.N = a.N; g.first = a.first; g.count = a.count; g.planner_seq = a.planner_seq; g.dtf = (float)c->hm.m.dt; g.dim2 = a.dim2;
         g.hv_scale = c->hm.m.hv_scale; g.ha_scale = c->hm.m.ha_scale; g.z2d = c->hm.m.z2d;
         g.state = a.state; g.traj_prev = a.traj_prev;
         g.radius = a.radius; g.radius_obs = a.radius_obs; g.downwash = a.downwash; g.downwash_obs = a.downwash_obs; g.vmax = a.vmax; g.amax = a.amax;
         g.order = (a.cap_tp > 0) ? a.order : nullptr; g.iters = a.iters; g.nrows = a.nrows; g.obs_bound = a.obs_bound;
+        // phase A's walks over all agents: candidates of the priority rule by position, the disturbance checks once per agent
+        const bool alt = a.general_all || (a.reset_thr > 0.0 && a.ever);
+        g.goal_mode = a.goal_mode; g.prio_thr = a.priority_dist_threshold;
+        g.checks = (alt && a.reset_thr > 0.0 && a.planner_seq >= 2 && a.planner_mode == 0 && a.ever != nullptr) ? 1 : 0;
+        g.reset_thr = a.reset_thr; g.ever = a.ever;
         HIPCHK(c, launch_neigh(g, st));
-        a.nl_list = g.list; a.nl_count = g.cnt; a.nl_cap = g.list_cap;
+        a.nv = g.view;
     }
     HIPCHK(c, launch_plan(a, smem, st));
     if (c->d_spill) HIPCHK(c, launch_plan_spill(a, c->spill_slots, plan_smem_bytes(c->hm.m.n_terms, c->hm.m.n_entries, 0), st));
@@ -1952,11 +1970,15 @@ int lsc_last_row_counts(lsc_ctx *c, int *rows /*[N]*/)
 }
 
 // read-back of the neighbour-list lengths of the last tick (diagnostics)
-int lsc_neighbour_counts(lsc_ctx *c, int *units /*[N]*/)
+int lsc_neighbour_counts(lsc_ctx *c, int *units /*[N]*/, int *priority_candidates /*[N] or null*/)
 {
     if (!c || !units || c->N == 0) return LSC_EINVAL;
     if (!c->neigh.cnt) { c->err = "this context builds no neighbour lists (fewer than 512 agents, prune != 1, or LSC_NO_NEIGHBOUR_LISTS)"; return LSC_ESTATE; }
     HIPCHK(c, hipMemcpy(units, c->neigh.cnt, sizeof(int) * (size_t)c->N, hipMemcpyDeviceToHost));
+    if (priority_candidates) {
+        HIPCHK(c, hipMemcpy(priority_candidates, c->neigh.pcnt, sizeof(int) * (size_t)c->N, hipMemcpyDeviceToHost));
+        for (int q = 0; q < c->N; q++) if (priority_candidates[q] >= 0) priority_candidates[q] &= 0xffff;      // (bit 30: the swarm's disturbance bit)
+    }
     return LSC_OK;
 }
 

@@ -17,6 +17,7 @@ namespace lsc {
 
 struct PlanArgs;
 struct NeighArgs;
+struct NeighView;
 // an argument block read where it lies, in the kernarg segment: constant address space => scalar loads, no private copy
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const __attribute__((address_space(4))) PlanArgs KArgs;
@@ -37,11 +38,9 @@ struct PlanArgs {
     float *obs_bound;          // throughput build: [N][4] bounding sphere of every agent's predicted control points, or null
     int cap_tp;                // > 0: use the 256-lane throughput build with this row capacity and smem_tp bytes of LDS
     size_t smem_tp;
-    NeighArgs *neigh;          // HOST pointer (never read on the device), or null: the context's neighbour-list buffers; launch_plan runs the two
-                               // kernels of lsc_neigh.hip in front of the tick of a large swarm and fills the three fields below
-    const unsigned short *nl_list;   // [N][nl_cap] per agent: the units (obstacle * M + segment) phase B has to look at, ascending
-    const int *nl_count;       // [N] entries of the agent's list; < 0: no list (capacity overflow), the agent culls by itself
-    int nl_cap;
+    NeighArgs *neigh;          // HOST pointer (never read on the device), or null: the context's neighbour-list buffers; run_plan (lsc_abi.cpp) launches
+                               // the two kernels of lsc_neigh.hip in front of the tick of a large swarm and sets nv
+    const NeighView *nv;       // device: the lists those kernels left for this tick, or null (every agent walks all the others, as small swarms do)
     const float *state;        // [N][9]
     const float *goal;         // [N][3] current goal (mode/goal static) or desired goal (prior_based)
     int goal_mode;             // 0 static, 1 prior_based: goalPlanningWithPriority runs in phase A of the plan kernel
@@ -91,6 +90,16 @@ constexpr int PROF_PHASES = 16;
 // (one workgroup per agent of the shard: the cells its reach overlaps -> sphere tests -> a sorted unit list in HBM).
 constexpr int NEIGH_SLOTS = 12;                  // agents a grid bucket holds (one 32-byte sector: a tagged counter + 12 indices); the rest overflows
 constexpr int NEIGH_MIN_AGENTS = 512;            // swarms below this keep the in-kernel cull
+constexpr int NEIGH_PRIO_CAP = 64;               // candidates of the priority rule an agent's list holds
+// what phase A / B of plan_agent read of the lists (device memory, written once per lsc_set_agents: the pointers do not change)
+struct NeighView {
+    const unsigned short *list;                  // [N][cap] per agent: the units (obstacle * M + segment) phase B has to look at, ascending
+    const int *cnt;                              // [N] entries of the agent's list; < 0: no list (capacity overflow), the agent culls by itself
+    const unsigned short *plist;                 // [N][pcap] agents within priority_dist_threshold of the agent's position (goalPlanningWithPriority's candidates)
+    const int *pcnt;                             // [N] -1: no information (the agent scans everybody); else entries of plist | (1 << 30 when ANY agent of the
+                                                 // swarm is off its plan or was: the disturbance checks of phase A, made once by the build kernel)
+    int cap, pcap;
+};
 struct NeighArgs {
     int N, first, count, planner_seq;
     float dtf;
@@ -104,7 +113,7 @@ struct NeighArgs {
     float *seg_bound;                            // [N][M][4] bounding sphere of the predicted control points of each segment
     float *reach;                                // [N][M] per segment max_i(|c_{0,2} - p_{m,i}| + reach radius of c_{m,i}), rounded up
     unsigned long long *cells;                   // [hmask + 1][4] buckets: tag << 32 | count, then NEIGH_SLOTS agent indices (16 bit)
-    unsigned long long *glob;                    // [8] tagged maxima: obstacle-side radius, overflow count, cell bounding box (6)
+    unsigned long long *glob;                    // [16] tagged maxima: obstacle-side radius, overflow count, cell bounding box (6), somebody is off its plan
     unsigned short *ovf;                         // [ovf_cap] agents whose bucket was full
     int ovf_cap;
     unsigned tag, hmask;                         // tag of this tick (buckets of older ticks count as empty: nothing is ever cleared)
@@ -113,6 +122,16 @@ struct NeighArgs {
     unsigned short *list;                        // [N][list_cap]
     int *cnt;                                    // [N]
     int list_cap;
+    // phase A's walks over all agents (see NeighView)
+    int goal_mode;                               // 1: goalPlanningWithPriority runs in phase A -> candidates by position
+    double prio_thr;                             // priority_dist_threshold
+    unsigned short *plist;                       // [N][plist_cap]
+    int *pcnt;                                   // [N]
+    int plist_cap;
+    int checks;                                  // the plan kernel's disturbance checks are on (reset_threshold > 0, LSC mode, planner_seq >= 2)
+    double reset_thr;
+    unsigned char *ever;                         // [N] persistent "was seen off its plan" flags
+    const NeighView *view;                       // device copy of the view over list / cnt / plist / pcnt
 };
 hipError_t launch_neigh(const NeighArgs &a, hipStream_t st);
 

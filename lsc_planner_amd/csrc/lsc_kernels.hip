@@ -609,6 +609,15 @@ __device__ __forceinline__ void pin_values(double (&a)[14])
 }
 #undef LSC_P
 
+// a pointer that is the same in all lanes, moved to scalar registers
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+
 // phase stamps (PROF variant only): cycles of lane 0 spent per phase, accumulated per agent
 enum { PH_SETUP = 0, PH_LSC, PH_INIT, PH_P1, PH_REDUCE, PH_ASSEMBLE, PH_FACTOR, PH_SOLVE, PH_P2, PH_P3, PH_P45, PH_OUT,
        PH_RED_BUCKETS /* part of PH_REDUCE: the LSC-bucket sums of wave 0, before the barrier */, PH_RED_GATHER /* the axis-row gather, clocked by the last lane */,
@@ -739,8 +748,18 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         r.ev = a.ever ? (int)a.ever[qj] : 0;
         return r;
     };
+    // Large swarms (lsc_neigh.hip): the agents within priority_dist_threshold of this one -- all the priority rule can act on -- come as a short
+    // list, and "somebody is off its plan" as one bit of its count: no walk over all N agents (at 1024 agents four rounds of 64-byte loads per
+    // lane, at 8192 thirty-two).  n_pc < 0: no such information, everybody is scanned as in small swarms.
+    // (every value read through the view is the same for all lanes, and SAID to be: loaded by vector instructions they would sit in vector
+    //  registers across the phases -- the production instantiations went from no scratch to 12 bytes per lane)
+    const NeighView *const nv = a.nv;
+    const int pc_word = nv ? __builtin_amdgcn_readfirstlane(nv->pcnt[qi]) : -1;
+    const int n_pc = pc_word >= 0 ? (pc_word & 0xffff) : -1;
+    const bool swarm_slack = pc_word >= 0 && ((pc_word >> 30) & 1) != 0;
+    const unsigned short *const plist = nv ? uniform_ptr(nv->plist) + (size_t)qi * __builtin_amdgcn_readfirstlane(nv->pcap) : nullptr;
     ScanIn sc0;
-    if (a.goal_mode == 1) sc0 = scan_load(tid < N ? tid : 0);
+    if (a.goal_mode == 1) sc0 = scan_load(n_pc >= 0 ? (tid < n_pc ? (int)plist[tid] : qi) : (tid < N ? tid : 0));
     else {
 #pragma unroll
         for (int k = 0; k < 3; k++) sc0.s[k] = sc0.g[k] = sc0.tl[k] = sc0.tf[k] = sc0.t1[k] = 0.f;
@@ -786,7 +805,8 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         own_slack = own_now || a.ever[qi] != 0;
         any_slack = own_slack ? 1 : 0;
         if (a.goal_mode != 1) {
-            for (int qj = tid; qj < N; qj += NT) {
+            if (n_pc >= 0) any_slack |= swarm_slack ? 1 : 0;      // (checked once per agent by the build kernel of the neighbour lists, flags set there)
+            else for (int qj = tid; qj < N; qj += NT) {
                 const bool nw = off_plan(qj);
                 if (nw) a.ever[qj] = 1;
                 any_slack |= (nw || a.ever[qj] != 0) ? 1 : 0;
@@ -817,7 +837,10 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         double best = 1e9;
         int bq = 0x7fffffff;
         bool first_round = true;
-        for (int qj = tid; qj < N; qj += NT) {
+        const int n_scan = n_pc >= 0 ? n_pc : N;
+        if (checks && n_pc >= 0) any_slack |= swarm_slack ? 1 : 0;
+        for (int sj = tid; sj < n_scan; sj += NT) {
+            const int qj = n_pc >= 0 ? (int)plist[sj] : sj;
             const ScanIn in = first_round ? sc0 : scan_load(qj);      // (first round: fetched at the top of the kernel)
             first_round = false;
             bool slack_j = false;
@@ -1038,12 +1061,20 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         // Large swarms: the units worth looking at come as a list from lsc_neigh.hip (built through a uniform grid in front of the tick: a
         // superset of what the cull below keeps, in the same ascending order -- the exact per-row test decides in both cases, so the rows
         // are the same); an agent without a list (capacity overflow there) culls by itself.
-        const int n_given = (a.nl_count != nullptr && md.prune == 1 && !a.out_normal && n_units > 0) ? a.nl_count[qi] : -1;
-        const bool given = n_given >= 0;
-        const unsigned short *glist = a.nl_list + (size_t)qi * a.nl_cap;
-        bool cull = !given && md.prune == 1 && !a.out_normal && n_units > NT && n_units <= 0xffff;
-        int n_list = given ? n_given : n_units;
-        if (cull) {
+        const NeighView *const nvb = a.nv;
+        const int n_given = (nvb != nullptr && md.prune == 1 && !a.out_normal && n_units > 0) ? __builtin_amdgcn_readfirstlane(nvb->cnt[qi]) : -1;
+        const bool given = n_given >= 0 && n_given <= list_cap;
+        bool cull = md.prune == 1 && !a.out_normal && n_units > NT && n_units <= 0xffff;
+        int n_list = n_units;
+        if (given) {
+            // the list moves into the LDS slots of the in-kernel cull's own list: the GJK pass below reads it there (read from HBM inside the
+            // pass, the address and the entry cost the production kernels the registers that keep them free of scratch)
+            const unsigned short *glist = uniform_ptr(nvb->list) + (size_t)qi * __builtin_amdgcn_readfirstlane(nvb->cap);
+            for (int i = tid; i < n_given; i += NT) ulist[i] = glist[i];
+            cull = true;
+            n_list = n_given;
+            __syncthreads();
+        } else if (cull) {
             if (tid == 0) S.listfull = 0;
             // Reach of every control point (distance from c_{0,2} + radius of its reachable box), per segment (cullB) and overall (cullA), one
             // lane of wave 0 per control point.  (Five lanes walking six points each, then one lane walking all thirty, were ~450 instructions on
@@ -1165,7 +1196,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         for (int base = 0; base < n_list; base += NT) {
             const int pos_u = base + tid;
             const bool live = pos_u < n_list;
-            const int u = live ? (given ? (int)glist[pos_u] : (cull ? (int)ulist[pos_u] : pos_u)) : 0;
+            const int u = live ? (cull ? (int)ulist[pos_u] : pos_u) : 0;
             const int oi = live ? u / M : 0, m = live ? u % M : 0;
             const int qj = oi < qi ? oi : oi + 1;
             F3 nrm = F3{0.f, 0.f, 0.f};
@@ -2880,8 +2911,8 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
         // throughput build: smaller capacity (an agent beyond it takes the second pass), two workgroups per CU
         t.cap = a.cap_tp;
         if (a.cap_tp <= 0) t.obs_bound = nullptr;
-        // (with neighbour lists -- a.nl_count -- both the bounds and the launch order were left by lsc_neigh.hip's kernels in front of this call)
-        if ((t.order || t.obs_bound) && !a.nl_count) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
+        // (with neighbour lists -- a.nv -- both the bounds and the launch order were left by lsc_neigh.hip's kernels in front of this call)
+        if ((t.order || t.obs_bound) && !a.nv) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
         if (a.prof) hipLaunchKernelGGL(lsc_plan_tp_prof_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
         else if (a.solver >= 1 && !d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL((lsc_plan_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); }
         else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
@@ -2892,7 +2923,7 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
     // obstacle-level cull every workgroup walks all 5 (N - 1) units through the unit-level cull -- ten passes of loads and two barriers each
     // at N = 1024, 18.6 of an agent's 50.6 us.  The bounding spheres cost one small launch (lsc_prep_kernel, ~4 us) in front of the tick.
     t.order = nullptr;                            // filled by lsc_prep_kernel only
-    if (a.nl_count) {}                            // (bounds left by lsc_neigh.hip's build kernel: an agent without a list falls back to them)
+    if (a.nv) {}                                  // (bounds left by lsc_neigh.hip's build kernel: an agent without a list falls back to them)
     else if (t.obs_bound && a.N >= 512 && !a.out_normal) hipLaunchKernelGGL(lsc_prep_kernel, dim3((32 * a.N + 255) / 256), dim3(256), 0, st, t);
     else t.obs_bound = nullptr;
     // solver 1: the active-set solve first (3-D worlds, production kernels); everything else keeps the interior point alone
@@ -2920,7 +2951,7 @@ hipError_t launch_plan_batch(const PlanArgs *a, int n, size_t smem, hipStream_t 
         if (alt_i != alt || (a[i].dim2 != 0) != d2 || a[i].prof || a[i].out_normal || a[i].trace) return hipErrorInvalidValue;
         b.a[i] = a[i];
         b.a[i].order = nullptr; b.a[i].obs_bound = nullptr;      // (filled by lsc_prep_kernel only: the throughput build is not batched)
-        b.a[i].nl_count = nullptr; b.a[i].nl_list = nullptr; b.a[i].neigh = nullptr;
+        b.a[i].nv = nullptr; b.a[i].neigh = nullptr;
         grid = a[i].count > grid ? a[i].count : grid;
     }
     for (int i = n; i < PLAN_BATCH_MAX; i++) { b.a[i] = a[0]; b.a[i].count = 0; }
@@ -2939,7 +2970,7 @@ hipError_t launch_plan_spill(const PlanArgs &a, int slots, size_t smem, hipStrea
     if (a.count == 0 || slots < 1 || !a.spill_ws) return hipSuccess;
     const int grid = a.count < slots ? a.count : slots;
     PlanArgs t = a;
-    if (!uses_throughput_build(a) && !a.nl_count) t.obs_bound = nullptr;      // (bounds of this tick exist only behind the throughput launch or the neighbour-list build)
+    if (!uses_throughput_build(a) && !a.nv) t.obs_bound = nullptr;      // (bounds of this tick exist only behind the throughput launch or the neighbour-list build)
     if (a.dim2) hipLaunchKernelGGL(lsc_plan_spill_kernel<true>, dim3(grid), dim3(NT), smem, st, t);
     else hipLaunchKernelGGL(lsc_plan_spill_kernel<false>, dim3(grid), dim3(NT), smem, st, t);
     return hipGetLastError();

@@ -257,13 +257,13 @@ class SwarmPlanner:
         self._check(self.L.lsc_last_row_counts(self.ctx, _ip(rows)))
         return rows
 
-    def neighbour_counts(self):
-        """Units (obstacle, segment) the LSC build of each agent was handed in the last tick (-1: no list), or None when the context
-        builds no neighbour lists (swarms below 512 agents)."""
-        units = np.zeros(self.N, np.int32)
-        if self.L.lsc_neighbour_counts(self.ctx, _ip(units)) != 0:
+    def neighbour_counts(self, priority=False):
+        """Units (obstacle, segment) the LSC build of each agent was handed in the last tick (-1: no list) -- with priority=True also the
+        number of candidates of the priority rule -- or None when the context builds no neighbour lists (swarms below 512 agents)."""
+        units, prio = np.zeros(self.N, np.int32), np.zeros(self.N, np.int32)
+        if self.L.lsc_neighbour_counts(self.ctx, _ip(units), _ip(prio) if priority else None) != 0:
             return None
-        return units
+        return (units, prio) if priority else units
 
     def row_capacity(self):
         """(rows of the LDS pass in the latency build, rows in the throughput build or 0)."""

@@ -48,35 +48,55 @@ def _fly(L, planners, ms, ticks, check):
         state = next_state_host(traj)
 
 
-@pytest.mark.parametrize("n,world,ticks", [(1024, (-20, -20, 0, 20, 20, 5), 40), (640, (-9, -9, 0, 9, 9, 3.0), 25)])
-def test_neighbour_lists_change_nothing_but_the_time(L, n, world, ticks):
+@pytest.mark.parametrize("n,world,ticks,cfg", [(1024, (-20, -20, 0, 20, 20, 5), 40, dict(goal_mode="prior_based", reset_threshold=0.15)),
+                                               (1024, (-20, -20, 0, 20, 20, 5), 12, dict()),
+                                               (640, (-9, -9, 0, 9, 9, 3.0), 25, dict(goal_mode="prior_based")),
+                                               (640, (-9, -9, 0, 9, 9, 3.0), 12, dict(reset_threshold=0.15))])
+def test_neighbour_lists_change_nothing_but_the_time(L, n, world, ticks, cfg):
     """Swarms of >= 512 agents get their (obstacle, segment) units as a sorted list from the grid kernels instead of walking all obstacles:
     a superset of what the in-kernel cull keeps, in the same order, and the exact per-row test decides in both cases -- so plans, costs,
-    statuses, iteration and row counts are bit-identical to the context without lists (LSC_NO_NEIGHBOUR_LISTS: the round-5 cull) and to
-    prune = 3 (no cull at all), tick after tick of a mission in which the swarm mixes (the second world is crowded: 640 agents in
-    18 x 18 x 3 m)."""
+    statuses, goals, iteration and row counts are bit-identical to the context without lists (LSC_NO_NEIGHBOUR_LISTS: the round-5 cull)
+    and to prune = 3 (no cull at all), tick after tick of a mission in which the swarm mixes (the second world is crowded: 640 agents in
+    18 x 18 x 3 m).  With prior_based goals the candidates of the priority rule (src/traj_planner.cpp:540-608) come from the same grid,
+    and with reset_threshold the disturbance checks (:866-878, 1047-1061) are made by the build kernel: at tick 9 agent 7 is pushed
+    0.3 m off its plan and the whole swarm switches to the slack-variable QPs, in all three contexts alike."""
     ms = L.random_swarm(n, world=world, seed=20260930, min_sep=0.5)
-    a = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
+    with _Env(LSC_NEIGH_ALWAYS=1):      # (lists are used only where they pay -- two rounds of workgroups or >= 2048 agents --: the tests force them)
+        a = L.SwarmPlanner(ms, L.PlannerConfig(prune=1, **cfg))
     with _Env(LSC_NO_NEIGHBOUR_LISTS=1):
-        b = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
-    c = L.SwarmPlanner(ms, L.PlannerConfig(prune=3))
+        b = L.SwarmPlanner(ms, L.PlannerConfig(prune=1, **cfg))
+    c = L.SwarmPlanner(ms, L.PlannerConfig(prune=3, **cfg))
     assert a.neighbour_counts() is not None and b.neighbour_counts() is None and c.neighbour_counts() is None
-    seen = []
-
-    def check(tick, g):
+    seen, cands, retreats = [], [], 0
+    from lsc_planner_amd.planner import next_state_host
+    state, traj = _start(ms)
+    for tick in range(1, ticks + 1):
+        if tick == 9 and cfg.get("reset_threshold"):
+            state[7, 0] += 0.3
+        g = [p.plan(state, ms.goal, traj) for p in (a, b, c)]
         for k in ("traj", "cost", "status", "iters"):
             assert np.array_equal(g[0][k], g[1][k]), (tick, k)
-            if tick <= 6 or tick % 8 == 0:
+            if tick <= 10 or tick % 8 == 0:
                 assert np.array_equal(g[0][k], g[2][k]), (tick, k)
         assert np.array_equal(a.row_counts(), b.row_counts()), tick
-        units = a.neighbour_counts()
-        assert (units >= 0).mean() > (0.999 if n == 1024 else 0.5), tick    # (nearly) every agent had a list: in the crowded world some exceed its 1024 units
-        units = np.where(units < 0, 5 * (n - 1), units)
-        assert (units * 6 >= a.row_counts()).all(), tick                  # ... that held every unit its rows came from
-        seen.append(units.mean())
-
-    _fly(L, [a, b, c], ms, ticks, check)
-    assert max(seen) < 5 * (n - 1) / 4, seen                              # and a list is a fraction of the 5 (N - 1) units there are
+        assert np.array_equal(a.last_goals(), b.last_goals()) and np.array_equal(a.last_goals(), c.last_goals()), tick
+        units, prio = a.neighbour_counts(priority=True)
+        if not (cfg.get("reset_threshold") and tick >= 9):                   # (a disturbed swarm plans in lsc_general_kernel: no LSC units at all)
+            assert (units >= 0).mean() > (0.999 if n == 1024 else 0.5), tick    # (nearly) every agent had a list: in the crowded world some exceed its 1024 units
+            units = np.where(units < 0, 5 * (n - 1), units)
+            assert (units * 6 >= a.row_counts()).all(), tick                  # ... that held every unit its rows came from
+            seen.append(units.mean())
+        assert (prio >= 0).all(), tick
+        cands.append(int(prio.sum()))
+        if cfg.get("goal_mode") == "prior_based":
+            retreats += int((np.linalg.norm(a.last_goals() - state[:, :3], axis=1) < 0.55).sum())
+        traj = g[0]["traj"]
+        state = next_state_host(traj)
+    assert max(seen) < 5 * (n - 1) / (4 if n == 1024 else 1), seen            # a list is a fraction of the 5 (N - 1) units there are
+    if cfg.get("goal_mode") == "prior_based":
+        assert sum(cands) > 0 and (n == 1024 or retreats > 0), (cands, retreats)   # the rule had candidates, and in the crowd it fired
+    else:
+        assert sum(cands) == 0
     for p in (a, b, c):
         p.close()
 
@@ -91,16 +111,19 @@ def test_neighbour_list_overflow_paths_plan_the_same_bits(L, env):
     walks; a full overflow list, a query over too many cells, too many candidates or a list beyond its capacity leave the agent without a
     list (count -1) and its own phase B culls as it did in round 5."""
     ms = L.random_swarm(600, world=(-12, -12, 0, 12, 12, 3.0), seed=11)
-    with _Env(**env):
-        a = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
-    b = L.SwarmPlanner(ms, L.PlannerConfig(prune=3))
+    cfg = dict(goal_mode="prior_based", reset_threshold=0.15, priority_dist_threshold=0.8)      # (candidates of the priority rule in every tick)
+    with _Env(LSC_NEIGH_ALWAYS=1, **env):
+        a = L.SwarmPlanner(ms, L.PlannerConfig(prune=1, **cfg))
+    b = L.SwarmPlanner(ms, L.PlannerConfig(prune=3, **cfg))
     none, some = [], []
 
     def check(tick, g):
         for k in ("traj", "cost", "status", "iters"):
             assert np.array_equal(g[0][k], g[1][k]), (tick, k)
         assert np.array_equal(a.row_counts(), b.row_counts()), tick
-        u = a.neighbour_counts()
+        assert np.array_equal(a.last_goals(), b.last_goals()), tick
+        u, pr = a.neighbour_counts(priority=True)
+        assert ((pr < 0) == (u < 0)).all() or "LSC_NEIGH_LIST_CAP" in env      # (a unit list beyond its capacity does not take the priority candidates with it)
         none.append(int((u < 0).sum())); some.append(int((u >= 0).sum()))
 
     _fly(L, [a, b], ms, 8, check)
@@ -120,7 +143,8 @@ def test_neighbour_lists_of_a_shard_and_of_the_four_segment_build(L):
     from lsc_planner_amd.planner import next_state_host
     ms = L.random_swarm(768, world=(-16, -16, 0, 16, 16, 4.0), seed=5)
     whole = L.SwarmPlanner(ms, L.PlannerConfig(prune=3))
-    part = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
+    with _Env(LSC_NEIGH_ALWAYS=1):
+        part = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
     whole.set_shard(300, 200); part.set_shard(300, 200)        # (the same build of the plan kernel: 200 agents take the 512-lane one)
     state, traj = _start(ms)
     full = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
@@ -132,7 +156,9 @@ def test_neighbour_lists_of_a_shard_and_of_the_four_segment_build(L):
         traj = full.plan(state, ms.goal, traj)["traj"]; state = next_state_host(traj)
     whole.close(); part.close(); full.close()
     cfg = dict(dt=0.5, horizon=2.0)
-    a = LL.SwarmPlanner(ms, LL.PlannerConfig(prune=1, **cfg)); b = LL.SwarmPlanner(ms, LL.PlannerConfig(prune=3, **cfg))
+    with _Env(LSC_NEIGH_ALWAYS=1):
+        a = LL.SwarmPlanner(ms, LL.PlannerConfig(prune=1, **cfg))
+    b = LL.SwarmPlanner(ms, LL.PlannerConfig(prune=3, **cfg))
     state, traj = _start(ms)
     traj = np.zeros((ms.qn, 3, 24), np.float32)
     for tick in range(1, 6):
@@ -142,3 +168,23 @@ def test_neighbour_lists_of_a_shard_and_of_the_four_segment_build(L):
         assert (a.neighbour_counts() >= 0).all()
         traj = g["traj"]; state = next_state_host(traj, dt=0.5)
     a.close(); b.close()
+
+
+def test_neighbour_lists_are_used_where_they_pay(L):
+    """The lists cost two launches in front of the tick: a context uses them when its shard takes more than one round of throughput
+    workgroups or the swarm has >= 2048 agents (profiles/r06_neighbour_lists.log), not for a one-round shard of a smaller swarm."""
+    ms = L.random_swarm(1024, seed=20260929)
+    whole, part = L.SwarmPlanner(ms, L.PlannerConfig()), L.SwarmPlanner(ms, L.PlannerConfig())
+    part.set_shard(0, 128)
+    state, traj = _start(ms)
+    whole.plan(state, ms.goal, traj); part.plan(state, ms.goal, traj)
+    assert (whole.neighbour_counts() >= 0).all()
+    assert (part.neighbour_counts()[:128] == 0).all()         # (never written: the buffer starts zeroed)
+    whole.close(); part.close()
+    ms = L.random_swarm(2048, world=(-28, -28, 0, 28, 28, 5), seed=3)
+    part = L.SwarmPlanner(ms, L.PlannerConfig())
+    part.set_shard(256, 256)
+    state, traj = _start(ms)
+    part.plan(state, ms.goal, traj)
+    assert (part.neighbour_counts()[256:512] > 0).all()
+    part.close()

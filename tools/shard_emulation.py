@@ -10,7 +10,10 @@ world-size-1 communicator, `python bench.py --unfused`; the xGMI figure is the d
 What this shows without an 8-GPU box: where the per-tick latency floor of one workgroup per agent caps the speed-up.
 Needs a GPU; nothing here touches oracle/ or /root/reference.
 
-    python tools/shard_emulation.py [--workload random1024|forest256] [--ticks 60] [--static-goal]
+    python tools/shard_emulation.py [--workload random1024|forest256] [--ticks 60] [--static-goal] [--agents 8192 --shards 1,8]
+
+--agents N (random workload only): a seeded random swarm of N agents in a world of random1024's density (40 m x sqrt(N / 1024) square,
+5 m high): what weak scaling beyond one GPU's 1024 agents plans per rank.
 """
 import argparse
 import json
@@ -30,6 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--static-goal", action="store_true")
     ap.add_argument("--shards", default="1,2,4,8")
+    ap.add_argument("--agents", type=int, default=1024)
     a = ap.parse_args()
     import torch
     import lsc_planner_amd as L
@@ -37,7 +41,8 @@ def main():
     dev = torch.device("cuda", 0)
     bt = None
     if a.workload == "random1024":
-        ms = L.random_swarm(1024, seed=20260929)
+        half = 20.0 * (a.agents / 1024.0) ** 0.5
+        ms = L.random_swarm(a.agents, seed=20260929) if a.agents == 1024 else L.random_swarm(a.agents, world=(-half, -half, 0, half, half, 5), seed=20260929)
     else:
         ms, bt = bench.forest256_mission(L)
     N = ms.qn
@@ -84,7 +89,8 @@ def main():
         tick = np.max(np.stack([x[:n] for x in per]), axis=0)              # slowest shard of every tick
         plan_mean = [round(float(p.kernel_times_ms(0).mean()), 4) for p in pls]
         st = status.cpu().numpy()
-        line = {"workload": a.workload, "goal_mode": goal_mode, "agents": N, "shards": G, "agents_per_shard": rows, "ticks": a.ticks,
+        nl = pls[0].neighbour_counts()
+        line = {"workload": a.workload if N == 1024 or bt else f"random{N}", "neighbour_lists": nl is not None, "goal_mode": goal_mode, "agents": N, "shards": G, "agents_per_shard": rows, "ticks": a.ticks,
                 "slowest_shard_ms": {"mean": round(float(tick.mean()), 4), "p99": round(float(np.percentile(tick, 99)), 4)},
                 "plan_kernel_ms_mean_per_shard": plan_mean,
                 "agent_replans_per_s_projected_without_collective": round(N / (float(tick.mean()) * 1e-3), 0),
