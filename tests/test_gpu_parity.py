@@ -334,7 +334,7 @@ def test_symmetric_missions_under_the_default_solver_follow_the_oracle_tick_by_t
     from lsc_planner_amd.planner import next_state_host
     ms = golden_mission(ticks, name)
     N = ms.qn
-    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based"))          # the library's default solver
+    pl = L.SwarmPlanner(ms, L.PlannerConfig(goal_mode="prior_based", solver="active_set"))   # the library's default solver (named: LSC_SOLVER re-runs this file under the other one)
     sw = oracle_swarm(oracle, ms)
     state = np.zeros((N, 9), np.float32); state[:, :3] = ms.start
     traj = np.zeros((N, 3, 30), np.float32)

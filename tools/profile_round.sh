@@ -21,7 +21,9 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats_general -o general -- $GENERAL --
 # 2. counters, each group in its own pass, kernel trace only
 # (fourth pass, round 5: the LDS side north_star asks for -- SQ_LDS_IDX_ACTIVE = all LDS-array cycles, SQ_LDS_BANK_CONFLICT = the extra
 #  cycles of bank conflicts, SQ_ACTIVE_INST_LDS / SQ_WAIT_INST_LDS = wave-cycles on / waiting for LDS instructions; MI355X_MICROARCH.md, LDS section)
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"; do
+# (fifth and sixth pass, round 6: the instruction stream -- requests / hits / misses of the instruction cache the CUs share in pairs, fetches
+#  and the requests that reach the L2: what a 99 KB kernel executed nearly straight-line pays for its text)
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_WAIT_ANY SQC_TC_INST_REQ SQC_TC_REQ"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_bench_$tag -o bench -- $BENCH --steps 30 > /dev/null 2> $OUT/pmc_bench_$tag.err
   rocprofv3 --kernel-trace --pmc $grp -d $OUT/pmc_forest_$tag -o forest -- $FOREST --ticks 10 > /dev/null 2> $OUT/pmc_forest_$tag.err
