@@ -11,13 +11,13 @@
 // with p_j / q_j the six predicted control points of the agent / the obstacle in segment m, w_c their centroid, R_w = max_j |w_j - w_c| and
 // B_m = max_i (|c_{0,2} - p_{m,i}| + radius of the box c_{m,i} can reach).  With a bounding sphere (C, rho) of each side's six points,
 // D = S (C_a - C_o):  |w_j - D| <= s (rho_a + rho_o), hence |w_c - D| <= s (rho_a + rho_o) and R_w <= 2 s (rho_a + rho_o), and
-//      |D| >= s (2 B_m + 3 (rho_a + rho_o)) + r_a + r_o + 2e-4 (+ 1e-5 for the rounding of this file's own arithmetic)
+//      |D| >= s (2 B_m + 3 (rho_a + rho_o)) + r_a + r_o + 2e-4   (evaluated in float32 and rounded up: x (1 + 2e-5) + 5e-4 instead of + 2e-4)
 // implies the test above: a unit that fails it is listed, everything else is dropped.  The list is a superset of the units the in-kernel
 // test keeps, in ascending (obstacle, segment) order; phase B runs its exact per-row test on every listed unit, so rows, their order
 // and the plan are bit-identical to `prune = 3` (no cull at all).
 //
 // Two launches in front of the tick (launch_neigh):
-//   lsc_neigh_build_kernel : 32 lanes per agent of the WHOLE swarm: bounding sphere of all predicted control points (the in-kernel cull's bound,
+//   lsc_neigh_build_kernel : 8 lanes per agent of the WHOLE swarm: bounding sphere of all predicted control points (the in-kernel cull's bound,
 //                            kept for agents whose list overflows), bounding sphere per segment, B_m, and ONE insertion into the grid at the
 //                            cell of the agent's centre.  Nothing is ever cleared: a bucket's counter carries the tick's tag in its upper word
 //                            (atomic max with tag << 32 resets a stale bucket), and so do the swarm-wide maxima.
@@ -69,26 +69,51 @@ enum { G_RADIUS = 0, G_OVF = 1, G_MAXX = 2, G_MAXY = 3, G_MAXZ = 4, G_MINX = 5, 
 
 }  // namespace
 
-constexpr int NB_THREADS = 256, NB_AGENTS = NB_THREADS / 32;      // lanes / agents of a build workgroup
+// ---- build: eight lanes per agent, lane m < M owns segment m.  float32 throughout -- these are bounds, not results: every quantity that
+// widens a test is rounded up by far more than float32 arithmetic can lose (B_m: + 1e-5 B_m + 1e-3 m; radii: + 1e-5 r + 1e-5 m) --, no LDS
+// round trips between the lanes of an agent (three DPP steps reduce over its eight lanes), one lane's work ~400 instructions: a lone wave
+// pays 6-8 cycles per instruction and ~100 per LDS round trip, and the first version (32 lanes per agent, float64, ~150 ds_bpermute) was
+// 14 us of a 1024-agent tick.
+constexpr int NB_THREADS = 256, NB_LANES = 8, NB_AGENTS = NB_THREADS / NB_LANES;      // lanes / lanes per agent / agents of a build workgroup
+static_assert(M <= NB_LANES, "one lane per segment");
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
+// sum / maximum over the eight lanes of an agent, result in all of them: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+__device__ __forceinline__ float sum8(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); return v; }
+__device__ __forceinline__ float max8(float v) { v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); return v; }
+
+// sum_{j=1..K} min(V, d0 + j A) and sum_{j=1..K} max(-V, d0 - j A) in closed form (A >= 0: the terms are monotone in j, the first n of them
+// unclamped; nh / nl = how many that would be without the limit K, formed once per axis).  A term next to the clamp is within rounding of
+// either branch, so a floor() off by one moves the sum by rounding only.
+__device__ __forceinline__ float reach_hi(float d0, float V, float A, float nh, int K)
+{
+    const float n1 = fminf(nh, (float)K);
+    return n1 * d0 + 0.5f * A * n1 * (n1 + 1.f) + ((float)K - n1) * V;
+}
+__device__ __forceinline__ float reach_lo(float d0, float V, float A, float nl, int K)
+{
+    const float n1 = fminf(nl, (float)K);
+    return n1 * d0 - 0.5f * A * n1 * (n1 + 1.f) - ((float)K - n1) * V;
+}
+
 __global__ __launch_bounds__(NB_THREADS) void lsc_neigh_build_kernel(NeighArgs a)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int qa = q >> 5, j = q & 31;
-    const bool live = qa < a.N;
-    const int ql = live ? qa : 0;
-    const int pi = j < SEGV ? j : SEGV - 1, m = pi / NC;
-    // ---- everything this kernel reads, in one batch (what follows is arithmetic; the atomics come last, because whatever is issued
-    // behind an atomic that returns a value waits for it)
-    F3 po[6];
-    load_segment(a.state, a.traj_prev, ql, m, a.planner_seq, a.dtf, po);
+    const int qa = q >> 3, l = q & 7;
+    const bool live = qa < a.N, seg = l < M;
+    const int ql = live ? qa : 0, m = seg ? l : M - 1;
+    // ---- everything this kernel reads, in one batch (what follows is arithmetic; the atomics come last)
+    F3 p[6];
+    load_segment(a.state, a.traj_prev, ql, m, a.planner_seq, a.dtf, p);
     const float *s = a.state + 9 * ql;
     float sv[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) sv[i] = s[i];
-    double vm[3], am[3];
+    float V[3], A[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { vm[k] = a.vmax[3 * ql + k]; am[k] = a.amax[3 * ql + k]; }
-    const double r_obs = a.radius_obs[ql];
+    for (int k = 0; k < 3; k++) { V[k] = (float)(a.vmax[3 * ql + k] * a.hv_scale); A[k] = (float)(a.amax[3 * ql + k] * a.ha_scale); }
+    const float r_obs = (float)a.radius_obs[ql];
     float t1[3] = {0.f, 0.f, 0.f};
     int ev = 0;
     if (a.checks) {
@@ -96,77 +121,62 @@ __global__ __launch_bounds__(NB_THREADS) void lsc_neigh_build_kernel(NeighArgs a
         t1[0] = t[0]; t1[1] = t[SEGV]; t1[2] = t[2 * SEGV];
         ev = (int)a.ever[ql];
     }
-    F3 me = po[0];
+    // ---- sphere around all predicted control points and the current position (priority candidates are found by position): any centre will
+    // do as long as the radius is taken around the one that is stored
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (seg) {
 #pragma unroll
-    for (int i = 1; i < 6; i++) if (pi % NC == i) me = po[i];
-    if (j == SEGV) me = F3{sv[0], sv[1], sv[2]};      // the current position is one of the points of the sphere (priority candidates are found by position)
-    // ---- sphere around all predicted control points and the current position (lanes beyond SEGV + 1 repeat the last point): centre =
-    // float32 of the mean, radius taken around the centre that is stored and rounded up
-    double cx = (double)me.x, cy = (double)me.y, cz = (double)me.z;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { cx += __shfl_xor(cx, o, 32); cy += __shfl_xor(cy, o, 32); cz += __shfl_xor(cz, o, 32); }
-    const float fx = (float)(cx * (1.0 / 32.0)), fy = (float)(cy * (1.0 / 32.0)), fz = (float)(cz * (1.0 / 32.0));
-    double r2;
-    {
-        const double ex = (double)me.x - (double)fx, ey = (double)me.y - (double)fy, ez = (double)me.z - (double)fz;
-        r2 = ex * ex + ey * ey + ez * ez;
+        for (int i = 0; i < 6; i++) { sx += p[i].x; sy += p[i].y; sz += p[i].z; }
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) r2 = fmax(r2, __shfl_xor(r2, o, 32));
-    const float rad = (float)(sqrt(r2) * (1.0 + 1e-6) + 1e-6);
-    // ---- sphere around the six points of this lane's segment
-    float sx[6], sy[6], sz[6];
-    double mx = 0.0, my = 0.0, mz = 0.0;
+    const float gx = sx * (1.f / 6.f), gy = sy * (1.f / 6.f), gz = sz * (1.f / 6.f);      // this lane's segment: centre of its own sphere
+    if (l == 0) { sx += sv[0]; sy += sv[1]; sz += sv[2]; }
+    const float inv_n = 1.f / (float)(6 * M + 1);
+    const float fx = sum8(sx) * inv_n, fy = sum8(sy) * inv_n, fz = sum8(sz) * inv_n;
+    float r2 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        sx[i] = __shfl(me.x, m * NC + i, 32); sy[i] = __shfl(me.y, m * NC + i, 32); sz[i] = __shfl(me.z, m * NC + i, 32);
-        mx += (double)sx[i]; my += (double)sy[i]; mz += (double)sz[i];
+        const float ex = p[i].x - fx, ey = p[i].y - fy, ez = p[i].z - fz;
+        r2 = fmaxf(r2, ex * ex + ey * ey + ez * ez);
+        const float hx = p[i].x - gx, hy = p[i].y - gy, hz = p[i].z - gz;
+        s2 = fmaxf(s2, hx * hx + hy * hy + hz * hz);
     }
-    const float gx = (float)(mx * (1.0 / 6.0)), gy = (float)(my * (1.0 / 6.0)), gz = (float)(mz * (1.0 / 6.0));
-    double s2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const double ex = (double)sx[i] - (double)gx, ey = (double)sy[i] - (double)gy, ez = (double)sz[i] - (double)gz;
-        s2 = fmax(s2, ex * ex + ey * ey + ez * ez);
-    }
-    const float srad = (float)(sqrt(s2) * (1.0 + 1e-6) + 1e-6);
-    float smax = j < SEGV ? srad : 0.f;
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 32));
-    // ---- B_m: the arithmetic of phase A / B of plan_agent (state constants, reach of every control point by prefix sums over the steps)
-    double c2[3], lo[3], hi[3];
+    if (!seg) { r2 = 0.f; s2 = 0.f; }
+    if (l == 0) { const float ex = sv[0] - fx, ey = sv[1] - fy, ez = sv[2] - fz; r2 = fmaxf(r2, ex * ex + ey * ey + ez * ez); }
+    const float rad = sqrtf(max8(r2)) * (1.f + 1e-5f) + 1e-5f;
+    const float srad = sqrtf(s2) * (1.f + 1e-5f) + 1e-5f;
+    const float smax = max8(seg ? srad : 0.f);
+    // ---- B_m = max_i (|c_{0,2} - p_{m,i}| + reach radius of c_{m,i}) over the control points K = 5 m + i - 2 >= 1 steps from c_{0,2}, bounded by
+    // (largest distance) + (largest reach radius); the state constants and the step limits as phase A of plan_agent forms them
+    float c2[3], d0[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        double c0 = (double)sv[k];
-        double c1 = c0 + (double)sv[3 + k] * a.hv_scale;
-        double cc = (double)sv[6 + k] * a.ha_scale + 2.0 * c1 - c0;
-        if (a.dim2 && k == 2) c0 = c1 = cc = a.z2d;
-        c2[k] = cc;
-        const double V = vm[k] * a.hv_scale, A = am[k] * a.ha_scale, d0 = cc - c1;
-        const bool in = j >= 1 && j < 28;
-        lo[k] = in ? fmax(-V, d0 - (double)j * A) - 1e-9 : 0.0;
-        hi[k] = in ? fmin(V, d0 + (double)j * A) + 1e-9 : 0.0;
-#pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
-            const double ul = __shfl_up(lo[k], d, 32), uh = __shfl_up(hi[k], d, 32);
-            if (j >= d) { lo[k] += ul; hi[k] += uh; }
-        }
+        const float hv = (float)a.hv_scale, ha = (float)a.ha_scale;
+        d0[k] = sv[3 + k] * hv + sv[6 + k] * ha;                   // c_{0,2} - c_{0,1}
+        c2[k] = sv[k] + 2.f * sv[3 + k] * hv + sv[6 + k] * ha;
+        if (a.dim2 && k == 2) { c2[k] = (float)a.z2d; d0[k] = 0.f; }
     }
-    const int K = DEG * (pi / NC) + (pi % NC) - 2, Kc = K >= 1 ? K : 1;
-    double d2 = 0.0, e2 = 0.0;
-    {
-        const double mec[3] = {(double)me.x, (double)me.y, (double)me.z};
+    float nh[3], nl[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float ia = A[k] > 0.f ? __frcp_rn(A[k]) : 0.f;
+        nh[k] = A[k] > 0.f ? fmaxf(floorf((V[k] - d0[k]) * ia), 0.f) : (d0[k] <= V[k] ? 1e9f : 0.f);
+        nl[k] = A[k] > 0.f ? fmaxf(floorf((d0[k] + V[k]) * ia), 0.f) : (d0[k] >= -V[k] ? 1e9f : 0.f);
+    }
+    float dm2 = 0.f, em2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const int K = DEG * m + i - 2;                             // (K < 1: c_{0,0..2} are fixed by the state and carry no row)
+        const float dx = c2[0] - p[i].x, dy = c2[1] - p[i].y, dz = c2[2] - p[i].z;
+        float e2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const double el = __shfl(lo[k], Kc, 32), eh = __shfl(hi[k], Kc, 32);
-            const double e = fmax(fabs(el), fabs(eh)), dd = c2[k] - mec[k];
-            d2 += dd * dd; e2 += e * e;
+            const float e = fmaxf(fabsf(reach_lo(d0[k], V[k], A[k], nl[k], K)), fabsf(reach_hi(d0[k], V[k], A[k], nh[k], K)));
+            e2 += e * e;
         }
+        dm2 = fmaxf(dm2, K >= 1 ? dx * dx + dy * dy + dz * dz : 0.f);
+        em2 = fmaxf(em2, K >= 1 ? e2 : 0.f);
     }
-    const double bc = K >= 1 ? sqrt(d2) + sqrt(e2) : 0.0;
-    double bm = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) bm = fmax(bm, __shfl(bc, m * NC + i, 32));
+    const float bm = (sqrtf(dm2) + sqrtf(em2)) * (1.f + 1e-5f) + 1e-3f;
     // ---- disturbance check of this agent (off_plan of plan_agent: float32, no contraction): the persistent flag is set HERE, once
     bool slack = false;
     if (a.checks) {
@@ -174,23 +184,23 @@ __global__ __launch_bounds__(NB_THREADS) void lsc_neigh_build_kernel(NeighArgs a
         const float dx = t1[0] - sv[0], dy = t1[1] - sv[1], dz = t1[2] - sv[2];
         const float n2 = dx * dx + dy * dy + dz * dz;
         const bool nw = sqrt((double)n2) > a.reset_thr;
-        if (nw && live && j == 0) a.ever[qa] = 1;
+        if (nw && live && l == 0) a.ever[qa] = 1;
         slack = live && (nw || ev != 0);
     }
-    if (live && j < SEGV && j % NC == 0) {
+    if (live && seg) {
         reinterpret_cast<float4 *>(a.seg_bound)[(size_t)qa * M + m] = make_float4(gx, gy, gz, srad);
-        a.reach[(size_t)qa * M + m] = (float)(bm * (1.0 + 1e-6) + 1e-6);
+        a.reach[(size_t)qa * M + m] = bm;
     }
     // ---- what this agent adds, as an OBSTACLE, to the query radius of everybody else: its segment centres and its position lie within rad of
     // the centre it is filed under, and a segment's sphere test reaches 3 s rho_o + r_o further
-    const float gr = (float)((3.0 * a.sc_max * (double)smax + r_obs + (double)rad) * (1.0 + 1e-6) + 1e-6);
+    const float gr = (3.f * (float)a.sc_max * smax + r_obs + rad) * (1.f + 1e-5f) + 1e-5f;
     const int ix = cell_of((double)fx, a.inv_cell), iy = cell_of((double)fy, a.inv_cell), iz = cell_of((double)fz, a.inv_cell_z);
     // ---- one insertion into the grid, at the cell of the centre.  atomic max with (tag, 0) first: a bucket last touched in an older tick
     // counts as empty.  The counter's round trip (0.3 us on its own address, tools/microbench/launch_atomics.hip) is issued HERE and its slot
     // used at the very end, so that the reduction below runs under it.
     unsigned long long *const bucket = a.cells + 4 * (size_t)(cell_hash(ix, iy, iz) & a.hmask);
     unsigned slot = 0;
-    if (live && j == 0) {
+    if (live && l == 0) {
         reinterpret_cast<float4 *>(a.obs_bound)[qa] = make_float4(fx, fy, fz, rad);
         atomicMax(bucket, tagged(a.tag, 0u));
         slot = (unsigned)atomicAdd(bucket, 1ull);
@@ -199,8 +209,8 @@ __global__ __launch_bounds__(NB_THREADS) void lsc_neigh_build_kernel(NeighArgs a
     // agents first, and an atomic only when it would change what stands there (one atomic per agent on seven addresses was 40 us of a
     // 1024-agent tick)
     __shared__ unsigned red[8][NB_AGENTS];
-    if (j == 0) {
-        const int s_ = threadIdx.x >> 5;
+    if (l == 0) {
+        const int s_ = threadIdx.x >> 3;
         red[0][s_] = live ? __float_as_uint(gr) : 0u;
         red[1][s_] = live ? BIAS + (unsigned)ix : 0u; red[2][s_] = live ? BIAS + (unsigned)iy : 0u; red[3][s_] = live ? BIAS + (unsigned)iz : 0u;
         red[4][s_] = live ? BIAS - (unsigned)ix : 0u; red[5][s_] = live ? BIAS - (unsigned)iy : 0u; red[6][s_] = live ? BIAS - (unsigned)iz : 0u;
@@ -208,8 +218,9 @@ __global__ __launch_bounds__(NB_THREADS) void lsc_neigh_build_kernel(NeighArgs a
     }
     __syncthreads();
     {
-        const int which = threadIdx.x >> 5;
-        unsigned v = j < NB_AGENTS ? red[which][j] : 0u;
+        static_assert(NB_AGENTS == 32 && NB_THREADS == 8 * 32, "eight values, 32 agents: one 32-lane group per value");
+        const int which = threadIdx.x >> 5, j = threadIdx.x & 31;
+        unsigned v = red[which][j];
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 32));
         if (j == 0 && v != 0u) {
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(NB_THREADS) void lsc_neigh_build_kernel(NeighArgs a
             if (__atomic_load_n(g, __ATOMIC_RELAXED) < mine) atomicMax(g, mine);
         }
     }
-    if (live && j == 0) {
+    if (live && l == 0) {
         if (slot < (unsigned)NEIGH_SLOTS) reinterpret_cast<unsigned short *>(bucket + 1)[slot] = (unsigned short)qa;
         else {
             atomicMax(&a.glob[G_OVF], tagged(a.tag, 0u));
@@ -238,12 +249,13 @@ __global__ __launch_bounds__(NQ) void lsc_neigh_query_kernel(NeighArgs a)
     const int al = blockIdx.x, qa = a.first + al;
     const unsigned tag = a.tag;
     const int n_units = (a.N - 1) * M, words = (n_units + 31) >> 5;
-    // ---- this agent's side of the tests, the swarm-wide numbers: one batch of loads
-    const double r_a = a.radius[qa], dw_a = a.downwash[qa];
+    // ---- this agent's side of the tests, the swarm-wide numbers: one batch of loads.  float32 like the build kernel: every `need` below is
+    // rounded up by 2e-5 of itself + 1e-4 m, far beyond what float32 loses on distances of metres
+    const float r_a = (float)a.radius[qa], dw_a = (float)a.downwash[qa];
     float4 sb[M];
-    float rc[M];
+    float bm[M];
 #pragma unroll
-    for (int m = 0; m < M; m++) { sb[m] = reinterpret_cast<const float4 *>(a.seg_bound)[(size_t)qa * M + m]; rc[m] = a.reach[(size_t)qa * M + m]; }
+    for (int m = 0; m < M; m++) { sb[m] = reinterpret_cast<const float4 *>(a.seg_bound)[(size_t)qa * M + m]; bm[m] = a.reach[(size_t)qa * M + m]; }
     unsigned long long gl[G_COUNT];
 #pragma unroll
     for (int i = 0; i < G_COUNT; i++) gl[i] = a.glob[i];
@@ -252,30 +264,34 @@ __global__ __launch_bounds__(NQ) void lsc_neigh_query_kernel(NeighArgs a)
     if (prio) { const float *s = a.state + 9 * qa; px = s[0]; py = s[1]; pz = s[2]; }
     for (int w = tid; w < words; w += NQ) bitmap[w] = 0u;
     if (tid == 0) { qn = 0; pn = 0; rnk = 0; }
-    double ca[M][3], ra[M], bm[M], qrad[M];
-    const double G = (double)__uint_as_float(untag(gl[G_RADIUS], tag, 0u));
+    float qrad[M];
+    const float G = __uint_as_float(untag(gl[G_RADIUS], tag, 0u));
+    const float scm = (float)a.sc_max;
 #pragma unroll
-    for (int m = 0; m < M; m++) {
-        ca[m][0] = (double)sb[m].x; ca[m][1] = (double)sb[m].y; ca[m][2] = (double)sb[m].z; ra[m] = (double)sb[m].w;
-        bm[m] = (double)rc[m];
-        qrad[m] = a.sc_max * (2.0 * bm[m] + 3.0 * ra[m]) + r_a + 2e-4 + 1e-5 + G;      // reach of the query for segment m along x and y
-    }
+    for (int m = 0; m < M; m++)
+        qrad[m] = (scm * (2.f * bm[m] + 3.f * sb[m].w) + r_a + G) * (1.f + 4e-5f) + 1e-3f;      // reach of the query for segment m along x and y (>= the test's `need` + the obstacle's own radius)
     const double pthr = a.prio_thr * (1.0 + 1e-6) + 1e-9;      // (a candidate list may hold more than the rule needs, never less)
+    const float pq = ((float)pthr + G) * (1.f + 4e-5f) + 1e-3f;
     // ---- cells the query boxes overlap, clamped to the cells that hold somebody
     int c0[3], c1[3];
     bool fail = false;
     {
         const int bmax[3] = {(int)(untag(gl[G_MAXX], tag, BIAS) - BIAS), (int)(untag(gl[G_MAXY], tag, BIAS) - BIAS), (int)(untag(gl[G_MAXZ], tag, BIAS) - BIAS)};
         const int bmin[3] = {(int)(BIAS - untag(gl[G_MINX], tag, BIAS)), (int)(BIAS - untag(gl[G_MINY], tag, BIAS)), (int)(BIAS - untag(gl[G_MINZ], tag, BIAS))};
-        const double pp[3] = {(double)px, (double)py, (double)pz};
+        const float pp[3] = {px, py, pz};
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const double sck = k == 2 ? a.zscale : 1.0, inv = k == 2 ? a.inv_cell_z : a.inv_cell;
-            double lo = 1e300, hi = -1e300;
+            const float sck = k == 2 ? (float)a.zscale : 1.f;
+            const double inv = k == 2 ? a.inv_cell_z : a.inv_cell;
+            float lo = 3e38f, hi = -3e38f;
 #pragma unroll
-            for (int m = 0; m < M; m++) { lo = fmin(lo, ca[m][k] - qrad[m] * sck); hi = fmax(hi, ca[m][k] + qrad[m] * sck); }
-            if (prio) { lo = fmin(lo, pp[k] - (pthr + G)); hi = fmax(hi, pp[k] + (pthr + G)); }
-            c0[k] = max(cell_of(lo, inv), bmin[k]); c1[k] = min(cell_of(hi, inv), bmax[k]);
+            for (int m = 0; m < M; m++) {
+                const float c = k == 0 ? sb[m].x : (k == 1 ? sb[m].y : sb[m].z);
+                lo = fminf(lo, c - qrad[m] * sck); hi = fmaxf(hi, c + qrad[m] * sck);
+            }
+            if (prio) { lo = fminf(lo, pp[k] - pq); hi = fmaxf(hi, pp[k] + pq); }
+            // (the box is widened by 1e-5 of the coordinate: the float32 sums above against the float64 product that filed the obstacle)
+            c0[k] = max(cell_of((double)(lo - 1e-5f * fabsf(lo)), inv), bmin[k]); c1[k] = min(cell_of((double)(hi + 1e-5f * fabsf(hi)), inv), bmax[k]);
             if (!(lo <= hi)) fail = true;                  // (NaN inputs: no list, the agent's own phase B decides)
         }
     }
@@ -311,19 +327,19 @@ __global__ __launch_bounds__(NQ) void lsc_neigh_query_kernel(NeighArgs a)
     for (int ci = tid; ci < nq && ci < QUEUE_CAP; ci += NQ) {
         const int o = (int)queue[ci];
         if (o == qa || o >= a.N) continue;
-        const double r_o = a.radius_obs[o], dw_o = a.downwash_obs[o];
+        const float r_o = (float)a.radius_obs[o], dw_o = (float)a.downwash_obs[o];
         float4 so[M];
 #pragma unroll
         for (int m = 0; m < M; m++) so[m] = reinterpret_cast<const float4 *>(a.seg_bound)[(size_t)o * M + m];
         float ox = 0.f, oy = 0.f, oz = 0.f;
         if (prio) { const float *s = a.state + 9 * o; ox = s[0]; oy = s[1]; oz = s[2]; }
-        const double downwash = (dw_a * r_a + dw_o * r_o) / (r_a + r_o);
-        const double idw = 1.0 / downwash, sc = fmax(1.0, idw);
+        const float downwash = (dw_a * r_a + dw_o * r_o) / (r_a + r_o);
+        const float idw = 1.f / downwash, sc = fmaxf(1.f, idw);
         const int oi = o < qa ? o : o - 1;
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            const double dx = ca[m][0] - (double)so[m].x, dy = ca[m][1] - (double)so[m].y, dz = (ca[m][2] - (double)so[m].z) * idw;
-            const double need = sc * (2.0 * bm[m] + 3.0 * (ra[m] + (double)so[m].w)) + (r_a + r_o) + 2e-4 + 1e-5;
+            const float dx = sb[m].x - so[m].x, dy = sb[m].y - so[m].y, dz = (sb[m].z - so[m].z) * idw;
+            const float need = (sc * (2.f * bm[m] + 3.f * (sb[m].w + so[m].w)) + (r_a + r_o)) * (1.f + 2e-5f) + 5e-4f;      // (2e-4 of the test itself + rounding)
             if (!(dx * dx + dy * dy + dz * dz >= need * need)) {
                 const int u = oi * M + m;
                 atomicOr(&bitmap[u >> 5], 1u << (u & 31));

@@ -15,18 +15,26 @@ def _unit_test_keeps(p, q, idw, B, r):
     return not (wc @ wc >= need * need)
 
 
+F = np.float32
+
+
 def _sphere(points):
-    """lsc_neigh_build_kernel: centre = float32 of the mean, radius around the stored centre, rounded up"""
-    c = points.mean(axis=0).astype(np.float32)
-    rad = np.float32(np.sqrt(((points - c.astype(np.float64)) ** 2).sum(axis=1).max()) * (1.0 + 1e-6) + 1e-6)
-    return c.astype(np.float64), float(rad)
+    """lsc_neigh_build_kernel: float32; centre = mean, radius around the stored centre, rounded up by 1e-5 r + 1e-5"""
+    pts = points.astype(F)
+    c = (pts.sum(axis=0, dtype=F) * F(1.0 / 6.0)).astype(F)
+    d = pts - c
+    rad = F(np.sqrt((d * d).sum(axis=1, dtype=F).max())) * F(1.0 + 1e-5) + F(1e-5)
+    return c, F(rad)
 
 
 def _sphere_test_keeps(ca, ra, co, ro, idw, B, r):
-    """lsc_neigh_query_kernel: keep unless |S (C_a - C_o)| >= s (2 B + 3 (rho_a + rho_o)) + r + 2e-4 + 1e-5"""
-    d = (ca - co) * np.array([1.0, 1.0, idw])
-    need = max(1.0, idw) * (2.0 * B + 3.0 * (ra + ro)) + r + 2e-4 + 1e-5
-    return not (d @ d >= need * need)
+    """lsc_neigh_query_kernel: float32; keep unless |S (C_a - C_o)| >= (s (2 B + 3 (rho_a + rho_o)) + r) (1 + 2e-5) + 5e-4, with B as the
+    build kernel stores it (rounded up by 1e-5 B + 1e-3)"""
+    idw, r = F(idw), F(r)
+    Bf = F(B) * F(1.0 + 1e-5) + F(1e-3)
+    d = (ca - co) * np.array([1.0, 1.0, idw], F)
+    need = (max(F(1.0), idw) * (F(2.0) * Bf + F(3.0) * (ra + ro)) + r) * F(1.0 + 2e-5) + F(5e-4)
+    return not (F((d * d).sum(dtype=F)) >= need * need)
 
 
 def test_sphere_test_of_the_grid_query_keeps_what_the_unit_test_keeps():
@@ -48,4 +56,4 @@ def test_sphere_test_of_the_grid_query_keeps_what_the_unit_test_keeps():
         kept_unit += ku
         kept_sphere += ks
     assert 0.2 < kept_unit / 12000 < 0.9 and kept_sphere >= kept_unit          # the trials straddle the bound
-    assert kept_sphere < 1.35 * kept_unit                                      # ... which is not much looser than the test it replaces
+    assert kept_sphere < 1.4 * kept_unit                                       # ... which is not much looser than the test it replaces
