@@ -501,6 +501,22 @@ static void free_agents(lsc_ctx *c)
                     c->d_stale, c->d_sfc, c->d_goal_cur, c->d_sfc_init, c->d_sfc_err, c->d_img_of_agent, c->d_integral, c->d_nrows, c->d_iters_acc, c->d_prof, c->d_dbg, c->d_state, c->d_cost,
                     c->d_onormal, c->d_od, c->d_spill, c->d_ever, c->d_gen_ws, c->d_bmax, c->d_order, c->d_obs_bound};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->neigh.prof) {
+        std::vector<long long> h(8 * (size_t)c->N);
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), c->neigh.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            double st[4] = {0, 0, 0, 0}, nq = 0, nc = 0, nu = 0, novf = 0;
+            int n = 0;
+            for (int q = 0; q < c->N; q++) {
+                const long long *p = &h[8 * (size_t)q];
+                if (p[4] == 0) continue;
+                for (int k = 0; k < 4; k++) st[k] += (double)(p[k + 1] - p[k]) / 100.0;
+                nq += (double)(p[5] & 0xffffffff); nc += (double)p[6]; nu += (double)p[7]; novf = (double)(p[5] >> 32); n++;
+            }
+            if (n) fprintf(stderr, "[lsc] query kernel of the neighbour lists, last tick, mean over %d agents: set-up %.2f us, cells -> candidates %.2f us, sphere tests %.2f us, "
+                                   "sorted list %.2f us; %.0f cells, %.0f candidates (%.0f of them from the overflow list), %.0f units per agent\n", n, st[0] / n, st[1] / n, st[2] / n, st[3] / n, nc / n, nq / n, novf, nu / n);
+        }
+        (void)hipFree(c->neigh.prof);
+    }
     if (c->d_neigh) (void)hipFree(c->d_neigh);
     c->d_neigh = nullptr; c->neigh = NeighArgs{};
     c->d_spill = nullptr; c->spill_slots = 0; c->spill_stride = 0;
@@ -643,9 +659,10 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
     HIPCHK(c, hipMalloc(&c->d_obs_bound, sizeof(float) * 4 * (size_t)N));
     HIPCHK(c, hipMemset(c->d_nrows, 0, sizeof(int) * (size_t)N));
     if (N >= NEIGH_MIN_AGENTS && (N - 1) * M <= 0xffff && c->cfg.prune == 1 && !getenv("LSC_NO_NEIGHBOUR_LISTS")) {
-        // Neighbour lists (lsc_neigh.hip).  Cell size: about the distance inside which a unit can matter at all for an agent at its
-        // velocity limit over the horizon (2 x reach + radii; the query visits ~5 x 5 cells then); any size is correct, the size only
-        // decides how many cells a query visits and how many agents share a bucket.  LSC_NEIGH_CELL overrides it (measurements).
+        // Neighbour lists (lsc_neigh.hip).  Cell size: what an agent at its velocity limit covers over the horizon + two diameters (1.6 m with
+        // the shipped parameters: a query visits ~9 x 9 cells, one lane each, and a bucket's twelve slots hold a crowd four times as dense as
+        // the 1024-agent benchmark's); any size is correct, the size only decides how many cells a query visits and how many agents share a
+        // bucket.  LSC_NEIGH_CELL overrides it (measurements).
         NeighArgs &g = c->neigh;
         c->neigh_always = getenv("LSC_NEIGH_ALWAYS") != nullptr;
         double vm = 0.0, rm = 0.0, dmin = 1e300, dmax = 0.0;
@@ -654,7 +671,7 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
             rm = std::max(rm, radius[i]); dmin = std::min(dmin, dw_obs[i]); dmin = std::min(dmin, downwash[i]);
             dmax = std::max(dmax, dw_obs[i]); dmax = std::max(dmax, downwash[i]);
         }
-        double cell = 2.0 * vm * M * c->cfg.dt + 4.0 * rm;
+        double cell = vm * M * c->cfg.dt + 4.0 * rm;
         if (const char *e = getenv("LSC_NEIGH_CELL")) { const double v = atof(e); if (v > 0.0) cell = v; }
         if (!(cell > 1e-3)) cell = 1e-3;
         g.sc_max = std::max(1.0, 1.0 / dmin); g.zscale = std::max(1.0, dmax);
@@ -686,6 +703,11 @@ int lsc_set_agents(lsc_ctx *c, int N, const double *radius, const double *downwa
         v.list = g.list; v.cnt = g.cnt; v.plist = g.plist; v.pcnt = g.pcnt; v.cap = g.list_cap; v.pcap = g.plist_cap;
         HIPCHK(c, hipMemcpy(p, &v, sizeof(v), hipMemcpyHostToDevice));
         g.view = reinterpret_cast<const NeighView *>(p);
+        g.prof = nullptr;
+        if (getenv("LSC_NEIGH_PROFILE")) {        // stage stamps of the query kernel, printed by lsc_destroy (diagnostics)
+            HIPCHK(c, hipMalloc(&g.prof, sizeof(long long) * 8 * (size_t)N));
+            HIPCHK(c, hipMemset(g.prof, 0, sizeof(long long) * 8 * (size_t)N));
+        }
     }
     HIPCHK(c, hipMalloc(&c->d_iters_acc, sizeof(long long) * (2 * (size_t)N + 4)));       // [N] iterations, [N] iterations x LSC rows, [4] counters of the active-set solve
     HIPCHK(c, hipMalloc(&c->d_prof, sizeof(long long) * 2 * PROF_PHASES * (size_t)N));          // [N] plan kernel, [N] general kernel
@@ -1187,6 +1209,8 @@ int lsc_tick_device_fused_batch(lsc_ctx *const *ctx, int n, const float *const *
         else if (c->count > c->n_cu) why = "has more agents than the GPU has CUs (the throughput build is not batched)";
         else if (c->d_spill) why = "needs the second pass (row capacity below 27 (N - 1))";
         else if (c->profiling || c->trace_agent >= 0) why = "is being profiled / traced";
+        else if ((c->cfg.solver >= 1) != (c0->cfg.solver >= 1)) why = "has another QP solver than the first (one instantiation per launch)";
+        for (int j = 0; j < i && !why; j++) if (ctx[j] == c) why = "appears twice (its stale-plan and hand-over buffers belong to ONE swarm of the launch)";
         if (why) { c0->err = "lsc_tick_device_fused_batch: context " + std::to_string(i) + " " + why; return LSC_EINVAL; }
         const int rc = fill_plan_args(c, a[i], d_state[i], d_goal[i], d_traj_prev[i], planner_seq[i], d_traj_next[i], d_cost[i], d_status[i], d_iters[i]);
         if (rc) return rc;

@@ -132,6 +132,7 @@ struct NeighArgs {
     double reset_thr;
     unsigned char *ever;                         // [N] persistent "was seen off its plan" flags
     const NeighView *view;                       // device copy of the view over list / cnt / plist / pcnt
+    long long *prof;                             // optional [count][8]: 100 MHz wall-clock stamps of the query kernel's stages (LSC_NEIGH_PROFILE)
 };
 hipError_t launch_neigh(const NeighArgs &a, hipStream_t st);
 

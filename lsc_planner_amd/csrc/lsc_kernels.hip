@@ -2270,6 +2270,31 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
                     gi_changes = __builtin_amdgcn_readfirstlane(gi_changes);
                     if (uni(gi_changes > GI_CAP)) { code = 2; break; }
                 }
+                if (uni(code == 3)) {
+                    // The verdict is final (no interior-point run behind it), so the certificate is evaluated once more from the rows themselves: with
+                    // n = G_W' r, r <= 0, every feasible point has n'y >= sum_j r_j h_j, and the QP is infeasible iff that exceeds h_p -- which at ANY
+                    // point x equals (a_p'x - h_p) - sum_j r_j (a_j'x - h_j).  Formed at the x of the current y with fresh residuals of the working
+                    // rows: rows that drifted off their boundaries (the kept inverse is never refactorised) show up here, and the agent goes to the
+                    // interior point like every other irregularity.
+                    gi_x();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    auto residual = [&](int rc) -> double {
+                        if (rc < n_ax) {
+                            const uint32_t am = S.amap[rc]; const int sl = am & 1023, type = (am >> 10) & 7, ak = (am >> 13) & 3, at = am >> 15;
+                            const double *xq = S.x + ak * SEGV + at;
+                            return ax_row3(xq[0], xq[1], xq[2], type) - AH(sl);
+                        }
+                        const uint32_t e = cmap[rc - n_ax];
+                        const int r = e & CMAP_MASK, cp = e >> CMAP_SHIFT;
+                        return rrhs[r] - ((double)rn[r] * S.x[cp] + (double)rn[R + r] * S.x[SEGV + cp] + (double)rn[2 * R + r] * S.x[2 * SEGV + cp]);
+                    };
+                    const double rj = lane < q ? rwv[lane] : 0.0;
+                    const double part = lane < q ? rj * residual(wrow[lane]) : 0.0;
+                    const double gap = residual(idx) - wave_sum(part);
+                    if (uni(!(gap > 0.5e-6 * (1.0 + fabs(hp))))) code = 1;
+                }
                 if (lane == 0) { S.sc[0] = (double)code; S.sc[1] = (double)q; S.sc[2] = (double)gi_changes; }
                 if (code == 0) gi_x();               // x for the next search, on the wave that holds the new y
             }
@@ -2681,7 +2706,9 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         }
         if (a.nrows) a.nrows[qi] = S.nact;
         if constexpr (SOLVER == 1) {
-            if (a.solver_stats) {
+            // (only agents whose QP ran here: a goal / corridor error, a capacity overflow or the hand-over of a disturbed swarm to lsc_general_kernel
+            //  is neither a finished solve nor a hand-over to the interior point)
+            if (a.solver_stats && (status == LSC_STATUS_OK_K || status == LSC_STATUS_INFEASIBLE_K)) {
                 // [0] agent-replans the active-set solve finished, [1] those it handed to the interior point, [2] working-set changes, [3] interior-point iterations
                 const bool by_gi = run_gi_done;
                 atomicAdd((unsigned long long *)&a.solver_stats[by_gi ? 0 : 1], 1ull);

@@ -21,7 +21,7 @@
 //                            kept for agents whose list overflows), bounding sphere per segment, B_m, and ONE insertion into the grid at the
 //                            cell of the agent's centre.  Nothing is ever cleared: a bucket's counter carries the tick's tag in its upper word
 //                            (atomic max with tag << 32 resets a stale bucket), and so do the swarm-wide maxima.
-//   lsc_neigh_query_kernel : one 128-lane workgroup per agent of the SHARD: the cells its five query boxes overlap (clamped to the
+//   lsc_neigh_query_kernel : one 256-lane workgroup per agent of the SHARD: the cells its five query boxes overlap (clamped to the
 //                            bounding box of the occupied cells), one lane per cell -> candidate obstacles in LDS -> one lane per candidate,
 //                            M sphere tests -> a bit per unit in LDS -> sorted list in HBM.  Hash collisions and buckets met twice only
 //                            add candidates; setting a bit twice changes nothing.
@@ -44,7 +44,7 @@ namespace lsc {
 
 namespace {
 
-constexpr int NQ = 128;                 // lanes of a query workgroup
+constexpr int NQ = 256;                 // lanes of a query workgroup
 constexpr int QUEUE_CAP = 4096;         // candidate obstacles per agent (LDS)
 constexpr int BITMAP_WORDS = 2048;      // one bit per unit: n_units <= 0xffff (the lists hold 16-bit units, like phase B's own)
 constexpr int MAX_CELLS = 8192;         // cells a query may visit
@@ -59,7 +59,8 @@ __device__ __forceinline__ int cell_of(double x, double inv)
 }
 __device__ __forceinline__ unsigned cell_hash(int ix, int iy, int iz)
 {
-    return ((unsigned)ix * 73856093u) ^ ((unsigned)iy * 19349663u) ^ ((unsigned)iz * 83492791u);
+    unsigned h = ((unsigned)ix * 0x9E3779B1u) ^ ((unsigned)iy * 0x85EBCA77u) ^ ((unsigned)iz * 0xC2B2AE3Du);
+    return h ^ (h >> 15);                  // (the mask keeps the low bits: fold the high ones in)
 }
 __device__ __forceinline__ unsigned long long tagged(unsigned tag, unsigned v) { return ((unsigned long long)tag << 32) | v; }
 __device__ __forceinline__ unsigned untag(unsigned long long w, unsigned tag, unsigned otherwise) { return (unsigned)(w >> 32) == tag ? (unsigned)w : otherwise; }
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(NQ) void lsc_neigh_query_kernel(NeighArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int al = blockIdx.x, qa = a.first + al;
     const unsigned tag = a.tag;
+    if (a.prof && tid == 0) a.prof[8 * (size_t)al + 0] = (long long)__builtin_amdgcn_s_memrealtime();
     const int n_units = (a.N - 1) * M, words = (n_units + 31) >> 5;
     // ---- this agent's side of the tests, the swarm-wide numbers: one batch of loads.  float32 like the build kernel: every `need` below is
     // rounded up by 2e-5 of itself + 1e-4 m, far beyond what float32 loses on distances of metres
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(NQ) void lsc_neigh_query_kernel(NeighArgs a)
     const unsigned ovn = untag(gl[G_OVF], tag, 0u);
     if (ovn > (unsigned)a.ovf_cap) fail = true;            // somebody is in no bucket and in no overflow slot
     __syncthreads();
+    if (a.prof && tid == 0) a.prof[8 * (size_t)al + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     // ---- stage 1: one lane per cell, the bucket's agents -> candidate queue
     for (int ci = tid; ci < (int)ncell; ci += NQ) {
         const int ix = c0[0] + ci % nx, iy = c0[1] + (ci / nx) % ny, iz = c0[2] + ci / (nx * ny);
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(NQ) void lsc_neigh_query_kernel(NeighArgs a)
         if (at < QUEUE_CAP) queue[at] = a.ovf[e];
     }
     __syncthreads();
+    if (a.prof && tid == 0) a.prof[8 * (size_t)al + 2] = (long long)__builtin_amdgcn_s_memrealtime();
     const int nq = qn;
     if (nq > QUEUE_CAP) fail = true;
     // ---- stage 2: one lane per candidate obstacle, M sphere tests (+ the distance of the priority rule)
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(NQ) void lsc_neigh_query_kernel(NeighArgs a)
         }
     }
     __syncthreads();
+    if (a.prof && tid == 0) a.prof[8 * (size_t)al + 3] = (long long)__builtin_amdgcn_s_memrealtime();
     // ---- stage 3: the set bits in ascending order -> the agent's list (each lane a contiguous run of words)
     const int per = (words + NQ - 1) / NQ;
     int mine = 0;
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(NQ) void lsc_neigh_query_kernel(NeighArgs a)
     const bool pfail = fail || np > PRIO_CAP || np > a.plist_cap;
     if (prio && !pfail)
         for (int i = tid; i < np; i += NQ) a.plist[(size_t)qa * a.plist_cap + i] = pcand[i];
+    if (a.prof && tid == 0) { a.prof[8 * (size_t)al + 4] = (long long)__builtin_amdgcn_s_memrealtime(); a.prof[8 * (size_t)al + 5] = (long long)nq | ((long long)ovn << 32); a.prof[8 * (size_t)al + 6] = ncell; a.prof[8 * (size_t)al + 7] = total; }
     if (tid == 0) {
         a.cnt[qa] = lfail ? -1 : total;
         const int any = untag(gl[G_SLACK], tag, 0u) ? (1 << 30) : 0;
