@@ -55,7 +55,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (guide: half the 157.3 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-PMC_FILES = ("profiles/r05_pmc_summary.json", "profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json")
+PMC_FILES = ("profiles/r06_pmc_summary.json", "profiles/r05_pmc_summary.json", "profiles/r04_pmc_summary.json", "profiles/r03_pmc_summary.json")
 
 
 def pmc_kernel(key):
@@ -91,6 +91,14 @@ def pmc_utilisation(key):
         out["lds_active_share_of_wave_cycles"] = round(d["SQ_ACTIVE_INST_LDS"] / wc, 4)
     if "SQ_WAIT_INST_LDS" in d:
         out["lds_wait_share_of_wave_cycles"] = round(d["SQ_WAIT_INST_LDS"] / wc, 4)
+    if d.get("SQC_ICACHE_REQ"):
+        # the instruction stream (round 6): requests of the instruction cache two CUs share, those that missed (a miss some other wave already
+        # has in flight counted apart), and -- an upper bound for everything on the instruction side -- wave-cycles waiting for an instruction to issue
+        out["icache_hit_rate"] = round(d.get("SQC_ICACHE_HITS", 0.0) / d["SQC_ICACHE_REQ"], 4)
+        out["icache_misses_per_wave"] = round(d.get("SQC_ICACHE_MISSES", 0.0) / max(1.0, d.get("SQ_WAVES", 1.0)), 2)
+        out["icache_duplicate_misses_per_wave"] = round(d.get("SQC_ICACHE_MISSES_DUPLICATE", 0.0) / max(1.0, d.get("SQ_WAVES", 1.0)), 2)
+        if "SQ_WAIT_INST_ANY" in d:
+            out["wait_inst_any_share_of_wave_cycles"] = round(d["SQ_WAIT_INST_ANY"] / wc, 4)
     if d.get("SQ_LDS_IDX_ACTIVE"):
         out["lds_bank_conflict_share_of_lds_cycles"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"], 4)
         if d.get("SQ_BUSY_CYCLES"):

@@ -2752,10 +2752,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ... its instrumented variant (lsc_phase_profile on a shard larger than the chip: where the throughput build's time goes)
+template <int SOLVER = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void lsc_plan_tp_prof_kernel(PlanArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    plan_agent<true, false, false, 256, false>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
+    plan_agent<true, false, false, 256, false, const PlanArgs, SOLVER>(a, a.order ? a.order[blockIdx.x] : (int)blockIdx.x, smem_raw, nullptr);
 }
 
 // ... and the throughput build with the alternate-mode hooks
@@ -2899,7 +2900,7 @@ hipError_t init_device_kernels()
                          reinterpret_cast<const void *>(&lsc_plan_alt_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_alt_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_tp_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<true>),
-                         reinterpret_cast<const void *>(&lsc_plan_tp_prof_kernel),
+                         reinterpret_cast<const void *>(&lsc_plan_tp_prof_kernel<0>), reinterpret_cast<const void *>(&lsc_plan_tp_prof_kernel<1>),
                          reinterpret_cast<const void *>(&lsc_plan_tp_kernel<false, 1>), reinterpret_cast<const void *>(&lsc_plan_alt_tp_kernel<false, 1>),
                          reinterpret_cast<const void *>(&lsc_plan_spill_kernel<false>), reinterpret_cast<const void *>(&lsc_plan_spill_kernel<true>),
                          reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, false>), reinterpret_cast<const void *>(&lsc_plan_batch_kernel<false, true>),
@@ -2940,7 +2941,8 @@ hipError_t launch_plan(const PlanArgs &a, size_t smem, hipStream_t st)
         if (a.cap_tp <= 0) t.obs_bound = nullptr;
         // (with neighbour lists -- a.nv -- both the bounds and the launch order were left by lsc_neigh.hip's kernels in front of this call)
         if ((t.order || t.obs_bound) && !a.nv) hipLaunchKernelGGL(lsc_prep_kernel, dim3(((t.obs_bound ? 32 * a.N : 16 * a.count) + 255) / 256), dim3(256), 0, st, t);
-        if (a.prof) hipLaunchKernelGGL(lsc_plan_tp_prof_kernel, dim3(a.count), dim3(256), a.smem_tp, st, t);
+        if (a.prof && a.solver >= 1) hipLaunchKernelGGL(lsc_plan_tp_prof_kernel<1>, dim3(a.count), dim3(256), a.smem_tp, st, t);
+        else if (a.prof) hipLaunchKernelGGL(lsc_plan_tp_prof_kernel<0>, dim3(a.count), dim3(256), a.smem_tp, st, t);
         else if (a.solver >= 1 && !d2) { if (alt) hipLaunchKernelGGL((lsc_plan_alt_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL((lsc_plan_tp_kernel<false, 1>), dim3(a.count), dim3(256), a.smem_tp, st, t); }
         else if (alt) { if (d2) hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_alt_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
         else { if (d2) hipLaunchKernelGGL(lsc_plan_tp_kernel<true>, dim3(a.count), dim3(256), a.smem_tp, st, t); else hipLaunchKernelGGL(lsc_plan_tp_kernel<false>, dim3(a.count), dim3(256), a.smem_tp, st, t); }
