@@ -725,7 +725,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     }
 #endif
     // phase B scratch, aliased onto arrays that are first written later: rows in arrival order (rs .. rt2, 32 B per row,
-    // written by phase C's start) and the pre-cull's unit list (rrhs .. cmap, written by the scatter that ends phase B)
+    // written by phase C's start) and the pre-cull's unit list (rn .. cmap, written by the scatter that ends phase B)
     struct TmpRow { double rhs; float nx, ny, nz; uint32_t cp_pos; };
     static_assert(sizeof(TmpRow) <= 4 * sizeof(double), "a temporary row fits the (rs, rz, rt1, rt2) slot of a row");
     TmpRow *tmp_rows = reinterpret_cast<TmpRow *>(rs);
@@ -1056,8 +1056,12 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
         // dropped before the GJK and the surviving units -- the same rows in the same order as without the cull, hence
         // bit-identical plans -- are compacted so that whole waves do not idle behind a few near obstacles.
         const int prune_mode = md.prune == 3 ? 1 : md.prune;      // 3: exact test only (parity tests of the cull itself)
-        uint16_t *ulist = reinterpret_cast<uint16_t *>(rrhs);     // rrhs, rn, cmap (24 B per row) are first written by the scatter
-        const int list_cap = SPILL ? 0x7fffffff : 4 * R + 6 * R + 2 * R;
+        // The unit list lives in rn .. cmap (16 B per row, contiguous, first written by the scatter that ends phase B).  (Until round 6 it started
+        // at rrhs with a capacity of 12 R entries "in rrhs, rn and cmap" -- but indexed linearly, so that entries beyond 4 R lay in rs .. rt2,
+        // where the GJK passes put their temporary rows: a swarm crowded enough for more than 4 R surviving units per agent -- 1024 agents in
+        // 14 x 14 x 9 m, found by tests/fuzz_neighbours.py -- read overwritten entries and faulted.)
+        uint16_t *ulist = reinterpret_cast<uint16_t *>(rn);
+        const int list_cap = 8 * R;
         // Large swarms: the units worth looking at come as a list from lsc_neigh.hip (built through a uniform grid in front of the tick: a
         // superset of what the cull below keeps, in the same ascending order -- the exact per-row test decides in both cases, so the rows
         // are the same); an agent without a list (capacity overflow there) culls by itself.

@@ -188,3 +188,88 @@ def test_neighbour_lists_are_used_where_they_pay(L):
     part.plan(state, ms.goal, traj)
     assert (part.neighbour_counts()[256:512] > 0).all()
     part.close()
+
+
+@pytest.mark.parametrize("planar", [False, True])
+def test_neighbour_lists_with_mixed_agents_and_in_a_planar_world(L, planar):
+    """Agents of different radius, downwash and speed limits -- the grid's query radius uses the swarm's extremes (largest obstacle-side
+    radius, smallest / largest downwash), each sphere test the pair's own numbers -- and a planar world (world/dimension 2: every agent at
+    z = z_2d, rows without their z term): bit-identical to the contexts without lists / without any cull."""
+    from lsc_planner_amd.planner import next_state_host
+    rng = np.random.default_rng(12)
+    n = 600
+    ms = L.random_swarm(n, world=(-14, -14, 0, 14, 14, 4.0), seed=21, min_sep=0.9)
+    ms.radius[:] = rng.choice([0.1, 0.15, 0.25], n)
+    ms.downwash[:] = rng.choice([1.0, 2.0, 3.0], n) if not planar else 2.0
+    ms.max_vel[:] = rng.choice([0.6, 1.0, 1.4], n)[:, None]
+    ms.max_acc[:] = rng.choice([1.5, 2.0, 3.0], n)[:, None]
+    cfg = dict(goal_mode="prior_based", priority_dist_threshold=0.7)
+    if planar:
+        cfg.update(world_dimension=2, world_z_2d=1.0)
+        ms.start[:, 2] = 1.0; ms.goal[:, 2] = 1.0
+    with _Env(LSC_NEIGH_ALWAYS=1):
+        a = L.SwarmPlanner(ms, L.PlannerConfig(prune=1, **cfg))
+    with _Env(LSC_NO_NEIGHBOUR_LISTS=1):
+        b = L.SwarmPlanner(ms, L.PlannerConfig(prune=1, **cfg))
+    c = L.SwarmPlanner(ms, L.PlannerConfig(prune=3, **cfg))
+    state, traj = _start(ms)
+    for tick in range(1, 16):
+        g = [p.plan(state, ms.goal, traj) for p in (a, b, c)]
+        for k in ("traj", "cost", "status", "iters"):
+            assert np.array_equal(g[0][k], g[1][k]) and np.array_equal(g[0][k], g[2][k]), (tick, k)
+        assert np.array_equal(a.row_counts(), c.row_counts()), tick
+        assert np.array_equal(a.last_goals(), c.last_goals()), tick
+        units, prio = a.neighbour_counts(priority=True)
+        assert (units >= 0).mean() > 0.9 and (prio >= 0).all(), tick
+        traj = g[0]["traj"]
+        state = next_state_host(traj)
+        if planar:
+            state[:, 2] = 1.0; state[:, 5] = 0.0; state[:, 8] = 0.0
+    for p in (a, b, c):
+        p.close()
+
+
+def test_neighbour_list_fuzzer(L):
+    """Three seeds of tests/fuzz_neighbours.py (random sizes, densities, agent constants, goal modes, disturbances, cell sizes): lists against
+    no cull at all, every tick the same bits.  The large-count run: profiles/r06_neighbour_fuzz.log."""
+    import fuzz_neighbours
+    for seed in (101, 102, 103):
+        r = fuzz_neighbours.one_seed(L, seed, 8)
+        assert not isinstance(r, str), r
+
+
+def test_crowded_swarm_with_more_surviving_units_than_the_old_list_held(L):
+    """1024 agents of mixed size in 14 x 14 x 9 m (seed 50 of tests/fuzz_neighbours.py): nearly every obstacle is near, an agent keeps up to
+    ~2 500 rows and thousands of units survive the in-kernel cull.  Until round 6 that list was indexed linearly from rrhs over 12 R entries
+    "in rrhs, rn and cmap" -- arrays that are not contiguous --, so entries beyond 4 R lay where the GJK passes put their temporary rows, and
+    the kernel read overwritten unit indices: a memory fault at tick 3, with or without the neighbour lists.  Both cull paths against no
+    cull at all, through the tick that faulted."""
+    from lsc_planner_amd.planner import next_state_host
+    rng = np.random.default_rng(50)
+    n = 1024
+    for _ in range(4):
+        rng.random()                                        # (not the fuzzer's draws: only the world matters)
+    half = float(np.sqrt(n / 0.6 / 9.0) / 2.0)
+    ms = L.random_swarm(n, world=(-half, -half, 0, half, half, 9.0), seed=50, min_sep=0.7)
+    ms.radius[:] = rng.choice([0.1, 0.15, 0.2], n)
+    ms.downwash[:] = rng.choice([1.0, 1.5, 2.0, 3.0], n)
+    ms.max_vel[:] = rng.choice([0.5, 1.0, 1.5], n)[:, None]
+    ms.max_acc[:] = rng.choice([1.0, 2.0, 4.0], n)[:, None]
+    with _Env(LSC_NEIGH_ALWAYS=1):
+        a = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
+    with _Env(LSC_NO_NEIGHBOUR_LISTS=1):
+        b = L.SwarmPlanner(ms, L.PlannerConfig(prune=1))
+    c = L.SwarmPlanner(ms, L.PlannerConfig(prune=3))
+    state, traj = _start(ms)
+    most = 0
+    for tick in range(1, 6):
+        g = [p.plan(state, ms.goal, traj) for p in (a, b, c)]
+        for k in ("traj", "cost", "status", "iters"):
+            assert np.array_equal(g[0][k], g[2][k]) and np.array_equal(g[1][k], g[2][k]), (tick, k)
+        assert np.array_equal(a.row_counts(), c.row_counts()) and np.array_equal(b.row_counts(), c.row_counts()), tick
+        most = max(most, int(c.row_counts().max()))
+        traj = g[2]["traj"]
+        state = next_state_host(traj)
+    assert most > 1500                                      # (rows of the fullest agent; its surviving units outnumber the first 4 R = 1836 entries of the old list)
+    for p in (a, b, c):
+        p.close()
