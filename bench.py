@@ -506,6 +506,9 @@ def main():
                     help="circle64: BASELINE configs[2], weak scaling (64 agents per GPU); random1024: configs[4], one 1024-agent "
                          "swarm (seed 20260929) sharded over the GPUs, strong scaling; forest256: configs[3] as written (256 agents, "
                          "simple_forest, world [-5,5]^2 x [0,2.5], seed 20260928), strong scaling")
+    ap.add_argument("--agents", type=int, default=0,
+                    help="--workload random1024 only: this many agents instead of 1024, in a world of the same density (40 m x sqrt(N / 1024) square, "
+                         "5 m high): e.g. 8192 agents, on one GPU or sharded over --gpus 8 at 1024 per rank")
     ap.add_argument("--missions", type=int, default=4,
                     help="extra leg (single GPU, circle64 workload): this many independent 64-agent missions in flight together, one context and "
                          "stream each -- the reference's mission-list outer loop as a batch axis; reported as `concurrent_missions` NEXT TO the "
@@ -576,8 +579,14 @@ def main():
     strong = args.workload != "circle64"
     bt_path = None
     if args.workload == "random1024":
-        ms = L.random_swarm(1024, seed=20260929)
-        layout = "1024-agent random swarm (world [-20,20]^2 x [0,5], seed 20260929: BASELINE configs[4])"
+        if args.agents in (0, 1024):
+            ms = L.random_swarm(1024, seed=20260929)
+            layout = "1024-agent random swarm (world [-20,20]^2 x [0,5], seed 20260929: BASELINE configs[4])"
+        else:
+            # configs[4]'s density with another number of agents (round 6: swarms beyond one GPU's 1024 agents; tools/shard_emulation.py --agents)
+            half = 20.0 * (args.agents / 1024.0) ** 0.5
+            ms = L.random_swarm(args.agents, world=(-half, -half, 0, half, half, 5), seed=20260929)
+            layout = f"{args.agents}-agent random swarm of BASELINE configs[4]'s density (world [-{half:.1f},{half:.1f}]^2 x [0,5], seed 20260929)"
     elif args.workload == "forest256":
         ms, bt_path = forest256_mission(L)
         layout = ("256-agent random swarm in world/simple_forest.bt (world [-5,5]^2 x [0,2.5], seed 20260928: BASELINE configs[3] as "

@@ -1923,7 +1923,7 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
     //   ST_CORR : corrector right-hand side, same factor, combined direction, step
     // Start: warm (y = free control points of the shifted previous plan, every row centred on mu0) when enabled,
     // with the cold start as fallback; cold only otherwise.
-    enum { ST_COLD = 0, ST_PRED = 1, ST_CORR = 2 };
+    enum { ST_COLD = 0, ST_PRED = 1, ST_CORR = 2, ST_START_WARM = 3, ST_START_COLD = 4 };      // (the last two: the next pass of the loop prepares that start first)
     int phase = ST_PRED, attempt = md.ws_mu0 > 0.0 ? 0 : 1, spent = 0;
     double alpha = 1.0, gap = 0.0, rpmax = 0.0, mu = 0.0, smu = 0.0, tau = 0.99;
     bool gap_ok = false;
@@ -2390,28 +2390,36 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             // A handed-over agent goes straight to the COLD start: what the active-set solve gives up on -- a working set beyond its capacity, an
             // infeasible QP -- is what the warm start (shifted previous plan, every row centred) fails on too, and its failed attempt was half of
             // the hand-over's cost (configs[3], tools/forest_stats.py: 26 -> 16 interior-point iterations per hand-over, plan kernel 0.51 -> 0.34 ms
-            // with static goals, 0.28 -> 0.17 ms with grid goals).  The cold start was the last word on every verdict anyway.
-            attempt = 1;
+            // with static goals, 0.28 -> 0.17 ms with grid goals).
+            // ... but the cold start is NOT the last word on a verdict (round 6, found by the M = 4 fuzzer at seed 9500131): on a QP whose feasible
+            // set is tiny it can run into its divergence test where the warm start -- and the oracle -- converge.  attempt 2: cold first, and
+            // when THAT fails the warm start gets the second opinion the cold start used to give it (only agents whose cold start fails pay).
+            attempt = md.ws_mu0 > 0.0 ? 2 : 1;
             __syncthreads();
             for (int e = tid; e < n_entries; e += NT) kconst[e] = kconst_of(ent[2 * e]);
             slot_entries();
             __syncthreads();
         }
-        if (attempt == 0) {
-            // An agent with few surviving LSC rows (most agents of a sparse swarm) is close to its unconstrained optimum: it
-            // starts a third as far from the boundary.  Over 36 missions this takes 10 % off the ticks of random swarms and
-            // leaves crossing swarms where they were (profiles/r02_solver_knob_sweeps.log).  Not in corridor worlds: there the
-            // box rows, which this count does not see, are what is active (the 256-agent forest loses 2.6 % with the rule).
-            prepare_warm((nact < WS_FEW_ROWS && !md.use_sfc) ? md.ws_mu0 * (1.0 / 3.0) : md.ws_mu0);
-            phase = ST_PRED;
-        } else {
-            prepare_cold();
-            phase = ST_COLD;
-        }
     }
-    stamp(PH_INIT);
+    // (one call site per start: the second opinion below re-enters here through the phase)
+    phase = attempt == 0 ? ST_START_WARM : ST_START_COLD;
+    if (!run) stamp(PH_INIT);
 
     while (run) {
+        if (phase >= ST_START_WARM) {
+            if (phase == ST_START_WARM) {
+                // An agent with few surviving LSC rows (most agents of a sparse swarm) is close to its unconstrained optimum: it
+                // starts a third as far from the boundary.  Over 36 missions this takes 10 % off the ticks of random swarms and
+                // leaves crossing swarms where they were (profiles/r02_solver_knob_sweeps.log).  Not in corridor worlds: there the
+                // box rows, which this count does not see, are what is active (the 256-agent forest loses 2.6 % with the rule).
+                prepare_warm((nact < WS_FEW_ROWS && !md.use_sfc) ? md.ws_mu0 * (1.0 / 3.0) : md.ws_mu0);
+                phase = ST_PRED;
+            } else {
+                prepare_cold();
+                phase = ST_COLD;
+            }
+            stamp(PH_INIT);
+        }
         bool failed = false;
         // ---------------------------------------------------------------- before the linear solve
         if (phase == ST_PRED) {
@@ -2646,13 +2654,18 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             }
         }
         if (failed) {
-            if (attempt == 0) {
-                // warm start did not converge: fall back to the cold start
+            // warm start did not converge: fall back to the cold start.  Cold start of a handed-over agent (attempt 2) did not converge: the
+            // warm start's second opinion -- but only when the cold start gave up ON A FEASIBLE POINT WITH A CLOSED GAP (primal residual at
+            // round-off, gap within the relaxed acceptance test's 1e-7): then "infeasible" would be a wrong verdict, whatever made the start
+            // fail (seed 9500131: gap 1e-11, residual 1e-15, the step still 4e-7 when K lost definiteness), and the other start converges.
+            // An infeasible QP never gets there -- its multipliers run away, also when the iterates stand on a point that violates nothing
+            // by more than 1e-9 (the marginal infeasibilities of corridor worlds) --; those agents keep paying ONE start (configs[3]: 16
+            // instead of 26 iterations per hand-over).
+            if (attempt == 0 || (attempt == 2 && rpmax <= 1e-9 * hmax && gap <= 1e-7 * (1.0 + fabs(obj)))) {
+                phase = attempt == 0 ? ST_START_COLD : ST_START_WARM;
                 attempt = 1;
                 spent += iters;
                 iters = 0;
-                prepare_cold();
-                phase = ST_COLD;
             } else {
                 break;
             }

@@ -4,7 +4,8 @@
 // Reference behaviour being replaced: the obstacle loop of TrajPlanner::generateLSC, `for (int oi = 0; oi < N_obs; oi++)`
 // (src/traj_planner.cpp:1335-1407) -- there every agent builds the 27 rows against every other agent, O(N^2) per tick; phase B of the plan
 // kernel (lsc_kernels.hip) drops the rows that are provably redundant inside the box a control point can reach, and since round 2 decided
-// WHICH units to look at by walking all obstacles' bounding spheres (O(N) per agent: 19 of an agent's 43 us at N = 1024).
+// WHICH units to look at by walking all obstacles' bounding spheres (O(N) per agent: 6.7 us of an agent's 46 at N = 1024, ~270 of ~315 at
+// N = 8192 together with phase A's two walks below).
 //
 // The test that may drop a unit (obstacle o, segment m) before the GJK -- phase B's own, lsc_kernels.hip "spatial pre-cull" -- is
 //      |w_c| >= 2 s B_m + r_a + r_o + 2e-4 + R_w,     w_j = S (p_j - q_j),  S = diag(1, 1, 1 / downwash),  s = max(1, 1 / downwash),
@@ -72,7 +73,7 @@ enum { G_RADIUS = 0, G_OVF = 1, G_MAXX = 2, G_MAXY = 3, G_MAXZ = 4, G_MINX = 5, 
 
 // ---- build: eight lanes per agent, lane m < M owns segment m.  float32 throughout -- these are bounds, not results: every quantity that
 // widens a test is rounded up by far more than float32 arithmetic can lose (B_m: + 1e-5 B_m + 1e-3 m; radii: + 1e-5 r + 1e-5 m) --, no LDS
-// round trips between the lanes of an agent (three DPP steps reduce over its eight lanes), one lane's work ~400 instructions: a lone wave
+// round trips between the lanes of an agent (three DPP steps reduce over its eight lanes), one lane's work ~1 200 instructions: a lone wave
 // pays 6-8 cycles per instruction and ~100 per LDS round trip, and the first version (32 lanes per agent, float64, ~150 ds_bpermute) was
 // 14 us of a 1024-agent tick.
 constexpr int NB_THREADS = 256, NB_LANES = 8, NB_AGENTS = NB_THREADS / NB_LANES;      // lanes / lanes per agent / agents of a build workgroup
@@ -177,7 +178,8 @@ __global__ __launch_bounds__(NB_THREADS) void lsc_neigh_build_kernel(NeighArgs a
         dm2 = fmaxf(dm2, K >= 1 ? dx * dx + dy * dy + dz * dz : 0.f);
         em2 = fmaxf(em2, K >= 1 ? e2 : 0.f);
     }
-    const float bm = (sqrtf(dm2) + sqrtf(em2)) * (1.f + 1e-5f) + 1e-3f;
+    // (+ 1e-5 of the coordinates' size: c_{0,2} is formed in float32 here and in float64 in phase A -- half an ulp of a coordinate apart)
+    const float bm = (sqrtf(dm2) + sqrtf(em2)) * (1.f + 1e-5f) + 1e-3f + 1e-5f * (fabsf(c2[0]) + fabsf(c2[1]) + fabsf(c2[2]));
     // ---- disturbance check of this agent (off_plan of plan_agent: float32, no contraction): the persistent flag is set HERE, once
     bool slack = false;
     if (a.checks) {

@@ -273,3 +273,52 @@ def test_crowded_swarm_with_more_surviving_units_than_the_old_list_held(L):
     assert most > 1500                                      # (rows of the fullest agent; its surviving units outnumber the first 4 R = 1836 entries of the old list)
     for p in (a, b, c):
         p.close()
+
+
+def test_neighbour_lists_far_from_the_origin(L):
+    """The grid kernels form their bounds in float32 (rounded up); at coordinates of kilometres a float32 ulp is 0.5 mm, so the bounds carry a
+    term proportional to the coordinates.  A 600-agent swarm 5 km from the origin plans the same bits with the lists as without any cull."""
+    from lsc_planner_amd.planner import next_state_host
+    off = np.array([5000.0, -3000.0, 200.0], np.float32)
+    ms = L.random_swarm(600, world=(-12, -12, 0, 12, 12, 3.0), seed=31)
+    ms.start[:] = ms.start + off; ms.goal[:] = ms.goal + off
+    ms.world_min[:] = ms.world_min + off; ms.world_max[:] = ms.world_max + off
+    cfg = dict(goal_mode="prior_based", priority_dist_threshold=0.8)
+    with _Env(LSC_NEIGH_ALWAYS=1):
+        a = L.SwarmPlanner(ms, L.PlannerConfig(prune=1, **cfg))
+    b = L.SwarmPlanner(ms, L.PlannerConfig(prune=3, **cfg))
+    state, traj = _start(ms)
+    for tick in range(1, 13):
+        ga, gb = a.plan(state, ms.goal, traj), b.plan(state, ms.goal, traj)
+        for k in ("traj", "cost", "status", "iters"):
+            assert np.array_equal(ga[k], gb[k]), (tick, k)
+        assert np.array_equal(a.row_counts(), b.row_counts()) and np.array_equal(a.last_goals(), b.last_goals()), tick
+        assert (a.neighbour_counts() >= 0).all()
+        traj = ga["traj"]; state = next_state_host(traj)
+    a.close(); b.close()
+
+
+def test_instance_where_the_cold_start_alone_called_a_feasible_qp_infeasible():
+    """Found by the M = 4 fuzzer in round 6 (seed 9500131, tick 3): twelve agents in a 10 m world, half-second segments.  Agent 10 is handed
+    to the interior point, whose COLD start (the only one a handed-over agent got since round 5) converges to gap 1e-11 on a feasible point
+    and then loses its factorisation before the step-length test passes -- status 1 where the oracle, and the warm start, find the optimum
+    1.27613.  A handed-over agent whose cold start gives up on a feasible point with a closed gap now gets the warm start's second opinion;
+    agents whose cold start diverges (infeasible QPs) still pay one start.  Pins statuses, costs and plans against the oracle's."""
+    import lsc_planner_amd as L
+    from lsc_planner_amd.mission import Mission
+    from lsc_planner_amd.planner import PlannerConfig
+    from tolerances import COST_ATOL, COST_RTOL, FUZZ_TRAJ_ATOL_HALF_SECOND
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_found_m4_cold_start_9500131.npz"))
+    L.load_library(4)
+    ms = Mission(d["state"][:, :3].copy(), d["goal"].copy(), d["wmin"], d["wmax"], d["radius"], d["dw"], d["vmax"], d["amax"], d["vnom"], name="replay")
+    pl = L.SwarmPlanner(ms, PlannerConfig(goal_mode="static", dt=0.5, horizon=2.0, solver="active_set"))
+    assert pl.M == 4
+    pl.plan(d["state"], d["goal"], d["traj"])               # (sequence number 1 takes the current-velocity model: only to move it on)
+    pl.iterations_total(reset=True)
+    g = pl.plan(d["state"], d["goal"], d["traj"])
+    st = pl.solver_stats()
+    pl.close()
+    assert st["handed_over"] >= 1, st
+    assert np.array_equal(g["status"], d["ostatus"]) and (g["status"] == 0).all(), g["status"]
+    assert (np.abs(g["cost"] - d["ocost"]) <= COST_RTOL * np.abs(d["ocost"]) + COST_ATOL).all(), np.abs(g["cost"] - d["ocost"])
+    assert np.abs(g["traj"].astype(np.float64) - d["otraj"]).max() <= FUZZ_TRAJ_ATOL_HALF_SECOND
