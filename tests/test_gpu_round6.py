@@ -322,3 +322,28 @@ def test_instance_where_the_cold_start_alone_called_a_feasible_qp_infeasible():
     assert np.array_equal(g["status"], d["ostatus"]) and (g["status"] == 0).all(), g["status"]
     assert (np.abs(g["cost"] - d["ocost"]) <= COST_RTOL * np.abs(d["ocost"]) + COST_ATOL).all(), np.abs(g["cost"] - d["ocost"])
     assert np.abs(g["traj"].astype(np.float64) - d["otraj"]).max() <= FUZZ_TRAJ_ATOL_HALF_SECOND
+
+
+def test_simulator_flies_a_large_swarm_the_same_with_and_without_the_lists(L, tmp_path):
+    """The C++ host side (lsc_sim: device-resident fused ticks, safety ratio on the device, result CSV) with a 640-agent swarm: 25 ticks with
+    the neighbour lists forced on write the same result CSV as 25 ticks with round 5's walks over all agents."""
+    import csv
+    import subprocess
+    from test_gpu_sim import SIM, _write_mission
+    ms = L.random_swarm(640, world=(-14, -14, 0, 14, 14, 4.0), seed=8)
+    mp = tmp_path / "random640.json"
+    _write_mission(str(mp), ms)
+    outs = []
+    for name, env in (("lists", dict(LSC_NEIGH_ALWAYS="1")), ("walks", dict(LSC_NO_NEIGHBOUR_LISTS="1"))):
+        d = tmp_path / name
+        d.mkdir()
+        r = subprocess.run([SIM, "--mission", str(mp), "--csv", str(d), "--quiet", "--max-iter", "25", "--reset-threshold", "0.15"],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode in (0, 1, 2), r.stdout + r.stderr            # (25 ticks do not finish the mission: the run ends at --max-iter)
+        assert "total flight time:" in r.stdout or "max" in (r.stdout + r.stderr).lower(), r.stdout + r.stderr
+        rows = list(csv.reader(open(d / "result_LSC_640agents.csv")))
+        assert rows[0][:15] == "id,t,px,py,pz,vx,vy,vz,ax,ay,az,planning_time,qp_cost,planning_report,size".split(",")
+        # (everything but the wall-clock column planning_time, as strings: positions, velocities, accelerations, costs, reports)
+        outs.append([[v for j, v in enumerate(r_) if j % 15 != 11] for r_ in rows[1:]])
+    same = outs[0] == outs[1]                                # (a plain bool: pytest's diff of two 300 KB tables takes minutes)
+    assert len(outs[0]) >= 48 and len(outs[0][0]) == 640 * 14 and same
