@@ -33,7 +33,7 @@ struct PlanArgs {
     int dim2;                  // world/dimension == 2: the launch takes the planar instantiation of the plan kernels (a compile-time switch)
     int cap;                   // LSC rows the LDS pass holds (total over the 27 control points; compact layout)
     int solver;                // 0 interior point; 1 dual active set first, interior point as fallback (lsc_config.solver)
-    long long *solver_stats;   // optional [4] running counters of the active-set solve (lsc_solver_stats)
+    long long *solver_stats;   // optional [N][4] running counters of the active-set solve, per agent (lsc_solver_stats sums them)
     int *order;                // throughput build: launch order of the shard's agents (longest first), or null
     float *obs_bound;          // throughput build: [N][4] bounding sphere of every agent's predicted control points, or null
     int cap_tp;                // > 0: use the 256-lane throughput build with this row capacity and smem_tp bytes of LDS

@@ -2728,9 +2728,11 @@ __device__ __forceinline__ void plan_agent(ArgsT &a, const int al, unsigned char
             if (a.solver_stats && (status == LSC_STATUS_OK_K || status == LSC_STATUS_INFEASIBLE_K)) {
                 // [0] agent-replans the active-set solve finished, [1] those it handed to the interior point, [2] working-set changes, [3] interior-point iterations
                 const bool by_gi = run_gi_done;
-                atomicAdd((unsigned long long *)&a.solver_stats[by_gi ? 0 : 1], 1ull);
-                atomicAdd((unsigned long long *)&a.solver_stats[2], (unsigned long long)gi_changes);
-                if (!by_gi) atomicAdd((unsigned long long *)&a.solver_stats[3], (unsigned long long)(iters - gi_changes));
+                // (this agent's own four counters: lsc_solver_stats sums over the agents)
+                long long *st = a.solver_stats + 4 * (size_t)qi;
+                atomicAdd((unsigned long long *)&st[by_gi ? 0 : 1], 1ull);
+                atomicAdd((unsigned long long *)&st[2], (unsigned long long)gi_changes);
+                if (!by_gi) atomicAdd((unsigned long long *)&st[3], (unsigned long long)(iters - gi_changes));
             }
         }
         if (a.dbg) { a.dbg[4 * qi] = S.sc[5]; a.dbg[4 * qi + 1] = S.sc[6]; a.dbg[4 * qi + 2] = spent > 0 ? 1000.0 + (double)spent : rv[3]; a.dbg[4 * qi + 3] = obj; }
